@@ -189,13 +189,16 @@ class COCSys:
         mu = 0.0
         lam = np.zeros((N + 1, n))
         info = dict(iters=0, converged=False)
+        # Hessian model of the stage: dgrid * d2H/d(x,u)2 evaluated with costate scale HL.
+        # HL=0 -> Gauss-Newton (robust far from the optimum), HL=1 -> Newton-like polish.
+        HL = 0.0
         for it in range(max_iter):
             # linearise the shooting map along (X, U)
             A, B, qx, qu = [], [], [], []
             for k in range(N):
                 _, _, M = self.grid_map(time_grid[k], X[k], U[k], e, DT, derivs=True)
                 A.append(M[:n, :n]); B.append(M[:n, n:]); qx.append(M[n, :n]); qu.append(M[n, n:])
-            # backward sweep: exact costate + Newton/DDP gains
+            # backward sweep: exact costate + DDP gains
             while True:
                 Vx = self._call('dhx', time_grid[-1], X[N], e).ravel()
                 Vxx = self._call('ddhxx', time_grid[-1], X[N], e)
@@ -206,15 +209,16 @@ class COCSys:
                 ok = True
                 gnorm = 0.0
                 for k in range(N - 1, -1, -1):
-                    Hxx = self._call('ddHxx', time_grid[k], X[k], U[k], lam_k, e) * dgrid
-                    Hxu = self._call('ddHxu', time_grid[k], X[k], U[k], lam_k, e) * dgrid
-                    Huu = self._call('ddHuu', time_grid[k], X[k], U[k], lam_k, e) * dgrid
+                    Hxx = self._call('ddHxx', time_grid[k], X[k], U[k], HL * lam_k, e) * dgrid
+                    Hxu = self._call('ddHxu', time_grid[k], X[k], U[k], HL * lam_k, e) * dgrid
+                    Huu = self._call('ddHuu', time_grid[k], X[k], U[k], HL * lam_k, e) * dgrid
                     Qx = qx[k] + A[k].T @ Vx
                     Qu = qu[k] + B[k].T @ Vx
                     Qxx = Hxx + A[k].T @ Vxx @ A[k]
                     Qux = Hxu.T + B[k].T @ Vxx @ A[k]
-                    Quu = Huu + B[k].T @ Vxx @ B[k] + mu * np.eye(m)
-                    Quu = 0.5 * (Quu + Quu.T)
+                    Quu0 = Huu + B[k].T @ Vxx @ B[k]
+                    Quu0 = 0.5 * (Quu0 + Quu0.T)
+                    Quu = Quu0 + mu * np.eye(m)
                     try:
                         Lc = np.linalg.cholesky(Quu)
                     except np.linalg.LinAlgError:
@@ -224,9 +228,9 @@ class COCSys:
                     kff[k] = -sol(Qu)
                     K[k] = -sol(Qux)
                     dV1 += kff[k] @ Qu
-                    dV2 += 0.5 * kff[k] @ Quu @ kff[k]
-                    Vx = Qx + K[k].T @ Quu @ kff[k] + K[k].T @ Qu + Qux.T @ kff[k]
-                    Vxx = Qxx + K[k].T @ Quu @ K[k] + K[k].T @ Qux + Qux.T @ K[k]
+                    dV2 += 0.5 * kff[k] @ Quu0 @ kff[k]
+                    Vx = Qx + K[k].T @ Quu0 @ kff[k] + K[k].T @ Qu + Qux.T @ kff[k]
+                    Vxx = Qxx + K[k].T @ Quu0 @ K[k] + K[k].T @ Qux + Qux.T @ K[k]
                     Vxx = 0.5 * (Vxx + Vxx.T)
                     # exact discrete costate  lambda_k = q_x + A^T lambda_{k+1}
                     gnorm = max(gnorm, np.max(np.abs(qu[k] + B[k].T @ lam_k)))
@@ -234,7 +238,10 @@ class COCSys:
                     lam[k] = lam_k
                 if ok:
                     break
-                mu = max(10 * mu, 1e-6)
+                if HL > 0:
+                    HL = 0.0            # Newton model indefinite here: fall back to Gauss-Newton
+                else:
+                    mu = max(10 * mu, 1e-6)
             info.update(iters=it, grad_inf=gnorm)
             if gnorm < tol * (1 + abs(J)):
                 info['converged'] = True
@@ -257,11 +264,16 @@ class COCSys:
                     break
                 alpha *= 0.5
             if not accepted:
+                if HL > 0:
+                    HL = 0.0
+                    continue
                 mu = max(10 * mu, 1e-6)
                 if mu > 1e8:
                     break
                 continue
             mu = mu / 10 if mu > 1e-9 else 0.0
+            # switch to the Newton-like model once full GN steps only buy small decreases
+            HL = 1.0 if (alpha == 1.0 and (J - Jn) < 1e-2 * (abs(Jn) + 1e-12)) else 0.0
             X, U, J = np.array(Xn), Un, Jn
         self.last_info = info
         self.last_cost = J
