@@ -1,0 +1,116 @@
+/* lfsd_cpdp.h — C ABI of the MI355X-native batched Continuous-PDP solver.
+ *
+ * One shared library is built per optimal-control model (dimensions and the
+ * model's derivative code are compiled in); every library exports exactly the
+ * symbols below.  All array arguments are DEVICE pointers (hipMalloc'd memory,
+ * e.g. torch tensors' data_ptr()), row-major, batch-major; `stream` is a
+ * hipStream_t passed as void* (NULL = default stream).  dtype: 0 = float32,
+ * 1 = float64 (the arithmetic type of every array in the call).
+ * Every function returns 0 on success, a negative LFSD_E* code on bad
+ * arguments, or a positive hipError_t if a launch failed.
+ *
+ * Reference interface each entry point replaces (wanxinjin/Learning-from-
+ * Sparse-Demonstrations @ v1):
+ *   lfsd_coc_solve        CPDP/CPDP.py:92-198   COCSys.cocSolver (and :486-594 time-varying)
+ *   lfsd_aux_solve        CPDP/CPDP.py:301-381  COCSys.auxSysSolver (and :706-786)
+ *                         + lib/QuadAlgorithm.py:616-673 getloss_pos_corrections / getloss_corrections
+ *                           (Examples/*.py getloss_corrections)
+ *   lfsd_optimizer_step   lib/QuadAlgorithm.py:454-578 Vanilla/Nesterov/Adam/Nadam/AMSGrad
+ *   lfsd_lookahead        lib/QuadAlgorithm.py:478 (Nesterov look-ahead point)
+ */
+#ifndef LFSD_CPDP_H
+#define LFSD_CPDP_H
+#include <stddef.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LFSD_ABI_VERSION 1
+#define LFSD_F32 0
+#define LFSD_F64 1
+#define LFSD_EINVAL (-1)   /* bad argument (null pointer, non-positive size, unknown enum) */
+#define LFSD_ENOSPC (-2)   /* workspace too small */
+
+/* status[] values written by lfsd_coc_solve */
+#define LFSD_ST_CONVERGED 1   /* max |dJ/du| < tol * (1 + |J|)                         */
+#define LFSD_ST_STALLED   2   /* no step improves J beyond rounding: converged to precision */
+#define LFSD_ST_MAXITER   3
+#define LFSD_ST_FAILED    4   /* non-finite cost / regularisation exhausted            */
+
+/* optimizer methods (lib/QuadAlgorithm.py:164-188) */
+#define LFSD_OPT_VANILLA  0
+#define LFSD_OPT_NESTEROV 1
+#define LFSD_OPT_ADAM     2
+#define LFSD_OPT_NADAM    3
+#define LFSD_OPT_AMSGRAD  4
+
+typedef struct lfsd_model_info {
+  int abi_version;
+  int n_state, n_control, n_auxvar, n_const;   /* n_const may be 0 */
+  int time_varying;                            /* 1: COCSys_TimeVarying semantics */
+  int lanes_per_trajectory;                    /* lane-group width G the kernels were built with */
+  int is_emulator;                             /* 1 only for the CPU SIMT-emulator test build */
+  const char* name;
+  const char* hash;
+} lfsd_model_info;
+
+int lfsd_get_model_info(lfsd_model_info* out);
+/* default value of runtime constant i (the number the reference would have baked into the CasADi graph) */
+double lfsd_const_default(int i);
+
+/* bytes of device scratch lfsd_coc_solve needs for `batch` trajectories */
+size_t lfsd_coc_workspace_bytes(int dtype, int batch, int n_grid);
+
+/* Solve `batch` independent optimal-control problems (the NLP of CPDP.py:110-175:
+ * n_grid shooting intervals, steps_per_grid RK4 steps each, piecewise-constant control).
+ *   ini_state [B][n_state]   horizon [B]   auxvar [B][n_auxvar]
+ *   consts    [B][n_const] (const_per_traj=1) or [n_const] (const_per_traj=0); may be NULL if n_const==0
+ *   u_init    [B][n_grid][n_control] initial guess, or NULL for zeros
+ * outputs (CPDP.py:186-196):
+ *   state_grid [B][n_grid+1][n_state], control_grid [B][n_grid+1][n_control] (last row repeated),
+ *   costate_grid [B][n_grid+1][n_state] (== IPOPT lam_g), cost [B], iters [B], status [B]      */
+int lfsd_coc_solve(int dtype, int batch, int n_grid, int steps_per_grid,
+                   const void* ini_state, const void* horizon, const void* auxvar,
+                   const void* consts, int const_per_traj, const void* u_init,
+                   void* state_grid, void* control_grid, void* costate_grid,
+                   void* cost, int* iters, int* status,
+                   int max_iter, double tol,
+                   void* workspace, size_t workspace_bytes, void* stream);
+
+/* Differentiate the maximum principle along the solved trajectories and evaluate the
+ * sparse-demonstration loss and its gradient.
+ *   Z_grid  [B][n_grid+1][n_state+n_auxvar][n_state]  out: Riccati pair [P W], column-major
+ *           (P_k, W_k of CPDP.py:329-338)
+ *   iface_idx [n_iface] int32: state components exposed by the interface function
+ *   taus [B][n_waypoints], waypoints [B][n_waypoints][n_iface]
+ *   loss [B], grad [B][n_auxvar]:  loss = sum_k |y(tau_k)-wp_k|^2, grad = sum_k (y-wp)^T dy/dx dx/dtheta
+ *           (no factor 2, exactly as lib/QuadAlgorithm.py:630-637)
+ *   auxX_grid [B][n_grid+1][n_auxvar][n_state], auxU_grid [B][n_grid+1][n_auxvar][n_control]:
+ *           optional (NULL to skip) grids of dx/dtheta and du/dtheta (CPDP.py:352-381), column-major
+ *   substeps: coarse split-steps per grid interval (a 2x finer sweep is run alongside and
+ *           Richardson-extrapolated); 0 selects the default (4).                                */
+int lfsd_aux_solve(int dtype, int batch, int n_grid,
+                   const void* horizon, const void* auxvar, const void* consts, int const_per_traj,
+                   const void* state_grid, const void* control_grid, const void* costate_grid,
+                   void* Z_grid,
+                   int n_waypoints, int n_iface, const int* iface_idx,
+                   const void* taus, const void* waypoints,
+                   void* loss, void* grad, void* auxX_grid, void* auxU_grid,
+                   int substeps, void* stream);
+
+/* theta <- update(theta, grad) for every trajectory; m/v/vhat are optimizer state [B][n_param]
+ * (m: Nesterov velocity or first moment; v: second moment; vhat: AMSGrad max; unused ones may be NULL).
+ * proj_lo [n_param] or NULL: theta <- max(theta, proj_lo) after the step (the examples' projection
+ * current_parameter[0] = fmax(current_parameter[0], 1e-8)).  iter_idx counts from 0.                */
+int lfsd_optimizer_step(int dtype, int method, int batch, int n_param, int iter_idx,
+                        double lr, double mu, double beta1, double beta2, double eps,
+                        void* theta, const void* grad, void* m, void* v, void* vhat,
+                        const void* proj_lo, void* stream);
+
+/* out = theta + mu * v   (Nesterov look-ahead, [B][n_param]) */
+int lfsd_lookahead(int dtype, long long n, double mu, const void* theta, const void* v, void* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

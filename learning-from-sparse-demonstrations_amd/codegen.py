@@ -1,0 +1,292 @@
+"""sympy -> HIP device code for one optimal-control model.
+
+Replaces what CasADi does for the reference at CPDP/CPDP.py:49-79 (Function
+objects for dyn / cost / final cost and their Jacobians) and CPDP.py:201-248
+(``diffPMP``: first and second derivatives of the Hamiltonian) — but instead of
+an interpreted expression graph evaluated one trajectory at a time on the CPU,
+the derivatives are emitted as straight-line, CSE'd, *sparse* device code that
+the kernels in ``csrc/cpdp_kernels.h`` inline.
+
+Emitted per model (``struct Model`` in namespace ``lfsd_gen``):
+
+* ``dyn_cost``        f(x,u), c(x,u)                       (line-search roll-outs)
+* ``dyn_cost_jvp``    f, c and their directional derivative along a per-lane
+                      tangent (dx,du): the RK4 sensitivity sweep of the shooting map
+* ``final_cost / final_grad / final_hess_mul``
+* ``ham_hess_mul``    [Hxx Hxu; Hux Huu] applied to a per-lane vector (DDP backward)
+* ``pmp_coeffs``      every structurally non-zero entry of fx, fu, fe, Hxx, Hxu,
+                      Hxe, Hue (+ dense Huu) packed into one array that is staged
+                      in LDS, and ``<mat>_mul / <mat>_mulT`` operators that apply
+                      those packed matrices with compile-time offsets (auxiliary
+                      Riccati / sensitivity pass, CPDP.py:253-298).
+"""
+import hashlib
+
+import sympy as sp
+from sympy.printing.c import C99CodePrinter
+
+CODEGEN_VERSION = 3
+
+
+class ModelSpec:
+    def __init__(self, state, control, auxvar, consts, time, dyn, path_cost, final_cost,
+                 time_varying=False, const_defaults=None, name="model"):
+        self.state, self.control, self.auxvar, self.consts = list(state), list(control), list(auxvar), list(consts)
+        self.time = time
+        self.dyn = sp.Matrix(dyn)
+        self.path_cost = sp.sympify(path_cost)
+        self.final_cost = sp.sympify(final_cost)
+        self.time_varying = bool(time_varying)
+        self.const_defaults = list(const_defaults or [0.0] * len(self.consts))
+        self.name = name
+        self._canon()
+
+    def _canon(self):
+        n, m, p, nc = len(self.state), len(self.control), len(self.auxvar), len(self.consts)
+        self.X = [sp.Symbol('x%d' % i, real=True) for i in range(n)]
+        self.U = [sp.Symbol('u%d' % i, real=True) for i in range(m)]
+        self.E = [sp.Symbol('e%d' % i, real=True) for i in range(p)]
+        self.C = [sp.Symbol('c%d' % i, real=True) for i in range(nc)]
+        self.L = [sp.Symbol('l%d' % i, real=True) for i in range(n)]
+        self.Tt = sp.Symbol('tt', real=True)
+        sub = dict(zip(self.state, self.X))
+        sub.update(zip(self.control, self.U))
+        sub.update(zip(self.auxvar, self.E))
+        sub.update(zip(self.consts, self.C))
+        sub[self.time] = self.Tt
+        self.f = self.dyn.xreplace(sub)
+        self.c = self.path_cost.xreplace(sub)
+        self.h = self.final_cost.xreplace(sub)
+        allowed = set(self.X + self.U + self.E + self.C + [self.Tt])
+        stray = (self.f.free_symbols | self.c.free_symbols | self.h.free_symbols) - allowed
+        if stray:
+            raise ValueError("model expressions contain undeclared symbols: %s" % sorted(map(str, stray)))
+        if self.h.free_symbols & set(self.U):
+            raise ValueError("final cost must not depend on the control")
+        self.n, self.m, self.p, self.nc = n, m, p, nc
+
+    def hash(self):
+        key = "v%d|%d %d %d %d %d|%s|%s|%s" % (CODEGEN_VERSION, self.n, self.m, self.p, self.nc, self.time_varying,
+                                               sp.srepr(self.f), sp.srepr(self.c), sp.srepr(self.h))
+        return hashlib.sha1(key.encode()).hexdigest()[:16]
+
+
+class _HipPrinter(C99CodePrinter):
+    def _print_Float(self, e):
+        return 'T(%r)' % float(e)
+
+    def _print_Integer(self, e):
+        return 'T(%d)' % int(e)
+
+    def _print_Rational(self, e):
+        return '(T(%d)/T(%d))' % (e.p, e.q)
+
+    def _print_Pi(self, e):
+        return 'T(3.141592653589793)'
+
+    def _print_Pow(self, e):
+        b, ex = e.base, e.exp
+        if ex.is_Integer:
+            k = int(ex)
+            bs = self.parenthesize(b, 1000)
+            if k == -1:
+                return '(T(1)/%s)' % bs
+            if 0 < k <= 4:
+                return '(' + '*'.join([bs] * k) + ')'
+            if -4 <= k < 0:
+                return '(T(1)/(' + '*'.join([bs] * (-k)) + '))'
+        if ex == sp.Rational(1, 2):
+            return 'sqrt(%s)' % self._print(b)
+        if ex == sp.Rational(-1, 2):
+            return '(T(1)/sqrt(%s))' % self._print(b)
+        return 'pow(%s, %s)' % (self._print(b), self._print(ex))
+
+
+_P = _HipPrinter()
+
+
+def _pr(e):
+    return _P.doprint(e)
+
+
+def _body(inputs, outputs, indent='    '):
+    """inputs: list of (symbol, c_expr_to_load); outputs: list of (c_lvalue, sympy_expr).
+    Returns C statements computing all outputs with common sub-expression elimination."""
+    exprs = [sp.sympify(e) for _, e in outputs]
+    repl, red = sp.cse(exprs, symbols=sp.numbered_symbols('w_'), order='none')
+    used = set()
+    for _, r in repl:
+        used |= r.free_symbols
+    for r in red:
+        used |= r.free_symbols
+    lines = []
+    for sym, load in inputs:
+        if sym in used:
+            lines.append('%sconst T %s = %s;' % (indent, sym, load))
+    for s, r in repl:
+        lines.append('%sconst T %s = %s;' % (indent, s, _pr(r)))
+    for (lv, _), r in zip(outputs, red):
+        lines.append('%s%s = %s;' % (indent, lv, _pr(r)))
+    return '\n'.join(lines)
+
+
+def _loads(spec, with_u=True, with_l=False):
+    ins = [(spec.Tt, 't')]
+    ins += [(s, 'x[%d]' % i) for i, s in enumerate(spec.X)]
+    if with_u:
+        ins += [(s, 'u[%d]' % i) for i, s in enumerate(spec.U)]
+    if with_l:
+        ins += [(s, 'l[%d]' % i) for i, s in enumerate(spec.L)]
+    ins += [(s, 'e[%d]' % i) for i, s in enumerate(spec.E)]
+    ins += [(s, 'c[%d]' % i) for i, s in enumerate(spec.C)]
+    return ins
+
+
+def _nz(e):
+    return sp.sympify(e) != 0
+
+
+class _Sparse:
+    """Structurally sparse matrix packed row-major into the coefficient array."""
+
+    def __init__(self, name, mat, off):
+        self.name, self.mat, self.off = name, mat, off
+        self.entries = []          # (row, col, offset, expr)
+        o = off
+        for r in range(mat.shape[0]):
+            for cidx in range(mat.shape[1]):
+                if _nz(mat[r, cidx]):
+                    self.entries.append((r, cidx, o, mat[r, cidx]))
+                    o += 1
+        self.end = o
+
+    def emit_ops(self):
+        nr, ncol = self.mat.shape
+        out = []
+        for suffix, transposed in (('mul', False), ('mulT', True)):
+            rows = {}
+            for (r, cc, o, _) in self.entries:
+                i, k = (cc, r) if transposed else (r, cc)
+                rows.setdefault(i, []).append('L[%d]*v[%d]' % (o, k))
+            nout = ncol if transposed else nr
+            lines = []
+            for i in range(nout):
+                terms = rows.get(i)
+                if terms:
+                    lines.append('    y[%d] = (ACC ? y[%d] : T(0)) + %s;' % (i, i, ' + '.join(terms)))
+                else:
+                    lines.append('    if (!ACC) y[%d] = T(0);' % i)
+            out.append('  // y[%d] %s %s%s * v[%d]   (%d non-zeros)\n'
+                       '  template<bool ACC, class T> static LFSD_DEV void %s_%s(const T* L, const T* v, T* y) {\n%s\n  }'
+                       % (nout, '(+)=', self.name, "^T" if transposed else "", nr if transposed else ncol,
+                          len(self.entries), self.name, suffix, '\n'.join(lines)))
+        return '\n'.join(out)
+
+
+def emit_header(spec):
+    n, m, p, nc = spec.n, spec.m, spec.p, spec.nc
+    X, U, E, L = sp.Matrix(spec.X), sp.Matrix(spec.U), sp.Matrix(spec.E), sp.Matrix(spec.L)
+    f, c, h = spec.f, spec.c, spec.h
+    fx, fu, fe = f.jacobian(X), f.jacobian(U), f.jacobian(E)
+    cx, cu = sp.Matrix([c]).jacobian(X), sp.Matrix([c]).jacobian(U)
+    H = c + (f.T * L)[0, 0]
+    Hx = sp.Matrix([H]).jacobian(X).T
+    Hu = sp.Matrix([H]).jacobian(U).T
+    Hxx, Hxu, Hxe = Hx.jacobian(X), Hx.jacobian(U), Hx.jacobian(E)
+    Huu, Hue = Hu.jacobian(U), Hu.jacobian(E)
+    hx = sp.Matrix([h]).jacobian(X).T
+    hxx, hxe = hx.jacobian(X), hx.jacobian(E)
+
+    dX = sp.Matrix([sp.Symbol('dx%d' % i, real=True) for i in range(n)])
+    dU = sp.Matrix([sp.Symbol('du%d' % i, real=True) for i in range(m)])
+    oE = sp.Matrix([sp.Symbol('oe%d' % i, real=True) for i in range(p)])
+    tang = [(s, 'dx[%d]' % i) for i, s in enumerate(dX)] + [(s, 'du[%d]' % i) for i, s in enumerate(dU)]
+    tang_e = [(s, 'dx[%d]' % i) for i, s in enumerate(dX)] + [(s, 'oe[%d]' % i) for i, s in enumerate(oE)]
+
+    S = []
+    S.append('// AUTO-GENERATED by codegen.py (version %d) — do not edit.  model "%s" hash %s'
+             % (CODEGEN_VERSION, spec.name, spec.hash()))
+    S.append('#pragma once')
+    S.append('namespace lfsd_gen {')
+    S.append('struct Model {')
+    S.append('  static constexpr int NX = %d, NU = %d, NP = %d, NC = %d;' % (n, m, p, max(nc, 1)))
+    S.append('  static constexpr int NC_REAL = %d;' % nc)
+    S.append('  static constexpr bool TIME_VARYING = %s;' % ('true' if spec.time_varying else 'false'))
+    S.append('  static const char* name() { return "%s"; }' % spec.name)
+    S.append('  static const char* hash() { return "%s"; }' % spec.hash())
+    S.append('  static double const_default(int i) { static const double v[%d] = {%s}; return v[i]; }'
+             % (max(nc, 1), ', '.join(repr(float(v)) for v in (spec.const_defaults or [0.0])) if nc else '0.0'))
+
+    sig_xu = 'T t, const T* x, const T* u, const T* e, const T* c'
+    # 1. dynamics + running cost
+    S.append('  template<class T> static LFSD_DEV void dyn_cost(%s, T* f, T& q) {' % sig_xu)
+    S.append(_body(_loads(spec), [('f[%d]' % i, f[i]) for i in range(n)] + [('q', c)]))
+    S.append('  }')
+    # 2. + directional derivative
+    df = fx * dX + fu * dU
+    dq = (cx * dX)[0, 0] + (cu * dU)[0, 0]
+    S.append('  template<class T> static LFSD_DEV void dyn_cost_jvp(%s, const T* dx, const T* du, T* f, T& q, T* df, T& dq) {' % sig_xu)
+    S.append(_body(_loads(spec) + tang, [('f[%d]' % i, f[i]) for i in range(n)] + [('q', c)] +
+                   [('df[%d]' % i, df[i]) for i in range(n)] + [('dq', dq)]))
+    S.append('  }')
+    # 3. final cost
+    sig_x = 'T t, const T* x, const T* e, const T* c'
+    S.append('  template<class T> static LFSD_DEV T final_cost(%s) {\n    T hval;' % sig_x)
+    S.append(_body(_loads(spec, with_u=False), [('hval', h)]))
+    S.append('    return hval;\n  }')
+    S.append('  template<class T> static LFSD_DEV void final_grad(%s, T* hx) {' % sig_x)
+    S.append(_body(_loads(spec, with_u=False), [('hx[%d]' % i, hx[i]) for i in range(n)]))
+    S.append('  }')
+    yfin = hxx * dX + hxe * oE
+    S.append('  // y = hxx*dx + hxe*oe')
+    S.append('  template<class T> static LFSD_DEV void final_hess_mul(%s, const T* dx, const T* oe, T* y) {' % sig_x)
+    S.append(_body(_loads(spec, with_u=False) + tang_e, [('y[%d]' % i, yfin[i]) for i in range(n)]))
+    S.append('  }')
+    # 4. Hamiltonian Hessian applied to a vector
+    sig_xul = 'T t, const T* x, const T* u, const T* l, const T* e, const T* c'
+    yx = Hxx * dX + Hxu * dU
+    yu = Hxu.T * dX + Huu * dU
+    S.append('  // yx = Hxx*dx + Hxu*du ; yu = Hux*dx + Huu*du   (H = c + l.f, CPDP.py:218)')
+    S.append('  template<class T> static LFSD_DEV void ham_hess_mul(%s, const T* dx, const T* du, T* yx, T* yu) {' % sig_xul)
+    S.append(_body(_loads(spec, with_l=True) + tang, [('yx[%d]' % i, yx[i]) for i in range(n)] +
+                   [('yu[%d]' % i, yu[i]) for i in range(m)]))
+    S.append('  }')
+    # 5. packed PMP coefficients
+    mats = []
+    off = 0
+    for nm, mat in (('fx', fx), ('fu', fu), ('fe', fe), ('Hxx', Hxx), ('Hxu', Hxu), ('Hxe', Hxe), ('Hue', Hue)):
+        sm = _Sparse(nm, mat, off)
+        mats.append(sm)
+        off = sm.end
+    off_huu = off
+    off_ihuu = off_huu + m * m
+    ncoef = ((off_ihuu + m * m + 3) // 4) * 4
+    S.append('  static constexpr int OFF_HUU = %d, OFF_IHUU = %d, NCOEF = %d;' % (off_huu, off_ihuu, ncoef))
+    outs = []
+    for sm in mats:
+        outs += [('L[%d]' % o, ex) for (_, _, o, ex) in sm.entries]
+    outs += [('L[%d]' % (off_huu + a * m + b), Huu[a, b]) for a in range(m) for b in range(m)]
+    S.append('  // packed: ' + ', '.join('%s[%d..%d)' % (sm.name, sm.off, sm.end) for sm in mats) +
+             ', Huu dense, Huu^-1 dense (filled by the kernel)')
+    S.append('  template<class T> static LFSD_DEV void pmp_coeffs(%s, T* L) {' % sig_xul)
+    S.append(_body(_loads(spec, with_l=True), outs))
+    S.append('  }')
+    for sm in mats:
+        S.append(sm.emit_ops())
+    # G[a*NU+b] (+)= sum_i S[i*NU+a] * fu[i][b]    (S = rows of B^T P gathered in LDS)
+    fu_sm = mats[1]
+    cols = {}
+    for (r, cc, o, _) in fu_sm.entries:
+        cols.setdefault(cc, []).append((r, o))
+    lines = []
+    for a in range(m):
+        for b in range(m):
+            terms = ['S[%d]*L[%d]' % (r * m + a, o) for (r, o) in cols.get(b, [])]
+            lines.append('    G[%d] = (ACC ? G[%d] : T(0))%s;' % (a * m + b, a * m + b,
+                                                                  (' + ' + ' + '.join(terms)) if terms else ''))
+    S.append('  // G = S^T fu  with S an NX x NU row-major matrix (e.g. S = P fu  ->  G = fu^T P fu)')
+    S.append('  template<bool ACC, class T> static LFSD_DEV void fu_gram(const T* L, const T* S, T* G) {\n%s\n  }'
+             % '\n'.join(lines))
+    S.append('};')
+    S.append('}  // namespace lfsd_gen')
+    return '\n'.join(S) + '\n'

@@ -1,0 +1,1090 @@
+// Batched Continuous-PDP kernels for gfx950 (MI355X).
+//
+// One *lane group* of G lanes (G | 64, one 64-lane wavefront per workgroup) owns
+// one trajectory.  Matrices of the per-trajectory recursions are held
+// "column per lane": lane j keeps column j of the n x (n+m) shooting
+// sensitivity, of V_xx, of the Riccati pair Z = [P W], of the auxiliary state
+// X = dx/dtheta.  Quantities every column needs (the current state, costate,
+// gains, packed Jacobian/Hessian entries) are group-uniform and are exchanged
+// through LDS.  Per-trajectory records in HBM are trajectory-major, so each
+// wavefront streams its own contiguous record.
+//
+// What each kernel replaces in the reference (CPDP/CPDP.py):
+//   oc_solve_kernel       COCSys.cocSolver            CPDP.py:92-198  (IPOPT NLP solve ->
+//                         batched DDP on the identical RK4 multiple-shooting discretisation;
+//                         returns state/control/costate grids, costate == lam_g)
+//   aux_riccati_kernel    COCSys.auxSysSolver part 1  CPDP.py:316-338 (Riccati sweep for P, W)
+//   aux_forward_kernel    COCSys.auxSysSolver part 2  CPDP.py:340-381 (dx/dtheta forward sweep)
+//                         + getloss_*corrections      lib/QuadAlgorithm.py:616-673
+//   optimizer_kernel      Vanilla/Nesterov/Adam/Nadam/AMSGrad updates  lib/QuadAlgorithm.py:454-578
+//
+// The same source builds for the GPU with hipcc and, with -DLFSD_EMU, for the CPU
+// SIMT emulator in tests/emu (test infrastructure; never used by the product path).
+#pragma once
+
+#if defined(LFSD_EMU)
+#include "simt_emu.h"
+#else
+#include <hip/hip_runtime.h>
+#define LFSD_DEV __device__ __forceinline__
+#endif
+
+namespace lfsd {
+
+enum Status { ST_RUNNING = 0, ST_CONVERGED = 1, ST_STALLED = 2, ST_MAXITER = 3, ST_FAILED = 4 };
+enum OptMethod { OPT_VANILLA = 0, OPT_NESTEROV = 1, OPT_ADAM = 2, OPT_NADAM = 3, OPT_AMSGRAD = 4 };
+
+template <typename T> struct Eps;
+template <> struct Eps<float> { static LFSD_DEV float v() { return 1.1920929e-07f; } };
+template <> struct Eps<double> { static LFSD_DEV double v() { return 2.220446049250313e-16; } };
+
+template <typename T> LFSD_DEV T t_abs(T a) { return a < T(0) ? -a : a; }
+template <typename T> LFSD_DEV T t_max(T a, T b) { return a > b ? a : b; }
+template <typename T> LFSD_DEV T t_min(T a, T b) { return a < b ? a : b; }
+template <typename T> LFSD_DEV bool t_finite(T a) { return (a - a) == T(0); }
+LFSD_DEV float t_sqrt(float a) { return sqrtf(a); }
+LFSD_DEV double t_sqrt(double a) { return sqrt(a); }
+LFSD_DEV float t_floor(float a) { return floorf(a); }
+LFSD_DEV double t_floor(double a) { return floor(a); }
+LFSD_DEV float t_pow(float a, float b) { return powf(a, b); }
+LFSD_DEV double t_pow(double a, double b) { return pow(a, b); }
+
+// ---- tiny dense helpers on group-uniform n x n matrices (row-major, in registers) -----------
+// Cholesky A = L L^T in place (lower); false if not positive definite.
+template <int n, typename T> LFSD_DEV bool chol_factor(T* A) {
+  bool ok = true;
+#pragma unroll
+  for (int j = 0; j < n; ++j) {
+    T d = A[j * n + j];
+#pragma unroll
+    for (int k = 0; k < j; ++k) d -= A[j * n + k] * A[j * n + k];
+    if (!(d > T(0))) { ok = false; d = T(1); }
+    d = t_sqrt(d);
+    A[j * n + j] = d;
+    const T inv = T(1) / d;
+#pragma unroll
+    for (int i = j + 1; i < n; ++i) {
+      T s = A[i * n + j];
+#pragma unroll
+      for (int k = 0; k < j; ++k) s -= A[i * n + k] * A[j * n + k];
+      A[i * n + j] = s * inv;
+    }
+  }
+  return ok;
+}
+template <int n, typename T> LFSD_DEV void chol_solve(const T* Lm, T* b) {
+#pragma unroll
+  for (int i = 0; i < n; ++i) {
+    T s = b[i];
+#pragma unroll
+    for (int k = 0; k < i; ++k) s -= Lm[i * n + k] * b[k];
+    b[i] = s / Lm[i * n + i];
+  }
+#pragma unroll
+  for (int i = n - 1; i >= 0; --i) {
+    T s = b[i];
+#pragma unroll
+    for (int k = i + 1; k < n; ++k) s -= Lm[k * n + i] * b[k];
+    b[i] = s / Lm[i * n + i];
+  }
+}
+// LU without pivoting, in place (unit lower + upper).  For I + small and SPD-like matrices.
+template <int n, typename T> LFSD_DEV void lu_factor(T* A) {
+#pragma unroll
+  for (int j = 0; j < n; ++j) {
+    const T inv = T(1) / A[j * n + j];
+#pragma unroll
+    for (int i = j + 1; i < n; ++i) {
+      const T f = A[i * n + j] * inv;
+      A[i * n + j] = f;
+#pragma unroll
+      for (int k = j + 1; k < n; ++k) A[i * n + k] -= f * A[j * n + k];
+    }
+  }
+}
+template <int n, typename T> LFSD_DEV void lu_solve(const T* A, T* b) {
+#pragma unroll
+  for (int i = 0; i < n; ++i) {
+#pragma unroll
+    for (int k = 0; k < i; ++k) b[i] -= A[i * n + k] * b[k];
+  }
+#pragma unroll
+  for (int i = n - 1; i >= 0; --i) {
+#pragma unroll
+    for (int k = i + 1; k < n; ++k) b[i] -= A[i * n + k] * b[k];
+    b[i] /= A[i * n + i];
+  }
+}
+template <int n, typename T> LFSD_DEV void mat_inverse(const T* A, T* Ainv) {
+  T F[n * n];
+#pragma unroll
+  for (int i = 0; i < n * n; ++i) F[i] = A[i];
+  lu_factor<n>(F);
+#pragma unroll
+  for (int c = 0; c < n; ++c) {
+    T b[n];
+#pragma unroll
+    for (int i = 0; i < n; ++i) b[i] = (i == c) ? T(1) : T(0);
+    lu_solve<n>(F, b);
+#pragma unroll
+    for (int i = 0; i < n; ++i) Ainv[i * n + c] = b[i];
+  }
+}
+template <int n, typename T> LFSD_DEV void matvec(const T* A, const T* v, T* y) {
+#pragma unroll
+  for (int i = 0; i < n; ++i) {
+    T s = T(0);
+#pragma unroll
+    for (int k = 0; k < n; ++k) s += A[i * n + k] * v[k];
+    y[i] = s;
+  }
+}
+
+// =====================================================================================
+//  Optimal-control solve
+// =====================================================================================
+template <typename T> struct OcArgs {
+  int batch, n_grid, steps_per_grid, max_iter;
+  const T* ini_state;   // [B][NX]
+  const T* horizon;     // [B]
+  const T* auxvar;      // [B][NP]
+  const T* consts;      // [B or 1][NC]
+  int const_stride;     // NC or 0
+  const T* u_init;      // [B][N][NU] or nullptr (zeros, the reference's w0 for unbounded controls)
+  T* state_grid;        // [B][N+1][NX]
+  T* control_grid;      // [B][N+1][NU]  (last row repeats row N-1, CPDP.py:191)
+  T* costate_grid;      // [B][N+1][NX]
+  T* cost;              // [B]
+  int* iters;           // [B]
+  int* status;          // [B]
+  T* ws;                // per-trajectory scratch, ws_stride elements each
+  long long ws_stride;
+  T tol;                // stop when max|dJ/du| < tol*(1+|J|)
+};
+
+template <class M> struct OcLayout {
+  static constexpr int NX = M::NX, NU = M::NU, NXU = NX + NU;
+  // scratch per trajectory (elements)
+  static long long ws_elems(int N) {
+    return 2LL * (N + 1) * NX + 2LL * N * NU + 1LL * N * NXU * (NX + 1) + 1LL * N * NX * NU + 1LL * N * NU +
+           1LL * (N + 1) * NX;
+  }
+  // LDS per group (elements)
+  static constexpr int LDS_V = 0;
+  static constexpr int LDS_M = LDS_V + NX * NX;
+  static constexpr int LDS_K = LDS_M + NXU * NX;
+  static constexpr int LDS_QUX = LDS_K + NX * NU;
+  static constexpr int LDS_QUU = LDS_QUX + NX * NU;
+  static constexpr int LDS_QU = LDS_QUU + NU * NU;
+  static constexpr int LDS_VX = LDS_QU + NU;
+  static constexpr int LDS_LAM = LDS_VX + NX;
+  static constexpr int LDS_RED = LDS_LAM + NX;       // G entries
+  template <int G> static constexpr int lds_elems() { return ((LDS_RED + G + 3) / 4) * 4; }
+};
+
+template <class M, typename T, int G> struct OcSolver {
+  static constexpr int NX = M::NX, NU = M::NU, NP = M::NP, NC = M::NC, NXU = NX + NU;
+  static constexpr int NALPHA = (G < 10) ? G : 10;
+  using Lay = OcLayout<M>;
+
+  int lane, N, S;
+  T e[NP], c[NC], x0[NX];
+  T horizon, dgrid, DT;
+  T *xb[2], *ub[2], *Mws, *Kws, *kws, *lds;
+  T* lam_out;   // costate grid of this trajectory (or scratch when invalid)
+
+  LFSD_DEV T tk(int k) const { return M::TIME_VARYING ? dgrid * T(k) : T(0); }
+
+  // One RK4 step of (x, q) with frozen control; optionally with the per-lane tangent (m, mq).
+  template <bool SENS>
+  LFSD_DEV void rk4_step(T t, T* x, T& q, const T* u, T* m, T& mq, const T* du) const {
+    T xs[NX], ms[NX], ax[NX], am[NX], f[NX], d[NX], cq, dq, aq, adq;
+    const T hh = DT * T(0.5);
+    if (SENS) M::dyn_cost_jvp(t, x, u, e, c, m, du, f, cq, d, dq); else M::dyn_cost(t, x, u, e, c, f, cq);
+    aq = cq; if (SENS) adq = dq;
+#pragma unroll
+    for (int i = 0; i < NX; ++i) { ax[i] = f[i]; xs[i] = x[i] + hh * f[i]; if (SENS) { am[i] = d[i]; ms[i] = m[i] + hh * d[i]; } }
+    if (SENS) M::dyn_cost_jvp(t, xs, u, e, c, ms, du, f, cq, d, dq); else M::dyn_cost(t, xs, u, e, c, f, cq);
+    aq += T(2) * cq; if (SENS) adq += T(2) * dq;
+#pragma unroll
+    for (int i = 0; i < NX; ++i) { ax[i] += T(2) * f[i]; xs[i] = x[i] + hh * f[i]; if (SENS) { am[i] += T(2) * d[i]; ms[i] = m[i] + hh * d[i]; } }
+    if (SENS) M::dyn_cost_jvp(t, xs, u, e, c, ms, du, f, cq, d, dq); else M::dyn_cost(t, xs, u, e, c, f, cq);
+    aq += T(2) * cq; if (SENS) adq += T(2) * dq;
+#pragma unroll
+    for (int i = 0; i < NX; ++i) { ax[i] += T(2) * f[i]; xs[i] = x[i] + DT * f[i]; if (SENS) { am[i] += T(2) * d[i]; ms[i] = m[i] + DT * d[i]; } }
+    if (SENS) M::dyn_cost_jvp(t, xs, u, e, c, ms, du, f, cq, d, dq); else M::dyn_cost(t, xs, u, e, c, f, cq);
+    aq += cq; if (SENS) adq += dq;
+    const T h6 = DT / T(6);
+#pragma unroll
+    for (int i = 0; i < NX; ++i) { x[i] += h6 * (ax[i] + f[i]); if (SENS) m[i] += h6 * (am[i] + d[i]); }
+    q += h6 * aq; if (SENS) mq += h6 * adq;
+  }
+
+  // closed-loop control  u = ubar + alpha*kff + K (x - xbar)   (all operands group-uniform loads)
+  LFSD_DEV void control(int cur, int k, const T* x, T alpha, bool gains, T* u) const {
+    const T* ubk = ub[cur] + k * NU;
+#pragma unroll
+    for (int a = 0; a < NU; ++a) u[a] = ubk[a];
+    if (gains) {
+      const T* xbk = xb[cur] + k * NX;
+      const T* Kk = Kws + k * NX * NU;
+      const T* kk = kws + k * NU;
+#pragma unroll
+      for (int a = 0; a < NU; ++a) u[a] += alpha * kk[a];
+#pragma unroll
+      for (int i = 0; i < NX; ++i) {
+        const T dx = x[i] - xbk[i];
+#pragma unroll
+        for (int a = 0; a < NU; ++a) u[a] += Kk[i * NU + a] * dx;
+      }
+    }
+  }
+
+  // Roll the (closed-loop) nominal out into buffer `nxt` and linearise the shooting map along it:
+  // lane j < NX+NU propagates column j of d(x_{k+1}, Q_k)/d(x_k, u_k) through the RK4 stages.
+  LFSD_DEV T rollout_sens(int cur, int nxt, T alpha, bool gains) {
+    T x[NX], u[NU], J = T(0);
+#pragma unroll
+    for (int i = 0; i < NX; ++i) x[i] = x0[i];
+    for (int k = 0; k < N; ++k) {
+      control(cur, k, x, alpha, gains, u);
+      if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < NX; ++i) xb[nxt][k * NX + i] = x[i];
+#pragma unroll
+        for (int a = 0; a < NU; ++a) ub[nxt][k * NU + a] = u[a];
+      }
+      T m[NX], du[NU], mq = T(0), q = T(0);
+#pragma unroll
+      for (int i = 0; i < NX; ++i) m[i] = (lane == i) ? T(1) : T(0);
+#pragma unroll
+      for (int a = 0; a < NU; ++a) du[a] = (lane == NX + a) ? T(1) : T(0);
+      const T t = tk(k);
+      for (int s = 0; s < S; ++s) rk4_step<true>(t, x, q, u, m, mq, du);
+      J += q;
+      if (lane < NXU) {
+        T* col = Mws + ((long long)k * NXU + lane) * (NX + 1);
+#pragma unroll
+        for (int i = 0; i < NX; ++i) col[i] = m[i];
+        col[NX] = mq;
+      }
+    }
+    if (lane == 0) {
+#pragma unroll
+      for (int i = 0; i < NX; ++i) xb[nxt][N * NX + i] = x[i];
+    }
+    J += M::final_cost(tk(N), x, e, c);
+    return J;
+  }
+
+  // Backward sweep on buffer `cur`: DDP gains + exact discrete costate (== IPOPT's lam_g).
+  // HL scales the costate inside the Hessian model (0: Gauss-Newton, 1: Newton-like).
+  LFSD_DEV bool backward(int cur, T HL, T mu, T& gnorm, T& dV1, T& dV2) {
+    T* ldsV = lds + Lay::LDS_V;  T* ldsM = lds + Lay::LDS_M;  T* ldsK = lds + Lay::LDS_K;
+    T* ldsQux = lds + Lay::LDS_QUX;  T* ldsQuu = lds + Lay::LDS_QUU;  T* ldsQu = lds + Lay::LDS_QU;
+    T* ldsVx = lds + Lay::LDS_VX;  T* ldsLam = lds + Lay::LDS_LAM;  T* ldsRed = lds + Lay::LDS_RED;
+    T Vx[NX], lam[NX], vcol[NX], xk[NX], uk[NU];
+    bool ok = true;
+    T gl_max = T(0);
+    dV1 = T(0); dV2 = T(0);
+    {
+      const T* xN = xb[cur] + N * NX;
+#pragma unroll
+      for (int i = 0; i < NX; ++i) xk[i] = xN[i];
+      M::final_grad(tk(N), xk, e, c, Vx);
+      T ox[NX], oe[NP];
+#pragma unroll
+      for (int i = 0; i < NX; ++i) { ox[i] = (lane == i) ? T(1) : T(0); lam[i] = Vx[i]; }
+#pragma unroll
+      for (int i = 0; i < NP; ++i) oe[i] = T(0);
+      M::final_hess_mul(tk(N), xk, e, c, ox, oe, vcol);
+      if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < NX; ++i) lam_out[N * NX + i] = lam[i];
+      }
+    }
+    for (int k = N - 1; k >= 0; --k) {
+      T m[NX], mq = T(0);
+      if (lane < NXU) {
+        const T* col = Mws + ((long long)k * NXU + lane) * (NX + 1);
+#pragma unroll
+        for (int i = 0; i < NX; ++i) m[i] = col[i];
+        mq = col[NX];
+      } else {
+#pragma unroll
+        for (int i = 0; i < NX; ++i) m[i] = T(0);
+      }
+      {
+        const T* xp = xb[cur] + k * NX;  const T* up = ub[cur] + k * NU;
+#pragma unroll
+        for (int i = 0; i < NX; ++i) xk[i] = xp[i];
+#pragma unroll
+        for (int a = 0; a < NU; ++a) uk[a] = up[a];
+      }
+      if (lane < NX) {
+#pragma unroll
+        for (int i = 0; i < NX; ++i) ldsV[lane * NX + i] = vcol[i];
+      }
+      if (lane < NXU) {
+#pragma unroll
+        for (int i = 0; i < NX; ++i) ldsM[lane * NX + i] = m[i];
+      }
+      __syncthreads();
+      // Y = Vxx' m_j ;  Qcol = [A B]^T Y
+      T Y[NX], Qcol[NXU];
+#pragma unroll
+      for (int i = 0; i < NX; ++i) {
+        T s = T(0);
+#pragma unroll
+        for (int kk = 0; kk < NX; ++kk) s += ldsV[i * NX + kk] * m[kk];
+        Y[i] = s;
+      }
+#pragma unroll
+      for (int r = 0; r < NXU; ++r) {
+        T s = T(0);
+#pragma unroll
+        for (int i = 0; i < NX; ++i) s += ldsM[r * NX + i] * Y[i];
+        Qcol[r] = s;
+      }
+      {
+        T ox[NX], ou[NU], ls[NX], hx[NX], hu[NU];
+#pragma unroll
+        for (int i = 0; i < NX; ++i) { ox[i] = (lane == i) ? T(1) : T(0); ls[i] = HL * lam[i]; }
+#pragma unroll
+        for (int a = 0; a < NU; ++a) ou[a] = (lane == NX + a) ? T(1) : T(0);
+        M::ham_hess_mul(tk(k), xk, uk, ls, e, c, ox, ou, hx, hu);
+#pragma unroll
+        for (int i = 0; i < NX; ++i) Qcol[i] += dgrid * hx[i];
+#pragma unroll
+        for (int a = 0; a < NU; ++a) Qcol[NX + a] += dgrid * hu[a];
+      }
+      T Qg = mq, gl = mq;
+#pragma unroll
+      for (int i = 0; i < NX; ++i) { Qg += m[i] * Vx[i]; gl += m[i] * lam[i]; }
+      T Quxj[NU];
+#pragma unroll
+      for (int a = 0; a < NU; ++a) Quxj[a] = Qcol[NX + a];
+      if (lane < NX) {
+#pragma unroll
+        for (int a = 0; a < NU; ++a) ldsQux[lane * NU + a] = Quxj[a];
+      } else if (lane < NXU) {
+        const int b = lane - NX;
+#pragma unroll
+        for (int a = 0; a < NU; ++a) ldsQuu[b * NU + a] = Quxj[a];
+        ldsQu[b] = Qg;
+        gl_max = t_max(gl_max, t_abs(gl));
+      }
+      __syncthreads();
+      T Quu0[NU * NU], Lc[NU * NU], Qu[NU], kff[NU], Kj[NU], t1[NU];
+#pragma unroll
+      for (int a = 0; a < NU; ++a) {
+        Qu[a] = ldsQu[a];
+#pragma unroll
+        for (int b = 0; b < NU; ++b) Quu0[a * NU + b] = T(0.5) * (ldsQuu[b * NU + a] + ldsQuu[a * NU + b]);
+      }
+#pragma unroll
+      for (int i = 0; i < NU * NU; ++i) Lc[i] = Quu0[i];
+#pragma unroll
+      for (int a = 0; a < NU; ++a) Lc[a * NU + a] += mu;
+      ok = chol_factor<NU>(Lc) && ok;
+#pragma unroll
+      for (int a = 0; a < NU; ++a) { kff[a] = -Qu[a]; Kj[a] = -Quxj[a]; }
+      chol_solve<NU>(Lc, kff);
+      chol_solve<NU>(Lc, Kj);
+      T qk[NU];
+      matvec<NU>(Quu0, kff, qk);
+#pragma unroll
+      for (int a = 0; a < NU; ++a) { dV1 += kff[a] * Qu[a]; dV2 += T(0.5) * kff[a] * qk[a]; }
+      T Vxj = Qg;
+#pragma unroll
+      for (int a = 0; a < NU; ++a) Vxj += Kj[a] * (qk[a] + Qu[a]) + Quxj[a] * kff[a];
+      if (lane < NX) {
+#pragma unroll
+        for (int a = 0; a < NU; ++a) ldsK[lane * NU + a] = Kj[a];
+        ldsVx[lane] = Vxj;
+        ldsLam[lane] = gl;
+        T* Kout = Kws + ((long long)k * NX + lane) * NU;
+#pragma unroll
+        for (int a = 0; a < NU; ++a) Kout[a] = Kj[a];
+      }
+      if (lane == 0) {
+#pragma unroll
+        for (int a = 0; a < NU; ++a) kws[k * NU + a] = kff[a];
+      }
+      __syncthreads();
+      matvec<NU>(Quu0, Kj, t1);
+#pragma unroll
+      for (int a = 0; a < NU; ++a) t1[a] += Quxj[a];
+#pragma unroll
+      for (int i = 0; i < NX; ++i) {
+        T s = Qcol[i];
+#pragma unroll
+        for (int a = 0; a < NU; ++a) s += ldsK[i * NU + a] * t1[a] + ldsQux[i * NU + a] * Kj[a];
+        vcol[i] = s;
+        Vx[i] = ldsVx[i];
+        lam[i] = ldsLam[i];
+      }
+      if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < NX; ++i) lam_out[k * NX + i] = lam[i];
+      }
+      // symmetrise V_xx through LDS (ldsV of this stage has been fully consumed above)
+      if (lane < NX) {
+#pragma unroll
+        for (int i = 0; i < NX; ++i) ldsV[lane * NX + i] = vcol[i];
+      }
+      __syncthreads();
+      if (lane < NX) {
+#pragma unroll
+        for (int i = 0; i < NX; ++i) vcol[i] = T(0.5) * (vcol[i] + ldsV[i * NX + lane]);
+      }
+      __syncthreads();
+    }
+    ldsRed[lane] = gl_max;
+    __syncthreads();
+    gnorm = T(0);
+#pragma unroll
+    for (int a = 0; a < NU; ++a) gnorm = t_max(gnorm, ldsRed[NX + a]);
+    __syncthreads();
+    if (!t_finite(gnorm) || !t_finite(dV1) || !t_finite(dV2)) ok = false;
+    return ok;
+  }
+
+  // Lane l tries step length 2^-l (all candidate roll-outs run concurrently in the group).
+  // Returns the index of the largest accepted step (or -1) and the best cost seen.
+  LFSD_DEV int linesearch(int cur, T J, T dV1, T dV2, T& alpha_out, T& Jmin) {
+    T* ldsRed = lds + Lay::LDS_RED;
+    T alpha = T(0);
+    if (lane < NALPHA) { alpha = T(1); for (int i = 0; i < lane; ++i) alpha *= T(0.5); }
+    T x[NX], u[NU], Ja = T(0), dummy = T(0);
+#pragma unroll
+    for (int i = 0; i < NX; ++i) x[i] = x0[i];
+    for (int k = 0; k < N; ++k) {
+      control(cur, k, x, alpha, true, u);
+      T q = T(0);
+      const T t = tk(k);
+      for (int s = 0; s < S; ++s) rk4_step<false>(t, x, q, u, x, dummy, u);
+      Ja += q;
+    }
+    Ja += M::final_cost(tk(N), x, e, c);
+    ldsRed[lane] = Ja;
+    __syncthreads();
+    int ia = -1;
+    Jmin = J;
+    T a = T(1);
+    alpha_out = T(0);
+    const T flat = T(8) * Eps<T>::v() * t_abs(J);
+    for (int l = 0; l < NALPHA; ++l) {
+      const T Jl = ldsRed[l];
+      const T expected = -(a * dV1 + a * a * dV2);
+      const bool okl = t_finite(Jl) && ((J - Jl) >= T(1e-4) * expected - flat) && (Jl < J);
+      if (okl && ia < 0) { ia = l; alpha_out = a; }
+      if (t_finite(Jl)) Jmin = t_min(Jmin, Jl);
+      a *= T(0.5);
+    }
+    __syncthreads();
+    return ia;
+  }
+};
+
+template <class M, typename T, int G>
+__global__ void __launch_bounds__(64) oc_solve_kernel(OcArgs<T> a) {
+  using Sol = OcSolver<M, T, G>;
+  using Lay = OcLayout<M>;
+  constexpr int NX = M::NX, NU = M::NU, NP = M::NP, NC = M::NC;
+  constexpr int GPB = 64 / G;
+  static_assert(64 % G == 0 && G >= NX + NU, "lane group must hold one column of [A B] per lane");
+  __shared__ T lds_all[GPB * Lay::template lds_elems<G>()];
+  __shared__ int vote[2];
+  Sol s;
+  const int gib = threadIdx.x / G;
+  s.lane = threadIdx.x % G;
+  const long long slot = (long long)blockIdx.x * GPB + gib;      // scratch slot (padded batch)
+  const bool valid = slot < a.batch;
+  const long long traj = valid ? slot : (long long)a.batch - 1;
+  s.N = a.n_grid; s.S = a.steps_per_grid;
+  s.lds = lds_all + gib * Lay::template lds_elems<G>();
+#pragma unroll
+  for (int i = 0; i < NP; ++i) s.e[i] = a.auxvar[traj * NP + i];
+#pragma unroll
+  for (int i = 0; i < NC; ++i) s.c[i] = a.consts[traj * a.const_stride + i];
+#pragma unroll
+  for (int i = 0; i < NX; ++i) s.x0[i] = a.ini_state[traj * NX + i];
+  s.horizon = a.horizon[traj];
+  s.dgrid = s.horizon / T(s.N);
+  s.DT = s.dgrid / T(s.S);
+  const int N = s.N;
+  T* w = a.ws + slot * a.ws_stride;
+  s.xb[0] = w; w += (N + 1) * NX;
+  s.xb[1] = w; w += (N + 1) * NX;
+  s.ub[0] = w; w += N * NU;
+  s.ub[1] = w; w += N * NU;
+  s.Mws = w; w += (long long)N * (NX + NU) * (NX + 1);
+  s.Kws = w; w += (long long)N * NX * NU;
+  s.kws = w; w += N * NU;
+  // padding groups (slot >= batch) clone the last trajectory and keep their costates in scratch
+  s.lam_out = valid ? a.costate_grid + traj * (N + 1) * NX : w;
+
+  // initial guess into buffer 1, then "roll out" 1 -> 0 without gains
+  for (int i = s.lane; i < N * NU; i += G) s.ub[1][i] = a.u_init ? a.u_init[traj * N * NU + i] : T(0);
+  __syncthreads();
+  int cur = 0;
+  T J = s.rollout_sens(1, 0, T(0), false);
+  __syncthreads();
+  T mu = T(0), HL = T(0);
+  int status = ST_RUNNING, it = 0;
+  bool need_bw = true;      // costates on `lam_out` are stale
+  T gnorm = T(0), dV1 = T(0), dV2 = T(0);
+  if (!t_finite(J)) status = ST_FAILED;
+  for (; it < a.max_iter; ++it) {
+    if (threadIdx.x == 0) vote[0] = 0;
+    __syncthreads();
+    if (status == ST_RUNNING) vote[0] = 1;
+    __syncthreads();
+    if (!vote[0]) break;
+    __syncthreads();
+    const bool bw_ok = s.backward(cur, HL, mu, gnorm, dV1, dV2);
+    need_bw = false;
+    bool try_step = false;
+    if (status == ST_RUNNING) {
+      if (!bw_ok) {
+        if (HL > T(0)) HL = T(0);
+        else { mu = t_max(mu * T(10), T(1e-6)); if (mu > T(1e8)) status = ST_FAILED; }
+      } else if (gnorm < a.tol * (T(1) + t_abs(J))) {
+        status = ST_CONVERGED;
+      } else {
+        try_step = true;
+      }
+    }
+    T alpha = T(0), Jmin = J;
+    const int ia = s.linesearch(cur, J, dV1, dV2, alpha, Jmin);
+    bool accept = false;
+    if (try_step) {
+      if (ia >= 0) accept = true;
+      else if (HL > T(0)) HL = T(0);
+      else if (mu > T(1e6) || (J - Jmin) <= T(8) * Eps<T>::v() * t_abs(J)) status = ST_STALLED;
+      else mu = t_max(mu * T(10), T(1e-6));
+    }
+    if (threadIdx.x == 0) vote[1] = 0;
+    __syncthreads();
+    if (accept) vote[1] = 1;
+    __syncthreads();
+    if (vote[1]) {
+      const T Jn = s.rollout_sens(cur, cur ^ 1, accept ? alpha : T(0), accept);
+      cur ^= 1;
+      need_bw = true;
+      if (accept) {
+        mu = (mu > T(1e-9)) ? mu * T(0.1) : T(0);
+        HL = (ia == 0 && (J - Jn) < T(1e-2) * t_abs(Jn)) ? T(1) : T(0);
+        J = Jn;
+      }
+    }
+    __syncthreads();
+  }
+  if (status == ST_RUNNING) status = ST_MAXITER;
+  if (threadIdx.x == 0) vote[0] = 0;
+  __syncthreads();
+  if (need_bw) vote[0] = 1;
+  __syncthreads();
+  if (vote[0]) s.backward(cur, T(0), T(0), gnorm, dV1, dV2);     // refresh costates on the final nominal
+  __syncthreads();
+  if (valid) {
+    T* xo = a.state_grid + traj * (N + 1) * NX;
+    T* uo = a.control_grid + traj * (N + 1) * NU;
+    for (int i = s.lane; i < (N + 1) * NX; i += G) xo[i] = s.xb[cur][i];
+    for (int i = s.lane; i < (N + 1) * NU; i += G) uo[i] = s.ub[cur][(i < N * NU) ? i : i - NU];
+    if (s.lane == 0) { a.cost[traj] = J; a.iters[traj] = it; a.status[traj] = status; }
+  }
+}
+
+// =====================================================================================
+//  Auxiliary control system (differentiated maximum principle)
+// =====================================================================================
+template <typename T> struct AuxArgs {
+  int batch, n_grid, substeps;    // substeps = coarse Strang steps per grid interval (fine = 2x, Richardson)
+  const T* horizon;               // [B]
+  const T* auxvar;                // [B][NP]
+  const T* consts; int const_stride;
+  const T* state_grid;            // [B][N+1][NX]
+  const T* control_grid;          // [B][N+1][NU]
+  const T* costate_grid;          // [B][N+1][NX]
+  T* Z_grid;                      // [B][N+1][NX+NP][NX]   column-major Z = [P W]
+  // forward sweep / loss
+  int n_waypoints, n_iface;
+  const int* iface_idx;           // [n_iface] state components the interface exposes
+  const T* taus;                  // [B][n_waypoints]
+  const T* waypoints;             // [B][n_waypoints][n_iface]
+  T* loss;                        // [B]
+  T* grad;                        // [B][NP]
+  T* auxX_grid;                   // [B][N+1][NP][NX] or nullptr  (dx/dtheta, column-major)
+  T* auxU_grid;                   // [B][N+1][NP][NU] or nullptr
+};
+
+template <class M> struct AuxLayout {
+  static constexpr int NX = M::NX, NU = M::NU, NP = M::NP, NZ = NX + NP, NNODE = 5;
+  static constexpr int LDS_L = 0;
+  static constexpr int LDS_S = LDS_L + NNODE * M::NCOEF;
+  static constexpr int LDS_T = LDS_S + NX * NU;
+  static constexpr int LDS_END = LDS_T + NX * NZ;
+  static constexpr int lds_elems() { return ((LDS_END + 3) / 4) * 4; }
+};
+
+template <class M, typename T, int G> struct AuxCtx {
+  static constexpr int NX = M::NX, NU = M::NU, NP = M::NP, NC = M::NC, NZ = NX + NP;
+  using Lay = AuxLayout<M>;
+  int lane;
+  T e[NP], c[NC];
+  T xa_[NX], ua_[NU], la_[NX], xb_[NX], ub_[NU], lb_[NX];   // grid values at both ends of the interval
+  T t_a, dgrid;
+  T* lds;
+  T ox[NX], oe[NP];    // one-hot selectors of this lane's column
+
+  LFSD_DEV void load_interval(const AuxArgs<T>& a, long long traj, int k, int N) {
+    const T* xs = a.state_grid + (traj * (N + 1) + k) * NX;
+    const T* us = a.control_grid + (traj * (N + 1) + k) * NU;
+    const T* ls = a.costate_grid + (traj * (N + 1) + k) * NX;
+#pragma unroll
+    for (int i = 0; i < NX; ++i) { xa_[i] = xs[i]; xb_[i] = xs[NX + i]; la_[i] = ls[i]; lb_[i] = ls[NX + i]; }
+#pragma unroll
+    for (int i = 0; i < NU; ++i) { ua_[i] = us[i]; ub_[i] = us[NU + i]; }
+    t_a = M::TIME_VARYING ? dgrid * T(k) : T(0);
+  }
+  // Lane `node` (< 5) evaluates the packed PMP coefficients at its own time node s (fraction of the
+  // interval) on the reference's linear interpolant of (x,u,lambda) (CPDP.py:320-323) and stages them in LDS.
+  LFSD_DEV void stage_nodes(T s_first, T s_step) {
+    if (lane < Lay::NNODE) {
+      const T s = s_first + s_step * T(lane);
+      T x[NX], u[NU], l[NX];
+#pragma unroll
+      for (int i = 0; i < NX; ++i) { x[i] = xa_[i] + s * (xb_[i] - xa_[i]); l[i] = la_[i] + s * (lb_[i] - la_[i]); }
+#pragma unroll
+      for (int i = 0; i < NU; ++i) u[i] = ua_[i] + s * (ub_[i] - ua_[i]);
+      T* L = lds + Lay::LDS_L + lane * M::NCOEF;
+      M::pmp_coeffs(t_a + s * dgrid, x, u, l, e, c, L);
+      T Huu[NU * NU], iH[NU * NU];
+#pragma unroll
+      for (int i = 0; i < NU * NU; ++i) Huu[i] = L[M::OFF_HUU + i];
+      mat_inverse<NU>(Huu, iH);       // casadi.pinv(ddHuu) of a nonsingular Huu (CPDP.py:262)
+#pragma unroll
+      for (int i = 0; i < NU * NU; ++i) L[M::OFF_IHUU + i] = iH[i];
+    }
+    __syncthreads();
+  }
+  LFSD_DEV const T* node(int i) const { return lds + Lay::LDS_L + i * M::NCOEF; }
+
+  // ---- Riccati (backward in time; tau = -t) -------------------------------------------------
+  // stiff sub-flow  dZ/dtau = -P R Z,  R = fu Huu^-1 fu^T :   Z <- Z - P fu (Huu/dt + fu^T P fu)^-1 fu^T Z
+  LFSD_DEV void ric_stiff(T* z, const T* L, T dt) {
+    T* ldsS = lds + Lay::LDS_S;
+    T s[NU];
+    M::template fu_mulT<false>(L, z, s);
+    if (lane < NX) {
+#pragma unroll
+      for (int a = 0; a < NU; ++a) ldsS[lane * NU + a] = s[a];
+    }
+    __syncthreads();
+    T Gm[NU * NU];
+    const T idt = T(1) / dt;
+#pragma unroll
+    for (int i = 0; i < NU * NU; ++i) Gm[i] = L[M::OFF_HUU + i] * idt;
+    M::template fu_gram<true>(L, ldsS, Gm);
+    lu_factor<NU>(Gm);
+    lu_solve<NU>(Gm, s);
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+      T d = T(0);
+#pragma unroll
+      for (int a = 0; a < NU; ++a) d += ldsS[i * NU + a] * s[a];
+      z[i] -= d;
+    }
+    __syncthreads();
+  }
+  // non-stiff part  dZ/dtau = [Qt qt] + A^T Z + P [A rt]   (A, Qt, rt, qt of CPDP.py:265-269)
+  LFSD_DEV void ric_rhs(const T* z, const T* L, T* y) {
+    T* ldsT = lds + Lay::LDS_T;
+    const T* iH = L + M::OFF_IHUU;
+    T s[NU], v[NU], hu[NU], w[NU], nv[NU], r[NP];
+    M::template fu_mulT<false>(L, z, s);
+    matvec<NU>(iH, s, v);
+    M::template Hxu_mulT<false>(L, ox, hu);
+    M::template Hue_mul<true>(L, oe, hu);
+    matvec<NU>(iH, hu, w);
+#pragma unroll
+    for (int a = 0; a < NU; ++a) { nv[a] = -v[a]; w[a] = -(w[a] + v[a]); }
+    M::template fx_mulT<false>(L, z, y);
+    if (lane < NX) {
+      T tv[NX];
+#pragma unroll
+      for (int i = 0; i < NX; ++i) tv[i] = y[i];
+      M::template Hxu_mul<true>(L, nv, tv);
+      M::template fe_mulT<false>(L, z, r);
+      M::template Hue_mulT<true>(L, nv, r);
+#pragma unroll
+      for (int i = 0; i < NX; ++i) ldsT[lane * NZ + i] = tv[i];
+#pragma unroll
+      for (int i = 0; i < NP; ++i) ldsT[lane * NZ + NX + i] = r[i];
+    }
+    M::template Hxx_mul<true>(L, ox, y);
+    M::template Hxe_mul<true>(L, oe, y);
+    M::template Hxu_mul<true>(L, w, y);
+    __syncthreads();
+    if (lane < NZ) {
+#pragma unroll
+      for (int i = 0; i < NX; ++i) y[i] += ldsT[i * NZ + lane];
+    }
+    __syncthreads();
+  }
+  LFSD_DEV void ric_strang(T* z, int n0, int n1, int n2, T h) {
+    ric_stiff(z, node(n0), h * T(0.5));
+    T k[NX], acc[NX], zs[NX];
+    ric_rhs(z, node(n0), k);
+#pragma unroll
+    for (int i = 0; i < NX; ++i) { acc[i] = k[i]; zs[i] = z[i] + T(0.5) * h * k[i]; }
+    ric_rhs(zs, node(n1), k);
+#pragma unroll
+    for (int i = 0; i < NX; ++i) { acc[i] += T(2) * k[i]; zs[i] = z[i] + T(0.5) * h * k[i]; }
+    ric_rhs(zs, node(n1), k);
+#pragma unroll
+    for (int i = 0; i < NX; ++i) { acc[i] += T(2) * k[i]; zs[i] = z[i] + h * k[i]; }
+    ric_rhs(zs, node(n2), k);
+#pragma unroll
+    for (int i = 0; i < NX; ++i) z[i] += h / T(6) * (acc[i] + k[i]);
+    ric_stiff(z, node(n2), h * T(0.5));
+  }
+
+  // ---- forward auxiliary state -----------------------------------------------------------------
+  // lanes < NX carry P columns (interpolated), lanes NX..NX+NP carry X = dx/dtheta columns and W columns.
+  // stiff sub-flow  X' = -fu K X,  K = Huu^-1 fu^T P : implicit midpoint in Woodbury form.
+  LFSD_DEV void fwd_stiff(T* xa, const T* zt, const T* L, T dt) {
+    T* ldsS = lds + Lay::LDS_S;
+    const T* iH = L + M::OFF_IHUU;
+    T s[NU], kj[NU];
+    M::template fu_mulT<false>(L, zt, s);          // P lanes: fu^T p_j
+    matvec<NU>(iH, s, kj);
+    if (lane < NX) {
+#pragma unroll
+      for (int a = 0; a < NU; ++a) ldsS[lane * NU + a] = kj[a];
+    }
+    __syncthreads();
+    T Mx[NU * NU], kx[NU];
+    M::template fu_gram<false>(L, ldsS, Mx);       // K fu
+#pragma unroll
+    for (int i = 0; i < NU * NU; ++i) Mx[i] *= T(0.5) * dt;
+#pragma unroll
+    for (int a = 0; a < NU; ++a) Mx[a * NU + a] += T(1);
+#pragma unroll
+    for (int a = 0; a < NU; ++a) kx[a] = T(0);
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+#pragma unroll
+      for (int a = 0; a < NU; ++a) kx[a] += ldsS[i * NU + a] * xa[i];
+    }
+    lu_factor<NU>(Mx);
+    lu_solve<NU>(Mx, kx);
+#pragma unroll
+    for (int a = 0; a < NU; ++a) kx[a] *= -dt;
+    M::template fu_mul<true>(L, kx, xa);
+    __syncthreads();
+  }
+  // non-stiff part  X' = fx X + fe - fu Huu^-1 (Hux X + Hue + fu^T W)
+  LFSD_DEV void fwd_rhs(const T* xa, const T* wt, const T* L, T* y) {
+    const T* iH = L + M::OFF_IHUU;
+    T s[NU], v[NU];
+    M::template fu_mulT<false>(L, wt, s);
+    M::template Hue_mul<true>(L, oe, s);
+    M::template Hxu_mulT<true>(L, xa, s);
+    matvec<NU>(iH, s, v);
+#pragma unroll
+    for (int a = 0; a < NU; ++a) v[a] = -v[a];
+    M::template fx_mul<false>(L, xa, y);
+    M::template fe_mul<true>(L, oe, y);
+    M::template fu_mul<true>(L, v, y);
+  }
+  // zA/zB: this lane's Z column at both interval ends; sA..: node fractions
+  LFSD_DEV void fwd_strang(T* xa, const T* zA, const T* zB, int n0, int n1, int n2, T s0, T s1, T s2, T h) {
+    T zt[NX], k[NX], acc[NX], xs[NX];
+#pragma unroll
+    for (int i = 0; i < NX; ++i) zt[i] = zA[i] + s0 * (zB[i] - zA[i]);
+    fwd_stiff(xa, zt, node(n0), h * T(0.5));
+    fwd_rhs(xa, zt, node(n0), k);
+#pragma unroll
+    for (int i = 0; i < NX; ++i) { acc[i] = k[i]; xs[i] = xa[i] + T(0.5) * h * k[i]; zt[i] = zA[i] + s1 * (zB[i] - zA[i]); }
+    fwd_rhs(xs, zt, node(n1), k);
+#pragma unroll
+    for (int i = 0; i < NX; ++i) { acc[i] += T(2) * k[i]; xs[i] = xa[i] + T(0.5) * h * k[i]; }
+    fwd_rhs(xs, zt, node(n1), k);
+#pragma unroll
+    for (int i = 0; i < NX; ++i) { acc[i] += T(2) * k[i]; xs[i] = xa[i] + h * k[i]; zt[i] = zA[i] + s2 * (zB[i] - zA[i]); }
+    fwd_rhs(xs, zt, node(n2), k);
+#pragma unroll
+    for (int i = 0; i < NX; ++i) xa[i] += h / T(6) * (acc[i] + k[i]);
+    fwd_stiff(xa, zt, node(n2), h * T(0.5));
+  }
+  // auxiliary control at a grid point (CPDP.py:295):  U = -Huu^-1((Hux + fu^T P) X + fu^T W + Hue)
+  LFSD_DEV void aux_control(const T* xa, const T* zt, const T* L, T* uo) {
+    T* ldsS = lds + Lay::LDS_S;
+    const T* iH = L + M::OFF_IHUU;
+    T s[NU];
+    M::template fu_mulT<false>(L, zt, s);
+    if (lane < NX) {
+#pragma unroll
+      for (int a = 0; a < NU; ++a) ldsS[lane * NU + a] = s[a];
+    }
+    __syncthreads();
+    M::template Hue_mul<true>(L, oe, s);         // X lanes: s = fu^T w_j + Hue e_j
+    M::template Hxu_mulT<true>(L, xa, s);
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+#pragma unroll
+      for (int a = 0; a < NU; ++a) s[a] += ldsS[i * NU + a] * xa[i];
+    }
+    matvec<NU>(iH, s, uo);
+#pragma unroll
+    for (int a = 0; a < NU; ++a) uo[a] = -uo[a];
+    __syncthreads();
+  }
+};
+
+template <class M, typename T, int G> LFSD_DEV void aux_setup(AuxCtx<M, T, G>& s, const AuxArgs<T>& a, long long traj,
+                                                            T* lds_all) {
+  constexpr int NX = M::NX, NP = M::NP, NC = M::NC;
+  using Lay = AuxLayout<M>;
+  const int gib = threadIdx.x / G;
+  s.lane = threadIdx.x % G;
+  s.lds = lds_all + gib * Lay::lds_elems();
+#pragma unroll
+  for (int i = 0; i < NP; ++i) s.e[i] = a.auxvar[traj * NP + i];
+#pragma unroll
+  for (int i = 0; i < NC; ++i) s.c[i] = a.consts[traj * a.const_stride + i];
+  s.dgrid = a.horizon[traj] / T(a.n_grid);
+#pragma unroll
+  for (int i = 0; i < NX; ++i) s.ox[i] = (s.lane == i) ? T(1) : T(0);
+#pragma unroll
+  for (int i = 0; i < NP; ++i) s.oe[i] = (s.lane == NX + i) ? T(1) : T(0);
+}
+
+template <class M, typename T, int G>
+__global__ void __launch_bounds__(64) aux_riccati_kernel(AuxArgs<T> a) {
+  using Ctx = AuxCtx<M, T, G>;
+  using Lay = AuxLayout<M>;
+  constexpr int NX = M::NX, NP = M::NP, NZ = NX + NP;
+  constexpr int GPB = 64 / G;
+  static_assert(64 % G == 0 && G >= NZ && G >= Lay::NNODE, "lane group must hold one column of [P W] per lane");
+  __shared__ T lds_all[GPB * Lay::lds_elems()];
+  const long long slot = (long long)blockIdx.x * GPB + threadIdx.x / G;
+  const bool valid = slot < a.batch;
+  const long long traj = valid ? slot : (long long)a.batch - 1;
+  Ctx s;
+  aux_setup<M, T, G>(s, a, traj, lds_all);
+  const int N = a.n_grid, Sa = a.substeps;
+  const int lane = s.lane;
+  T* Zt = a.Z_grid + traj * (long long)(N + 1) * NZ * NX;
+  T z[NX];
+  {
+    T xN[NX];
+    const T* xs = a.state_grid + (traj * (N + 1) + N) * NX;
+#pragma unroll
+    for (int i = 0; i < NX; ++i) xN[i] = xs[i];
+    const T tN = M::TIME_VARYING ? s.dgrid * T(N) : T(0);
+    M::final_hess_mul(tN, xN, s.e, s.c, s.ox, s.oe, z);      // [ddhxx ddhxe], CPDP.py:330-331
+    if (lane >= NZ) {
+#pragma unroll
+      for (int i = 0; i < NX; ++i) z[i] = T(0);
+    }
+    if (valid && lane < NZ) {
+#pragma unroll
+      for (int i = 0; i < NX; ++i) Zt[((long long)N * NZ + lane) * NX + i] = z[i];
+    }
+  }
+  T* ldsT = s.lds + Lay::LDS_T;
+  const T hc = s.dgrid / T(Sa);
+  const T ds = T(1) / T(4 * Sa);
+  for (int k = N - 1; k >= 0; --k) {
+    s.load_interval(a, traj, k, N);
+    for (int unit = 0; unit < Sa; ++unit) {
+      const T s_hi = T(1) - T(unit) / T(Sa);
+      s.stage_nodes(s_hi, -ds);                  // node i sits at fraction s_hi - i/(4 Sa)
+      T zc[NX], zf[NX];
+#pragma unroll
+      for (int i = 0; i < NX; ++i) { zc[i] = z[i]; zf[i] = z[i]; }
+      s.ric_strang(zc, 0, 2, 4, hc);
+      s.ric_strang(zf, 0, 1, 2, hc * T(0.5));
+      s.ric_strang(zf, 2, 3, 4, hc * T(0.5));
+#pragma unroll
+      for (int i = 0; i < NX; ++i) z[i] = (T(4) * zf[i] - zc[i]) / T(3);     // Richardson (Strang is O(h^2), symmetric)
+    }
+    // keep P symmetric (the closed-form stiff update relies on it) and store the grid value
+    if (lane < NX) {
+#pragma unroll
+      for (int i = 0; i < NX; ++i) ldsT[lane * NZ + i] = z[i];
+    }
+    __syncthreads();
+    if (lane < NX) {
+#pragma unroll
+      for (int i = 0; i < NX; ++i) z[i] = T(0.5) * (z[i] + ldsT[i * NZ + lane]);
+    }
+    __syncthreads();
+    if (valid && lane < NZ) {
+#pragma unroll
+      for (int i = 0; i < NX; ++i) Zt[((long long)k * NZ + lane) * NX + i] = z[i];
+    }
+  }
+}
+
+template <class M, typename T, int G>
+__global__ void __launch_bounds__(64) aux_forward_kernel(AuxArgs<T> a) {
+  using Ctx = AuxCtx<M, T, G>;
+  using Lay = AuxLayout<M>;
+  constexpr int NX = M::NX, NU = M::NU, NP = M::NP, NZ = NX + NP;
+  constexpr int GPB = 64 / G;
+  __shared__ T lds_all[GPB * Lay::lds_elems()];
+  const long long slot = (long long)blockIdx.x * GPB + threadIdx.x / G;
+  const bool valid = slot < a.batch;
+  const long long traj = valid ? slot : (long long)a.batch - 1;
+  Ctx s;
+  aux_setup<M, T, G>(s, a, traj, lds_all);
+  const int N = a.n_grid, Sa = a.substeps;
+  const int lane = s.lane;
+  const bool xlane = (lane >= NX) && (lane < NZ);
+  const T* Zt = a.Z_grid + traj * (long long)(N + 1) * NZ * NX;
+  T xa[NX], zA[NX], zB[NX];
+#pragma unroll
+  for (int i = 0; i < NX; ++i) { xa[i] = T(0); zA[i] = T(0); zB[i] = T(0); }     // X(0) = 0, CPDP.py:355
+  T loss = T(0), gacc = T(0);
+  const T hc = s.dgrid / T(Sa);
+  const T ds = T(1) / T(4 * Sa);
+  T* Xo = a.auxX_grid ? a.auxX_grid + traj * (long long)(N + 1) * NP * NX : nullptr;
+  T* Uo = a.auxU_grid ? a.auxU_grid + traj * (long long)(N + 1) * NP * NU : nullptr;
+  if (valid && Xo && xlane) {
+#pragma unroll
+    for (int i = 0; i < NX; ++i) Xo[(long long)(lane - NX) * NX + i] = T(0);
+  }
+  for (int k = 0; k < N; ++k) {
+    s.load_interval(a, traj, k, N);
+    if (lane < NZ) {
+#pragma unroll
+      for (int i = 0; i < NX; ++i) { zA[i] = Zt[((long long)k * NZ + lane) * NX + i]; zB[i] = Zt[((long long)(k + 1) * NZ + lane) * NX + i]; }
+    }
+    T xprev[NX];
+#pragma unroll
+    for (int i = 0; i < NX; ++i) xprev[i] = xa[i];
+    for (int unit = 0; unit < Sa; ++unit) {
+      const T s_lo = T(unit) / T(Sa);
+      s.stage_nodes(s_lo, ds);
+      if (Uo && unit == 0) {
+        T uo[NU];
+        s.aux_control(xa, zA, s.node(0), uo);
+        if (valid && xlane) {
+#pragma unroll
+          for (int b = 0; b < NU; ++b) Uo[((long long)k * NP + (lane - NX)) * NU + b] = uo[b];
+        }
+      }
+      T xc[NX], xf[NX];
+#pragma unroll
+      for (int i = 0; i < NX; ++i) { xc[i] = xa[i]; xf[i] = xa[i]; }
+      s.fwd_strang(xc, zA, zB, 0, 2, 4, s_lo, s_lo + T(2) * ds, s_lo + T(4) * ds, hc);
+      s.fwd_strang(xf, zA, zB, 0, 1, 2, s_lo, s_lo + ds, s_lo + T(2) * ds, hc * T(0.5));
+      s.fwd_strang(xf, zA, zB, 2, 3, 4, s_lo + T(2) * ds, s_lo + T(3) * ds, s_lo + T(4) * ds, hc * T(0.5));
+#pragma unroll
+      for (int i = 0; i < NX; ++i) xa[i] = xlane ? (T(4) * xf[i] - xc[i]) / T(3) : T(0);
+      if (Uo && k == N - 1 && unit == Sa - 1) {
+        T uo[NU];
+        s.aux_control(xa, zB, s.node(4), uo);
+        if (valid && xlane) {
+#pragma unroll
+          for (int b = 0; b < NU; ++b) Uo[((long long)N * NP + (lane - NX)) * NU + b] = uo[b];
+        }
+      }
+    }
+    if (valid && Xo && xlane) {
+#pragma unroll
+      for (int i = 0; i < NX; ++i) Xo[((long long)(k + 1) * NP + (lane - NX)) * NX + i] = xa[i];
+    }
+    // loss and gradient contributions of the waypoints that fall into this interval
+    // (linear interpolation of the grid values, exactly what opt_sol(t)/auxsys_sol(t) do: CPDP.py:386)
+    for (int w = 0; w < a.n_waypoints; ++w) {
+      const T tau = a.taus[traj * a.n_waypoints + w];
+      int kw = (int)t_floor(tau / s.dgrid);
+      kw = kw < 0 ? 0 : (kw > N - 1 ? N - 1 : kw);
+      if (kw != k) continue;
+      const T sw = (tau - T(k) * s.dgrid) / s.dgrid;
+      T rvec[NX];
+#pragma unroll
+      for (int i = 0; i < NX; ++i) rvec[i] = T(0);
+      for (int q = 0; q < a.n_iface; ++q) {
+        const int idx = a.iface_idx[q];
+        const T target = a.waypoints[(traj * a.n_waypoints + w) * a.n_iface + q];
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+          if (i == idx) {
+            const T cur = s.xa_[i] + sw * (s.xb_[i] - s.xa_[i]);
+            const T r = cur - target;
+            rvec[i] += r;
+            loss += r * r;
+          }
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < NX; ++i) gacc += rvec[i] * (xprev[i] + sw * (xa[i] - xprev[i]));
+    }
+  }
+  if (valid) {
+    if (lane == 0) a.loss[traj] = loss;
+    if (xlane) a.grad[traj * NP + (lane - NX)] = gacc;
+  }
+}
+
+// =====================================================================================
+//  Parameter update rules (lib/QuadAlgorithm.py:454-578), one thread per (trajectory, parameter)
+// =====================================================================================
+template <typename T> struct OptArgs {
+  int batch, n_param, method, iter_idx;      // iter_idx starts from 0 (QuadAlgorithm.py:507)
+  T lr, mu, beta1, beta2, eps;
+  T* theta;            // [B][p]  in/out
+  const T* grad;       // [B][p]
+  T* m;                // [B][p]  Nesterov velocity / first moment
+  T* v;                // [B][p]  second moment
+  T* vhat;             // [B][p]  AMSGrad running max
+  const T* proj_lo;    // [p] lower bound applied after the step (-inf = none); examples clamp theta[0] >= 1e-8
+};
+
+template <typename T> __global__ void optimizer_kernel(OptArgs<T> a) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long long)a.batch * a.n_param) return;
+  const int j = (int)(i % a.n_param);
+  const T g = a.grad[i];
+  T th = a.theta[i];
+  const T idx = T(a.iter_idx + 1);
+  if (a.method == OPT_VANILLA) {
+    th -= a.lr * g;
+  } else if (a.method == OPT_NESTEROV) {
+    // grad was evaluated at the look-ahead point theta + mu*v (QuadAlgorithm.py:478-486)
+    const T vel = a.mu * a.m[i] - a.lr * g;
+    a.m[i] = vel;
+    th += vel;
+  } else {
+    const T mm = a.beta1 * a.m[i] + (T(1) - a.beta1) * g;
+    const T vv = a.beta2 * a.v[i] + (T(1) - a.beta2) * g * g;
+    a.m[i] = mm; a.v[i] = vv;
+    if (a.method == OPT_AMSGRAD) {
+      const T vh = t_max(a.vhat[i], vv);
+      a.vhat[i] = vh;
+      th -= a.lr * mm / (t_sqrt(vh) + a.eps);
+    } else {
+      const T c1 = T(1) - t_pow(a.beta1, idx), c2 = T(1) - t_pow(a.beta2, idx);
+      const T mh = mm / c1, vh = vv / c2;
+      if (a.method == OPT_ADAM) th -= a.lr * mh / (t_sqrt(vh) + a.eps);
+      else th -= a.lr * (a.beta1 * mh + (T(1) - a.beta1) / c1 * g) / (t_sqrt(vh) + a.eps);
+    }
+  }
+  if (a.proj_lo) th = t_max(th, a.proj_lo[j]);
+  a.theta[i] = th;
+}
+
+// look-ahead point of Nesterov: out = theta + mu * v   (QuadAlgorithm.py:478)
+template <typename T> __global__ void lookahead_kernel(long long n, T mu, const T* theta, const T* v, T* out) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = theta[i] + mu * v[i];
+}
+
+}  // namespace lfsd

@@ -1,0 +1,197 @@
+// C ABI (include/lfsd_cpdp.h) over the kernels of cpdp_kernels.h for ONE model.
+// Build:  hipcc -x hip --offload-arch=gfx950 -DLFSD_MODEL_HEADER='"gen/<hash>.h"' -DLFSD_G=<lanes> ...
+// (tests/emu builds the same file with g++ -DLFSD_EMU for the CPU SIMT emulator.)
+#include "cpdp_kernels.h"
+#include LFSD_MODEL_HEADER
+#include "../../include/lfsd_cpdp.h"
+
+#ifndef LFSD_G
+#error "LFSD_G (lanes per trajectory) must be defined by the build"
+#endif
+
+using Model = lfsd_gen::Model;
+static constexpr int G = LFSD_G;
+static constexpr int GPB = 64 / G;
+
+#if defined(LFSD_EMU)
+#define LFSD_LAUNCH(kern, grid, block, stream, args) emu::launch(dim3(grid), dim3(block), [&] { kern(args); })
+static int launch_status() { return 0; }
+#else
+#define LFSD_LAUNCH(kern, grid, block, stream, args) \
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(block), 0, (hipStream_t)(stream), args)
+static int launch_status() { return (int)hipGetLastError(); }
+#endif
+
+extern "C" int lfsd_get_model_info(lfsd_model_info* out) {
+  if (!out) return LFSD_EINVAL;
+  out->abi_version = LFSD_ABI_VERSION;
+  out->n_state = Model::NX; out->n_control = Model::NU; out->n_auxvar = Model::NP; out->n_const = Model::NC_REAL;
+  out->time_varying = Model::TIME_VARYING ? 1 : 0;
+  out->lanes_per_trajectory = G;
+#if defined(LFSD_EMU)
+  out->is_emulator = 1;
+#else
+  out->is_emulator = 0;
+#endif
+  out->name = Model::name();
+  out->hash = Model::hash();
+  return 0;
+}
+
+extern "C" double lfsd_const_default(int i) {
+  if (i < 0 || i >= Model::NC_REAL) return 0.0;
+  return Model::const_default(i);
+}
+
+static long long padded_batch(int batch) { return ((long long)(batch + GPB - 1) / GPB) * GPB; }
+
+extern "C" size_t lfsd_coc_workspace_bytes(int dtype, int batch, int n_grid) {
+  if (batch <= 0 || n_grid <= 0 || (dtype != LFSD_F32 && dtype != LFSD_F64)) return 0;
+  const size_t es = dtype == LFSD_F32 ? 4 : 8;
+  return (size_t)padded_batch(batch) * (size_t)lfsd::OcLayout<Model>::ws_elems(n_grid) * es;
+}
+
+template <typename T>
+static int coc_solve_t(int batch, int n_grid, int steps_per_grid, const void* ini_state, const void* horizon,
+                       const void* auxvar, const void* consts, int const_per_traj, const void* u_init,
+                       void* state_grid, void* control_grid, void* costate_grid, void* cost, int* iters, int* status,
+                       int max_iter, double tol, void* workspace, size_t workspace_bytes, void* stream) {
+  lfsd::OcArgs<T> a;
+  a.batch = batch; a.n_grid = n_grid; a.steps_per_grid = steps_per_grid; a.max_iter = max_iter;
+  a.ini_state = (const T*)ini_state; a.horizon = (const T*)horizon; a.auxvar = (const T*)auxvar;
+  a.consts = consts ? (const T*)consts : (const T*)horizon;      // NC_REAL == 0: any readable word, never used
+  a.const_stride = (consts && const_per_traj) ? Model::NC : 0;
+  a.u_init = (const T*)u_init;
+  a.state_grid = (T*)state_grid; a.control_grid = (T*)control_grid; a.costate_grid = (T*)costate_grid;
+  a.cost = (T*)cost; a.iters = iters; a.status = status;
+  a.ws = (T*)workspace; a.ws_stride = lfsd::OcLayout<Model>::ws_elems(n_grid);
+  a.tol = (T)tol;
+  const size_t need = (size_t)padded_batch(batch) * (size_t)a.ws_stride * sizeof(T);
+  if (workspace_bytes < need) return LFSD_ENOSPC;
+  const unsigned grid = (unsigned)(padded_batch(batch) / GPB);
+  LFSD_LAUNCH((lfsd::oc_solve_kernel<Model, T, G>), grid, 64, stream, a);
+  return launch_status();
+}
+
+extern "C" int lfsd_coc_solve(int dtype, int batch, int n_grid, int steps_per_grid, const void* ini_state,
+                              const void* horizon, const void* auxvar, const void* consts, int const_per_traj,
+                              const void* u_init, void* state_grid, void* control_grid, void* costate_grid, void* cost,
+                              int* iters, int* status, int max_iter, double tol, void* workspace,
+                              size_t workspace_bytes, void* stream) {
+  if (batch <= 0 || n_grid <= 0 || steps_per_grid <= 0 || max_iter < 0 || !(tol >= 0)) return LFSD_EINVAL;
+  if (!ini_state || !horizon || !auxvar || !state_grid || !control_grid || !costate_grid || !cost || !iters ||
+      !status || !workspace)
+    return LFSD_EINVAL;
+  if (Model::NC_REAL > 0 && !consts) return LFSD_EINVAL;
+  if (dtype == LFSD_F32)
+    return coc_solve_t<float>(batch, n_grid, steps_per_grid, ini_state, horizon, auxvar, consts, const_per_traj, u_init,
+                              state_grid, control_grid, costate_grid, cost, iters, status, max_iter, tol, workspace,
+                              workspace_bytes, stream);
+  if (dtype == LFSD_F64)
+    return coc_solve_t<double>(batch, n_grid, steps_per_grid, ini_state, horizon, auxvar, consts, const_per_traj,
+                               u_init, state_grid, control_grid, costate_grid, cost, iters, status, max_iter, tol,
+                               workspace, workspace_bytes, stream);
+  return LFSD_EINVAL;
+}
+
+template <typename T>
+static int aux_solve_t(int batch, int n_grid, const void* horizon, const void* auxvar, const void* consts,
+                       int const_per_traj, const void* state_grid, const void* control_grid, const void* costate_grid,
+                       void* Z_grid, int n_waypoints, int n_iface, const int* iface_idx, const void* taus,
+                       const void* waypoints, void* loss, void* grad, void* auxX_grid, void* auxU_grid, int substeps,
+                       void* stream) {
+  lfsd::AuxArgs<T> a;
+  a.batch = batch; a.n_grid = n_grid; a.substeps = substeps > 0 ? substeps : 4;
+  a.horizon = (const T*)horizon; a.auxvar = (const T*)auxvar;
+  a.consts = consts ? (const T*)consts : (const T*)horizon;
+  a.const_stride = (consts && const_per_traj) ? Model::NC : 0;
+  a.state_grid = (const T*)state_grid; a.control_grid = (const T*)control_grid; a.costate_grid = (const T*)costate_grid;
+  a.Z_grid = (T*)Z_grid;
+  a.n_waypoints = n_waypoints; a.n_iface = n_iface; a.iface_idx = iface_idx;
+  a.taus = (const T*)taus; a.waypoints = (const T*)waypoints;
+  a.loss = (T*)loss; a.grad = (T*)grad; a.auxX_grid = (T*)auxX_grid; a.auxU_grid = (T*)auxU_grid;
+  const unsigned grid = (unsigned)(padded_batch(batch) / GPB);
+  LFSD_LAUNCH((lfsd::aux_riccati_kernel<Model, T, G>), grid, 64, stream, a);
+  int rc = launch_status();
+  if (rc) return rc;
+  LFSD_LAUNCH((lfsd::aux_forward_kernel<Model, T, G>), grid, 64, stream, a);
+  return launch_status();
+}
+
+extern "C" int lfsd_aux_solve(int dtype, int batch, int n_grid, const void* horizon, const void* auxvar,
+                              const void* consts, int const_per_traj, const void* state_grid, const void* control_grid,
+                              const void* costate_grid, void* Z_grid, int n_waypoints, int n_iface,
+                              const int* iface_idx, const void* taus, const void* waypoints, void* loss, void* grad,
+                              void* auxX_grid, void* auxU_grid, int substeps, void* stream) {
+  if (batch <= 0 || n_grid <= 0 || n_waypoints < 0 || n_iface < 0 || substeps < 0) return LFSD_EINVAL;
+  if (!horizon || !auxvar || !state_grid || !control_grid || !costate_grid || !Z_grid || !loss || !grad)
+    return LFSD_EINVAL;
+  if (n_waypoints > 0 && (n_iface <= 0 || !iface_idx || !taus || !waypoints)) return LFSD_EINVAL;
+  if (Model::NC_REAL > 0 && !consts) return LFSD_EINVAL;
+  if (dtype == LFSD_F32)
+    return aux_solve_t<float>(batch, n_grid, horizon, auxvar, consts, const_per_traj, state_grid, control_grid,
+                              costate_grid, Z_grid, n_waypoints, n_iface, iface_idx, taus, waypoints, loss, grad,
+                              auxX_grid, auxU_grid, substeps, stream);
+  if (dtype == LFSD_F64)
+    return aux_solve_t<double>(batch, n_grid, horizon, auxvar, consts, const_per_traj, state_grid, control_grid,
+                               costate_grid, Z_grid, n_waypoints, n_iface, iface_idx, taus, waypoints, loss, grad,
+                               auxX_grid, auxU_grid, substeps, stream);
+  return LFSD_EINVAL;
+}
+
+template <typename T>
+static int opt_step_t(int method, int batch, int n_param, int iter_idx, double lr, double mu, double beta1,
+                      double beta2, double eps, void* theta, const void* grad, void* m, void* v, void* vhat,
+                      const void* proj_lo, void* stream) {
+  lfsd::OptArgs<T> a;
+  a.batch = batch; a.n_param = n_param; a.method = method; a.iter_idx = iter_idx;
+  a.lr = (T)lr; a.mu = (T)mu; a.beta1 = (T)beta1; a.beta2 = (T)beta2; a.eps = (T)eps;
+  a.theta = (T*)theta; a.grad = (const T*)grad; a.m = (T*)m; a.v = (T*)v; a.vhat = (T*)vhat;
+  a.proj_lo = (const T*)proj_lo;
+  const long long n = (long long)batch * n_param;
+  const unsigned grid = (unsigned)((n + 63) / 64);
+  LFSD_LAUNCH((lfsd::optimizer_kernel<T>), grid, 64, stream, a);
+  return launch_status();
+}
+
+extern "C" int lfsd_optimizer_step(int dtype, int method, int batch, int n_param, int iter_idx, double lr, double mu,
+                                   double beta1, double beta2, double eps, void* theta, const void* grad, void* m,
+                                   void* v, void* vhat, const void* proj_lo, void* stream) {
+  if (batch <= 0 || n_param <= 0 || iter_idx < 0 || !theta || !grad) return LFSD_EINVAL;
+  if (method < LFSD_OPT_VANILLA || method > LFSD_OPT_AMSGRAD) return LFSD_EINVAL;
+  if (method == LFSD_OPT_NESTEROV && !m) return LFSD_EINVAL;
+  if (method >= LFSD_OPT_ADAM && (!m || !v)) return LFSD_EINVAL;
+  if (method == LFSD_OPT_AMSGRAD && !vhat) return LFSD_EINVAL;
+  if (dtype == LFSD_F32)
+    return opt_step_t<float>(method, batch, n_param, iter_idx, lr, mu, beta1, beta2, eps, theta, grad, m, v, vhat,
+                             proj_lo, stream);
+  if (dtype == LFSD_F64)
+    return opt_step_t<double>(method, batch, n_param, iter_idx, lr, mu, beta1, beta2, eps, theta, grad, m, v, vhat,
+                              proj_lo, stream);
+  return LFSD_EINVAL;
+}
+
+extern "C" int lfsd_lookahead(int dtype, long long n, double mu, const void* theta, const void* v, void* out,
+                              void* stream) {
+  if (n <= 0 || !theta || !v || !out) return LFSD_EINVAL;
+  const unsigned grid = (unsigned)((n + 63) / 64);
+  if (dtype == LFSD_F32) {
+    const float muf = (float)mu; const float* th = (const float*)theta; const float* vv = (const float*)v; float* o = (float*)out;
+#if defined(LFSD_EMU)
+    emu::launch(dim3(grid), dim3(64), [&] { lfsd::lookahead_kernel<float>(n, muf, th, vv, o); });
+#else
+    hipLaunchKernelGGL((lfsd::lookahead_kernel<float>), dim3(grid), dim3(64), 0, (hipStream_t)stream, n, muf, th, vv, o);
+#endif
+    return launch_status();
+  }
+  if (dtype == LFSD_F64) {
+    const double* th = (const double*)theta; const double* vv = (const double*)v; double* o = (double*)out;
+#if defined(LFSD_EMU)
+    emu::launch(dim3(grid), dim3(64), [&] { lfsd::lookahead_kernel<double>(n, mu, th, vv, o); });
+#else
+    hipLaunchKernelGGL((lfsd::lookahead_kernel<double>), dim3(grid), dim3(64), 0, (hipStream_t)stream, n, mu, th, vv, o);
+#endif
+    return launch_status();
+  }
+  return LFSD_EINVAL;
+}

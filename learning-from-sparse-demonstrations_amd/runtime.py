@@ -1,0 +1,296 @@
+"""ctypes binding of the C ABI in include/lfsd_cpdp.h + the hipcc build of one model library.
+
+PyTorch is plumbing here: tensors own the HBM buffers and the HIP stream; every
+numeric step of the hot path runs in the model's shared library.  There is no
+CPU fallback: a missing library is built with hipcc or the call fails loudly.
+"""
+import ctypes
+import os
+import shutil
+import subprocess
+
+import torch
+
+PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+CSRC_DIR = os.path.join(PKG_DIR, "csrc")
+GEN_DIR = os.path.join(CSRC_DIR, "gen")
+BUILD_DIR = os.path.join(CSRC_DIR, "build")
+INCLUDE_DIR = os.path.join(os.path.dirname(PKG_DIR), "include")
+
+LFSD_F32, LFSD_F64 = 0, 1
+STATUS = {1: "converged", 2: "stalled", 3: "maxiter", 4: "failed"}
+OPT_METHODS = {"Vanilla": 0, "Nesterov": 1, "Adam": 2, "Nadam": 3, "AMSGrad": 4}
+
+
+class LfsdError(RuntimeError):
+    pass
+
+
+class _ModelInfo(ctypes.Structure):
+    _fields_ = [("abi_version", ctypes.c_int), ("n_state", ctypes.c_int), ("n_control", ctypes.c_int),
+                ("n_auxvar", ctypes.c_int), ("n_const", ctypes.c_int), ("time_varying", ctypes.c_int),
+                ("lanes_per_trajectory", ctypes.c_int), ("is_emulator", ctypes.c_int),
+                ("name", ctypes.c_char_p), ("hash", ctypes.c_char_p)]
+
+
+def lanes_for(n, m, p):
+    need = max(n + m, n + p, 8)
+    g = 8
+    while g < need:
+        g *= 2
+    if g > 64:
+        raise LfsdError("model too wide for one wavefront per trajectory: n+max(m,p) = %d > 64" % need)
+    return g
+
+
+def find_hipcc():
+    for cand in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", shutil.which("hipcc")):
+        if cand and os.path.exists(cand):
+            return cand
+    raise LfsdError("hipcc not found: the HIP model library cannot be built")
+
+
+def library_path(model_hash):
+    return os.path.join(BUILD_DIR, "liblfsd_%s.so" % model_hash)
+
+
+def header_path(model_hash):
+    return os.path.join(GEN_DIR, "%s.h" % model_hash)
+
+
+def write_header(spec, force=False):
+    from . import codegen
+    os.makedirs(GEN_DIR, exist_ok=True)
+    hp = header_path(spec.hash())
+    if force or not os.path.exists(hp):
+        src = codegen.emit_header(spec)
+        tmp = hp + ".tmp%d" % os.getpid()
+        with open(tmp, "w") as f:
+            f.write(src)
+        os.replace(tmp, hp)
+    return hp
+
+
+def hipcc_command(spec, out, extra=()):
+    g = lanes_for(spec.n, spec.m, spec.p)
+    return [find_hipcc(), "-x", "hip", "--offload-arch=gfx950", "-std=c++17", "-O3", "-fPIC", "-shared",
+            "-fno-signed-zeros",
+            "-DLFSD_G=%d" % g, '-DLFSD_MODEL_HEADER="gen/%s.h"' % spec.hash(),
+            "-I" + CSRC_DIR, os.path.join(CSRC_DIR, "lfsd_capi.cpp"), "-o", out] + list(extra)
+
+
+def build_library(spec, force=False, verbose=False):
+    """Generate the model header and compile the gfx950 shared library in-tree (csrc/build/)."""
+    os.makedirs(BUILD_DIR, exist_ok=True)
+    out = library_path(spec.hash())
+    write_header(spec, force=force)
+    deps = [header_path(spec.hash()), os.path.join(CSRC_DIR, "cpdp_kernels.h"), os.path.join(CSRC_DIR, "lfsd_capi.cpp"),
+            os.path.join(INCLUDE_DIR, "lfsd_cpdp.h")]
+    if not force and os.path.exists(out) and all(os.path.getmtime(out) >= os.path.getmtime(d) for d in deps):
+        return out
+    tmp = out + ".tmp%d" % os.getpid()
+    cmd = hipcc_command(spec, tmp)
+    if verbose:
+        print(" ".join(cmd))
+    r = subprocess.run(cmd, cwd=CSRC_DIR, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise LfsdError("hipcc failed for model %s:\n%s\n%s" % (spec.name, r.stdout[-4000:], r.stderr[-4000:]))
+    os.replace(tmp, out)
+    return out
+
+
+_DT = {torch.float32: LFSD_F32, torch.float64: LFSD_F64}
+
+
+class ModelLibrary:
+    """One loaded model library (all entry points of include/lfsd_cpdp.h)."""
+
+    EXPORTS = ("lfsd_get_model_info", "lfsd_const_default", "lfsd_coc_workspace_bytes", "lfsd_coc_solve",
+               "lfsd_aux_solve", "lfsd_optimizer_step", "lfsd_lookahead")
+
+    def __init__(self, path):
+        if not os.path.exists(path):
+            raise LfsdError("model library %s does not exist (build it with __graft_entry__.build() or "
+                            "COCSys.compile())" % path)
+        self.path = path
+        self.lib = ctypes.CDLL(path)
+        for sym in self.EXPORTS:
+            if not hasattr(self.lib, sym):
+                raise LfsdError("%s does not export %s" % (path, sym))
+        L = self.lib
+        vp, ci, cd = ctypes.c_void_p, ctypes.c_int, ctypes.c_double
+        L.lfsd_get_model_info.argtypes = [ctypes.POINTER(_ModelInfo)]
+        L.lfsd_const_default.argtypes = [ci]
+        L.lfsd_const_default.restype = cd
+        L.lfsd_coc_workspace_bytes.argtypes = [ci, ci, ci]
+        L.lfsd_coc_workspace_bytes.restype = ctypes.c_size_t
+        L.lfsd_coc_solve.argtypes = [ci, ci, ci, ci, vp, vp, vp, vp, ci, vp, vp, vp, vp, vp, vp, vp, ci, cd, vp,
+                                     ctypes.c_size_t, vp]
+        L.lfsd_aux_solve.argtypes = [ci, ci, ci, vp, vp, vp, ci, vp, vp, vp, vp, ci, ci, vp, vp, vp, vp, vp, vp, vp,
+                                     ci, vp]
+        L.lfsd_optimizer_step.argtypes = [ci, ci, ci, ci, ci, cd, cd, cd, cd, cd, vp, vp, vp, vp, vp, vp, vp]
+        L.lfsd_lookahead.argtypes = [ci, ctypes.c_longlong, cd, vp, vp, vp, vp]
+        info = _ModelInfo()
+        rc = L.lfsd_get_model_info(ctypes.byref(info))
+        if rc != 0 or info.abi_version != 1:
+            raise LfsdError("ABI mismatch in %s" % path)
+        self.n_state, self.n_control, self.n_auxvar, self.n_const = (info.n_state, info.n_control, info.n_auxvar,
+                                                                      info.n_const)
+        self.time_varying = bool(info.time_varying)
+        self.lanes = info.lanes_per_trajectory
+        self.is_emulator = bool(info.is_emulator)
+        self.name = info.name.decode()
+        self.hash = info.hash.decode()
+        self.const_defaults = [L.lfsd_const_default(i) for i in range(self.n_const)]
+
+    # ---- argument plumbing ---------------------------------------------------------------
+    def _check(self, t, shape, dtype, name, optional=False):
+        if t is None:
+            if optional:
+                return None
+            raise LfsdError("%s is required" % name)
+        if not isinstance(t, torch.Tensor):
+            raise LfsdError("%s must be a torch tensor" % name)
+        if tuple(t.shape) != tuple(shape):
+            raise LfsdError("%s has shape %s, expected %s" % (name, tuple(t.shape), tuple(shape)))
+        if t.dtype != dtype:
+            raise LfsdError("%s has dtype %s, expected %s" % (name, t.dtype, dtype))
+        if not t.is_contiguous():
+            raise LfsdError("%s must be contiguous" % name)
+        if self.is_emulator:
+            if t.device.type != "cpu":
+                raise LfsdError("the SIMT-emulator test library only takes CPU tensors (%s)" % name)
+        elif t.device.type != "cuda":
+            raise LfsdError("%s lives on %s: the HIP library needs device memory (no CPU fallback)" % (name, t.device))
+        return t
+
+    @staticmethod
+    def _p(t):
+        return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+    def _stream(self, ref):
+        if self.is_emulator:
+            return None
+        return ctypes.c_void_p(torch.cuda.current_stream(ref.device).cuda_stream)
+
+    @staticmethod
+    def _rc(rc, what):
+        if rc != 0:
+            raise LfsdError("%s failed with code %d" % (what, rc))
+
+    # ---- entry points ----------------------------------------------------------------------
+    def coc_workspace_bytes(self, dtype, batch, n_grid):
+        return int(self.lib.lfsd_coc_workspace_bytes(_DT[dtype], batch, n_grid))
+
+    def coc_solve(self, ini_state, horizon, auxvar, consts, n_grid, steps_per_grid=4, u_init=None, max_iter=100,
+                  tol=None, workspace=None, out=None):
+        dt = ini_state.dtype
+        B = ini_state.shape[0]
+        n, m, p, nc = self.n_state, self.n_control, self.n_auxvar, self.n_const
+        self._check(ini_state, (B, n), dt, "ini_state")
+        self._check(horizon, (B,), dt, "horizon")
+        self._check(auxvar, (B, p), dt, "auxvar")
+        per_traj = 0
+        if nc:
+            if consts is None:
+                raise LfsdError("consts is required (n_const=%d)" % nc)
+            if consts.dim() == 2:
+                self._check(consts, (B, nc), dt, "consts")
+                per_traj = 1
+            else:
+                self._check(consts, (nc,), dt, "consts")
+        else:
+            consts = None
+        self._check(u_init, (B, n_grid, m), dt, "u_init", optional=True)
+        dev = ini_state.device
+        if out is None:
+            out = dict(state_grid=torch.empty((B, n_grid + 1, n), dtype=dt, device=dev),
+                       control_grid=torch.empty((B, n_grid + 1, m), dtype=dt, device=dev),
+                       costate_grid=torch.empty((B, n_grid + 1, n), dtype=dt, device=dev),
+                       cost=torch.empty((B,), dtype=dt, device=dev),
+                       iters=torch.zeros((B,), dtype=torch.int32, device=dev),
+                       status=torch.zeros((B,), dtype=torch.int32, device=dev))
+        need = self.coc_workspace_bytes(dt, B, n_grid)
+        if workspace is None or workspace.numel() * workspace.element_size() < need:
+            workspace = torch.empty((need + 7) // 8, dtype=torch.int64, device=dev)
+        if tol is None:
+            tol = 2e-5 if dt == torch.float32 else 1e-9
+        rc = self.lib.lfsd_coc_solve(_DT[dt], B, n_grid, steps_per_grid, self._p(ini_state), self._p(horizon),
+                                     self._p(auxvar), self._p(consts), per_traj, self._p(u_init),
+                                     self._p(out["state_grid"]), self._p(out["control_grid"]),
+                                     self._p(out["costate_grid"]), self._p(out["cost"]), self._p(out["iters"]),
+                                     self._p(out["status"]), int(max_iter), float(tol), self._p(workspace),
+                                     workspace.numel() * workspace.element_size(), self._stream(ini_state))
+        self._rc(rc, "lfsd_coc_solve")
+        out["workspace"] = workspace
+        return out
+
+    def aux_solve(self, horizon, auxvar, consts, state_grid, control_grid, costate_grid, taus, waypoints, iface_idx,
+                  substeps=0, want_grids=False, Z_grid=None, out=None):
+        dt = state_grid.dtype
+        B, N1, n = state_grid.shape
+        N = N1 - 1
+        m, p, nc = self.n_control, self.n_auxvar, self.n_const
+        dev = state_grid.device
+        self._check(horizon, (B,), dt, "horizon")
+        self._check(auxvar, (B, p), dt, "auxvar")
+        self._check(state_grid, (B, N + 1, self.n_state), dt, "state_grid")
+        self._check(control_grid, (B, N + 1, m), dt, "control_grid")
+        self._check(costate_grid, (B, N + 1, n), dt, "costate_grid")
+        per_traj = 0
+        if nc:
+            if consts is None:
+                raise LfsdError("consts is required (n_const=%d)" % nc)
+            if consts.dim() == 2:
+                self._check(consts, (B, nc), dt, "consts")
+                per_traj = 1
+            else:
+                self._check(consts, (nc,), dt, "consts")
+        else:
+            consts = None
+        nw = 0 if taus is None else taus.shape[1]
+        ni = 0 if iface_idx is None else iface_idx.shape[0]
+        if nw:
+            self._check(taus, (B, nw), dt, "taus")
+            self._check(waypoints, (B, nw, ni), dt, "waypoints")
+            self._check(iface_idx, (ni,), torch.int32, "iface_idx")
+        if Z_grid is None:
+            Z_grid = torch.empty((B, N + 1, n + p, n), dtype=dt, device=dev)
+        if out is None:
+            out = dict(loss=torch.zeros((B,), dtype=dt, device=dev), grad=torch.zeros((B, p), dtype=dt, device=dev))
+        auxX = auxU = None
+        if want_grids:
+            auxX = torch.empty((B, N + 1, p, n), dtype=dt, device=dev)
+            auxU = torch.empty((B, N + 1, p, m), dtype=dt, device=dev)
+        rc = self.lib.lfsd_aux_solve(_DT[dt], B, N, self._p(horizon), self._p(auxvar), self._p(consts), per_traj,
+                                     self._p(state_grid), self._p(control_grid), self._p(costate_grid),
+                                     self._p(Z_grid), nw, ni, self._p(iface_idx), self._p(taus), self._p(waypoints),
+                                     self._p(out["loss"]), self._p(out["grad"]), self._p(auxX), self._p(auxU),
+                                     int(substeps), self._stream(state_grid))
+        self._rc(rc, "lfsd_aux_solve")
+        out["Z_grid"] = Z_grid
+        out["auxX_grid"], out["auxU_grid"] = auxX, auxU
+        return out
+
+    def optimizer_step(self, method, theta, grad, iter_idx, lr, mu=0.9, beta1=0.9, beta2=0.999, eps=1e-8, m=None,
+                       v=None, vhat=None, proj_lo=None):
+        dt = theta.dtype
+        B, p = theta.shape
+        for nm, t in (("theta", theta), ("grad", grad)):
+            self._check(t, (B, p), dt, nm)
+        for nm, t in (("m", m), ("v", v), ("vhat", vhat)):
+            self._check(t, (B, p), dt, nm, optional=True)
+        self._check(proj_lo, (p,), dt, "proj_lo", optional=True)
+        rc = self.lib.lfsd_optimizer_step(_DT[dt], OPT_METHODS[method] if isinstance(method, str) else int(method), B,
+                                          p, int(iter_idx), float(lr), float(mu), float(beta1), float(beta2),
+                                          float(eps), self._p(theta), self._p(grad), self._p(m), self._p(v),
+                                          self._p(vhat), self._p(proj_lo), self._stream(theta))
+        self._rc(rc, "lfsd_optimizer_step")
+
+    def lookahead(self, theta, v, mu, out=None):
+        if out is None:
+            out = torch.empty_like(theta)
+        rc = self.lib.lfsd_lookahead(_DT[theta.dtype], theta.numel(), float(mu), self._p(theta), self._p(v),
+                                     self._p(out), self._stream(theta))
+        self._rc(rc, "lfsd_lookahead")
+        return out
