@@ -1,0 +1,389 @@
+"""Host-side mirror of the reference's ``CPDP`` module (CPDP/CPDP.py).
+
+Same classes, method names and argument meaning as the reference —
+``COCSys`` (CPDP.py:9-390) and ``COCSys_TimeVarying`` (CPDP.py:394-786) —
+with the numerics executed by the model's HIP library on the GPU:
+
+=====================  =====================================================
+reference               here
+=====================  =====================================================
+setDyn/setPathCost/...  keep sympy expressions (symbolic.SX instead of casadi.SX)
+diffPMP/raccatiODE/     derivative code is *generated and compiled*
+auxSysODE               (codegen.py) instead of building CasADi Functions
+cocSolver               lfsd_coc_solve  (IPOPT -> batched DDP, same NLP)
+auxSysSolver            lfsd_aux_solve  (solve_ivp BDF/RK45 -> split-step RK4
+                        + Richardson on the same ODEs and interpolants)
+=====================  =====================================================
+
+Beyond the reference's one-trajectory calls there are ``*Batch`` methods that
+keep everything in HBM for thousands of trajectories, and ``SparseDemoLearner``
+that runs the outer learning iteration (loss, gradient, parameter update) of
+the examples / lib/QuadAlgorithm.py on the device.
+"""
+import numpy as np
+import sympy as sp
+import scipy.interpolate as ip
+import torch
+
+from . import symbolic, codegen, runtime
+from .runtime import LfsdError, ModelLibrary
+
+
+class COCSys:
+    time_varying = False
+
+    def __init__(self, project_name="myOc"):
+        self.sys_name = project_name
+        self.time = sp.Symbol('time', real=True)
+        self.device = torch.device("cuda", 0) if torch.cuda.is_available() else None
+        self.dtype = torch.float32
+        self._lib = None
+        self._lib_override = None
+        self.aux_substeps = 0           # 0 = library default
+        self.max_iter = 100
+        self.tol = None
+
+    # ---- model definition (CPDP.py:15-87) ------------------------------------------------------
+    def setAuxvarVariable(self, auxvar=None):
+        if auxvar is None:
+            auxvar = symbolic.SX.sym('auxvar')
+        self.auxvar = symbolic._flat([auxvar])
+        self.n_auxvar = len(self.auxvar)
+        self._lib = None
+
+    def _bounds(self, lb, ub, what):
+        lb, ub = list(lb), list(ub)
+        if any(np.isfinite(v) and abs(v) < 1e19 for v in lb + ub):
+            raise NotImplementedError("finite %s bounds are not supported by the HIP solver (the reference's "
+                                      "examples never set them)" % what)
+
+    def setStateVariable(self, state, state_lb=[], state_ub=[]):
+        self.state = symbolic._flat([state])
+        self.n_state = len(self.state)
+        self._bounds(state_lb, state_ub, "state")
+        self._lib = None
+
+    def setControlVariable(self, control, control_lb=[], control_ub=[]):
+        self.control = symbolic._flat([control])
+        self.n_control = len(self.control)
+        self._bounds(control_lb, control_ub, "control")
+        self._lib = None
+
+    def setTimeVariable(self, t=None):
+        self.time = t if t is not None else sp.Symbol('time', real=True)
+
+    def setDyn(self, ode):
+        if not hasattr(self, 'auxvar'):
+            self.setAuxvarVariable()
+        self.dyn = sp.Matrix(symbolic._flat([ode]))
+        self._lib = None
+
+    def setPathCost(self, path_cost):
+        if not hasattr(self, 'auxvar'):
+            self.setAuxvarVariable()
+        self.path_cost = sp.sympify(path_cost)
+        self._lib = None
+
+    def setFinalCost(self, final_cost):
+        if not hasattr(self, 'auxvar'):
+            self.setAuxvarVariable()
+        self.final_cost = sp.sympify(final_cost)
+        self._lib = None
+
+    def setIntegrator(self, n_grid=10, steps_per_grid=4):
+        self.n_grid = n_grid
+        self.steps_per_grid = steps_per_grid
+
+    # ---- extensions ---------------------------------------------------------------------------
+    def setDevice(self, device=None, dtype=None):
+        if device is not None:
+            self.device = torch.device(device)
+        if dtype is not None:
+            self.dtype = dtype
+
+    def setSolverOptions(self, max_iter=None, tol=None, aux_substeps=None):
+        if max_iter is not None:
+            self.max_iter = int(max_iter)
+        if tol is not None:
+            self.tol = float(tol)
+        if aux_substeps is not None:
+            self.aux_substeps = int(aux_substeps)
+
+    def use_library(self, path_or_lib):
+        """Bind an already built model library (tests use this to inject the SIMT-emulator build)."""
+        self._lib_override = path_or_lib if isinstance(path_or_lib, ModelLibrary) else ModelLibrary(path_or_lib)
+        self._lib = None
+
+    # ---- model -> HIP library -------------------------------------------------------------------
+    def model_spec(self, name=None):
+        for attr in ('state', 'control', 'dyn', 'path_cost', 'final_cost'):
+            assert hasattr(self, attr), {"state": "Define the state variable first!",
+                                         "control": "Define the control variable first!",
+                                         "dyn": "Define the system dynamics first!",
+                                         "path_cost": "Define the running cost/reward function first!",
+                                         "final_cost": "Define the final cost/reward function first!"}[attr]
+        known = set(self.state) | set(self.control) | set(self.auxvar) | {self.time}
+        free = (self.dyn.free_symbols | self.path_cost.free_symbols | self.final_cost.free_symbols) - known
+        bad = [s for s in free if not symbolic.is_const(s)]
+        if bad:
+            raise LfsdError("free symbols that are neither state, control, auxvar nor const(): %s" % bad)
+        consts = sorted(free, key=lambda s: int(str(s).rsplit('__k', 1)[1]))
+        tv = self.time_varying and (self.time in (self.dyn.free_symbols | self.path_cost.free_symbols |
+                                                  self.final_cost.free_symbols))
+        return codegen.ModelSpec(self.state, self.control, self.auxvar, consts, self.time, self.dyn, self.path_cost,
+                                 self.final_cost, time_varying=tv,
+                                 const_defaults=[symbolic.const_default(s) for s in consts],
+                                 name=name or self.sys_name)
+
+    def compile(self, force=False, verbose=False):
+        if self._lib is not None and not force:
+            return self._lib
+        spec = self.model_spec()
+        if self._lib_override is not None:
+            lib = self._lib_override
+            if lib.hash != spec.hash():
+                raise LfsdError("bound library was built for a different model (%s vs %s)" % (lib.hash, spec.hash()))
+        else:
+            lib = ModelLibrary(runtime.build_library(spec, force=force, verbose=verbose))
+        self._spec = spec
+        self._lib = lib
+        self.const_values = list(lib.const_defaults)
+        return lib
+
+    # the reference builds CasADi Functions here (CPDP.py:201-298); for us that is the code generator
+    def diffPMP(self):
+        self.compile()
+
+    def raccatiODE(self):
+        self.compile()
+
+    def auxSysODE(self):
+        self.compile()
+
+    # ---- batched device API ------------------------------------------------------------------------
+    def _dev(self):
+        lib = self.compile()
+        if lib.is_emulator:
+            return torch.device("cpu")
+        if self.device is None or self.device.type != "cuda":
+            raise LfsdError("no GPU: the HIP solver has no CPU fallback")
+        return self.device
+
+    def _t(self, a, shape=None):
+        t = torch.as_tensor(np.asarray(a, dtype=np.float64) if not isinstance(a, torch.Tensor) else a)
+        t = t.to(device=self._dev(), dtype=self.dtype)
+        if shape is not None:
+            t = t.expand(shape) if t.dim() == len(shape) else t.reshape(shape)
+        return t.contiguous()
+
+    def consts_tensor(self, batch=None, overrides=None):
+        """Runtime constants: shared [n_const] (batch=None) or per-trajectory [B][n_const]."""
+        lib = self.compile()
+        base = torch.tensor(self.const_values, dtype=torch.float64)
+        if overrides:
+            names = [str(s).rsplit('__k', 1)[0] for s in self._spec.consts]
+            for k, v in overrides.items():
+                idx = [i for i, nm in enumerate(names) if nm == k]
+                if not idx:
+                    raise LfsdError("unknown constant %r (have %s)" % (k, names))
+                v = torch.as_tensor(v, dtype=torch.float64)
+                if v.dim() == 0:
+                    base[idx[0]] = v
+                else:
+                    if batch is None:
+                        batch = v.shape[0]
+                    if base.dim() == 1:
+                        base = base.repeat(batch, 1)
+                    base[:, idx[0]] = v
+        if batch is not None and base.dim() == 1:
+            base = base.repeat(batch, 1)
+        if lib.n_const == 0:
+            return None
+        return base.to(device=self._dev(), dtype=self.dtype).contiguous()
+
+    def cocSolverBatch(self, ini_state, horizon, auxvar, consts=None, u_init=None, workspace=None, out=None):
+        """Solve B problems. ini_state [B,n], horizon scalar or [B], auxvar [B,p] (or [p]) -> dict of device tensors."""
+        lib = self.compile()
+        if not hasattr(self, 'n_grid'):
+            self.setIntegrator()
+        x0 = self._t(ini_state)
+        if x0.dim() == 1:
+            x0 = x0.unsqueeze(0)
+        B = x0.shape[0]
+        th = self._t(auxvar)
+        if th.dim() == 1:
+            th = th.unsqueeze(0).expand(B, -1).contiguous()
+        hz = self._t(horizon)
+        if hz.dim() == 0:
+            hz = hz.expand(B).contiguous()
+        if consts is None:
+            consts = self.consts_tensor()
+        sol = lib.coc_solve(x0, hz, th, consts, self.n_grid, self.steps_per_grid, u_init=u_init,
+                            max_iter=self.max_iter, tol=self.tol, workspace=workspace, out=out)
+        sol.update(horizon=hz, auxvar=th, consts=consts, ini_state=x0, n_grid=self.n_grid)
+        return sol
+
+    def auxSysSolverBatch(self, sol, taus=None, waypoints=None, interface_idx=None, auxvar=None, want_grids=False,
+                          Z_grid=None, out=None):
+        """Differentiate the PMP along ``sol`` and (optionally) evaluate the sparse-waypoint loss + gradient."""
+        lib = self.compile()
+        B = sol["state_grid"].shape[0]
+        th = sol["auxvar"] if auxvar is None else self._t(auxvar, (B, lib.n_auxvar))
+        tt = wp = ii = None
+        if taus is not None:
+            tt = self._t(taus)
+            if tt.dim() == 1:
+                tt = tt.unsqueeze(0).expand(B, -1).contiguous()
+            wp = self._t(waypoints)
+            if wp.dim() == 2:
+                wp = wp.unsqueeze(0).expand(B, -1, -1).contiguous()
+            ii = torch.as_tensor(list(interface_idx), dtype=torch.int32, device=self._dev())
+        return lib.aux_solve(sol["horizon"], th, sol["consts"], sol["state_grid"], sol["control_grid"],
+                             sol["costate_grid"], tt, wp, ii, substeps=self.aux_substeps, want_grids=want_grids,
+                             Z_grid=Z_grid, out=out)
+
+    # ---- the reference's one-trajectory calls --------------------------------------------------------
+    def cocSolver(self, ini_state, horizon, auxvar_value=1, interplation_level=1, print_level=0):
+        """CPDP.py:92-198: returns (time_grid, opt_sol) with opt_sol(t) -> [x, u, lambda]."""
+        if not hasattr(self, 'n_grid'):
+            self.setIntegrator()
+        if type(ini_state) is list:
+            ini_state = np.array(ini_state).flatten()
+        e = np.atleast_1d(np.asarray(auxvar_value, dtype=np.float64)).ravel()
+        sol = self.cocSolverBatch(np.asarray(ini_state, dtype=np.float64)[None, :], float(horizon), e[None, :])
+        self.last_solution = sol
+        st = int(sol["status"][0])
+        if print_level:
+            print("lfsd coc_solve: status=%s iters=%d cost=%g" % (runtime.STATUS.get(st, st), int(sol["iters"][0]),
+                                                                 float(sol["cost"][0])))
+        time_grid = np.linspace(0, float(horizon), self.n_grid + 1)
+        grids = np.concatenate([sol[k][0].double().cpu().numpy() for k in ("state_grid", "control_grid",
+                                                                           "costate_grid")], axis=1)
+        return time_grid, self.interpolation(time_grid, grids, interplation_level)
+
+    def auxSysSolver(self, time_grid, opt_sol, auxvar_value=1):
+        """CPDP.py:301-381: returns auxsys_sol(t) -> [vec(dx/dtheta) (n*p, row-major), vec(du/dtheta) (m*p)]."""
+        lib = self.compile()
+        n, m, p = lib.n_state, lib.n_control, lib.n_auxvar
+        time_grid = np.asarray(time_grid, dtype=np.float64)
+        N = len(time_grid) - 1
+        g = np.asarray(opt_sol(time_grid), dtype=np.float64)
+        e = np.atleast_1d(np.asarray(auxvar_value, dtype=np.float64)).ravel()
+        sol = dict(state_grid=self._t(g[None, :, 0:n]), control_grid=self._t(g[None, :, n:n + m]),
+                   costate_grid=self._t(g[None, :, n + m:]), horizon=self._t([time_grid[-1] - time_grid[0]]),
+                   auxvar=self._t(e[None, :]), consts=self.consts_tensor())
+        aux = self.auxSysSolverBatch(sol, want_grids=True)
+        self.last_aux = aux
+        X = aux["auxX_grid"][0].double().cpu().numpy().transpose(0, 2, 1).reshape(N + 1, n * p)
+        U = aux["auxU_grid"][0].double().cpu().numpy().transpose(0, 2, 1).reshape(N + 1, m * p)
+        return self.interpolation(time_grid, np.concatenate((X, U), axis=1))
+
+    def interpolation(self, x, y, method=1):
+        """CPDP.py:384-390."""
+        if method == 1:
+            return ip.interp1d(x, y, axis=0)
+        if method == 2:
+            return ip.interp1d(x, y, axis=0, kind='cubic')
+
+
+class COCSys_TimeVarying(COCSys):
+    """CPDP.py:394-786 — dynamics / costs may depend on the time symbol given to ``setTimeVariable``."""
+    time_varying = True
+
+
+class SparseDemoLearner:
+    """The outer learning iteration of the examples, batched on the device.
+
+    One iteration (Examples/robotarm_random.py:67-73, lib/QuadAlgorithm.py:454-578):
+        solve OC at theta -> differentiate PMP -> waypoint loss & gradient -> parameter update -> projection.
+    ``mode='independent'``: every trajectory (seed) owns its theta and optimizer state.
+    ``mode='shared'``: one theta for all demonstrations; the gradient is summed over the batch and
+    all-reduced over ``process_group`` (RCCL) before a single update.
+    """
+
+    def __init__(self, oc, ini_state, horizon, taus, waypoints, interface_idx, theta0, method="Vanilla",
+                 learning_rate=1e-2, mu=0.9, beta_1=0.9, beta_2=0.999, epsilon=1e-8, proj_lo=None, consts=None,
+                 mode="independent", process_group=None, true_loss_print_flag=False):
+        self.oc, self.method, self.lr, self.mu = oc, method, learning_rate, mu
+        self.b1, self.b2, self.eps = beta_1, beta_2, epsilon
+        if method not in runtime.OPT_METHODS:
+            raise Exception("Wrong optimization method type!")
+        self.mode, self.pg = mode, process_group
+        self.lib = oc.compile()
+        x0 = oc._t(ini_state)
+        self.x0 = x0.unsqueeze(0) if x0.dim() == 1 else x0
+        B = self.B = self.x0.shape[0]
+        p = self.lib.n_auxvar
+        hz = oc._t(horizon)
+        self.hz = hz.expand(B).contiguous() if hz.dim() == 0 else hz
+        tt = oc._t(taus)
+        self.taus = tt.unsqueeze(0).expand(B, -1).contiguous() if tt.dim() == 1 else tt
+        wp = oc._t(waypoints)
+        self.wps = wp.unsqueeze(0).expand(B, -1, -1).contiguous() if wp.dim() == 2 else wp
+        self.iface = torch.as_tensor(list(interface_idx), dtype=torch.int32, device=self.x0.device)
+        th = oc._t(theta0)
+        th = th.unsqueeze(0) if th.dim() == 1 else th
+        if mode == "shared":
+            assert th.shape[0] == 1, "shared mode keeps a single parameter vector"
+            self.theta = th.clone()
+        else:
+            self.theta = th.expand(B, p).contiguous().clone()
+        self.consts = consts if consts is not None else oc.consts_tensor()
+        z = lambda: torch.zeros_like(self.theta)
+        self.m, self.v, self.vhat = z(), z(), z()
+        lo = torch.full((p,), -float("inf"), dtype=torch.float64)
+        for k, val in (proj_lo or {0: 1e-8}).items():      # examples: current_parameter[0] = fmax(., 1e-8)
+            lo[k] = val
+        self.proj_lo = lo.to(device=self.x0.device, dtype=self.theta.dtype)
+        self.iter_idx = 0
+        self.true_loss = true_loss_print_flag
+        self._ws = None
+        self._sol = None
+        self._aux = None
+        self._Z = None
+
+    def evaluate(self, theta):
+        """(loss [B], grad [B,p]) of every trajectory at parameters theta ([B,p] or [1,p])."""
+        th = theta if theta.shape[0] == self.B else theta.expand(self.B, -1).contiguous()
+        self._sol = self.oc.cocSolverBatch(self.x0, self.hz, th, consts=self.consts, workspace=self._ws,
+                                           out=self._sol_out())
+        self._ws = self._sol["workspace"]
+        self._aux = self.oc.auxSysSolverBatch(self._sol, self.taus, self.wps, self.iface, Z_grid=self._Z,
+                                              out=self._aux_out())
+        self._Z = self._aux["Z_grid"]
+        return self._aux["loss"], self._aux["grad"]
+
+    def _sol_out(self):
+        if self._sol is None:
+            return None
+        return {k: self._sol[k] for k in ("state_grid", "control_grid", "costate_grid", "cost", "iters", "status")}
+
+    def _aux_out(self):
+        if self._aux is None:
+            return None
+        return {k: self._aux[k] for k in ("loss", "grad")}
+
+    def step(self):
+        """One outer iteration; returns (loss, grad) evaluated where the update rule needs them."""
+        theta_eval = self.theta
+        if self.method == "Nesterov":
+            theta_eval = self.lib.lookahead(self.theta, self.m, self.mu)      # QuadAlgorithm.py:478
+        loss, grad = self.evaluate(theta_eval)
+        if self.mode == "shared":
+            g = grad.sum(dim=0, keepdim=True)
+            l = loss.sum().reshape(1)
+            if self.pg is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()):
+                buf = torch.cat([g.reshape(-1), l])
+                torch.distributed.all_reduce(buf, group=self.pg)              # RCCL over xGMI on the GPU
+                g, l = buf[:-1].reshape(1, -1), buf[-1:]
+            grad_used, loss_out = g.contiguous(), l
+        else:
+            grad_used, loss_out = grad, loss
+        self.lib.optimizer_step(self.method, self.theta, grad_used, self.iter_idx, self.lr, self.mu, self.b1,
+                                self.b2, self.eps, m=self.m, v=self.v, vhat=self.vhat, proj_lo=self.proj_lo)
+        self.iter_idx += 1
+        if self.method == "Nesterov" and self.true_loss:
+            loss_out, grad_used = self.evaluate(self.theta)                   # QuadAlgorithm.py:487-492
+            if self.mode == "shared":
+                loss_out, grad_used = loss_out.sum().reshape(1), grad_used.sum(dim=0, keepdim=True)
+        return loss_out, grad_used

@@ -25,7 +25,7 @@ import hashlib
 import sympy as sp
 from sympy.printing.c import C99CodePrinter
 
-CODEGEN_VERSION = 3
+CODEGEN_VERSION = 4
 
 
 class ModelSpec:
@@ -207,7 +207,10 @@ def emit_header(spec):
     S.append('// AUTO-GENERATED by codegen.py (version %d) — do not edit.  model "%s" hash %s'
              % (CODEGEN_VERSION, spec.name, spec.hash()))
     S.append('#pragma once')
-    S.append('namespace lfsd_gen {')
+    # one namespace per model: several model libraries live in one process and must not share
+    # weak/unique symbols (template instantiations, function-local statics)
+    S.append('#define LFSD_MODEL_NS lfsd_gen_%s' % spec.hash())
+    S.append('namespace LFSD_MODEL_NS {')
     S.append('struct Model {')
     S.append('  static constexpr int NX = %d, NU = %d, NP = %d, NC = %d;' % (n, m, p, max(nc, 1)))
     S.append('  static constexpr int NC_REAL = %d;' % nc)
@@ -288,5 +291,5 @@ def emit_header(spec):
     S.append('  template<bool ACC, class T> static LFSD_DEV void fu_gram(const T* L, const T* S, T* G) {\n%s\n  }'
              % '\n'.join(lines))
     S.append('};')
-    S.append('}  // namespace lfsd_gen')
+    S.append('}  // namespace LFSD_MODEL_NS')
     return '\n'.join(S) + '\n'

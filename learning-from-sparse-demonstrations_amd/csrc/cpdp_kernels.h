@@ -31,6 +31,17 @@
 
 namespace lfsd {
 
+// debug aid for the emulator build: start every kernel with NaN-filled LDS so that a read of
+// never-written shared memory cannot go unnoticed (tests build with -DLFSD_POISON_LDS)
+template <typename T> LFSD_DEV void poison_lds(T* p, int n) {
+#if defined(LFSD_POISON_LDS)
+  for (int i = threadIdx.x; i < n; i += 64) p[i] = T(0) / T(0);
+  __syncthreads();
+#else
+  (void)p; (void)n;
+#endif
+}
+
 enum Status { ST_RUNNING = 0, ST_CONVERGED = 1, ST_STALLED = 2, ST_MAXITER = 3, ST_FAILED = 4 };
 enum OptMethod { OPT_VANILLA = 0, OPT_NESTEROV = 1, OPT_ADAM = 2, OPT_NADAM = 3, OPT_AMSGRAD = 4 };
 
@@ -128,6 +139,61 @@ template <int n, typename T> LFSD_DEV void mat_inverse(const T* A, T* Ainv) {
     lu_solve<n>(F, b);
 #pragma unroll
     for (int i = 0; i < n; ++i) Ainv[i * n + c] = b[i];
+  }
+}
+template <int n, typename T> LFSD_DEV void matmul(const T* A, const T* B, T* C) {
+#pragma unroll
+  for (int i = 0; i < n; ++i) {
+#pragma unroll
+    for (int j = 0; j < n; ++j) {
+      T s = T(0);
+#pragma unroll
+      for (int k = 0; k < n; ++k) s += A[i * n + k] * B[k * n + j];
+      C[i * n + j] = s;
+    }
+  }
+}
+// P = phi1(M) = M^-1 (I - exp(-M)) for a small matrix with non-negative spectrum
+// (scaling and squaring: Taylor of degree 8 on M/2^s, then phi1(2A) = (I + e^-A) phi1(A) / 2).
+template <int n, typename T> LFSD_DEV void phi1_neg(const T* M, T* P) {
+  T nrm = T(0);
+#pragma unroll
+  for (int i = 0; i < n; ++i) {
+    T r = T(0);
+#pragma unroll
+    for (int j = 0; j < n; ++j) r += t_abs(M[i * n + j]);
+    nrm = t_max(nrm, r);
+  }
+  int sq = 0;
+  T sc = T(1);
+  while (nrm * sc > T(0.25) && sq < 60) { sc *= T(0.5); ++sq; }
+  T A[n * n], E[n * n], W[n * n];
+#pragma unroll
+  for (int i = 0; i < n * n; ++i) { A[i] = M[i] * sc; P[i] = T(0); }
+  const T ck[9] = {T(1), T(1) / T(2), T(1) / T(6), T(1) / T(24), T(1) / T(120), T(1) / T(720), T(1) / T(5040),
+                   T(1) / T(40320), T(1) / T(362880)};
+#pragma unroll
+  for (int i = 0; i < n; ++i) P[i * n + i] = ck[8];
+#pragma unroll
+  for (int k = 7; k >= 0; --k) {
+    matmul<n>(A, P, W);
+#pragma unroll
+    for (int i = 0; i < n * n; ++i) P[i] = -W[i];
+#pragma unroll
+    for (int i = 0; i < n; ++i) P[i * n + i] += ck[k];
+  }
+  matmul<n>(A, P, W);
+#pragma unroll
+  for (int i = 0; i < n * n; ++i) E[i] = -W[i];
+#pragma unroll
+  for (int i = 0; i < n; ++i) E[i * n + i] += T(1);
+  for (int it = 0; it < sq; ++it) {
+    matmul<n>(E, P, W);
+#pragma unroll
+    for (int i = 0; i < n * n; ++i) P[i] = T(0.5) * (P[i] + W[i]);
+    matmul<n>(E, E, W);
+#pragma unroll
+    for (int i = 0; i < n * n; ++i) E[i] = W[i];
   }
 }
 template <int n, typename T> LFSD_DEV void matvec(const T* A, const T* v, T* y) {
@@ -452,7 +518,7 @@ template <class M, typename T, int G> struct OcSolver {
 
   // Lane l tries step length 2^-l (all candidate roll-outs run concurrently in the group).
   // Returns the index of the largest accepted step (or -1) and the best cost seen.
-  LFSD_DEV int linesearch(int cur, T J, T dV1, T dV2, T& alpha_out, T& Jmin) {
+  LFSD_DEV int linesearch(int cur, T J, T dV1, T dV2, T& alpha_out, T& Jmin, bool& flat_full) {
     T* ldsRed = lds + Lay::LDS_RED;
     T alpha = T(0);
     if (lane < NALPHA) { alpha = T(1); for (int i = 0; i < lane; ++i) alpha *= T(0.5); }
@@ -474,6 +540,7 @@ template <class M, typename T, int G> struct OcSolver {
     T a = T(1);
     alpha_out = T(0);
     const T flat = T(8) * Eps<T>::v() * t_abs(J);
+    flat_full = t_finite(ldsRed[0]) && t_abs(ldsRed[0] - J) <= T(64) * Eps<T>::v() * t_abs(J);
     for (int l = 0; l < NALPHA; ++l) {
       const T Jl = ldsRed[l];
       const T expected = -(a * dV1 + a * a * dV2);
@@ -496,6 +563,7 @@ __global__ void __launch_bounds__(64) oc_solve_kernel(OcArgs<T> a) {
   static_assert(64 % G == 0 && G >= NX + NU, "lane group must hold one column of [A B] per lane");
   __shared__ T lds_all[GPB * Lay::template lds_elems<G>()];
   __shared__ int vote[2];
+  poison_lds(lds_all, GPB * Lay::template lds_elems<G>());
   Sol s;
   const int gib = threadIdx.x / G;
   s.lane = threadIdx.x % G;
@@ -532,9 +600,10 @@ __global__ void __launch_bounds__(64) oc_solve_kernel(OcArgs<T> a) {
   T J = s.rollout_sens(1, 0, T(0), false);
   __syncthreads();
   T mu = T(0), HL = T(0);
-  int status = ST_RUNNING, it = 0;
+  int status = ST_RUNNING, it = 0, my_iters = 0;
   bool need_bw = true;      // costates on `lam_out` are stale
   T gnorm = T(0), dV1 = T(0), dV2 = T(0);
+  T g_flat = T(-1);         // gradient norm at the last accepted noise-level ("flat") step; <0: none yet
   if (!t_finite(J)) status = ST_FAILED;
   for (; it < a.max_iter; ++it) {
     if (threadIdx.x == 0) vote[0] = 0;
@@ -547,6 +616,7 @@ __global__ void __launch_bounds__(64) oc_solve_kernel(OcArgs<T> a) {
     need_bw = false;
     bool try_step = false;
     if (status == ST_RUNNING) {
+      my_iters = it + 1;
       if (!bw_ok) {
         if (HL > T(0)) HL = T(0);
         else { mu = t_max(mu * T(10), T(1e-6)); if (mu > T(1e8)) status = ST_FAILED; }
@@ -557,14 +627,27 @@ __global__ void __launch_bounds__(64) oc_solve_kernel(OcArgs<T> a) {
       }
     }
     T alpha = T(0), Jmin = J;
-    const int ia = s.linesearch(cur, J, dV1, dV2, alpha, Jmin);
+    bool flat_full = false;
+    int ia = s.linesearch(cur, J, dV1, dV2, alpha, Jmin, flat_full);
     bool accept = false;
     if (try_step) {
-      if (ia >= 0) accept = true;
-      else if (HL > T(0)) HL = T(0);
-      else if (mu > T(1e6) || (J - Jmin) <= T(8) * Eps<T>::v() * t_abs(J)) status = ST_STALLED;
-      else mu = t_max(mu * T(10), T(1e-6));
+      if (ia >= 0) {
+        accept = true;
+      } else if (HL > T(0) && flat_full && (g_flat < T(0) || gnorm < T(0.7) * g_flat)) {
+        // Newton-like step whose cost change is below rounding noise: take it as long as the
+        // gradient norm keeps contracting (this is what lets fp32 reach its gradient floor)
+        accept = true; ia = 0; alpha = T(1); g_flat = gnorm;
+      } else if (HL > T(0)) {
+        HL = T(0);
+      } else if (mu > T(1e6) || (J - Jmin) <= T(8) * Eps<T>::v() * t_abs(J)) {
+        status = ST_STALLED;
+      } else {
+        mu = t_max(mu * T(10), T(1e-6));
+      }
     }
+#if defined(LFSD_TRACE)
+    if (s.lane == 0 && slot == 0) printf("it %d st %d bw_ok %d g %.6e J %.12e ia %d alpha %g accept %d HL %g mu %g dV1 %.4e dV2 %.4e Jmin %.12e\n", it, status, (int)bw_ok, (double)gnorm, (double)J, ia, (double)alpha, (int)accept, (double)HL, (double)mu, (double)dV1, (double)dV2, (double)Jmin);
+#endif
     if (threadIdx.x == 0) vote[1] = 0;
     __syncthreads();
     if (accept) vote[1] = 1;
@@ -593,7 +676,7 @@ __global__ void __launch_bounds__(64) oc_solve_kernel(OcArgs<T> a) {
     T* uo = a.control_grid + traj * (N + 1) * NU;
     for (int i = s.lane; i < (N + 1) * NX; i += G) xo[i] = s.xb[cur][i];
     for (int i = s.lane; i < (N + 1) * NU; i += G) uo[i] = s.ub[cur][(i < N * NU) ? i : i - NU];
-    if (s.lane == 0) { a.cost[traj] = J; a.iters[traj] = it; a.status[traj] = status; }
+    if (s.lane == 0) { a.cost[traj] = J; a.iters[traj] = my_iters; a.status[traj] = status; }
   }
 }
 
@@ -601,7 +684,9 @@ __global__ void __launch_bounds__(64) oc_solve_kernel(OcArgs<T> a) {
 //  Auxiliary control system (differentiated maximum principle)
 // =====================================================================================
 template <typename T> struct AuxArgs {
-  int batch, n_grid, substeps;    // substeps = coarse Strang steps per grid interval (fine = 2x, Richardson)
+  int batch, n_grid, substeps;    // substeps = minimum coarse split-steps per grid interval (fine = 2x, Richardson)
+  T rate_max;                     // refine an interval until  dt * |Huu^-1 fu^T P fu|_inf <= rate_max
+  int max_refine;                 // cap on that refinement (factor over `substeps`)
   const T* horizon;               // [B]
   const T* auxvar;                // [B][NP]
   const T* consts; int const_stride;
@@ -672,6 +757,39 @@ template <class M, typename T, int G> struct AuxCtx {
   }
   LFSD_DEV const T* node(int i) const { return lds + Lay::LDS_L + i * M::NCOEF; }
 
+  // |Huu^-1 fu^T P fu|_inf : rate of the stiff closed-loop modes at one node (P = first NX lanes' columns)
+  LFSD_DEV T stiff_rate(const T* zt, const T* L) {
+    T* ldsS = lds + Lay::LDS_S;
+    const T* iH = L + M::OFF_IHUU;
+    T s[NU], kj[NU];
+    M::template fu_mulT<false>(L, zt, s);
+    matvec<NU>(iH, s, kj);
+    if (lane < NX) {
+#pragma unroll
+      for (int a = 0; a < NU; ++a) ldsS[lane * NU + a] = kj[a];
+    }
+    __syncthreads();
+    T Mx[NU * NU];
+    M::template fu_gram<false>(L, ldsS, Mx);
+    T nrm = T(0);
+#pragma unroll
+    for (int a = 0; a < NU; ++a) {
+      T r = T(0);
+#pragma unroll
+      for (int b = 0; b < NU; ++b) r += t_abs(Mx[a * NU + b]);
+      nrm = t_max(nrm, r);
+    }
+    __syncthreads();
+    return nrm;
+  }
+  LFSD_DEV int units_for(T rate, int Sa, T rate_max, int max_refine) const {
+    T want = rate * dgrid / rate_max;
+    if (!t_finite(want)) want = T(Sa);
+    int u = Sa;
+    const long long cap = (long long)Sa * max_refine;
+    while ((T)u < want && (long long)u * 2 <= cap) u *= 2;
+    return u;
+  }
   // ---- Riccati (backward in time; tau = -t) -------------------------------------------------
   // stiff sub-flow  dZ/dtau = -P R Z,  R = fu Huu^-1 fu^T :   Z <- Z - P fu (Huu/dt + fu^T P fu)^-1 fu^T Z
   LFSD_DEV void ric_stiff(T* z, const T* L, T dt) {
@@ -754,7 +872,9 @@ template <class M, typename T, int G> struct AuxCtx {
 
   // ---- forward auxiliary state -----------------------------------------------------------------
   // lanes < NX carry P columns (interpolated), lanes NX..NX+NP carry X = dx/dtheta columns and W columns.
-  // stiff sub-flow  X' = -fu K X,  K = Huu^-1 fu^T P : implicit midpoint in Woodbury form.
+  // stiff sub-flow  X' = -fu K X,  K = Huu^-1 fu^T P (frozen over the sub-step), solved exactly:
+  //   X(dt) = X - dt fu phi1(dt K fu) K X,   phi1(M) = M^-1 (I - e^-M)   (m x m matrix function).
+  // (An A-stable rational step is not enough here: with a cheap control cost dt*|K fu| reaches O(10^2).)
   LFSD_DEV void fwd_stiff(T* xa, const T* zt, const T* L, T dt) {
     T* ldsS = lds + Lay::LDS_S;
     const T* iH = L + M::OFF_IHUU;
@@ -766,12 +886,11 @@ template <class M, typename T, int G> struct AuxCtx {
       for (int a = 0; a < NU; ++a) ldsS[lane * NU + a] = kj[a];
     }
     __syncthreads();
-    T Mx[NU * NU], kx[NU];
+    T Mx[NU * NU], Psi[NU * NU], kx[NU], y[NU];
     M::template fu_gram<false>(L, ldsS, Mx);       // K fu
 #pragma unroll
-    for (int i = 0; i < NU * NU; ++i) Mx[i] *= T(0.5) * dt;
-#pragma unroll
-    for (int a = 0; a < NU; ++a) Mx[a * NU + a] += T(1);
+    for (int i = 0; i < NU * NU; ++i) Mx[i] *= dt;
+    phi1_neg<NU>(Mx, Psi);
 #pragma unroll
     for (int a = 0; a < NU; ++a) kx[a] = T(0);
 #pragma unroll
@@ -779,11 +898,10 @@ template <class M, typename T, int G> struct AuxCtx {
 #pragma unroll
       for (int a = 0; a < NU; ++a) kx[a] += ldsS[i * NU + a] * xa[i];
     }
-    lu_factor<NU>(Mx);
-    lu_solve<NU>(Mx, kx);
+    matvec<NU>(Psi, kx, y);
 #pragma unroll
-    for (int a = 0; a < NU; ++a) kx[a] *= -dt;
-    M::template fu_mul<true>(L, kx, xa);
+    for (int a = 0; a < NU; ++a) y[a] *= -dt;
+    M::template fu_mul<true>(L, y, xa);
     __syncthreads();
   }
   // non-stiff part  X' = fx X + fe - fu Huu^-1 (Hux X + Hue + fu^T W)
@@ -871,6 +989,7 @@ __global__ void __launch_bounds__(64) aux_riccati_kernel(AuxArgs<T> a) {
   constexpr int GPB = 64 / G;
   static_assert(64 % G == 0 && G >= NZ && G >= Lay::NNODE, "lane group must hold one column of [P W] per lane");
   __shared__ T lds_all[GPB * Lay::lds_elems()];
+  poison_lds(lds_all, GPB * Lay::lds_elems());
   const long long slot = (long long)blockIdx.x * GPB + threadIdx.x / G;
   const bool valid = slot < a.batch;
   const long long traj = valid ? slot : (long long)a.batch - 1;
@@ -897,12 +1016,15 @@ __global__ void __launch_bounds__(64) aux_riccati_kernel(AuxArgs<T> a) {
     }
   }
   T* ldsT = s.lds + Lay::LDS_T;
-  const T hc = s.dgrid / T(Sa);
-  const T ds = T(1) / T(4 * Sa);
   for (int k = N - 1; k >= 0; --k) {
     s.load_interval(a, traj, k, N);
-    for (int unit = 0; unit < Sa; ++unit) {
-      const T s_hi = T(1) - T(unit) / T(Sa);
+    // stiffness-aware sub-stepping: P is largest at the later end of the interval (terminal transient)
+    s.stage_nodes(T(1), T(0));
+    const int units = s.units_for(s.stiff_rate(z, s.node(0)), Sa, a.rate_max, a.max_refine);
+    const T hc = s.dgrid / T(units);
+    const T ds = T(1) / T(4 * units);
+    for (int unit = 0; unit < units; ++unit) {
+      const T s_hi = T(1) - T(unit) / T(units);
       s.stage_nodes(s_hi, -ds);                  // node i sits at fraction s_hi - i/(4 Sa)
       T zc[NX], zf[NX];
 #pragma unroll
@@ -938,6 +1060,7 @@ __global__ void __launch_bounds__(64) aux_forward_kernel(AuxArgs<T> a) {
   constexpr int NX = M::NX, NU = M::NU, NP = M::NP, NZ = NX + NP;
   constexpr int GPB = 64 / G;
   __shared__ T lds_all[GPB * Lay::lds_elems()];
+  poison_lds(lds_all, GPB * Lay::lds_elems());
   const long long slot = (long long)blockIdx.x * GPB + threadIdx.x / G;
   const bool valid = slot < a.batch;
   const long long traj = valid ? slot : (long long)a.batch - 1;
@@ -951,8 +1074,6 @@ __global__ void __launch_bounds__(64) aux_forward_kernel(AuxArgs<T> a) {
 #pragma unroll
   for (int i = 0; i < NX; ++i) { xa[i] = T(0); zA[i] = T(0); zB[i] = T(0); }     // X(0) = 0, CPDP.py:355
   T loss = T(0), gacc = T(0);
-  const T hc = s.dgrid / T(Sa);
-  const T ds = T(1) / T(4 * Sa);
   T* Xo = a.auxX_grid ? a.auxX_grid + traj * (long long)(N + 1) * NP * NX : nullptr;
   T* Uo = a.auxU_grid ? a.auxU_grid + traj * (long long)(N + 1) * NP * NU : nullptr;
   if (valid && Xo && xlane) {
@@ -968,8 +1089,13 @@ __global__ void __launch_bounds__(64) aux_forward_kernel(AuxArgs<T> a) {
     T xprev[NX];
 #pragma unroll
     for (int i = 0; i < NX; ++i) xprev[i] = xa[i];
-    for (int unit = 0; unit < Sa; ++unit) {
-      const T s_lo = T(unit) / T(Sa);
+    s.stage_nodes(T(0), T(0.25));
+    const T rate = t_max(s.stiff_rate(zA, s.node(0)), s.stiff_rate(zB, s.node(4)));
+    const int units = s.units_for(rate, Sa, a.rate_max, a.max_refine);
+    const T hc = s.dgrid / T(units);
+    const T ds = T(1) / T(4 * units);
+    for (int unit = 0; unit < units; ++unit) {
+      const T s_lo = T(unit) / T(units);
       s.stage_nodes(s_lo, ds);
       if (Uo && unit == 0) {
         T uo[NU];
@@ -987,7 +1113,7 @@ __global__ void __launch_bounds__(64) aux_forward_kernel(AuxArgs<T> a) {
       s.fwd_strang(xf, zA, zB, 2, 3, 4, s_lo + T(2) * ds, s_lo + T(3) * ds, s_lo + T(4) * ds, hc * T(0.5));
 #pragma unroll
       for (int i = 0; i < NX; ++i) xa[i] = xlane ? (T(4) * xf[i] - xc[i]) / T(3) : T(0);
-      if (Uo && k == N - 1 && unit == Sa - 1) {
+      if (Uo && k == N - 1 && unit == units - 1) {
         T uo[NU];
         s.aux_control(xa, zB, s.node(4), uo);
         if (valid && xlane) {

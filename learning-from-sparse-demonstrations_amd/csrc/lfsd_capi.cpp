@@ -3,13 +3,14 @@
 // (tests/emu builds the same file with g++ -DLFSD_EMU for the CPU SIMT emulator.)
 #include "cpdp_kernels.h"
 #include LFSD_MODEL_HEADER
+#define LFSD_API extern "C" __attribute__((visibility("default")))
 #include "../../include/lfsd_cpdp.h"
 
 #ifndef LFSD_G
 #error "LFSD_G (lanes per trajectory) must be defined by the build"
 #endif
 
-using Model = lfsd_gen::Model;
+using Model = LFSD_MODEL_NS::Model;
 static constexpr int G = LFSD_G;
 static constexpr int GPB = 64 / G;
 
@@ -22,7 +23,7 @@ static int launch_status() { return 0; }
 static int launch_status() { return (int)hipGetLastError(); }
 #endif
 
-extern "C" int lfsd_get_model_info(lfsd_model_info* out) {
+LFSD_API int lfsd_get_model_info(lfsd_model_info* out) {
   if (!out) return LFSD_EINVAL;
   out->abi_version = LFSD_ABI_VERSION;
   out->n_state = Model::NX; out->n_control = Model::NU; out->n_auxvar = Model::NP; out->n_const = Model::NC_REAL;
@@ -38,14 +39,14 @@ extern "C" int lfsd_get_model_info(lfsd_model_info* out) {
   return 0;
 }
 
-extern "C" double lfsd_const_default(int i) {
+LFSD_API double lfsd_const_default(int i) {
   if (i < 0 || i >= Model::NC_REAL) return 0.0;
   return Model::const_default(i);
 }
 
 static long long padded_batch(int batch) { return ((long long)(batch + GPB - 1) / GPB) * GPB; }
 
-extern "C" size_t lfsd_coc_workspace_bytes(int dtype, int batch, int n_grid) {
+LFSD_API size_t lfsd_coc_workspace_bytes(int dtype, int batch, int n_grid) {
   if (batch <= 0 || n_grid <= 0 || (dtype != LFSD_F32 && dtype != LFSD_F64)) return 0;
   const size_t es = dtype == LFSD_F32 ? 4 : 8;
   return (size_t)padded_batch(batch) * (size_t)lfsd::OcLayout<Model>::ws_elems(n_grid) * es;
@@ -73,7 +74,7 @@ static int coc_solve_t(int batch, int n_grid, int steps_per_grid, const void* in
   return launch_status();
 }
 
-extern "C" int lfsd_coc_solve(int dtype, int batch, int n_grid, int steps_per_grid, const void* ini_state,
+LFSD_API int lfsd_coc_solve(int dtype, int batch, int n_grid, int steps_per_grid, const void* ini_state,
                               const void* horizon, const void* auxvar, const void* consts, int const_per_traj,
                               const void* u_init, void* state_grid, void* control_grid, void* costate_grid, void* cost,
                               int* iters, int* status, int max_iter, double tol, void* workspace,
@@ -102,6 +103,7 @@ static int aux_solve_t(int batch, int n_grid, const void* horizon, const void* a
                        void* stream) {
   lfsd::AuxArgs<T> a;
   a.batch = batch; a.n_grid = n_grid; a.substeps = substeps > 0 ? substeps : 4;
+  a.rate_max = (T)(8.0 / a.substeps); a.max_refine = 256;   // substeps = 4 -> dt*rate <= 2
   a.horizon = (const T*)horizon; a.auxvar = (const T*)auxvar;
   a.consts = consts ? (const T*)consts : (const T*)horizon;
   a.const_stride = (consts && const_per_traj) ? Model::NC : 0;
@@ -118,7 +120,7 @@ static int aux_solve_t(int batch, int n_grid, const void* horizon, const void* a
   return launch_status();
 }
 
-extern "C" int lfsd_aux_solve(int dtype, int batch, int n_grid, const void* horizon, const void* auxvar,
+LFSD_API int lfsd_aux_solve(int dtype, int batch, int n_grid, const void* horizon, const void* auxvar,
                               const void* consts, int const_per_traj, const void* state_grid, const void* control_grid,
                               const void* costate_grid, void* Z_grid, int n_waypoints, int n_iface,
                               const int* iface_idx, const void* taus, const void* waypoints, void* loss, void* grad,
@@ -154,7 +156,7 @@ static int opt_step_t(int method, int batch, int n_param, int iter_idx, double l
   return launch_status();
 }
 
-extern "C" int lfsd_optimizer_step(int dtype, int method, int batch, int n_param, int iter_idx, double lr, double mu,
+LFSD_API int lfsd_optimizer_step(int dtype, int method, int batch, int n_param, int iter_idx, double lr, double mu,
                                    double beta1, double beta2, double eps, void* theta, const void* grad, void* m,
                                    void* v, void* vhat, const void* proj_lo, void* stream) {
   if (batch <= 0 || n_param <= 0 || iter_idx < 0 || !theta || !grad) return LFSD_EINVAL;
@@ -171,7 +173,7 @@ extern "C" int lfsd_optimizer_step(int dtype, int method, int batch, int n_param
   return LFSD_EINVAL;
 }
 
-extern "C" int lfsd_lookahead(int dtype, long long n, double mu, const void* theta, const void* v, void* out,
+LFSD_API int lfsd_lookahead(int dtype, long long n, double mu, const void* theta, const void* v, void* out,
                               void* stream) {
   if (n <= 0 || !theta || !v || !out) return LFSD_EINVAL;
   const unsigned grid = (unsigned)((n + 63) / 64);

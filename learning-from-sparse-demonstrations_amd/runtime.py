@@ -74,7 +74,7 @@ def write_header(spec, force=False):
 def hipcc_command(spec, out, extra=()):
     g = lanes_for(spec.n, spec.m, spec.p)
     return [find_hipcc(), "-x", "hip", "--offload-arch=gfx950", "-std=c++17", "-O3", "-fPIC", "-shared",
-            "-fno-signed-zeros",
+            "-fno-signed-zeros", "-fvisibility=hidden",
             "-DLFSD_G=%d" % g, '-DLFSD_MODEL_HEADER="gen/%s.h"' % spec.hash(),
             "-I" + CSRC_DIR, os.path.join(CSRC_DIR, "lfsd_capi.cpp"), "-o", out] + list(extra)
 
@@ -214,7 +214,7 @@ class ModelLibrary:
         if workspace is None or workspace.numel() * workspace.element_size() < need:
             workspace = torch.empty((need + 7) // 8, dtype=torch.int64, device=dev)
         if tol is None:
-            tol = 2e-5 if dt == torch.float32 else 1e-9
+            tol = 1e-6 if dt == torch.float32 else 1e-9
         rc = self.lib.lfsd_coc_solve(_DT[dt], B, n_grid, steps_per_grid, self._p(ini_state), self._p(horizon),
                                      self._p(auxvar), self._p(consts), per_traj, self._p(u_init),
                                      self._p(out["state_grid"]), self._p(out["control_grid"]),

@@ -1,0 +1,65 @@
+"""The C-ABI libraries export every symbol include/lfsd_cpdp.h declares and reject bad arguments
+(no compute: there is no GPU in this tier)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+import lfsd_amd  # noqa: F401
+from lfsd_amd import models, runtime
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    src = open(os.path.join(ROOT, "include", "lfsd_cpdp.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(lfsd_[a-z_]+)\s*\(", src)))
+
+
+def test_header_declares_expected_entry_points():
+    assert declared_symbols() == sorted(runtime.ModelLibrary.EXPORTS)
+
+
+@pytest.mark.parametrize("name", sorted(models.ZOO))
+def test_hip_library_exports_all_symbols(name):
+    oc, _, _ = models.ZOO[name]()
+    spec = oc.model_spec()
+    path = runtime.library_path(spec.hash())
+    if not os.path.exists(path):
+        path = runtime.build_library(spec)
+    lib = ctypes.CDLL(path)
+    for sym in declared_symbols():
+        assert hasattr(lib, sym), (name, sym)
+    ml = runtime.ModelLibrary(path)
+    assert not ml.is_emulator
+    assert (ml.n_state, ml.n_control, ml.n_auxvar) == (spec.n, spec.m, spec.p)
+    assert ml.hash == spec.hash() and ml.lanes == runtime.lanes_for(spec.n, spec.m, spec.p)
+    assert ml.time_varying == spec.time_varying
+    # argument validation happens before any launch
+    assert lib.lfsd_coc_solve(0, 0, 10, 4, None, None, None, None, 0, None, None, None, None, None, None, None,
+                              10, ctypes.c_double(1e-6), None, ctypes.c_size_t(0), None) == -1
+    assert lib.lfsd_coc_solve(7, 1, 10, 4, None, None, None, None, 0, None, None, None, None, None, None, None,
+                              10, ctypes.c_double(1e-6), None, ctypes.c_size_t(0), None) == -1
+    lib.lfsd_coc_workspace_bytes.restype = ctypes.c_size_t
+    assert lib.lfsd_coc_workspace_bytes(0, 4096, 50) > 0
+    assert lib.lfsd_coc_workspace_bytes(3, 4096, 50) == 0
+
+
+def test_product_refuses_cpu_tensors():
+    """No CPU fallback: the HIP library must fail loudly when handed host memory."""
+    import torch
+    oc, _, d = models.pendulum()
+    lib = oc.compile()
+    x0 = torch.zeros((1, 2), dtype=torch.float32)
+    with pytest.raises(runtime.LfsdError):
+        lib.coc_solve(x0, torch.ones(1), torch.ones((1, 3)), torch.tensor(lib.const_defaults, dtype=torch.float32), 10)
+    if not torch.cuda.is_available():
+        with pytest.raises(runtime.LfsdError):
+            oc.cocSolver(d["ini_state"], 1.0, [1, 1, 1])
+
+
+def test_missing_library_is_loud(tmp_path):
+    with pytest.raises(runtime.LfsdError):
+        runtime.ModelLibrary(str(tmp_path / "liblfsd_missing.so"))

@@ -1,0 +1,66 @@
+"""Pins the oracle to the reference's own saved run (tests/golden/uav_golden.npz, extracted by
+tests/golden/make_uav_golden.py from data/uav_results_random_20210308113016.mat): the real
+CasADi+IPOPT+solve_ivp pipeline produced these (theta, loss, dtheta) triples."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import make_oracle
+
+G = np.load(os.path.join(os.path.dirname(__file__), "golden", "uav_golden.npz"))
+
+
+@pytest.fixture(scope="module")
+def quad():
+    oc = make_oracle("quadrotor", int(G["n_grid"]), goal=tuple(G["goal_r"]))
+    oc.diffPMP()
+    return oc
+
+
+@pytest.mark.parametrize("j", [0, 60])
+def test_oracle_reproduces_reference_loss_and_gradient(quad, j):
+    """Reference-faithful mode (solve_ivp BDF / RK45 at scipy default tolerances, CPDP.py:335,368)."""
+    from oracle.cpdp_oracle import getloss_corrections
+    th = G["lookahead_theta"][j]
+    tg, sol = quad.cocSolver(G["ini_state"], float(G["horizon"]), th)
+    assert quad.last_info["converged"]
+    aux = quad.auxSysSolver(tg, sol, th)
+    loss, grad = getloss_corrections(quad, G["taus"], G["waypoints"], sol, aux, [0, 1, 2])
+    assert abs(loss - G["loss_trace"][j]) <= 1e-8 * G["loss_trace"][j]
+    assert np.abs(grad - G["grad_trace"][j]).max() <= 1e-5 * np.abs(G["grad_trace"][j]).max()
+
+
+def test_oracle_reproduces_reference_final_trajectory(quad):
+    """opt_state_traj / opt_control_traj saved by QuadAlgorithm.py:306-317 at the last parameter."""
+    th = G["theta_trace"][-1]
+    tg, sol, X, U, L = quad.cocSolver(G["ini_state"], float(G["horizon"]), th, return_grids=True)
+    tr = sol(G["time_steps"])
+    assert np.abs(tr[:, :13] - G["opt_state_traj"]).max() < 1e-8
+    assert np.abs(tr[:, 13:17] - G["opt_control_traj"]).max() < 1e-8
+    # solver-independent KKT certificate (complex-step roll-outs only)
+    defect, gmax, lmax = quad.kkt_certificate(G["ini_state"], float(G["horizon"]), th, X, U, L)
+    assert defect < 1e-10 and gmax < 1e-7 and lmax < 1e-9
+
+
+def test_nesterov_rule_replays_reference_parameter_trace():
+    """lib/QuadAlgorithm.py:469-495 with the golden gradients must replay parameter_trace."""
+    from oracle.cpdp_oracle import Optimizer
+    opt = Optimizer("Nesterov", 7, float(G["learning_rate"]), mu=float(G["mu"]))
+    th = G["theta_trace"][0].copy()
+    for j in range(100):
+        assert np.allclose(opt.lookahead(th), G["lookahead_theta"][j], rtol=0, atol=1e-12)
+        th = opt.step(th, G["grad_trace"][j], j)
+        th[0] = max(th[0], 1e-8)
+        assert np.allclose(th, G["theta_trace"][j + 1], rtol=0, atol=1e-10)
+
+
+def test_kkt_certificate_other_robots():
+    for kind, n_grid, x0, T, th in (("pendulum", 10, [0.0, 0.0], 1.0, [2, 1, 1]),
+                                    ("robotarm", 12, [-np.pi / 2, 0, 0, 0], 1.0, [5., 1, 1, 1, 1]),
+                                    ("cartpole", 10, [0, 0, 0, 0], 1.0, [2., 0.5, 0.5, 0.5, 0.5])):
+        oc = make_oracle(kind, n_grid)
+        tg, sol, X, U, L = oc.cocSolver(x0, T, th, return_grids=True)
+        assert oc.last_info["converged"], kind
+        defect, gmax, lmax = oc.kkt_certificate(x0, T, th, X, U, L)
+        assert defect < 1e-10 and gmax < 1e-6 and lmax < 1e-7, (kind, defect, gmax, lmax)
