@@ -1,0 +1,202 @@
+#!/usr/bin/env python3
+"""Headline benchmark: CPDP outer iterations/sec over a batch of trajectories (BASELINE.json metric).
+
+Workload (BASELINE.json configs[2]): Quadrotor CPDP with time-warping on the quad_example waypoints
+(Examples/quad_example.py), n_grid ("horizon") 50, 4 RK4 steps per grid interval, batch 4096 seeds per GPU,
+each seed with its own random initial guess theta_0 and its own optimizer state.  One "step" = one complete
+outer iteration for every seed (lib/QuadAlgorithm.py:469-486, Nesterov, lr 0.01, mu 0.9):
+    look-ahead point -> optimal-control solve (cold start, as the reference) -> differentiated PMP
+    (Riccati + sensitivity sweeps) -> waypoint loss and d(theta) -> parameter update + projection,
+plus, for N > 1 GPUs, the all-reduce (RCCL) of the summed parameter gradient and loss.
+`value` = seeds * N * K / wall seconds  (trajectory outer-iterations per second, whole job).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--dtype f32|f64]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
+VALU_PEAK_TFLOPS = {"f32": 157.3, "f64": 78.6}
+
+
+def algorithmic_bytes(kernel, n, m, p, nc, N, nw, ni, es):
+    """Bytes one trajectory's launch MUST move (inputs read once + outputs written once), DESIGN.md section 4."""
+    grids = (N + 1) * (2 * n + m)
+    if kernel == "oc_solve":
+        return es * (n + 1 + p + nc + grids + 1) + 8
+    if kernel == "aux_riccati":
+        return es * (1 + p + nc + grids + (N + 1) * n * (n + p))
+    if kernel == "aux_forward":
+        return es * (1 + p + nc + grids + (N + 1) * n * (n + p) + nw * (1 + ni) + 1 + p)
+    raise KeyError(kernel)
+
+
+def cpu_baseline(d, n_grid, thetas, n_sample):
+    """The oracle (fp64 port of the reference pipeline, 1 host core) on a bounded sample of the same seeds."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from conftest import make_oracle
+    from oracle.cpdp_oracle import getloss_corrections
+    o = make_oracle("quadrotor", n_grid)
+    o.diffPMP()
+    t0 = time.time()
+    done = 0
+    for b in range(n_sample):
+        tg, sol = o.cocSolver(d["ini_state"], d["horizon"], thetas[b])
+        aux = o.auxSysSolver(tg, sol, thetas[b])          # reference settings: BDF + RK45 at scipy defaults
+        getloss_corrections(o, d["taus"], d["waypoints"], sol, aux, d["interface"])
+        done += 1
+        if time.time() - t0 > 30:
+            break
+    dt = time.time() - t0
+    return dict(value=done / dt, unit="trajectory outer-iterations/s", cores=1, kind="port",
+                sample="%d of the %d seeds, 1 outer iteration each, oracle/cpdp_oracle.py (numpy/scipy fp64, "
+                       "solve_ivp BDF+RK45 as CPDP.py:335,368) in %.1f s" % (done, len(thetas), dt))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=4096)
+    ap.add_argument("--n-grid", type=int, default=50)
+    ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
+    ap.add_argument("--substeps", type=int, default=4)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)       # "nccl" == RCCL on ROCm
+    assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no CPU fallback)"
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    import lfsd_amd  # noqa: F401
+    from lfsd_amd import CPDP, models
+    dtype = torch.float32 if args.dtype == "f32" else torch.float64
+    oc, env, d = models.quadrotor(n_grid=args.n_grid)
+    oc.setDevice(dev, dtype)
+    oc.setSolverOptions(aux_substeps=args.substeps)
+    lib = oc.compile()
+    assert not lib.is_emulator
+    B = args.batch
+    rng = np.random.default_rng(1234 + rank)                                # different seeds on every rank (weak scaling)
+    theta0 = np.array(d["theta0"])[None, :] + 0.05 * rng.standard_normal((B, lib.n_auxvar))
+    theta0[:, 0] = np.abs(theta0[:, 0]) + 0.5
+    x0 = np.tile(d["ini_state"], (B, 1))
+    L = CPDP.SparseDemoLearner(oc, x0, d["horizon"], d["taus"], d["waypoints"], d["interface"], theta0,
+                               method="Nesterov", learning_rate=1e-2, mu=0.9)
+
+    # per-kernel HIP events on the stream the kernels are launched on (torch's current stream)
+    names = ("oc_solve", "aux_riccati", "aux_forward", "update")
+    ev = {k: [] for k in names}
+
+    def step(record):
+        e = [torch.cuda.Event(enable_timing=True) for _ in range(5)] if record else None
+        theta_eval = L.lib.lookahead(L.theta, L.m, L.mu)
+        th = theta_eval
+        if record:
+            e[0].record()
+        L._sol = oc.cocSolverBatch(L.x0, L.hz, th, consts=L.consts, workspace=L._ws, out=L._sol_out())
+        L._ws = L._sol["workspace"]
+
+        def hook(name):
+            if record:
+                {"riccati": e[1], "forward": e[2], "end": e[3]}[name].record()
+        L._aux = oc.auxSysSolverBatch(L._sol, L.taus, L.wps, L.iface, Z_grid=L._Z, out=L._aux_out(), phase_hook=hook)
+        L._Z = L._aux["Z_grid"]
+        loss, grad = L._aux["loss"], L._aux["grad"]
+        if world > 1:
+            buf = torch.cat([grad.sum(dim=0), loss.sum().reshape(1)])
+            dist.all_reduce(buf)                                            # summed d(theta) + loss over all ranks
+        L.lib.optimizer_step(L.method, L.theta, grad, L.iter_idx, L.lr, L.mu, L.b1, L.b2, L.eps, m=L.m, v=L.v,
+                             vhat=L.vhat, proj_lo=L.proj_lo)
+        L.iter_idx += 1
+        if record:
+            e[4].record()
+            for k, (a, b) in zip(names, ((e[0], e[1]), (e[1], e[2]), (e[2], e[3]), (e[3], e[4]))):
+                ev[k].append((a, b))
+        return loss
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step(False)
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step(True)
+    sync()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    ktime = {k: float(np.mean([a.elapsed_time(b) for a, b in v])) for k, v in ev.items()}    # ms per launch
+    st = L._sol["status"].cpu().numpy()
+    it = L._sol["iters"].cpu().numpy()
+    if rank == 0:
+        n, m, p, nc = lib.n_state, lib.n_control, lib.n_auxvar, lib.n_const
+        es = 4 if args.dtype == "f32" else 8
+        dom = max(("oc_solve", "aux_riccati", "aux_forward"), key=lambda k: ktime[k])
+        nw, ni = L.taus.shape[1], len(d["interface"])
+        abytes = B * algorithmic_bytes(dom, n, m, p, nc, args.n_grid, nw, ni, es)
+        achieved = abytes / (ktime[dom] * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get(dom, {}).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "CPDP outer iterations/sec (batch trajectories)",
+            "value": B * world * args.steps / elapsed,
+            "unit": "trajectory outer-iterations/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": "Quadrotor (JinEnv, initCost_Polynomial, beta time-warp) CPDP on the quad_example "
+                                   "waypoints, n_grid(horizon) %d x 4 RK4 steps, batch %d seeds per GPU with random "
+                                   "initial guesses, Nesterov lr 0.01 mu 0.9, cold-start OC solve every iteration"
+                                   % (args.n_grid, B),
+                       "batch_per_gpu": B, "n_grid": args.n_grid, "steps_per_grid": 4, "aux_substeps": args.substeps,
+                       "oc_status_hist": np.bincount(st, minlength=5).tolist(), "oc_iters_mean": float(it.mean()),
+                       "loss_mean": float(loss.mean().item()),
+                       "kernel_ms": {k: round(v, 3) for k, v in ktime.items()}},
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "algorithmic_bytes_per_launch": abytes, "avg_launch_ms": ktime[dom],
+                         "note": "the per-trajectory recursions are latency/VALU-issue bound, not HBM bound: "
+                                 "algorithmic bytes are O(10 KB) per trajectory against O(10^8) FLOP of sequential "
+                                 "fp32 vector work; see DESIGN.md section 4"},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(d, args.n_grid, theta0, 4)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -12,7 +12,7 @@
  * Reference interface each entry point replaces (wanxinjin/Learning-from-
  * Sparse-Demonstrations @ v1):
  *   lfsd_coc_solve        CPDP/CPDP.py:92-198   COCSys.cocSolver (and :486-594 time-varying)
- *   lfsd_aux_solve        CPDP/CPDP.py:301-381  COCSys.auxSysSolver (and :706-786)
+ *   lfsd_aux_solve        CPDP/CPDP.py:301-381  COCSys.auxSysSolver (and :706-786)   [= lfsd_aux_riccati + lfsd_aux_forward]
  *                         + lib/QuadAlgorithm.py:616-673 getloss_pos_corrections / getloss_corrections
  *                           (Examples/*.py getloss_corrections)
  *   lfsd_optimizer_step   lib/QuadAlgorithm.py:454-578 Vanilla/Nesterov/Adam/Nadam/AMSGrad
@@ -97,6 +97,22 @@ int lfsd_aux_solve(int dtype, int batch, int n_grid,
                    const void* taus, const void* waypoints,
                    void* loss, void* grad, void* auxX_grid, void* auxU_grid,
                    int substeps, void* stream);
+
+/* The two phases of lfsd_aux_solve as separate launches (same arguments; lfsd_aux_solve == riccati then forward):
+ *   lfsd_aux_riccati  CPDP/CPDP.py:316-338  backward Riccati sweep, fills Z_grid
+ *   lfsd_aux_forward  CPDP/CPDP.py:340-381  forward sensitivity sweep from Z_grid + loss/gradient          */
+int lfsd_aux_riccati(int dtype, int batch, int n_grid,
+                     const void* horizon, const void* auxvar, const void* consts, int const_per_traj,
+                     const void* state_grid, const void* control_grid, const void* costate_grid,
+                     void* Z_grid, int substeps, void* stream);
+int lfsd_aux_forward(int dtype, int batch, int n_grid,
+                     const void* horizon, const void* auxvar, const void* consts, int const_per_traj,
+                     const void* state_grid, const void* control_grid, const void* costate_grid,
+                     const void* Z_grid,
+                     int n_waypoints, int n_iface, const int* iface_idx,
+                     const void* taus, const void* waypoints,
+                     void* loss, void* grad, void* auxX_grid, void* auxU_grid,
+                     int substeps, void* stream);
 
 /* theta <- update(theta, grad) for every trajectory; m/v/vhat are optimizer state [B][n_param]
  * (m: Nesterov velocity or first moment; v: second moment; vhat: AMSGrad max; unused ones may be NULL).

@@ -224,7 +224,7 @@ class COCSys:
         return sol
 
     def auxSysSolverBatch(self, sol, taus=None, waypoints=None, interface_idx=None, auxvar=None, want_grids=False,
-                          Z_grid=None, out=None):
+                          Z_grid=None, out=None, phase_hook=None):
         """Differentiate the PMP along ``sol`` and (optionally) evaluate the sparse-waypoint loss + gradient."""
         lib = self.compile()
         B = sol["state_grid"].shape[0]
@@ -240,7 +240,7 @@ class COCSys:
             ii = torch.as_tensor(list(interface_idx), dtype=torch.int32, device=self._dev())
         return lib.aux_solve(sol["horizon"], th, sol["consts"], sol["state_grid"], sol["control_grid"],
                              sol["costate_grid"], tt, wp, ii, substeps=self.aux_substeps, want_grids=want_grids,
-                             Z_grid=Z_grid, out=out)
+                             Z_grid=Z_grid, out=out, phase_hook=phase_hook)
 
     # ---- the reference's one-trajectory calls --------------------------------------------------------
     def cocSolver(self, ini_state, horizon, auxvar_value=1, interplation_level=1, print_level=0):

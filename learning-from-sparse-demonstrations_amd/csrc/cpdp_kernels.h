@@ -29,6 +29,11 @@
 #define LFSD_DEV __device__ __forceinline__
 #endif
 
+// register budget: measured on MI355X (tools/tune.py) 1 wave/SIMD with all 512 VGPR+AGPR beats 2-3 waves with scratch spills
+#ifndef LFSD_WAVES_PER_SIMD
+#define LFSD_WAVES_PER_SIMD 1
+#endif
+
 namespace lfsd {
 
 // debug aid for the emulator build: start every kernel with NaN-filled LDS so that a read of
@@ -155,7 +160,11 @@ template <int n, typename T> LFSD_DEV void matmul(const T* A, const T* B, T* C) 
 }
 // P = phi1(M) = M^-1 (I - exp(-M)) for a small matrix with non-negative spectrum
 // (scaling and squaring: Taylor of degree 8 on M/2^s, then phi1(2A) = (I + e^-A) phi1(A) / 2).
-template <int n, typename T> LFSD_DEV void phi1_neg(const T* M, T* P) {
+template <typename T> struct PhiDeg;
+template <> struct PhiDeg<float> { static constexpr int v = 6; };
+template <> struct PhiDeg<double> { static constexpr int v = 9; };
+// P = phi1(M), P2 = phi1(2M)
+template <int n, typename T> LFSD_DEV void phi1_neg(const T* M, T* P, T* P2) {
   T nrm = T(0);
 #pragma unroll
   for (int i = 0; i < n; ++i) {
@@ -170,12 +179,13 @@ template <int n, typename T> LFSD_DEV void phi1_neg(const T* M, T* P) {
   T A[n * n], E[n * n], W[n * n];
 #pragma unroll
   for (int i = 0; i < n * n; ++i) { A[i] = M[i] * sc; P[i] = T(0); }
-  const T ck[9] = {T(1), T(1) / T(2), T(1) / T(6), T(1) / T(24), T(1) / T(120), T(1) / T(720), T(1) / T(5040),
-                   T(1) / T(40320), T(1) / T(362880)};
+  const T ck[10] = {T(1), T(1) / T(2), T(1) / T(6), T(1) / T(24), T(1) / T(120), T(1) / T(720), T(1) / T(5040),
+                    T(1) / T(40320), T(1) / T(362880), T(1) / T(3628800)};
+  constexpr int DEG = PhiDeg<T>::v;       // |A| <= 1/4: truncation 4^-(DEG+1)/(DEG+2)! below round-off
 #pragma unroll
-  for (int i = 0; i < n; ++i) P[i * n + i] = ck[8];
+  for (int i = 0; i < n; ++i) P[i * n + i] = ck[DEG];
 #pragma unroll
-  for (int k = 7; k >= 0; --k) {
+  for (int k = DEG - 1; k >= 0; --k) {
     matmul<n>(A, P, W);
 #pragma unroll
     for (int i = 0; i < n * n; ++i) P[i] = -W[i];
@@ -195,6 +205,9 @@ template <int n, typename T> LFSD_DEV void phi1_neg(const T* M, T* P) {
 #pragma unroll
     for (int i = 0; i < n * n; ++i) E[i] = W[i];
   }
+  matmul<n>(E, P, W);
+#pragma unroll
+  for (int i = 0; i < n * n; ++i) P2[i] = T(0.5) * (P[i] + W[i]);
 }
 template <int n, typename T> LFSD_DEV void matvec(const T* A, const T* v, T* y) {
 #pragma unroll
@@ -555,7 +568,7 @@ template <class M, typename T, int G> struct OcSolver {
 };
 
 template <class M, typename T, int G>
-__global__ void __launch_bounds__(64) oc_solve_kernel(OcArgs<T> a) {
+__global__ void __launch_bounds__(64, LFSD_WAVES_PER_SIMD) oc_solve_kernel(OcArgs<T> a) {
   using Sol = OcSolver<M, T, G>;
   using Lay = OcLayout<M>;
   constexpr int NX = M::NX, NU = M::NU, NP = M::NP, NC = M::NC;
@@ -604,6 +617,8 @@ __global__ void __launch_bounds__(64) oc_solve_kernel(OcArgs<T> a) {
   bool need_bw = true;      // costates on `lam_out` are stale
   T gnorm = T(0), dV1 = T(0), dV2 = T(0);
   T g_flat = T(-1);         // gradient norm at the last accepted noise-level ("flat") step; <0: none yet
+  T J_ref = J;              // cost 4 iterations ago (stagnation window)
+  int it_ref = 0;
   if (!t_finite(J)) status = ST_FAILED;
   for (; it < a.max_iter; ++it) {
     if (threadIdx.x == 0) vote[0] = 0;
@@ -662,6 +677,11 @@ __global__ void __launch_bounds__(64) oc_solve_kernel(OcArgs<T> a) {
         J = Jn;
       }
     }
+    if (status == ST_RUNNING && it - it_ref >= 4) {
+      // four iterations that together gain less than rounding noise: converged to working precision
+      if (J_ref - J <= T(16) * Eps<T>::v() * t_abs(J)) status = ST_STALLED;
+      J_ref = J; it_ref = it;
+    }
     __syncthreads();
   }
   if (status == ST_RUNNING) status = ST_MAXITER;
@@ -710,7 +730,9 @@ template <class M> struct AuxLayout {
   static constexpr int LDS_L = 0;
   static constexpr int LDS_S = LDS_L + NNODE * M::NCOEF;
   static constexpr int LDS_T = LDS_S + NX * NU;
-  static constexpr int LDS_END = LDS_T + NX * NZ;
+  static constexpr int LDS_KN = LDS_T + NX * NZ;              // 3 stiff nodes x (NX x NU) feedback rows K^T
+  static constexpr int LDS_PSI = LDS_KN + 3 * NX * NU;        // 3 stiff nodes x {phi1(h/4 K fu), phi1(h/2 K fu)}
+  static constexpr int LDS_END = LDS_PSI + 3 * 2 * NU * NU;
   static constexpr int lds_elems() { return ((LDS_END + 3) / 4) * 4; }
 };
 
@@ -875,34 +897,54 @@ template <class M, typename T, int G> struct AuxCtx {
   // stiff sub-flow  X' = -fu K X,  K = Huu^-1 fu^T P (frozen over the sub-step), solved exactly:
   //   X(dt) = X - dt fu phi1(dt K fu) K X,   phi1(M) = M^-1 (I - e^-M)   (m x m matrix function).
   // (An A-stable rational step is not enough here: with a cheap control cost dt*|K fu| reaches O(10^2).)
-  LFSD_DEV void fwd_stiff(T* xa, const T* zt, const T* L, T dt) {
-    T* ldsS = lds + Lay::LDS_S;
-    const T* iH = L + M::OFF_IHUU;
-    T s[NU], kj[NU];
-    M::template fu_mulT<false>(L, zt, s);          // P lanes: fu^T p_j
-    matvec<NU>(iH, s, kj);
-    if (lane < NX) {
+  // fwd_prep: for the three stiff nodes (0, 2, 4) of a unit the P lanes gather K(t_node); then lanes 0..2
+  // each evaluate phi1 for ONE node (quarter and half step), so the matrix function costs one evaluation per unit.
+  LFSD_DEV void fwd_prep(const T* zA, const T* zB, T s0, T ds, T hq) {
+    T* ldsK = lds + Lay::LDS_KN;
+    T* ldsP = lds + Lay::LDS_PSI;
 #pragma unroll
-      for (int a = 0; a < NU; ++a) ldsS[lane * NU + a] = kj[a];
+    for (int r = 0; r < 3; ++r) {
+      const T* L = node(2 * r);
+      const T sr = s0 + T(2 * r) * ds;
+      T zt[NX], sv[NU], kj[NU];
+#pragma unroll
+      for (int i = 0; i < NX; ++i) zt[i] = zA[i] + sr * (zB[i] - zA[i]);
+      M::template fu_mulT<false>(L, zt, sv);
+      matvec<NU>(L + M::OFF_IHUU, sv, kj);
+      if (lane < NX) {
+#pragma unroll
+        for (int a = 0; a < NU; ++a) ldsK[(r * NX + lane) * NU + a] = kj[a];
+      }
     }
     __syncthreads();
-    T Mx[NU * NU], Psi[NU * NU], kx[NU], y[NU];
-    M::template fu_gram<false>(L, ldsS, Mx);       // K fu
+    if (lane < 3) {
+      T Mx[NU * NU], Pq[NU * NU], Ph[NU * NU];
+      M::template fu_gram<false>(node(2 * lane), ldsK + lane * NX * NU, Mx);       // K fu
 #pragma unroll
-    for (int i = 0; i < NU * NU; ++i) Mx[i] *= dt;
-    phi1_neg<NU>(Mx, Psi);
+      for (int i = 0; i < NU * NU; ++i) Mx[i] *= hq;
+      phi1_neg<NU>(Mx, Pq, Ph);
+#pragma unroll
+      for (int i = 0; i < NU * NU; ++i) { ldsP[lane * 2 * NU * NU + i] = Pq[i]; ldsP[(lane * 2 + 1) * NU * NU + i] = Ph[i]; }
+    }
+    __syncthreads();
+  }
+  // apply the prepared exact stiff step of node r (0..2); half = false: dt = hq, true: dt = 2 hq
+  LFSD_DEV void fwd_stiff(T* xa, int r, bool half, T hq) {
+    const T* Kn = lds + Lay::LDS_KN + r * NX * NU;
+    const T* Psi = lds + Lay::LDS_PSI + (r * 2 + (half ? 1 : 0)) * NU * NU;
+    T kx[NU], y[NU];
 #pragma unroll
     for (int a = 0; a < NU; ++a) kx[a] = T(0);
 #pragma unroll
     for (int i = 0; i < NX; ++i) {
 #pragma unroll
-      for (int a = 0; a < NU; ++a) kx[a] += ldsS[i * NU + a] * xa[i];
+      for (int a = 0; a < NU; ++a) kx[a] += Kn[i * NU + a] * xa[i];
     }
     matvec<NU>(Psi, kx, y);
+    const T dt = half ? T(2) * hq : hq;
 #pragma unroll
     for (int a = 0; a < NU; ++a) y[a] *= -dt;
-    M::template fu_mul<true>(L, y, xa);
-    __syncthreads();
+    M::template fu_mul<true>(node(2 * r), y, xa);
   }
   // non-stiff part  X' = fx X + fe - fu Huu^-1 (Hux X + Hue + fu^T W)
   LFSD_DEV void fwd_rhs(const T* xa, const T* wt, const T* L, T* y) {
@@ -918,12 +960,11 @@ template <class M, typename T, int G> struct AuxCtx {
     M::template fe_mul<true>(L, oe, y);
     M::template fu_mul<true>(L, v, y);
   }
-  // zA/zB: this lane's Z column at both interval ends; sA..: node fractions
-  LFSD_DEV void fwd_strang(T* xa, const T* zA, const T* zB, int n0, int n1, int n2, T s0, T s1, T s2, T h) {
+  // non-stiff RK4 step of length h over nodes (n0, n1, n2); zA/zB: this lane's Z column at both interval ends
+  LFSD_DEV void fwd_rk4(T* xa, const T* zA, const T* zB, int n0, int n1, int n2, T s0, T s1, T s2, T h) {
     T zt[NX], k[NX], acc[NX], xs[NX];
 #pragma unroll
     for (int i = 0; i < NX; ++i) zt[i] = zA[i] + s0 * (zB[i] - zA[i]);
-    fwd_stiff(xa, zt, node(n0), h * T(0.5));
     fwd_rhs(xa, zt, node(n0), k);
 #pragma unroll
     for (int i = 0; i < NX; ++i) { acc[i] = k[i]; xs[i] = xa[i] + T(0.5) * h * k[i]; zt[i] = zA[i] + s1 * (zB[i] - zA[i]); }
@@ -936,7 +977,6 @@ template <class M, typename T, int G> struct AuxCtx {
     fwd_rhs(xs, zt, node(n2), k);
 #pragma unroll
     for (int i = 0; i < NX; ++i) xa[i] += h / T(6) * (acc[i] + k[i]);
-    fwd_stiff(xa, zt, node(n2), h * T(0.5));
   }
   // auxiliary control at a grid point (CPDP.py:295):  U = -Huu^-1((Hux + fu^T P) X + fu^T W + Hue)
   LFSD_DEV void aux_control(const T* xa, const T* zt, const T* L, T* uo) {
@@ -982,7 +1022,7 @@ template <class M, typename T, int G> LFSD_DEV void aux_setup(AuxCtx<M, T, G>& s
 }
 
 template <class M, typename T, int G>
-__global__ void __launch_bounds__(64) aux_riccati_kernel(AuxArgs<T> a) {
+__global__ void __launch_bounds__(64, LFSD_WAVES_PER_SIMD) aux_riccati_kernel(AuxArgs<T> a) {
   using Ctx = AuxCtx<M, T, G>;
   using Lay = AuxLayout<M>;
   constexpr int NX = M::NX, NP = M::NP, NZ = NX + NP;
@@ -1054,7 +1094,7 @@ __global__ void __launch_bounds__(64) aux_riccati_kernel(AuxArgs<T> a) {
 }
 
 template <class M, typename T, int G>
-__global__ void __launch_bounds__(64) aux_forward_kernel(AuxArgs<T> a) {
+__global__ void __launch_bounds__(64, LFSD_WAVES_PER_SIMD) aux_forward_kernel(AuxArgs<T> a) {
   using Ctx = AuxCtx<M, T, G>;
   using Lay = AuxLayout<M>;
   constexpr int NX = M::NX, NU = M::NU, NP = M::NP, NZ = NX + NP;
@@ -1108,9 +1148,19 @@ __global__ void __launch_bounds__(64) aux_forward_kernel(AuxArgs<T> a) {
       T xc[NX], xf[NX];
 #pragma unroll
       for (int i = 0; i < NX; ++i) { xc[i] = xa[i]; xf[i] = xa[i]; }
-      s.fwd_strang(xc, zA, zB, 0, 2, 4, s_lo, s_lo + T(2) * ds, s_lo + T(4) * ds, hc);
-      s.fwd_strang(xf, zA, zB, 0, 1, 2, s_lo, s_lo + ds, s_lo + T(2) * ds, hc * T(0.5));
-      s.fwd_strang(xf, zA, zB, 2, 3, 4, s_lo + T(2) * ds, s_lo + T(3) * ds, s_lo + T(4) * ds, hc * T(0.5));
+      const T hq = hc * T(0.25);
+      s.fwd_prep(zA, zB, s_lo, ds, hq);
+      // coarse Strang step (stiff h/2, RK4 h, stiff h/2) and two fine ones; the two adjacent fine stiff
+      // quarter-steps at the middle node compose exactly into one half-step
+      s.fwd_stiff(xc, 0, true, hq);
+      s.fwd_rk4(xc, zA, zB, 0, 2, 4, s_lo, s_lo + T(2) * ds, s_lo + T(4) * ds, hc);
+      s.fwd_stiff(xc, 2, true, hq);
+      s.fwd_stiff(xf, 0, false, hq);
+      s.fwd_rk4(xf, zA, zB, 0, 1, 2, s_lo, s_lo + ds, s_lo + T(2) * ds, hc * T(0.5));
+      s.fwd_stiff(xf, 1, true, hq);
+      s.fwd_rk4(xf, zA, zB, 2, 3, 4, s_lo + T(2) * ds, s_lo + T(3) * ds, s_lo + T(4) * ds, hc * T(0.5));
+      s.fwd_stiff(xf, 2, false, hq);
+      __syncthreads();      // all reads of this unit's staged coefficients are done before the next staging
 #pragma unroll
       for (int i = 0; i < NX; ++i) xa[i] = xlane ? (T(4) * xf[i] - xc[i]) / T(3) : T(0);
       if (Uo && k == N - 1 && unit == units - 1) {

@@ -96,7 +96,7 @@ LFSD_API int lfsd_coc_solve(int dtype, int batch, int n_grid, int steps_per_grid
 }
 
 template <typename T>
-static int aux_solve_t(int batch, int n_grid, const void* horizon, const void* auxvar, const void* consts,
+static int aux_phase_t(int phases, int batch, int n_grid, const void* horizon, const void* auxvar, const void* consts,
                        int const_per_traj, const void* state_grid, const void* control_grid, const void* costate_grid,
                        void* Z_grid, int n_waypoints, int n_iface, const int* iface_idx, const void* taus,
                        const void* waypoints, void* loss, void* grad, void* auxX_grid, void* auxU_grid, int substeps,
@@ -113,32 +113,66 @@ static int aux_solve_t(int batch, int n_grid, const void* horizon, const void* a
   a.taus = (const T*)taus; a.waypoints = (const T*)waypoints;
   a.loss = (T*)loss; a.grad = (T*)grad; a.auxX_grid = (T*)auxX_grid; a.auxU_grid = (T*)auxU_grid;
   const unsigned grid = (unsigned)(padded_batch(batch) / GPB);
-  LFSD_LAUNCH((lfsd::aux_riccati_kernel<Model, T, G>), grid, 64, stream, a);
-  int rc = launch_status();
-  if (rc) return rc;
-  LFSD_LAUNCH((lfsd::aux_forward_kernel<Model, T, G>), grid, 64, stream, a);
-  return launch_status();
+  if (phases & 1) {
+    LFSD_LAUNCH((lfsd::aux_riccati_kernel<Model, T, G>), grid, 64, stream, a);
+    const int rc = launch_status();
+    if (rc) return rc;
+  }
+  if (phases & 2) {
+    LFSD_LAUNCH((lfsd::aux_forward_kernel<Model, T, G>), grid, 64, stream, a);
+    return launch_status();
+  }
+  return 0;
 }
 
-LFSD_API int lfsd_aux_solve(int dtype, int batch, int n_grid, const void* horizon, const void* auxvar,
-                              const void* consts, int const_per_traj, const void* state_grid, const void* control_grid,
-                              const void* costate_grid, void* Z_grid, int n_waypoints, int n_iface,
-                              const int* iface_idx, const void* taus, const void* waypoints, void* loss, void* grad,
-                              void* auxX_grid, void* auxU_grid, int substeps, void* stream) {
+static int aux_dispatch(int phases, int dtype, int batch, int n_grid, const void* horizon, const void* auxvar,
+                        const void* consts, int const_per_traj, const void* state_grid, const void* control_grid,
+                        const void* costate_grid, void* Z_grid, int n_waypoints, int n_iface, const int* iface_idx,
+                        const void* taus, const void* waypoints, void* loss, void* grad, void* auxX_grid,
+                        void* auxU_grid, int substeps, void* stream) {
   if (batch <= 0 || n_grid <= 0 || n_waypoints < 0 || n_iface < 0 || substeps < 0) return LFSD_EINVAL;
-  if (!horizon || !auxvar || !state_grid || !control_grid || !costate_grid || !Z_grid || !loss || !grad)
-    return LFSD_EINVAL;
-  if (n_waypoints > 0 && (n_iface <= 0 || !iface_idx || !taus || !waypoints)) return LFSD_EINVAL;
+  if (!horizon || !auxvar || !state_grid || !control_grid || !costate_grid || !Z_grid) return LFSD_EINVAL;
+  if ((phases & 2) && (!loss || !grad)) return LFSD_EINVAL;
+  if ((phases & 2) && n_waypoints > 0 && (n_iface <= 0 || !iface_idx || !taus || !waypoints)) return LFSD_EINVAL;
   if (Model::NC_REAL > 0 && !consts) return LFSD_EINVAL;
   if (dtype == LFSD_F32)
-    return aux_solve_t<float>(batch, n_grid, horizon, auxvar, consts, const_per_traj, state_grid, control_grid,
+    return aux_phase_t<float>(phases, batch, n_grid, horizon, auxvar, consts, const_per_traj, state_grid, control_grid,
                               costate_grid, Z_grid, n_waypoints, n_iface, iface_idx, taus, waypoints, loss, grad,
                               auxX_grid, auxU_grid, substeps, stream);
   if (dtype == LFSD_F64)
-    return aux_solve_t<double>(batch, n_grid, horizon, auxvar, consts, const_per_traj, state_grid, control_grid,
-                               costate_grid, Z_grid, n_waypoints, n_iface, iface_idx, taus, waypoints, loss, grad,
-                               auxX_grid, auxU_grid, substeps, stream);
+    return aux_phase_t<double>(phases, batch, n_grid, horizon, auxvar, consts, const_per_traj, state_grid,
+                               control_grid, costate_grid, Z_grid, n_waypoints, n_iface, iface_idx, taus, waypoints,
+                               loss, grad, auxX_grid, auxU_grid, substeps, stream);
   return LFSD_EINVAL;
+}
+
+LFSD_API int lfsd_aux_solve(int dtype, int batch, int n_grid, const void* horizon, const void* auxvar,
+                            const void* consts, int const_per_traj, const void* state_grid, const void* control_grid,
+                            const void* costate_grid, void* Z_grid, int n_waypoints, int n_iface,
+                            const int* iface_idx, const void* taus, const void* waypoints, void* loss, void* grad,
+                            void* auxX_grid, void* auxU_grid, int substeps, void* stream) {
+  return aux_dispatch(3, dtype, batch, n_grid, horizon, auxvar, consts, const_per_traj, state_grid, control_grid,
+                      costate_grid, Z_grid, n_waypoints, n_iface, iface_idx, taus, waypoints, loss, grad, auxX_grid,
+                      auxU_grid, substeps, stream);
+}
+
+LFSD_API int lfsd_aux_riccati(int dtype, int batch, int n_grid, const void* horizon, const void* auxvar,
+                              const void* consts, int const_per_traj, const void* state_grid,
+                              const void* control_grid, const void* costate_grid, void* Z_grid, int substeps,
+                              void* stream) {
+  return aux_dispatch(1, dtype, batch, n_grid, horizon, auxvar, consts, const_per_traj, state_grid, control_grid,
+                      costate_grid, Z_grid, 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
+                      substeps, stream);
+}
+
+LFSD_API int lfsd_aux_forward(int dtype, int batch, int n_grid, const void* horizon, const void* auxvar,
+                              const void* consts, int const_per_traj, const void* state_grid,
+                              const void* control_grid, const void* costate_grid, const void* Z_grid, int n_waypoints,
+                              int n_iface, const int* iface_idx, const void* taus, const void* waypoints, void* loss,
+                              void* grad, void* auxX_grid, void* auxU_grid, int substeps, void* stream) {
+  return aux_dispatch(2, dtype, batch, n_grid, horizon, auxvar, consts, const_per_traj, state_grid, control_grid,
+                      costate_grid, const_cast<void*>(Z_grid), n_waypoints, n_iface, iface_idx, taus, waypoints, loss,
+                      grad, auxX_grid, auxU_grid, substeps, stream);
 }
 
 template <typename T>

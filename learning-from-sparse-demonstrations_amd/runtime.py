@@ -106,7 +106,7 @@ class ModelLibrary:
     """One loaded model library (all entry points of include/lfsd_cpdp.h)."""
 
     EXPORTS = ("lfsd_get_model_info", "lfsd_const_default", "lfsd_coc_workspace_bytes", "lfsd_coc_solve",
-               "lfsd_aux_solve", "lfsd_optimizer_step", "lfsd_lookahead")
+               "lfsd_aux_solve", "lfsd_aux_riccati", "lfsd_aux_forward", "lfsd_optimizer_step", "lfsd_lookahead")
 
     def __init__(self, path):
         if not os.path.exists(path):
@@ -128,6 +128,9 @@ class ModelLibrary:
                                      ctypes.c_size_t, vp]
         L.lfsd_aux_solve.argtypes = [ci, ci, ci, vp, vp, vp, ci, vp, vp, vp, vp, ci, ci, vp, vp, vp, vp, vp, vp, vp,
                                      ci, vp]
+        L.lfsd_aux_riccati.argtypes = [ci, ci, ci, vp, vp, vp, ci, vp, vp, vp, vp, ci, vp]
+        L.lfsd_aux_forward.argtypes = [ci, ci, ci, vp, vp, vp, ci, vp, vp, vp, vp, ci, ci, vp, vp, vp, vp, vp, vp, vp,
+                                       ci, vp]
         L.lfsd_optimizer_step.argtypes = [ci, ci, ci, ci, ci, cd, cd, cd, cd, cd, vp, vp, vp, vp, vp, vp, vp]
         L.lfsd_lookahead.argtypes = [ci, ctypes.c_longlong, cd, vp, vp, vp, vp]
         info = _ModelInfo()
@@ -226,7 +229,9 @@ class ModelLibrary:
         return out
 
     def aux_solve(self, horizon, auxvar, consts, state_grid, control_grid, costate_grid, taus, waypoints, iface_idx,
-                  substeps=0, want_grids=False, Z_grid=None, out=None):
+                  substeps=0, want_grids=False, Z_grid=None, out=None, phase_hook=None):
+        """``phase_hook(name)``, if given, is called before/after each of the two launches
+        ("riccati", "forward") so a caller can bracket them with HIP events (bench.py)."""
         dt = state_grid.dtype
         B, N1, n = state_grid.shape
         N = N1 - 1
@@ -262,12 +267,18 @@ class ModelLibrary:
         if want_grids:
             auxX = torch.empty((B, N + 1, p, n), dtype=dt, device=dev)
             auxU = torch.empty((B, N + 1, p, m), dtype=dt, device=dev)
-        rc = self.lib.lfsd_aux_solve(_DT[dt], B, N, self._p(horizon), self._p(auxvar), self._p(consts), per_traj,
-                                     self._p(state_grid), self._p(control_grid), self._p(costate_grid),
-                                     self._p(Z_grid), nw, ni, self._p(iface_idx), self._p(taus), self._p(waypoints),
-                                     self._p(out["loss"]), self._p(out["grad"]), self._p(auxX), self._p(auxU),
-                                     int(substeps), self._stream(state_grid))
-        self._rc(rc, "lfsd_aux_solve")
+        common = (_DT[dt], B, N, self._p(horizon), self._p(auxvar), self._p(consts), per_traj,
+                  self._p(state_grid), self._p(control_grid), self._p(costate_grid), self._p(Z_grid))
+        tail = (nw, ni, self._p(iface_idx), self._p(taus), self._p(waypoints), self._p(out["loss"]),
+                self._p(out["grad"]), self._p(auxX), self._p(auxU), int(substeps), self._stream(state_grid))
+        if phase_hook is None:
+            self._rc(self.lib.lfsd_aux_solve(*common, *tail), "lfsd_aux_solve")
+        else:
+            phase_hook("riccati")
+            self._rc(self.lib.lfsd_aux_riccati(*common, int(substeps), self._stream(state_grid)), "lfsd_aux_riccati")
+            phase_hook("forward")
+            self._rc(self.lib.lfsd_aux_forward(*common, *tail), "lfsd_aux_forward")
+            phase_hook("end")
         out["Z_grid"] = Z_grid
         out["auxX_grid"], out["auxU_grid"] = auxX, auxU
         return out

@@ -26,9 +26,7 @@ def test_header_declares_expected_entry_points():
 def test_hip_library_exports_all_symbols(name):
     oc, _, _ = models.ZOO[name]()
     spec = oc.model_spec()
-    path = runtime.library_path(spec.hash())
-    if not os.path.exists(path):
-        path = runtime.build_library(spec)
+    path = runtime.build_library(spec)        # no-op when the in-tree .so is newer than its sources
     lib = ctypes.CDLL(path)
     for sym in declared_symbols():
         assert hasattr(lib, sym), (name, sym)

@@ -91,7 +91,7 @@ def test_robotarm_and_cartpole_fp32(emu):
         oc, d, sol, aux = run_case(emu, kind, torch.float64, thetas, taus, wps, n_grid, substeps=16)
         for b, th in enumerate(thetas):
             r = oracle_loss_grad(o, d["ini_state"], d["horizon"], th, taus, wps, d["interface"])
-            assert abs(aux["loss"][b].item() - r["loss"]) < 1e-7 * max(1.0, r["loss"]), kind
+            assert abs(aux["loss"][b].item() - r["loss"]) < 1e-6 * max(1.0, r["loss"]), kind
             assert rel(aux["grad"][b], r["grad"]) < 1e-4, kind
 
 

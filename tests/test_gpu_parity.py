@@ -1,0 +1,177 @@
+"""-m gpu tier: the real gfx950 libraries, called through the C ABI, vs the oracle and the golden fixture."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import lfsd_amd  # noqa: F401
+from lfsd_amd import CPDP, models, runtime
+from conftest import make_oracle, oracle_loss_grad
+
+pytestmark = pytest.mark.gpu
+G = np.load(os.path.join(os.path.dirname(__file__), "golden", "uav_golden.npz"))
+
+
+def rel(a, b):
+    a = a.detach().double().cpu().numpy() if isinstance(a, torch.Tensor) else np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-300)
+
+
+def gpu_model(kind, dtype, n_grid, substeps=8):
+    oc, env, d = models.ZOO[kind](n_grid=n_grid)
+    oc.setDevice("cuda:0", dtype)
+    oc.setSolverOptions(aux_substeps=substeps)
+    lib = oc.compile()
+    assert not lib.is_emulator, "the GPU tier must run the HIP library"
+    return oc, d
+
+
+# stated tolerances: fp64 (loss 1e-7, grad 1e-4 at 8-16 substeps); fp32 = fp64->fp32 tolerance of the
+# pipeline (loss 1e-4 well-conditioned / 2e-3 flat-cost problems, gradient 5e-3 / 2e-2)
+@pytest.mark.parametrize("dtype,ltol,gtol", [(torch.float64, 1e-7, 1e-4), (torch.float32, 1e-4, 5e-3)])
+def test_pendulum_vs_oracle(dtype, ltol, gtol):
+    oc, d = gpu_model("pendulum", dtype, 10, substeps=16)
+    thetas = np.array([[1.0, 0.5, 1.5], [2.0, 1.0, 1.0], [0.7, 1.3, 0.6]])
+    taus, wps = [0.0, 0.3, 0.6, 0.7, 1.0], [[0.0], [1.2], [2.1], [2.4], [2.9]]
+    sol = oc.cocSolverBatch(np.tile(d["ini_state"], (3, 1)), d["horizon"], thetas)
+    aux = oc.auxSysSolverBatch(sol, taus, wps, d["interface"], want_grids=True)
+    o = make_oracle("pendulum", 10)
+    assert set(sol["status"].tolist()) <= {1, 2}
+    for b in range(3):
+        r = oracle_loss_grad(o, d["ini_state"], d["horizon"], thetas[b], taus, wps, d["interface"])
+        assert rel(sol["state_grid"][b], r["X"]) < (1e-6 if dtype == torch.float64 else 5e-3)
+        assert abs(aux["loss"][b].item() - r["loss"]) < ltol * max(1.0, r["loss"])
+        assert rel(aux["grad"][b], r["grad"]) < gtol
+        n, p = 2, 3
+        assert rel(aux["auxX_grid"][b].permute(0, 2, 1).reshape(-1, n * p), r["vX"]) < (1e-3 if dtype == torch.float64 else 1e-2)
+
+
+@pytest.mark.parametrize("kind,n_grid,thetas,taus,wps", [
+    ("robotarm", 12, [[5., 1, 1, 1, 1], [3., 0.5, 2, 1.5, 0.2]], [0.3], [[-np.pi / 4, 2 * np.pi / 3]]),
+    ("cartpole", 10, [[1.0, 0.5, 0.5, 0.5, 0.5], [0.8, 2, 0.3, 1, 1]], [0.25, 0.8], [[0.1, 0.5], [0.0, 2.5]])])
+def test_robotarm_cartpole_vs_oracle(kind, n_grid, thetas, taus, wps):
+    o = make_oracle(kind, n_grid)
+    refs = None
+    for dtype, ltol, gtol in ((torch.float64, 1e-6, 1e-4), (torch.float32, 2e-3, 2e-2)):
+        oc, d = gpu_model(kind, dtype, n_grid, substeps=16)
+        refs = refs or [oracle_loss_grad(o, d["ini_state"], d["horizon"], th, taus, wps, d["interface"]) for th in thetas]
+        B = len(thetas)
+        sol = oc.cocSolverBatch(np.tile(d["ini_state"], (B, 1)), d["horizon"], np.array(thetas))
+        aux = oc.auxSysSolverBatch(sol, taus, wps, d["interface"])
+        for b in range(B):
+            assert abs(aux["loss"][b].item() - refs[b]["loss"]) < ltol * max(1.0, refs[b]["loss"]), (kind, dtype)
+            assert rel(aux["grad"][b], refs[b]["grad"]) < gtol, (kind, dtype)
+
+
+@pytest.mark.parametrize("dtype,ltol", [(torch.float64, 1e-6), (torch.float32, 1e-4)])
+def test_quadrotor_vs_reference_golden_run(dtype, ltol):
+    """(theta, loss, dtheta) triples produced by the reference's own CasADi+IPOPT+solve_ivp run.
+    Gradient tolerance 1e-2: the reference's solve_ivp (rtol 1e-3) is itself 5e-4..5e-3 off the exact ODE."""
+    oc, d = gpu_model("quadrotor", dtype, int(G["n_grid"]), substeps=4)
+    consts = oc.consts_tensor(overrides=dict(goal_r0=G["goal_r"][0], goal_r1=G["goal_r"][1], goal_r2=G["goal_r"][2]))
+    idx = list(range(0, 100, 3)) + [99]
+    sol = oc.cocSolverBatch(np.tile(G["ini_state"], (len(idx), 1)), float(G["horizon"]), G["lookahead_theta"][idx],
+                            consts=consts)
+    aux = oc.auxSysSolverBatch(sol, G["taus"], G["waypoints"], [0, 1, 2])
+    assert set(sol["status"].tolist()) <= {1, 2}
+    loss = aux["loss"].double().cpu().numpy()
+    assert np.all(np.abs(loss - G["loss_trace"][idx]) < ltol * G["loss_trace"][idx])
+    for k, j in enumerate(idx):
+        assert rel(aux["grad"][k], G["grad_trace"][j]) < 1e-2, j
+    if dtype == torch.float64:
+        oc.const_values = consts.tolist()
+        tg, opt = oc.cocSolver(G["ini_state"], float(G["horizon"]), G["theta_trace"][-1])
+        tr = opt(G["time_steps"])
+        assert np.abs(tr[:, :13] - G["opt_state_traj"]).max() < 1e-6
+        assert np.abs(tr[:, 13:17] - G["opt_control_traj"]).max() < 1e-6
+
+
+def test_quadrotor_loss_trace_parity_with_nesterov():
+    """Loss-vs-iteration parity with the CasADi CPU path: replay the reference's 100 Nesterov iterations
+    (lib/QuadAlgorithm.py:469-495, lr 0.01, mu 0.9) on the GPU in fp64 and compare the whole loss trace."""
+    oc, d = gpu_model("quadrotor", torch.float64, int(G["n_grid"]), substeps=8)
+    consts = oc.consts_tensor(overrides=dict(goal_r0=G["goal_r"][0], goal_r1=G["goal_r"][1], goal_r2=G["goal_r"][2]))
+    L = CPDP.SparseDemoLearner(oc, G["ini_state"], float(G["horizon"]), G["taus"], G["waypoints"], [0, 1, 2],
+                               G["theta_trace"][0], method="Nesterov", learning_rate=float(G["learning_rate"]),
+                               mu=float(G["mu"]), consts=consts)
+    losses = []
+    for j in range(40):
+        loss, grad = L.step()
+        losses.append(loss[0].item())
+    losses = np.array(losses)
+    # the trajectories of two optimisers fed slightly different gradients drift apart slowly: 2% over 40 iterations
+    assert np.all(np.abs(losses - G["loss_trace"][:40]) < 2e-2 * G["loss_trace"][:40]), losses
+    assert rel(L.theta[0], G["theta_trace"][40]) < 2e-2
+
+
+def test_full_size_properties_quadrotor_batch4096():
+    """BASELINE size (horizon 50, batch 4096): size-independent properties instead of the (slow) oracle."""
+    oc, d = gpu_model("quadrotor", torch.float32, 50, substeps=4)
+    B = 4096
+    rng = np.random.default_rng(0)
+    th = np.array(d["theta0"])[None, :] + 0.05 * rng.standard_normal((B, 7))
+    th[:, 0] = np.abs(th[:, 0]) + 0.5
+    th[B // 2:] = th[:B // 2]                       # duplicated seeds must give identical results
+    x0 = np.tile(d["ini_state"], (B, 1))
+    sol = oc.cocSolverBatch(x0, 1.0, th)
+    aux = oc.auxSysSolverBatch(sol, d["taus"], d["waypoints"], d["interface"])
+    st = sol["status"].cpu().numpy()
+    assert np.all((st == 1) | (st == 2)), np.bincount(st)
+    assert torch.isfinite(aux["loss"]).all() and torch.isfinite(aux["grad"]).all()
+    assert torch.equal(aux["loss"][:B // 2], aux["loss"][B // 2:]) and torch.equal(aux["grad"][:B // 2], aux["grad"][B // 2:])
+    X, U, Lm = sol["state_grid"], sol["control_grid"], sol["costate_grid"]
+    assert torch.allclose(X[:, 0], torch.as_tensor(x0, dtype=torch.float32, device=X.device))       # x(0) = ini_state
+    assert torch.equal(U[:, -1], U[:, -2])                                                         # CPDP.py:191
+    # P(t_k) symmetric, terminal W = d2h/dxde = 0 for this cost; X(0) = 0 implies grad finite
+    Z = aux["Z_grid"]
+    P = Z[:, :, :13, :]
+    assert (P - P.transpose(2, 3)).abs().max() < 1e-3 * P.abs().max()
+    assert Z[:, -1, 13:, :].abs().max() == 0
+    # a random subset against the fp64 path (fp64 is itself pinned to the oracle/golden above)
+    sub = rng.choice(B // 2, 64, replace=False)
+    oc64, _ = gpu_model("quadrotor", torch.float64, 50, substeps=4)
+    sol64 = oc64.cocSolverBatch(x0[sub], 1.0, th[sub])
+    aux64 = oc64.auxSysSolverBatch(sol64, d["taus"], d["waypoints"], d["interface"])
+    l32, l64 = aux["loss"][sub].double().cpu().numpy(), aux64["loss"].cpu().numpy()
+    assert np.all(np.abs(l32 - l64) < 1e-3 * np.maximum(1.0, l64))
+    g32, g64 = aux["grad"][sub].double().cpu().numpy(), aux64["grad"].cpu().numpy()
+    assert np.all(np.abs(g32 - g64).max(axis=1) < 2e-2 * np.abs(g64).max(axis=1))
+
+
+def test_shared_theta_gradient_is_sum_over_demonstrations():
+    oc, d = gpu_model("pendulum", torch.float64, 10, substeps=8)
+    B = 37                                            # ragged: not a multiple of the 8 groups per wavefront
+    rng = np.random.default_rng(1)
+    x0 = np.tile(d["ini_state"], (B, 1)) + 0.1 * rng.standard_normal((B, 2))
+    taus = np.tile([0.2, 0.5, 0.8], (B, 1))
+    wps = rng.uniform(0.2, 2.5, (B, 3, 1))
+    th0 = np.array([1.5, 0.8, 1.2])
+    Ls = CPDP.SparseDemoLearner(oc, x0, 1.0, taus, wps, [0], th0, method="Vanilla", learning_rate=1e-3, mode="shared")
+    Li = CPDP.SparseDemoLearner(oc, x0, 1.0, taus, wps, [0], th0, method="Vanilla", learning_rate=1e-3)
+    ls, gs = Ls.step()
+    li, gi = Li.step()
+    assert torch.allclose(ls, li.sum().reshape(1), rtol=1e-12) and torch.allclose(gs, gi.sum(0, keepdim=True), rtol=1e-12)
+    assert torch.allclose(Ls.theta, torch.as_tensor(th0, device=gs.device)[None] - 1e-3 * gs, rtol=1e-12)
+
+
+@pytest.mark.parametrize("method", ["Vanilla", "Nesterov", "Adam", "Nadam", "AMSGrad"])
+def test_optimizer_kernels(method):
+    from oracle.cpdp_oracle import Optimizer
+    oc, d = gpu_model("pendulum", torch.float64, 10)
+    lib = oc.compile()
+    rng = np.random.default_rng(3)
+    B, p = 5, 3
+    th_ref = rng.standard_normal((B, p))
+    theta = torch.tensor(th_ref.copy(), device="cuda:0")
+    m, v, vh = torch.zeros_like(theta), torch.zeros_like(theta), torch.zeros_like(theta)
+    lo = torch.tensor([1e-8, -np.inf, -np.inf], dtype=torch.float64, device="cuda:0")
+    ref = [Optimizer(method, p, 0.05) for _ in range(B)]
+    for it in range(6):
+        g = rng.standard_normal((B, p))
+        lib.optimizer_step(method, theta, torch.tensor(g, device="cuda:0"), it, 0.05, m=m, v=v, vhat=vh, proj_lo=lo)
+        for b in range(B):
+            th_ref[b] = ref[b].step(th_ref[b], g[b], it)
+            th_ref[b][0] = max(th_ref[b][0], 1e-8)
+        assert np.allclose(theta.cpu().numpy(), th_ref, rtol=1e-12, atol=1e-13)
