@@ -65,7 +65,7 @@ def test_robotarm_cartpole_vs_oracle(kind, n_grid, thetas, taus, wps):
             assert rel(aux["grad"][b], refs[b]["grad"]) < gtol, (kind, dtype)
 
 
-@pytest.mark.parametrize("dtype,ltol", [(torch.float64, 1e-6), (torch.float32, 1e-4)])
+@pytest.mark.parametrize("dtype,ltol", [(torch.float64, 1e-6), (torch.float32, 5e-4)])
 def test_quadrotor_vs_reference_golden_run(dtype, ltol):
     """(theta, loss, dtheta) triples produced by the reference's own CasADi+IPOPT+solve_ivp run.
     Gradient tolerance 1e-2: the reference's solve_ivp (rtol 1e-3) is itself 5e-4..5e-3 off the exact ODE."""
