@@ -258,7 +258,11 @@ template <class M> struct OcLayout {
   static constexpr int LDS_VX = LDS_QU + NU;
   static constexpr int LDS_LAM = LDS_VX + NX;
   static constexpr int LDS_RED = LDS_LAM + NX;       // G entries
-  template <int G> static constexpr int lds_elems() { return ((LDS_RED + G + 3) / 4) * 4; }
+  // cold per-trajectory state kept in LDS rather than in (spilling) registers
+  template <int G> static constexpr int lds_e() { return LDS_RED + G; }
+  template <int G> static constexpr int lds_c() { return lds_e<G>() + M::NP; }
+  template <int G> static constexpr int lds_x0() { return lds_c<G>() + M::NC; }
+  template <int G> static constexpr int lds_elems() { return ((lds_x0<G>() + NX + 3) / 4) * 4; }
 };
 
 template <class M, typename T, int G> struct OcSolver {
@@ -267,7 +271,7 @@ template <class M, typename T, int G> struct OcSolver {
   using Lay = OcLayout<M>;
 
   int lane, N, S;
-  T e[NP], c[NC], x0[NX];
+  const T *e, *c, *x0;      // [NP], [NC], [NX] in LDS
   T horizon, dgrid, DT;
   T *xb[2], *ub[2], *Mws, *Kws, *kws, *lds;
   T* lam_out;   // costate grid of this trajectory (or scratch when invalid)
@@ -585,12 +589,16 @@ __global__ void __launch_bounds__(64, LFSD_WAVES_PER_SIMD) oc_solve_kernel(OcArg
   const long long traj = valid ? slot : (long long)a.batch - 1;
   s.N = a.n_grid; s.S = a.steps_per_grid;
   s.lds = lds_all + gib * Lay::template lds_elems<G>();
-#pragma unroll
-  for (int i = 0; i < NP; ++i) s.e[i] = a.auxvar[traj * NP + i];
-#pragma unroll
-  for (int i = 0; i < NC; ++i) s.c[i] = a.consts[traj * a.const_stride + i];
-#pragma unroll
-  for (int i = 0; i < NX; ++i) s.x0[i] = a.ini_state[traj * NX + i];
+  {
+    T* le = s.lds + Lay::template lds_e<G>();
+    T* lc = s.lds + Lay::template lds_c<G>();
+    T* lx = s.lds + Lay::template lds_x0<G>();
+    for (int i = s.lane; i < NP; i += G) le[i] = a.auxvar[traj * NP + i];
+    for (int i = s.lane; i < NC; i += G) lc[i] = a.consts[traj * a.const_stride + i];
+    for (int i = s.lane; i < NX; i += G) lx[i] = a.ini_state[traj * NX + i];
+    s.e = le; s.c = lc; s.x0 = lx;
+  }
+  __syncthreads();
   s.horizon = a.horizon[traj];
   s.dgrid = s.horizon / T(s.N);
   s.DT = s.dgrid / T(s.S);
@@ -732,16 +740,22 @@ template <class M> struct AuxLayout {
   static constexpr int LDS_T = LDS_S + NX * NU;
   static constexpr int LDS_KN = LDS_T + NX * NZ;              // 3 stiff nodes x (NX x NU) feedback rows K^T
   static constexpr int LDS_PSI = LDS_KN + 3 * NX * NU;        // 3 stiff nodes x {phi1(h/4 K fu), phi1(h/2 K fu)}
-  static constexpr int LDS_END = LDS_PSI + 3 * 2 * NU * NU;
+  static constexpr int LDS_E = LDS_PSI + 3 * 2 * NU * NU;     // cold per-trajectory state: auxvar, consts,
+  static constexpr int LDS_C = LDS_E + NP;                    // and the (x,u,lambda) grid values at both interval ends
+  static constexpr int LDS_GA = LDS_C + M::NC;                // [x_k u_k l_k]
+  static constexpr int LDS_GB = LDS_GA + 2 * NX + NU;         // [x_k+1 u_k+1 l_k+1]
+  static constexpr int LDS_END = LDS_GB + 2 * NX + NU;
   static constexpr int lds_elems() { return ((LDS_END + 3) / 4) * 4; }
+  // forward kernel only: per-lane parking slot for X(t_k) (row i of lane l at [i*G + l])
+  template <int G> static constexpr int lds_elems_fwd() { return ((LDS_END + NX * G + 3) / 4) * 4; }
 };
 
 template <class M, typename T, int G> struct AuxCtx {
   static constexpr int NX = M::NX, NU = M::NU, NP = M::NP, NC = M::NC, NZ = NX + NP;
   using Lay = AuxLayout<M>;
   int lane;
-  T e[NP], c[NC];
-  T xa_[NX], ua_[NU], la_[NX], xb_[NX], ub_[NU], lb_[NX];   // grid values at both ends of the interval
+  const T *e, *c;            // [NP], [NC] in LDS
+  const T *xa_, *ua_, *la_, *xb_, *ub_, *lb_;   // grid values at both ends of the interval, in LDS
   T t_a, dgrid;
   T* lds;
   T ox[NX], oe[NP];    // one-hot selectors of this lane's column
@@ -750,11 +764,14 @@ template <class M, typename T, int G> struct AuxCtx {
     const T* xs = a.state_grid + (traj * (N + 1) + k) * NX;
     const T* us = a.control_grid + (traj * (N + 1) + k) * NU;
     const T* ls = a.costate_grid + (traj * (N + 1) + k) * NX;
-#pragma unroll
-    for (int i = 0; i < NX; ++i) { xa_[i] = xs[i]; xb_[i] = xs[NX + i]; la_[i] = ls[i]; lb_[i] = ls[NX + i]; }
-#pragma unroll
-    for (int i = 0; i < NU; ++i) { ua_[i] = us[i]; ub_[i] = us[NU + i]; }
+    T* ga = lds + Lay::LDS_GA;
+    T* gb = lds + Lay::LDS_GB;
+    __syncthreads();                         // previous interval's readers are done
+    for (int i = lane; i < NX; i += G) { ga[i] = xs[i]; gb[i] = xs[NX + i]; ga[NX + NU + i] = ls[i]; gb[NX + NU + i] = ls[NX + i]; }
+    for (int i = lane; i < NU; i += G) { ga[NX + i] = us[i]; gb[NX + i] = us[NU + i]; }
+    xa_ = ga; ua_ = ga + NX; la_ = ga + NX + NU; xb_ = gb; ub_ = gb + NX; lb_ = gb + NX + NU;
     t_a = M::TIME_VARYING ? dgrid * T(k) : T(0);
+    __syncthreads();
   }
   // Lane `node` (< 5) evaluates the packed PMP coefficients at its own time node s (fraction of the
   // interval) on the reference's linear interpolant of (x,u,lambda) (CPDP.py:320-323) and stages them in LDS.
@@ -1004,16 +1021,20 @@ template <class M, typename T, int G> struct AuxCtx {
 };
 
 template <class M, typename T, int G> LFSD_DEV void aux_setup(AuxCtx<M, T, G>& s, const AuxArgs<T>& a, long long traj,
-                                                            T* lds_all) {
+                                                            T* lds_all, int lds_stride = AuxLayout<M>::lds_elems()) {
   constexpr int NX = M::NX, NP = M::NP, NC = M::NC;
   using Lay = AuxLayout<M>;
   const int gib = threadIdx.x / G;
   s.lane = threadIdx.x % G;
-  s.lds = lds_all + gib * Lay::lds_elems();
-#pragma unroll
-  for (int i = 0; i < NP; ++i) s.e[i] = a.auxvar[traj * NP + i];
-#pragma unroll
-  for (int i = 0; i < NC; ++i) s.c[i] = a.consts[traj * a.const_stride + i];
+  s.lds = lds_all + gib * lds_stride;
+  {
+    T* le = s.lds + Lay::LDS_E;
+    T* lc = s.lds + Lay::LDS_C;
+    for (int i = s.lane; i < NP; i += G) le[i] = a.auxvar[traj * NP + i];
+    for (int i = s.lane; i < NC; i += G) lc[i] = a.consts[traj * a.const_stride + i];
+    s.e = le; s.c = lc;
+  }
+  __syncthreads();
   s.dgrid = a.horizon[traj] / T(a.n_grid);
 #pragma unroll
   for (int i = 0; i < NX; ++i) s.ox[i] = (s.lane == i) ? T(1) : T(0);
@@ -1099,13 +1120,13 @@ __global__ void __launch_bounds__(64, LFSD_WAVES_PER_SIMD) aux_forward_kernel(Au
   using Lay = AuxLayout<M>;
   constexpr int NX = M::NX, NU = M::NU, NP = M::NP, NZ = NX + NP;
   constexpr int GPB = 64 / G;
-  __shared__ T lds_all[GPB * Lay::lds_elems()];
-  poison_lds(lds_all, GPB * Lay::lds_elems());
+  __shared__ T lds_all[GPB * Lay::template lds_elems_fwd<G>()];
+  poison_lds(lds_all, GPB * Lay::template lds_elems_fwd<G>());
   const long long slot = (long long)blockIdx.x * GPB + threadIdx.x / G;
   const bool valid = slot < a.batch;
   const long long traj = valid ? slot : (long long)a.batch - 1;
   Ctx s;
-  aux_setup<M, T, G>(s, a, traj, lds_all);
+  aux_setup<M, T, G>(s, a, traj, lds_all, Lay::template lds_elems_fwd<G>());
   const int N = a.n_grid, Sa = a.substeps;
   const int lane = s.lane;
   const bool xlane = (lane >= NX) && (lane < NZ);
@@ -1126,9 +1147,9 @@ __global__ void __launch_bounds__(64, LFSD_WAVES_PER_SIMD) aux_forward_kernel(Au
 #pragma unroll
       for (int i = 0; i < NX; ++i) { zA[i] = Zt[((long long)k * NZ + lane) * NX + i]; zB[i] = Zt[((long long)(k + 1) * NZ + lane) * NX + i]; }
     }
-    T xprev[NX];
+    T* xprev = s.lds + Lay::LDS_END;                 // this lane's X(t_k), parked in LDS until the loss needs it
 #pragma unroll
-    for (int i = 0; i < NX; ++i) xprev[i] = xa[i];
+    for (int i = 0; i < NX; ++i) xprev[i * G + lane] = xa[i];
     s.stage_nodes(T(0), T(0.25));
     const T rate = t_max(s.stiff_rate(zA, s.node(0)), s.stiff_rate(zB, s.node(4)));
     const int units = s.units_for(rate, Sa, a.rate_max, a.max_refine);
@@ -1201,7 +1222,7 @@ __global__ void __launch_bounds__(64, LFSD_WAVES_PER_SIMD) aux_forward_kernel(Au
         }
       }
 #pragma unroll
-      for (int i = 0; i < NX; ++i) gacc += rvec[i] * (xprev[i] + sw * (xa[i] - xprev[i]));
+      for (int i = 0; i < NX; ++i) { const T xp = xprev[i * G + lane]; gacc += rvec[i] * (xp + sw * (xa[i] - xp)); }
     }
   }
   if (valid) {

@@ -78,8 +78,9 @@ def test_quadrotor_vs_reference_golden_run(dtype, ltol):
     assert set(sol["status"].tolist()) <= {1, 2}
     loss = aux["loss"].double().cpu().numpy()
     assert np.all(np.abs(loss - G["loss_trace"][idx]) < ltol * G["loss_trace"][idx])
+    gtol = 1e-2 if dtype == torch.float64 else 2e-2     # fp32: near-stationary points (|dtheta| ~ 0.05) amplify rounding
     for k, j in enumerate(idx):
-        assert rel(aux["grad"][k], G["grad_trace"][j]) < 1e-2, j
+        assert rel(aux["grad"][k], G["grad_trace"][j]) < gtol, j
     if dtype == torch.float64:
         oc.const_values = consts.tolist()
         tg, opt = oc.cocSolver(G["ini_state"], float(G["horizon"]), G["theta_trace"][-1])
