@@ -147,7 +147,7 @@ class COCSys:
             lib = ModelLibrary(runtime.build_library(spec, force=force, verbose=verbose))
         self._spec = spec
         self._lib = lib
-        self.const_values = list(lib.const_defaults)
+        self.const_values = list(spec.const_defaults)     # this instance's values; the library only fixes the structure
         return lib
 
     # the reference builds CasADi Functions here (CPDP.py:201-298); for us that is the code generator

@@ -238,3 +238,28 @@ def test_learning_loop_decreases_loss_like_the_example(emu):
         assert np.allclose(L.theta[0].numpy(), th_new, rtol=0, atol=1e-13)
         losses.append(loss[0].item())
     assert losses[-1] < losses[0]
+
+
+def test_quadalgorithm_driver_replays_reference_run_start(emu):
+    """lib/QuadAlgorithm.py driver mirror with the settings of Examples/quad_example_human_input.py: the first
+    Nesterov iterations must follow the reference's saved loss / parameter traces."""
+    from lfsd_amd.QuadAlgorithm import QuadAlgorithm, QuadPara, DemoSparse
+    from lfsd_amd.JinEnv import QuadStates
+    from conftest import build_emu_library
+    cfg = {"QUAD_AVERAGE_SPEED": 1.0, "LAB_SPACE_LIMIT": {"LIMIT_X": [-3.2, 3.2], "LIMIT_Y": [-1.6, 1.6], "LIMIT_Z": [0.0, 2.2]}}
+    S = QuadAlgorithm(cfg, QuadPara([1.0, 1.0, 1.0], 1.0, 1.0, 0.02), int(G["n_grid"]), dtype=torch.float64)
+    S.library = build_emu_library(models.quadrotor(n_grid=int(G["n_grid"]))[0])
+    S.load_optimization_function({"learning_rate": 0.01, "iter_num": 3, "method": "Nesterov", "mu": 0.9,
+                                  "true_loss_print_flag": False})
+    ini = QuadStates(position=[-2.0, -1.0, 0.6])
+    goal = QuadStates(position=[2.5, 1.0, 1.5])
+    demo = DemoSparse(waypoints=G["waypoints"].tolist(), time_list=G["taus"].tolist(), time_horizon=1.0)
+    res = S.run(ini, goal, demo, ObsList=[], print_flag=False, save_flag=False)
+    assert res["loss_trace"].shape[0] == 3
+    assert abs(res["loss_trace"][0, 0] - G["loss_trace"][0]) < 1e-7 * G["loss_trace"][0]
+    # later iterations inherit the reference's own gradient error (its solve_ivp rtol is 1e-3)
+    assert np.allclose(res["loss_trace"][:, 0], G["loss_trace"][:3], rtol=1e-3)
+    assert np.allclose(res["parameter_trace"][1:4, 0], G["theta_trace"][1:4], rtol=2e-3, atol=2e-4)
+    assert res["opt_state_traj"].shape == (101, 13) and res["opt_control_traj"].shape == (101, 4)
+    with pytest.raises(Exception, match="Wrong optimization method type!"):
+        S.load_optimization_function({"learning_rate": 0.01, "iter_num": 3, "method": "RMSprop"})
