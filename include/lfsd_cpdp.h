@@ -68,13 +68,17 @@ size_t lfsd_coc_workspace_bytes(int dtype, int batch, int n_grid);
  *   u_init    [B][n_grid][n_control] initial guess, or NULL for zeros
  * outputs (CPDP.py:186-196):
  *   state_grid [B][n_grid+1][n_state], control_grid [B][n_grid+1][n_control] (last row repeated),
- *   costate_grid [B][n_grid+1][n_state] (== IPOPT lam_g), cost [B], iters [B], status [B]      */
+ *   costate_grid [B][n_grid+1][n_state] (== IPOPT lam_g), cost [B], iters [B], status [B]
+ * solver: Gauss-Newton steps first, then Newton steps; `exact_after` = iteration from which the exact
+ *   Lagrangian Hessian of the RK4 stages (what IPOPT gets from CasADi) is forced: 16 is the default policy,
+ *   0 = exact from the first iteration, <0 = never (Gauss-Newton / Hamiltonian model only).
+ *   steps_per_grid <= 8.                                                                        */
 int lfsd_coc_solve(int dtype, int batch, int n_grid, int steps_per_grid,
                    const void* ini_state, const void* horizon, const void* auxvar,
                    const void* consts, int const_per_traj, const void* u_init,
                    void* state_grid, void* control_grid, void* costate_grid,
                    void* cost, int* iters, int* status,
-                   int max_iter, double tol,
+                   int max_iter, double tol, int exact_after,
                    void* workspace, size_t workspace_bytes, void* stream);
 
 /* Differentiate the maximum principle along the solved trajectories and evaluate the

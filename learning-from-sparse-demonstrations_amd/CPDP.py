@@ -42,6 +42,7 @@ class COCSys:
         self.aux_substeps = 0           # 0 = library default
         self.max_iter = 100
         self.tol = None
+        self.exact_after = 16            # iteration from which the exact stage Hessian is forced
 
     # ---- model definition (CPDP.py:15-87) ------------------------------------------------------
     def setAuxvarVariable(self, auxvar=None):
@@ -101,13 +102,15 @@ class COCSys:
         if dtype is not None:
             self.dtype = dtype
 
-    def setSolverOptions(self, max_iter=None, tol=None, aux_substeps=None):
+    def setSolverOptions(self, max_iter=None, tol=None, aux_substeps=None, exact_after=None):
         if max_iter is not None:
             self.max_iter = int(max_iter)
         if tol is not None:
             self.tol = float(tol)
         if aux_substeps is not None:
             self.aux_substeps = int(aux_substeps)
+        if exact_after is not None:
+            self.exact_after = int(exact_after)
 
     def use_library(self, path_or_lib):
         """Bind an already built model library (tests use this to inject the SIMT-emulator build)."""
@@ -219,7 +222,8 @@ class COCSys:
         if consts is None:
             consts = self.consts_tensor()
         sol = lib.coc_solve(x0, hz, th, consts, self.n_grid, self.steps_per_grid, u_init=u_init,
-                            max_iter=self.max_iter, tol=self.tol, workspace=workspace, out=out)
+                            max_iter=self.max_iter, tol=self.tol, workspace=workspace, out=out,
+                            exact_after=self.exact_after)
         sol.update(horizon=hz, auxvar=th, consts=consts, ini_state=x0, n_grid=self.n_grid)
         return sol
 

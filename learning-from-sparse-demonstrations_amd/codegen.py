@@ -25,7 +25,7 @@ import hashlib
 import sympy as sp
 from sympy.printing.c import C99CodePrinter
 
-CODEGEN_VERSION = 4
+CODEGEN_VERSION = 5
 
 
 class ModelSpec:
@@ -231,6 +231,20 @@ def emit_header(spec):
     S.append('  template<class T> static LFSD_DEV void dyn_cost_jvp(%s, const T* dx, const T* du, T* f, T& q, T* df, T& dq) {' % sig_xu)
     S.append(_body(_loads(spec) + tang, [('f[%d]' % i, f[i]) for i in range(n)] + [('q', c)] +
                    [('df[%d]' % i, df[i]) for i in range(n)] + [('dq', dq)]))
+    S.append('  }')
+    # 2b. two vector-Jacobian products at one point (second-order adjoint sweep through the RK4 stages):
+    #     y1x = fx^T v1 + w1*cx   (first-order stage adjoint, group-uniform)
+    #     y2x = fx^T v2, y2u = fu^T v2   (its per-lane tangent)
+    V1 = sp.Matrix([sp.Symbol('va%d' % i, real=True) for i in range(n)])
+    V2 = sp.Matrix([sp.Symbol('vb%d' % i, real=True) for i in range(n)])
+    W1 = sp.Symbol('wa', real=True)
+    y1x = fx.T * V1 + W1 * cx.T
+    y2x = fx.T * V2
+    y2u = fu.T * V2
+    vin = [(s_, 'v1[%d]' % i) for i, s_ in enumerate(V1)] + [(s_, 'v2[%d]' % i) for i, s_ in enumerate(V2)] + [(W1, 'w1')]
+    S.append('  template<class T> static LFSD_DEV void dyn_vjp2(%s, const T* v1, T w1, const T* v2, T* y1x, T* y2x, T* y2u) {' % sig_xu)
+    S.append(_body(_loads(spec) + vin, [('y1x[%d]' % i, y1x[i]) for i in range(n)] +
+                   [('y2x[%d]' % i, y2x[i]) for i in range(n)] + [('y2u[%d]' % i, y2u[i]) for i in range(m)]))
     S.append('  }')
     # 3. final cost
     sig_x = 'T t, const T* x, const T* e, const T* c'

@@ -67,14 +67,14 @@ LFSD_DEV double t_pow(double a, double b) { return pow(a, b); }
 
 // ---- tiny dense helpers on group-uniform n x n matrices (row-major, in registers) -----------
 // Cholesky A = L L^T in place (lower); false if not positive definite.
-template <int n, typename T> LFSD_DEV bool chol_factor(T* A) {
+template <int n, typename T> LFSD_DEV bool chol_factor(T* A, T& dmin) {
   bool ok = true;
 #pragma unroll
   for (int j = 0; j < n; ++j) {
     T d = A[j * n + j];
 #pragma unroll
     for (int k = 0; k < j; ++k) d -= A[j * n + k] * A[j * n + k];
-    if (!(d > T(0))) { ok = false; d = T(1); }
+    if (!(d > T(0))) { ok = false; if (d < dmin) dmin = d; d = T(1); }
     d = t_sqrt(d);
     A[j * n + j] = d;
     const T inv = T(1) / d;
@@ -239,14 +239,18 @@ template <typename T> struct OcArgs {
   T* ws;                // per-trajectory scratch, ws_stride elements each
   long long ws_stride;
   T tol;                // stop when max|dJ/du| < tol*(1+|J|)
+  int exact_after;      // iteration from which the exact stage Hessian is forced (0: from the start, <0: never)
+  int it_start;         // iteration counter to start from (phase 2 of a two-launch solve)
+  int resume;           // 1: continue only trajectories whose status is ST_MAXITER, warm-started from control_grid
 };
 
 template <class M> struct OcLayout {
   static constexpr int NX = M::NX, NU = M::NU, NXU = NX + NU;
   // scratch per trajectory (elements)
-  static long long ws_elems(int N) {
+  static constexpr int SMAX = 8;       // RK4 sub-steps per grid interval supported by the exact-Hessian sweep
+  template <int G> static long long ws_elems(int N) {
     return 2LL * (N + 1) * NX + 2LL * N * NU + 1LL * N * NXU * (NX + 1) + 1LL * N * NX * NU + 1LL * N * NU +
-           1LL * (N + 1) * NX;
+           1LL * (N + 1) * NX + 1LL * SMAX * NX * (1 + G);      // + sub-step start states (uniform | per lane)
   }
   // LDS per group (elements)
   static constexpr int LDS_V = 0;
@@ -262,10 +266,12 @@ template <class M> struct OcLayout {
   template <int G> static constexpr int lds_e() { return LDS_RED + G; }
   template <int G> static constexpr int lds_c() { return lds_e<G>() + M::NP; }
   template <int G> static constexpr int lds_x0() { return lds_c<G>() + M::NC; }
-  template <int G> static constexpr int lds_elems() { return ((lds_x0<G>() + NX + 3) / 4) * 4; }
+  // exact-Hessian sweep: per-lane slots for the 4 RK4 stage points (uniform copy + this lane's tangent)
+  template <int G> static constexpr int lds_ex() { return lds_x0<G>() + NX; }
+  template <int G> static constexpr int lds_elems() { return ((lds_ex<G>() + 8 * NX * G + 3) / 4) * 4; }
 };
 
-template <class M, typename T, int G> struct OcSolver {
+template <class M, typename T, int G, bool EXACT> struct OcSolver {
   static constexpr int NX = M::NX, NU = M::NU, NP = M::NP, NC = M::NC, NXU = NX + NU;
   static constexpr int NALPHA = (G < 10) ? G : 10;
   using Lay = OcLayout<M>;
@@ -273,7 +279,7 @@ template <class M, typename T, int G> struct OcSolver {
   int lane, N, S;
   const T *e, *c, *x0;      // [NP], [NC], [NX] in LDS
   T horizon, dgrid, DT;
-  T *xb[2], *ub[2], *Mws, *Kws, *kws, *lds;
+  T *xb[2], *ub[2], *Mws, *Kws, *kws, *lds, *exws;
   T* lam_out;   // costate grid of this trajectory (or scratch when invalid)
 
   LFSD_DEV T tk(int k) const { return M::TIME_VARYING ? dgrid * T(k) : T(0); }
@@ -360,16 +366,96 @@ template <class M, typename T, int G> struct OcSolver {
     return J;
   }
 
+  // Column `lane` of the exact Hessian of the stage Lagrangian  Q_k(x,u) + lam'^T F_k(x,u)  w.r.t. (x_k,u_k):
+  // second-order adjoint sweep through the S x 4 RK4 stages (tangent forward, adjoint + its tangent backward).
+  // No cross-lane traffic: every lane recomputes the group-uniform stage states and parks them, with its own
+  // tangents, in its private LDS slots (index (slot)*G + lane), so the routine may run under a divergent branch.
+  LFSD_DEV void stage_hessian_col(int k, const T* xk, const T* uk, const T* lam_next, T* hx, T* hu) {
+    constexpr int SMAX = Lay::SMAX;
+    T* ex = lds + Lay::template lds_ex<G>();
+    T* exu = exws;                           // [S][NX] uniform (all lanes store the same value)
+    T* exl = exws + SMAX * NX;               // [S][NX][G] per lane
+    const T t = tk(k);
+    const T h = DT;
+    T x[NX], m[NX], du[NU], q = T(0), mq = T(0);
+#pragma unroll
+    for (int i = 0; i < NX; ++i) { x[i] = xk[i]; m[i] = (lane == i) ? T(1) : T(0); }
+#pragma unroll
+    for (int a = 0; a < NU; ++a) du[a] = (lane == NX + a) ? T(1) : T(0);
+    for (int s = 0; s < S; ++s) {
+#pragma unroll
+      for (int i = 0; i < NX; ++i) { exu[s * NX + i] = x[i]; exl[(s * NX + i) * G + lane] = m[i]; }
+      rk4_step<true>(t, x, q, uk, m, mq, du);
+    }
+    T lam[NX], dlam[NX];
+#pragma unroll
+    for (int i = 0; i < NX; ++i) { lam[i] = lam_next[i]; dlam[i] = T(0); }
+#pragma unroll
+    for (int a = 0; a < NU; ++a) hu[a] = T(0);
+    const T wgt[4] = {h / T(6), h / T(3), h / T(3), h / T(6)};
+    const T car[4] = {h * T(0.5), h * T(0.5), h, T(0)};      // kappa_i = w_i*lam + car_i * ybar_{i+1}
+    const T adv[3] = {h * T(0.5), h * T(0.5), h};
+    for (int s = S - 1; s >= 0; --s) {
+      // recompute the four stage points of this sub-step and park them
+      T x0s[NX], m0s[NX];
+#pragma unroll
+      for (int i = 0; i < NX; ++i) { x0s[i] = exu[s * NX + i]; m0s[i] = exl[(s * NX + i) * G + lane]; }
+#pragma unroll
+      for (int i = 0; i < NX; ++i) { x[i] = x0s[i]; m[i] = m0s[i]; }
+      for (int st = 0; st < 4; ++st) {
+#pragma unroll
+        for (int i = 0; i < NX; ++i) { ex[(st * NX + i) * G + lane] = x[i]; ex[((4 + st) * NX + i) * G + lane] = m[i]; }
+        if (st < 3) {
+          T f[NX], d[NX], cq, dq;
+          M::dyn_cost_jvp(t, x, uk, e, c, m, du, f, cq, d, dq);
+#pragma unroll
+          for (int i = 0; i < NX; ++i) { x[i] = x0s[i] + adv[st] * f[i]; m[i] = m0s[i] + adv[st] * d[i]; }
+        }
+      }
+      T yb[NX], dyb[NX], lam_new[NX], dlam_new[NX];
+#pragma unroll
+      for (int i = 0; i < NX; ++i) { yb[i] = T(0); dyb[i] = T(0); lam_new[i] = lam[i]; dlam_new[i] = dlam[i]; }
+      for (int st = 3; st >= 0; --st) {
+        T kap[NX], dkap[NX], ls[NX], xs[NX], ms[NX], y1[NX], t2x[NX], t2u[NU], gx[NX], gu[NU];
+        const T w = wgt[st], cc = car[st], iw = T(1) / w;
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+          kap[i] = w * lam[i] + cc * yb[i];
+          dkap[i] = w * dlam[i] + cc * dyb[i];
+          ls[i] = kap[i] * iw;
+          xs[i] = ex[(st * NX + i) * G + lane];
+          ms[i] = ex[((4 + st) * NX + i) * G + lane];
+        }
+        M::dyn_vjp2(t, xs, uk, e, c, kap, w, dkap, y1, t2x, t2u);
+        M::ham_hess_mul(t, xs, uk, ls, e, c, ms, du, gx, gu);
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+          yb[i] = y1[i];
+          dyb[i] = t2x[i] + w * gx[i];
+          lam_new[i] += yb[i];
+          dlam_new[i] += dyb[i];
+        }
+#pragma unroll
+        for (int a = 0; a < NU; ++a) hu[a] += t2u[a] + w * gu[a];
+      }
+#pragma unroll
+      for (int i = 0; i < NX; ++i) { lam[i] = lam_new[i]; dlam[i] = dlam_new[i]; }
+    }
+#pragma unroll
+    for (int i = 0; i < NX; ++i) hx[i] = dlam[i];
+  }
+
   // Backward sweep on buffer `cur`: DDP gains + exact discrete costate (== IPOPT's lam_g).
-  // HL scales the costate inside the Hessian model (0: Gauss-Newton, 1: Newton-like).
-  LFSD_DEV bool backward(int cur, T HL, T mu, T& gnorm, T& dV1, T& dV2) {
+  // Stage Hessian model: mode 0 Gauss-Newton (cost curvature), 1 interval * Hamiltonian Hessian (cheap Newton-like),
+  // 2 exact Lagrangian Hessian of the RK4 stage (stage_hessian_col).
+  LFSD_DEV bool backward(int cur, int mode, T mu, T& gnorm, T& dV1, T& dV2, T& dmin) {
     T* ldsV = lds + Lay::LDS_V;  T* ldsM = lds + Lay::LDS_M;  T* ldsK = lds + Lay::LDS_K;
     T* ldsQux = lds + Lay::LDS_QUX;  T* ldsQuu = lds + Lay::LDS_QUU;  T* ldsQu = lds + Lay::LDS_QU;
     T* ldsVx = lds + Lay::LDS_VX;  T* ldsLam = lds + Lay::LDS_LAM;  T* ldsRed = lds + Lay::LDS_RED;
     T Vx[NX], lam[NX], vcol[NX], xk[NX], uk[NU];
     bool ok = true;
     T gl_max = T(0);
-    dV1 = T(0); dV2 = T(0);
+    dV1 = T(0); dV2 = T(0); dmin = T(0);
     {
       const T* xN = xb[cur] + N * NX;
 #pragma unroll
@@ -429,8 +515,25 @@ template <class M, typename T, int G> struct OcSolver {
         for (int i = 0; i < NX; ++i) s += ldsM[r * NX + i] * Y[i];
         Qcol[r] = s;
       }
-      {
+      if (EXACT && mode == 2) {
+        T hx[NX], hu[NU];
+        stage_hessian_col(k, xk, uk, lam, hx, hu);
+#if defined(LFSD_TRACE)
+        if (lane < NXU && blockIdx.x == 0 && threadIdx.x < G) {
+          printf("HCOL k %d lane %d x", k, lane); for (int i = 0; i < NX; ++i) printf(" %.17g", (double)xk[i]);
+          printf(" u"); for (int a = 0; a < NU; ++a) printf(" %.17g", (double)uk[a]);
+          printf(" l"); for (int i = 0; i < NX; ++i) printf(" %.17g", (double)lam[i]);
+          printf(" h"); for (int i = 0; i < NX; ++i) printf(" %.17g", (double)hx[i]); for (int a = 0; a < NU; ++a) printf(" %.17g", (double)hu[a]);
+          printf("\n");
+        }
+#endif
+#pragma unroll
+        for (int i = 0; i < NX; ++i) Qcol[i] += hx[i];
+#pragma unroll
+        for (int a = 0; a < NU; ++a) Qcol[NX + a] += hu[a];
+      } else {
         T ox[NX], ou[NU], ls[NX], hx[NX], hu[NU];
+        const T HL = (mode == 1) ? T(1) : T(0);
 #pragma unroll
         for (int i = 0; i < NX; ++i) { ox[i] = (lane == i) ? T(1) : T(0); ls[i] = HL * lam[i]; }
 #pragma unroll
@@ -469,7 +572,7 @@ template <class M, typename T, int G> struct OcSolver {
       for (int i = 0; i < NU * NU; ++i) Lc[i] = Quu0[i];
 #pragma unroll
       for (int a = 0; a < NU; ++a) Lc[a * NU + a] += mu;
-      ok = chol_factor<NU>(Lc) && ok;
+      if (ok) ok = chol_factor<NU>(Lc, dmin); else { T dd = T(0); chol_factor<NU>(Lc, dd); }   // first failing pivot sizes the shift
 #pragma unroll
       for (int a = 0; a < NU; ++a) { kff[a] = -Qu[a]; Kj[a] = -Quxj[a]; }
       chol_solve<NU>(Lc, kff);
@@ -571,9 +674,12 @@ template <class M, typename T, int G> struct OcSolver {
   }
 };
 
-template <class M, typename T, int G>
+// EXACT = false: lean instantiation without the exact-Hessian code (Gauss-Newton / Hamiltonian models only);
+// EXACT = true: may switch to the exact stage Hessians.  lfsd_coc_solve runs the lean kernel for the first
+// `exact_after` iterations and resumes the unfinished trajectories in the exact-capable one.
+template <class M, typename T, int G, bool EXACT>
 __global__ void __launch_bounds__(64, LFSD_WAVES_PER_SIMD) oc_solve_kernel(OcArgs<T> a) {
-  using Sol = OcSolver<M, T, G>;
+  using Sol = OcSolver<M, T, G, EXACT>;
   using Lay = OcLayout<M>;
   constexpr int NX = M::NX, NU = M::NU, NP = M::NP, NC = M::NC;
   constexpr int GPB = 64 / G;
@@ -585,8 +691,19 @@ __global__ void __launch_bounds__(64, LFSD_WAVES_PER_SIMD) oc_solve_kernel(OcArg
   const int gib = threadIdx.x / G;
   s.lane = threadIdx.x % G;
   const long long slot = (long long)blockIdx.x * GPB + gib;      // scratch slot (padded batch)
-  const bool valid = slot < a.batch;
-  const long long traj = valid ? slot : (long long)a.batch - 1;
+  const bool in_batch = slot < a.batch;
+  const long long traj = in_batch ? slot : (long long)a.batch - 1;
+  // phase 2 of a two-launch solve: only trajectories the first launch left at MAXITER are continued; the others
+  // ride along as clones whose outputs are not written
+  const bool valid = in_batch && (!a.resume || a.status[traj] == ST_MAXITER);
+  if (a.resume) {
+    if (threadIdx.x == 0) vote[0] = 0;
+    __syncthreads();
+    if (valid) vote[0] = 1;
+    __syncthreads();
+    if (!vote[0]) return;              // nothing to do in this workgroup
+    __syncthreads();
+  }
   s.N = a.n_grid; s.S = a.steps_per_grid;
   s.lds = lds_all + gib * Lay::template lds_elems<G>();
   {
@@ -611,22 +728,26 @@ __global__ void __launch_bounds__(64, LFSD_WAVES_PER_SIMD) oc_solve_kernel(OcArg
   s.Mws = w; w += (long long)N * (NX + NU) * (NX + 1);
   s.Kws = w; w += (long long)N * NX * NU;
   s.kws = w; w += N * NU;
+  s.exws = w; w += (long long)Lay::SMAX * NX * (1 + G);
   // padding groups (slot >= batch) clone the last trajectory and keep their costates in scratch
   s.lam_out = valid ? a.costate_grid + traj * (N + 1) * NX : w;
 
   // initial guess into buffer 1, then "roll out" 1 -> 0 without gains
-  for (int i = s.lane; i < N * NU; i += G) s.ub[1][i] = a.u_init ? a.u_init[traj * N * NU + i] : T(0);
+  for (int i = s.lane; i < N * NU; i += G)
+    s.ub[1][i] = a.resume ? a.control_grid[traj * (N + 1) * NU + i] : (a.u_init ? a.u_init[traj * N * NU + i] : T(0));
   __syncthreads();
   int cur = 0;
   T J = s.rollout_sens(1, 0, T(0), false);
   __syncthreads();
-  T mu = T(0), HL = T(0);
-  int status = ST_RUNNING, it = 0, my_iters = 0;
+  T mu = T(0);
+  int mode = 0;             // stage Hessian model: 0 Gauss-Newton, 1 Hamiltonian (cheap Newton-like), 2 exact
+  bool ham_ok = true;       // the cheap Newton-like model has not failed on this trajectory yet
+  int status = ST_RUNNING, it = a.it_start, my_iters = a.it_start;
   bool need_bw = true;      // costates on `lam_out` are stale
   T gnorm = T(0), dV1 = T(0), dV2 = T(0);
   T g_flat = T(-1);         // gradient norm at the last accepted noise-level ("flat") step; <0: none yet
-  T J_ref = J;              // cost 4 iterations ago (stagnation window)
-  int it_ref = 0;
+  T J_ref = J;              // cost 4 accepted steps ago (stagnation window)
+  int n_acc = 0;
   if (!t_finite(J)) status = ST_FAILED;
   for (; it < a.max_iter; ++it) {
     if (threadIdx.x == 0) vote[0] = 0;
@@ -635,14 +756,23 @@ __global__ void __launch_bounds__(64, LFSD_WAVES_PER_SIMD) oc_solve_kernel(OcArg
     __syncthreads();
     if (!vote[0]) break;
     __syncthreads();
-    const bool bw_ok = s.backward(cur, HL, mu, gnorm, dV1, dV2);
+    if (EXACT && mode < 2 && a.exact_after >= 0 && it >= a.exact_after) mode = 2;
+    T dmin = T(0);
+    const bool bw_ok = s.backward(cur, mode, mu, gnorm, dV1, dV2, dmin);
     need_bw = false;
     bool try_step = false;
     if (status == ST_RUNNING) {
       my_iters = it + 1;
       if (!bw_ok) {
-        if (HL > T(0)) HL = T(0);
-        else { mu = t_max(mu * T(10), T(1e-6)); if (mu > T(1e8)) status = ST_FAILED; }
+        // indefinite Q_uu: the cheap Newton-like model hands over to the exact one; otherwise Levenberg shift
+        if (mode == 1) { mode = 0; ham_ok = false; }     // back to Gauss-Newton until the exact model takes over
+        else {
+          if (mu == T(0) && mode == 2 && t_finite(dmin))
+            mu = t_min(t_max(T(-2) * dmin, T(1e-4)), T(1e6));     // first shift: the size of the negative pivot
+          else
+            mu = t_max(mu * T(10), mode == 2 ? T(1e-4) : T(1e-6));
+          if (mu > T(1e12)) status = ST_FAILED;
+        }
       } else if (gnorm < a.tol * (T(1) + t_abs(J))) {
         status = ST_CONVERGED;
       } else {
@@ -656,20 +786,21 @@ __global__ void __launch_bounds__(64, LFSD_WAVES_PER_SIMD) oc_solve_kernel(OcArg
     if (try_step) {
       if (ia >= 0) {
         accept = true;
-      } else if (HL > T(0) && flat_full && (g_flat < T(0) || gnorm < T(0.7) * g_flat)) {
+      } else if (mode >= 1 && flat_full && (g_flat < T(0) || gnorm < T(0.7) * g_flat)) {
         // Newton-like step whose cost change is below rounding noise: take it as long as the
         // gradient norm keeps contracting (this is what lets fp32 reach its gradient floor)
         accept = true; ia = 0; alpha = T(1); g_flat = gnorm;
-      } else if (HL > T(0)) {
-        HL = T(0);
-      } else if (mu > T(1e6) || (J - Jmin) <= T(8) * Eps<T>::v() * t_abs(J)) {
-        status = ST_STALLED;
-      } else {
-        mu = t_max(mu * T(10), T(1e-6));
+      } else if (mode == 1) {
+        mode = 0; ham_ok = false;
+      } else if (mu > T(1e10) ||
+                 ((J - Jmin) <= T(8) * Eps<T>::v() * t_abs(J) && (mode == 0 || flat_full || mu > T(1e6)))) {
+        status = ST_STALLED;      // no step length gains more than rounding noise
+      } else {                    // (exact model far from the optimum: indefinite direction -> larger shift)
+        mu = t_max(mu * T(10), mode == 2 ? T(1e-4) : T(1e-6));
       }
     }
 #if defined(LFSD_TRACE)
-    if (s.lane == 0 && slot == 0) printf("it %d st %d bw_ok %d g %.6e J %.12e ia %d alpha %g accept %d HL %g mu %g dV1 %.4e dV2 %.4e Jmin %.12e\n", it, status, (int)bw_ok, (double)gnorm, (double)J, ia, (double)alpha, (int)accept, (double)HL, (double)mu, (double)dV1, (double)dV2, (double)Jmin);
+    if (s.lane == 0 && slot == 0) printf("it %d st %d mode %d bw_ok %d g %.6e J %.12e ia %d alpha %g accept %d mu %g dV1 %.4e dV2 %.4e Jmin %.12e flat %d\n", it, status, mode, (int)bw_ok, (double)gnorm, (double)J, ia, (double)alpha, (int)accept, (double)mu, (double)dV1, (double)dV2, (double)Jmin, (int)flat_full);
 #endif
     if (threadIdx.x == 0) vote[1] = 0;
     __syncthreads();
@@ -680,15 +811,17 @@ __global__ void __launch_bounds__(64, LFSD_WAVES_PER_SIMD) oc_solve_kernel(OcArg
       cur ^= 1;
       need_bw = true;
       if (accept) {
-        mu = (mu > T(1e-9)) ? mu * T(0.1) : T(0);
-        HL = (ia == 0 && (J - Jn) < T(1e-2) * t_abs(Jn)) ? T(1) : T(0);
+        if (ia == 0) {
+          mu = (mu > T(1e-8)) ? mu * T(0.1) : T(0);
+          if (mode == 0 && ham_ok && (J - Jn) < T(1e-2) * t_abs(Jn)) mode = 1;     // close: Newton-like tail
+        }
         J = Jn;
+        if (++n_acc >= 4) {
+          // four accepted steps that together gain less than rounding noise: converged to working precision
+          if (status == ST_RUNNING && J_ref - J <= T(16) * Eps<T>::v() * t_abs(J)) status = ST_STALLED;
+          J_ref = J; n_acc = 0;
+        }
       }
-    }
-    if (status == ST_RUNNING && it - it_ref >= 4) {
-      // four iterations that together gain less than rounding noise: converged to working precision
-      if (J_ref - J <= T(16) * Eps<T>::v() * t_abs(J)) status = ST_STALLED;
-      J_ref = J; it_ref = it;
     }
     __syncthreads();
   }
@@ -697,7 +830,7 @@ __global__ void __launch_bounds__(64, LFSD_WAVES_PER_SIMD) oc_solve_kernel(OcArg
   __syncthreads();
   if (need_bw) vote[0] = 1;
   __syncthreads();
-  if (vote[0]) s.backward(cur, T(0), T(0), gnorm, dV1, dV2);     // refresh costates on the final nominal
+  { T dmin = T(0); if (vote[0]) s.backward(cur, 0, T(0), gnorm, dV1, dV2, dmin); }   // refresh costates on the final nominal
   __syncthreads();
   if (valid) {
     T* xo = a.state_grid + traj * (N + 1) * NX;

@@ -49,14 +49,15 @@ static long long padded_batch(int batch) { return ((long long)(batch + GPB - 1) 
 LFSD_API size_t lfsd_coc_workspace_bytes(int dtype, int batch, int n_grid) {
   if (batch <= 0 || n_grid <= 0 || (dtype != LFSD_F32 && dtype != LFSD_F64)) return 0;
   const size_t es = dtype == LFSD_F32 ? 4 : 8;
-  return (size_t)padded_batch(batch) * (size_t)lfsd::OcLayout<Model>::ws_elems(n_grid) * es;
+  return (size_t)padded_batch(batch) * (size_t)lfsd::OcLayout<Model>::template ws_elems<G>(n_grid) * es;
 }
 
 template <typename T>
 static int coc_solve_t(int batch, int n_grid, int steps_per_grid, const void* ini_state, const void* horizon,
                        const void* auxvar, const void* consts, int const_per_traj, const void* u_init,
                        void* state_grid, void* control_grid, void* costate_grid, void* cost, int* iters, int* status,
-                       int max_iter, double tol, void* workspace, size_t workspace_bytes, void* stream) {
+                       int max_iter, double tol, int exact_after, void* workspace, size_t workspace_bytes,
+                       void* stream) {
   lfsd::OcArgs<T> a;
   a.batch = batch; a.n_grid = n_grid; a.steps_per_grid = steps_per_grid; a.max_iter = max_iter;
   a.ini_state = (const T*)ini_state; a.horizon = (const T*)horizon; a.auxvar = (const T*)auxvar;
@@ -65,33 +66,51 @@ static int coc_solve_t(int batch, int n_grid, int steps_per_grid, const void* in
   a.u_init = (const T*)u_init;
   a.state_grid = (T*)state_grid; a.control_grid = (T*)control_grid; a.costate_grid = (T*)costate_grid;
   a.cost = (T*)cost; a.iters = iters; a.status = status;
-  a.ws = (T*)workspace; a.ws_stride = lfsd::OcLayout<Model>::ws_elems(n_grid);
+  a.ws = (T*)workspace; a.ws_stride = lfsd::OcLayout<Model>::template ws_elems<G>(n_grid);
   a.tol = (T)tol;
+  a.exact_after = exact_after;
   const size_t need = (size_t)padded_batch(batch) * (size_t)a.ws_stride * sizeof(T);
   if (workspace_bytes < need) return LFSD_ENOSPC;
   const unsigned grid = (unsigned)(padded_batch(batch) / GPB);
-  LFSD_LAUNCH((lfsd::oc_solve_kernel<Model, T, G>), grid, 64, stream, a);
+  a.it_start = 0; a.resume = 0;
+  if (exact_after < 0) {                       // Gauss-Newton / Hamiltonian models only
+    LFSD_LAUNCH((lfsd::oc_solve_kernel<Model, T, G, false>), grid, 64, stream, a);
+    return launch_status();
+  }
+  if (exact_after == 0) {                      // Newton from the first iteration
+    LFSD_LAUNCH((lfsd::oc_solve_kernel<Model, T, G, true>), grid, 64, stream, a);
+    return launch_status();
+  }
+  // default: lean kernel for the first `exact_after` iterations, then the exact-capable kernel resumes
+  // (warm-started from control_grid) the trajectories that are still at MAXITER
+  a.max_iter = max_iter < exact_after ? max_iter : exact_after;
+  LFSD_LAUNCH((lfsd::oc_solve_kernel<Model, T, G, false>), grid, 64, stream, a);
+  int rc = launch_status();
+  if (rc || max_iter <= exact_after) return rc;
+  a.max_iter = max_iter; a.it_start = exact_after; a.resume = 1;
+  LFSD_LAUNCH((lfsd::oc_solve_kernel<Model, T, G, true>), grid, 64, stream, a);
   return launch_status();
 }
 
 LFSD_API int lfsd_coc_solve(int dtype, int batch, int n_grid, int steps_per_grid, const void* ini_state,
                               const void* horizon, const void* auxvar, const void* consts, int const_per_traj,
                               const void* u_init, void* state_grid, void* control_grid, void* costate_grid, void* cost,
-                              int* iters, int* status, int max_iter, double tol, void* workspace,
-                              size_t workspace_bytes, void* stream) {
+                              int* iters, int* status, int max_iter, double tol, int exact_after,
+                              void* workspace, size_t workspace_bytes, void* stream) {
   if (batch <= 0 || n_grid <= 0 || steps_per_grid <= 0 || max_iter < 0 || !(tol >= 0)) return LFSD_EINVAL;
+  if (steps_per_grid > lfsd::OcLayout<Model>::SMAX) return LFSD_EINVAL;
   if (!ini_state || !horizon || !auxvar || !state_grid || !control_grid || !costate_grid || !cost || !iters ||
       !status || !workspace)
     return LFSD_EINVAL;
   if (Model::NC_REAL > 0 && !consts) return LFSD_EINVAL;
   if (dtype == LFSD_F32)
     return coc_solve_t<float>(batch, n_grid, steps_per_grid, ini_state, horizon, auxvar, consts, const_per_traj, u_init,
-                              state_grid, control_grid, costate_grid, cost, iters, status, max_iter, tol, workspace,
-                              workspace_bytes, stream);
+                              state_grid, control_grid, costate_grid, cost, iters, status, max_iter, tol, exact_after,
+                              workspace, workspace_bytes, stream);
   if (dtype == LFSD_F64)
     return coc_solve_t<double>(batch, n_grid, steps_per_grid, ini_state, horizon, auxvar, consts, const_per_traj,
                                u_init, state_grid, control_grid, costate_grid, cost, iters, status, max_iter, tol,
-                               workspace, workspace_bytes, stream);
+                               exact_after, workspace, workspace_bytes, stream);
   return LFSD_EINVAL;
 }
 

@@ -98,6 +98,9 @@ def rocket(n_grid=15):
     env.initCost2(wthrust=0.1)
     oc = _warp(env, CPDP.COCSys(), "rocket_cost2_tw", n_grid)
     ini = [10, -8, 3.] + [0.1, 0.0, -0.0] + JinEnv.toQuaternion(1, [0, -1, 1]) + [0, -0.0, 0.0]
+    # far initial state + 3 s horizon: Gauss-Newton stalls in a poor basin, Newton (exact stage Hessians) from the
+    # first iteration reaches the optimum
+    oc.setSolverOptions(exact_after=0, max_iter=600)
     return oc, env, dict(ini_state=ini, horizon=3.0, theta0=[1.0] + [0.5] * 11, lr=1e-3,
                          interface=[0, 1, 2, 6, 7, 8, 9], true_theta=[2] + [1] * 11)
 

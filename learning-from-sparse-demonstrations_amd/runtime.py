@@ -124,7 +124,7 @@ class ModelLibrary:
         L.lfsd_const_default.restype = cd
         L.lfsd_coc_workspace_bytes.argtypes = [ci, ci, ci]
         L.lfsd_coc_workspace_bytes.restype = ctypes.c_size_t
-        L.lfsd_coc_solve.argtypes = [ci, ci, ci, ci, vp, vp, vp, vp, ci, vp, vp, vp, vp, vp, vp, vp, ci, cd, vp,
+        L.lfsd_coc_solve.argtypes = [ci, ci, ci, ci, vp, vp, vp, vp, ci, vp, vp, vp, vp, vp, vp, vp, ci, cd, ci, vp,
                                      ctypes.c_size_t, vp]
         L.lfsd_aux_solve.argtypes = [ci, ci, ci, vp, vp, vp, ci, vp, vp, vp, vp, ci, ci, vp, vp, vp, vp, vp, vp, vp,
                                      ci, vp]
@@ -186,7 +186,7 @@ class ModelLibrary:
         return int(self.lib.lfsd_coc_workspace_bytes(_DT[dtype], batch, n_grid))
 
     def coc_solve(self, ini_state, horizon, auxvar, consts, n_grid, steps_per_grid=4, u_init=None, max_iter=100,
-                  tol=None, workspace=None, out=None):
+                  tol=None, workspace=None, out=None, exact_after=16):
         dt = ini_state.dtype
         B = ini_state.shape[0]
         n, m, p, nc = self.n_state, self.n_control, self.n_auxvar, self.n_const
@@ -222,7 +222,7 @@ class ModelLibrary:
                                      self._p(auxvar), self._p(consts), per_traj, self._p(u_init),
                                      self._p(out["state_grid"]), self._p(out["control_grid"]),
                                      self._p(out["costate_grid"]), self._p(out["cost"]), self._p(out["iters"]),
-                                     self._p(out["status"]), int(max_iter), float(tol), self._p(workspace),
+                                     self._p(out["status"]), int(max_iter), float(tol), int(exact_after), self._p(workspace),
                                      workspace.numel() * workspace.element_size(), self._stream(ini_state))
         self._rc(rc, "lfsd_coc_solve")
         out["workspace"] = workspace

@@ -156,6 +156,60 @@ class COCSys:
             return y[:n], y[n], M
         return y[:n], y[n]
 
+    def stage_hessian(self, tk, x, u, e, DT, lam_next):
+        """Exact Hessian w.r.t. (x_k, u_k) of the stage Lagrangian  Q_k(x,u) + lam_{k+1}^T F_k(x,u)
+        (the block of the NLP's Lagrangian Hessian that IPOPT gets from CasADi), by a second-order
+        adjoint sweep through the RK4 stages.  Also returns the first-order adjoint lam_k."""
+        n, m, S = self.n_state, self.n_control, self.steps_per_grid
+        h = DT
+        w = (h / 6, h / 3, h / 3, h / 6)
+        Ud = np.hstack([np.zeros((m, n)), np.eye(m)])
+        f = lambda xx: self._call('dyn', tk, xx, u, e).ravel()
+        fx = lambda xx: self._call('dfx', tk, xx, u, e)
+        fu = lambda xx: self._call('dfu', tk, xx, u, e)
+
+        def stages(x0s, X0):
+            xs, Xs, ks, ds = [x0s], [X0], [], []
+            for a in (h / 2, h / 2, h):
+                ks.append(f(xs[-1])); ds.append(fx(xs[-1]) @ Xs[-1] + fu(xs[-1]) @ Ud)
+                xs.append(x0s + a * ks[-1]); Xs.append(X0 + a * ds[-1])
+            ks.append(f(xs[-1])); ds.append(fx(xs[-1]) @ Xs[-1] + fu(xs[-1]) @ Ud)
+            return xs, Xs, ks, ds
+        x = np.asarray(x, dtype=float)
+        Xd = np.hstack([np.eye(n), np.zeros((n, m))])
+        starts = []
+        for _ in range(S):
+            starts.append((x.copy(), Xd.copy()))
+            xs, Xs, ks, ds = stages(x, Xd)
+            x = x + h / 6 * (ks[0] + 2 * ks[1] + 2 * ks[2] + ks[3])
+            Xd = Xd + h / 6 * (ds[0] + 2 * ds[1] + 2 * ds[2] + ds[3])
+        lam = np.asarray(lam_next, dtype=float).copy()
+        dlam = np.zeros((n, n + m))
+        du = np.zeros((m, n + m))
+        carry = (0.0, h, h / 2, h / 2)          # kappa_i = w_i*lam + carry_i * ybar_{i+1}
+        for s in range(S - 1, -1, -1):
+            xs, Xs, _, _ = stages(*starts[s])
+            yb_next, dyb_next = np.zeros(n), np.zeros((n, n + m))
+            lam_new, dlam_new = lam.copy(), dlam.copy()
+            for i in (3, 2, 1, 0):
+                c_i = carry[3 - i] if i < 3 else 0.0
+                kap = w[i] * lam + c_i * yb_next
+                dkap = w[i] * dlam + c_i * dyb_next
+                Fx, Fu = fx(xs[i]), fu(xs[i])
+                l = kap / w[i]
+                Hxx = self._call('ddHxx', tk, xs[i], u, l, e); Hxu = self._call('ddHxu', tk, xs[i], u, l, e)
+                Huu = self._call('ddHuu', tk, xs[i], u, l, e)
+                cx = self._call('dcx', tk, xs[i], u, e).ravel()
+                yb = Fx.T @ kap + w[i] * cx
+                dyb = Fx.T @ dkap + w[i] * (Hxx @ Xs[i] + Hxu @ Ud)
+                du = du + Fu.T @ dkap + w[i] * (Hxu.T @ Xs[i] + Huu @ Ud)
+                lam_new = lam_new + yb
+                dlam_new = dlam_new + dyb
+                yb_next, dyb_next = yb, dyb
+            lam, dlam = lam_new, dlam_new
+        Hz = np.vstack([dlam, du])
+        return 0.5 * (Hz + Hz.T), lam
+
     def rollout_cost(self, ini_state, horizon, e, U):
         """Objective J of the NLP (CPDP.py:157-175) for a control sequence (single shooting)."""
         N = self.n_grid
@@ -173,7 +227,7 @@ class COCSys:
 
     # ---- CPDP.py:92-198 -----------------------------------------------------
     def cocSolver(self, ini_state, horizon, auxvar_value=1, interplation_level=1, print_level=0,
-                  tol=1e-10, max_iter=300, U_init=None, return_grids=False):
+                  tol=1e-10, max_iter=300, U_init=None, return_grids=False, exact_after=16):
         self.diffPMP()
         if not hasattr(self, 'n_grid'):
             self.setIntegrator()
@@ -189,38 +243,54 @@ class COCSys:
         mu = 0.0
         lam = np.zeros((N + 1, n))
         info = dict(iters=0, converged=False)
-        # Hessian model of the stage: dgrid * d2H/d(x,u)2 evaluated with costate scale HL.
-        # HL=0 -> Gauss-Newton (robust far from the optimum), HL=1 -> Newton-like polish.
-        HL = 0.0
+        # Stage Hessian model.  exact=False: Gauss-Newton (cost curvature only: robust far from the optimum);
+        # exact=True: exact Lagrangian Hessian of the RK4 shooting stage (second-order adjoint) with a
+        # Levenberg shift mu on Q_uu when it is indefinite -- Newton's method on the NLP, as IPOPT runs it.
+        exact = False
+        gn_patience = exact_after       # same knob as lfsd_coc_solve's `exact_after`
+        zero_l = np.zeros(n)
         for it in range(max_iter):
-            # linearise the shooting map along (X, U)
             A, B, qx, qu = [], [], [], []
             for k in range(N):
                 _, _, M = self.grid_map(time_grid[k], X[k], U[k], e, DT, derivs=True)
                 A.append(M[:n, :n]); B.append(M[:n, n:]); qx.append(M[n, :n]); qu.append(M[n, n:])
-            # backward sweep: exact costate + DDP gains
-            while True:
-                Vx = self._call('dhx', time_grid[-1], X[N], e).ravel()
+            # exact discrete costates  lambda_k = q_x + A^T lambda_{k+1}
+            lam[N] = self._call('dhx', time_grid[-1], X[N], e).ravel()
+            gnorm = 0.0
+            for k in range(N - 1, -1, -1):
+                gnorm = max(gnorm, np.max(np.abs(qu[k] + B[k].T @ lam[k + 1])))
+                lam[k] = qx[k] + A[k].T @ lam[k + 1]
+            info.update(iters=it, grad_inf=gnorm)
+            if gnorm < tol * (1 + abs(J)):
+                info['converged'] = True
+                break
+            if gn_patience >= 0 and it >= gn_patience:
+                exact = True
+            Hs = []
+            for k in range(N):
+                if exact:
+                    Hs.append(self.stage_hessian(time_grid[k], X[k], U[k], e, DT, lam[k + 1])[0])
+                else:
+                    Hs.append(dgrid * np.block([
+                        [self._call('ddHxx', time_grid[k], X[k], U[k], zero_l, e),
+                         self._call('ddHxu', time_grid[k], X[k], U[k], zero_l, e)],
+                        [self._call('ddHxu', time_grid[k], X[k], U[k], zero_l, e).T,
+                         self._call('ddHuu', time_grid[k], X[k], U[k], zero_l, e)]]))
+            while True:      # backward sweep (retry with a larger shift when Q_uu is not positive definite)
+                Vx = lam[N].copy()
                 Vxx = self._call('ddhxx', time_grid[-1], X[N], e)
-                lam[N] = Vx
-                lam_k = Vx.copy()
                 kff = np.zeros((N, m)); K = np.zeros((N, m, n))
                 dV1 = dV2 = 0.0
                 ok = True
-                gnorm = 0.0
                 for k in range(N - 1, -1, -1):
-                    Hxx = self._call('ddHxx', time_grid[k], X[k], U[k], HL * lam_k, e) * dgrid
-                    Hxu = self._call('ddHxu', time_grid[k], X[k], U[k], HL * lam_k, e) * dgrid
-                    Huu = self._call('ddHuu', time_grid[k], X[k], U[k], HL * lam_k, e) * dgrid
                     Qx = qx[k] + A[k].T @ Vx
                     Qu = qu[k] + B[k].T @ Vx
-                    Qxx = Hxx + A[k].T @ Vxx @ A[k]
-                    Qux = Hxu.T + B[k].T @ Vxx @ A[k]
-                    Quu0 = Huu + B[k].T @ Vxx @ B[k]
+                    Qxx = Hs[k][:n, :n] + A[k].T @ Vxx @ A[k]
+                    Qux = Hs[k][n:, :n] + B[k].T @ Vxx @ A[k]
+                    Quu0 = Hs[k][n:, n:] + B[k].T @ Vxx @ B[k]
                     Quu0 = 0.5 * (Quu0 + Quu0.T)
-                    Quu = Quu0 + mu * np.eye(m)
                     try:
-                        Lc = np.linalg.cholesky(Quu)
+                        Lc = np.linalg.cholesky(Quu0 + mu * np.eye(m))
                     except np.linalg.LinAlgError:
                         ok = False
                         break
@@ -232,19 +302,12 @@ class COCSys:
                     Vx = Qx + K[k].T @ Quu0 @ kff[k] + K[k].T @ Qu + Qux.T @ kff[k]
                     Vxx = Qxx + K[k].T @ Quu0 @ K[k] + K[k].T @ Qux + Qux.T @ K[k]
                     Vxx = 0.5 * (Vxx + Vxx.T)
-                    # exact discrete costate  lambda_k = q_x + A^T lambda_{k+1}
-                    gnorm = max(gnorm, np.max(np.abs(qu[k] + B[k].T @ lam_k)))
-                    lam_k = qx[k] + A[k].T @ lam_k
-                    lam[k] = lam_k
                 if ok:
                     break
-                if HL > 0:
-                    HL = 0.0            # Newton model indefinite here: fall back to Gauss-Newton
-                else:
-                    mu = max(10 * mu, 1e-6)
-            info.update(iters=it, grad_inf=gnorm)
-            if gnorm < tol * (1 + abs(J)):
-                info['converged'] = True
+                mu = max(10 * mu, 1e-4)
+                if mu > 1e12:
+                    break
+            if not ok:
                 break
             # forward line search on the true NLP objective
             alpha = 1.0
@@ -264,16 +327,14 @@ class COCSys:
                     break
                 alpha *= 0.5
             if not accepted:
-                if HL > 0:
-                    HL = 0.0
-                    continue
-                mu = max(10 * mu, 1e-6)
-                if mu > 1e8:
+                mu = max(10 * mu, 1e-4)
+                if mu > 1e12:
                     break
                 continue
-            mu = mu / 10 if mu > 1e-9 else 0.0
-            # switch to the Newton-like model once full GN steps only buy small decreases
-            HL = 1.0 if (alpha == 1.0 and (J - Jn) < 1e-2 * (abs(Jn) + 1e-12)) else 0.0
+            if alpha == 1.0:
+                mu = mu / 10 if mu > 1e-8 else 0.0
+                if (J - Jn) < 1e-2 * (abs(Jn) + 1e-12):
+                    exact = True        # close: switch to Newton for the quadratic tail
             X, U, J = np.array(Xn), Un, Jn
         self.last_info = info
         self.last_cost = J

@@ -80,9 +80,9 @@ def make_oracle(kind, n_grid, **kw):
 TIGHT = dict(riccati_method='Radau', ivp_kwargs=dict(rtol=1e-10, atol=1e-12))
 
 
-def oracle_loss_grad(oc, ini_state, horizon, theta, taus, wps, iface, tight=True):
+def oracle_loss_grad(oc, ini_state, horizon, theta, taus, wps, iface, tight=True, **solver_kw):
     from oracle.cpdp_oracle import getloss_corrections
-    tg, sol, X, U, L = oc.cocSolver(ini_state, horizon, theta, return_grids=True)
+    tg, sol, X, U, L = oc.cocSolver(ini_state, horizon, theta, return_grids=True, **solver_kw)
     aux, PW, vX, vU = oc.auxSysSolver(tg, sol, theta, return_grids=True, **(TIGHT if tight else {}))
     loss, grad = getloss_corrections(oc, taus, wps, sol, aux, iface)
     return dict(loss=loss, grad=grad, X=X, U=U, L=L, PW=PW, vX=vX, vU=vU, info=oc.last_info)

@@ -263,3 +263,26 @@ def test_quadalgorithm_driver_replays_reference_run_start(emu):
     assert res["opt_state_traj"].shape == (101, 13) and res["opt_control_traj"].shape == (101, 4)
     with pytest.raises(Exception, match="Wrong optimization method type!"):
         S.load_optimization_function({"learning_rate": 0.01, "iter_num": 3, "method": "RMSprop"})
+
+
+def test_rocket_newton_mode_vs_oracle(emu):
+    """Examples/rocket_groundtruth.py (6-DoF powered landing, T=3): needs the exact stage Hessians (second-order
+    adjoint through the RK4 stages) from the first iteration; kernel and oracle must reach the same KKT point."""
+    oc, env, d = models.rocket(n_grid=15)
+    emu(oc)
+    oc.setDevice(dtype=torch.float64)
+    oc.setSolverOptions(aux_substeps=8)
+    th = d["true_theta"]
+    sol = oc.cocSolverBatch([d["ini_state"]], d["horizon"], [th])
+    assert sol["status"].tolist() == [1]
+    o = make_oracle("rocket", 15)
+    tg = np.linspace(0, d["horizon"], 16)
+    taus = tg[[1, 3, 6, 10, 13]]                                    # rocket_groundtruth.py:78
+    r0 = o.cocSolver(d["ini_state"], d["horizon"], th, return_grids=True, exact_after=0, max_iter=400)
+    assert o.last_info["converged"] and abs(o.last_cost - sol["cost"][0].item()) < 1e-8 * abs(o.last_cost)
+    wps = [np.concatenate([r0[1](t)[0:3], r0[1](t)[6:10]]) + 0.05 for t in taus]
+    r = oracle_loss_grad(o, d["ini_state"], d["horizon"], th, taus, wps, d["interface"], exact_after=0, max_iter=400)
+    aux = oc.auxSysSolverBatch(sol, taus, wps, d["interface"])
+    assert rel(sol["state_grid"][0], r["X"]) < 1e-6 and rel(sol["costate_grid"][0], r["L"]) < 1e-5
+    assert abs(aux["loss"][0].item() - r["loss"]) < 1e-7 * max(1.0, r["loss"])
+    assert rel(aux["grad"][0], r["grad"]) < 1e-3

@@ -176,3 +176,25 @@ def test_optimizer_kernels(method):
             th_ref[b] = ref[b].step(th_ref[b], g[b], it)
             th_ref[b][0] = max(th_ref[b][0], 1e-8)
         assert np.allclose(theta.cpu().numpy(), th_ref, rtol=1e-12, atol=1e-13)
+
+
+def test_rocket_newton_mode_vs_oracle():
+    """BASELINE configs[4] robot (Examples/rocket_groundtruth.py): exact stage Hessians from the first iteration."""
+    o = make_oracle("rocket", 15)
+    oc, d = gpu_model("rocket", torch.float64, 15, substeps=8)
+    th = d["true_theta"]
+    taus = np.linspace(0, d["horizon"], 16)[[1, 3, 6, 10, 13]]
+    r0 = o.cocSolver(d["ini_state"], d["horizon"], th, return_grids=True, exact_after=0, max_iter=400)
+    wps = [np.concatenate([r0[1](t)[0:3], r0[1](t)[6:10]]) + 0.05 for t in taus]
+    r = oracle_loss_grad(o, d["ini_state"], d["horizon"], th, taus, wps, d["interface"], exact_after=0, max_iter=400)
+    sol = oc.cocSolverBatch([d["ini_state"]] * 3, d["horizon"], [th] * 3)
+    aux = oc.auxSysSolverBatch(sol, taus, wps, d["interface"])
+    assert sol["status"].tolist() == [1, 1, 1]
+    assert abs(sol["cost"][0].item() - o.last_cost) < 1e-8 * abs(o.last_cost)
+    assert rel(sol["state_grid"][2], r["X"]) < 1e-6
+    assert abs(aux["loss"][1].item() - r["loss"]) < 1e-7 * max(1.0, r["loss"]) and rel(aux["grad"][1], r["grad"]) < 1e-3
+    oc32, _ = gpu_model("rocket", torch.float32, 15, substeps=8)
+    sol32 = oc32.cocSolverBatch([d["ini_state"]], d["horizon"], [th])
+    aux32 = oc32.auxSysSolverBatch(sol32, taus, wps, d["interface"])
+    assert sol32["status"].item() in (1, 2)
+    assert abs(aux32["loss"][0].item() - r["loss"]) < 2e-3 * max(1.0, r["loss"]) and rel(aux32["grad"][0], r["grad"]) < 2e-2
