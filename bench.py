@@ -164,7 +164,7 @@ def main():
         tpath = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get(dom, {}).get("hbm_bytes_per_launch")
+                traffic = json.load(open(tpath)).get(dom, {}).get("hbm_bytes_per_step")
             except Exception:
                 traffic = None
         out = {
