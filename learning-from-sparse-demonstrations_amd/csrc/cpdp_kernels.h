@@ -249,7 +249,7 @@ template <class M> struct OcLayout {
   // scratch per trajectory (elements)
   static constexpr int SMAX = 8;       // RK4 sub-steps per grid interval supported by the exact-Hessian sweep
   template <int G> static long long ws_elems(int N) {
-    return 2LL * (N + 1) * NX + 2LL * N * NU + 1LL * N * NXU * (NX + 1) + 1LL * N * NX * NU + 1LL * N * NU +
+    return 2LL * (N + 1) * NX + 2LL * N * NU + 2LL * N * NXU * (NX + 1) + 1LL * N * NX * NU + 1LL * N * NU +
            1LL * (N + 1) * NX + 1LL * SMAX * NX * (1 + G);      // + sub-step start states (uniform | per lane)
   }
   // LDS per group (elements)
@@ -279,7 +279,7 @@ template <class M, typename T, int G, bool EXACT> struct OcSolver {
   int lane, N, S;
   const T *e, *c, *x0;      // [NP], [NC], [NX] in LDS
   T horizon, dgrid, DT;
-  T *xb[2], *ub[2], *Mws, *Kws, *kws, *lds, *exws;
+  T *xb[2], *ub[2], *Mws[2], *Kws, *kws, *lds, *exws;
   T* lam_out;   // costate grid of this trajectory (or scratch when invalid)
 
   LFSD_DEV T tk(int k) const { return M::TIME_VARYING ? dgrid * T(k) : T(0); }
@@ -352,7 +352,7 @@ template <class M, typename T, int G, bool EXACT> struct OcSolver {
       for (int s = 0; s < S; ++s) rk4_step<true>(t, x, q, u, m, mq, du);
       J += q;
       if (lane < NXU) {
-        T* col = Mws + ((long long)k * NXU + lane) * (NX + 1);
+        T* col = Mws[nxt] + ((long long)k * NXU + lane) * (NX + 1);
 #pragma unroll
         for (int i = 0; i < NX; ++i) col[i] = m[i];
         col[NX] = mq;
@@ -475,7 +475,7 @@ template <class M, typename T, int G, bool EXACT> struct OcSolver {
     for (int k = N - 1; k >= 0; --k) {
       T m[NX], mq = T(0);
       if (lane < NXU) {
-        const T* col = Mws + ((long long)k * NXU + lane) * (NX + 1);
+        const T* col = Mws[cur] + ((long long)k * NXU + lane) * (NX + 1);
 #pragma unroll
         for (int i = 0; i < NX; ++i) m[i] = col[i];
         mq = col[NX];
@@ -725,7 +725,8 @@ __global__ void __launch_bounds__(64, LFSD_WAVES_PER_SIMD) oc_solve_kernel(OcArg
   s.xb[1] = w; w += (N + 1) * NX;
   s.ub[0] = w; w += N * NU;
   s.ub[1] = w; w += N * NU;
-  s.Mws = w; w += (long long)N * (NX + NU) * (NX + 1);
+  s.Mws[0] = w; w += (long long)N * (NX + NU) * (NX + 1);
+  s.Mws[1] = w; w += (long long)N * (NX + NU) * (NX + 1);
   s.Kws = w; w += (long long)N * NX * NU;
   s.kws = w; w += N * NU;
   s.exws = w; w += (long long)Lay::SMAX * NX * (1 + G);
@@ -742,6 +743,7 @@ __global__ void __launch_bounds__(64, LFSD_WAVES_PER_SIMD) oc_solve_kernel(OcArg
   T mu = T(0);
   int mode = 0;             // stage Hessian model: 0 Gauss-Newton, 1 Hamiltonian (cheap Newton-like), 2 exact
   bool ham_ok = true;       // the cheap Newton-like model has not failed on this trajectory yet
+  bool optimistic = true;   // try the full step directly (skips the parallel line search while alpha = 1 keeps working)
   int status = ST_RUNNING, it = a.it_start, my_iters = a.it_start;
   bool need_bw = true;      // costates on `lam_out` are stale
   T gnorm = T(0), dV1 = T(0), dV2 = T(0);
@@ -779,11 +781,22 @@ __global__ void __launch_bounds__(64, LFSD_WAVES_PER_SIMD) oc_solve_kernel(OcArg
         try_step = true;
       }
     }
+    // Step selection.  Optimistic groups roll the full step (alpha = 1) out together with its linearisation and
+    // keep it if it passes the Armijo test; only after a failure do they pay for the parallel line search.
+    const bool opt_try = try_step && optimistic;
+    const bool ls_try = try_step && !optimistic;
     T alpha = T(0), Jmin = J;
     bool flat_full = false;
-    int ia = s.linesearch(cur, J, dV1, dV2, alpha, Jmin, flat_full);
+    int ia = -1;
+    if (threadIdx.x == 0) vote[1] = 0;
+    __syncthreads();
+    if (ls_try) vote[1] = 1;
+    __syncthreads();
+    const bool any_ls = vote[1] != 0;
+    __syncthreads();
+    if (any_ls) ia = s.linesearch(cur, J, dV1, dV2, alpha, Jmin, flat_full);
     bool accept = false;
-    if (try_step) {
+    if (ls_try) {
       if (ia >= 0) {
         accept = true;
       } else if (mode >= 1 && flat_full && (g_flat < T(0) || gnorm < T(0.7) * g_flat)) {
@@ -800,17 +813,31 @@ __global__ void __launch_bounds__(64, LFSD_WAVES_PER_SIMD) oc_solve_kernel(OcArg
       }
     }
 #if defined(LFSD_TRACE)
-    if (s.lane == 0 && slot == 0) printf("it %d st %d mode %d bw_ok %d g %.6e J %.12e ia %d alpha %g accept %d mu %g dV1 %.4e dV2 %.4e Jmin %.12e flat %d\n", it, status, mode, (int)bw_ok, (double)gnorm, (double)J, ia, (double)alpha, (int)accept, (double)mu, (double)dV1, (double)dV2, (double)Jmin, (int)flat_full);
+    if (s.lane == 0 && slot == 0) printf("it %d st %d mode %d bw_ok %d g %.6e J %.12e opt %d ia %d alpha %g accept %d mu %g dV1 %.4e dV2 %.4e Jmin %.12e flat %d\n", it, status, mode, (int)bw_ok, (double)gnorm, (double)J, (int)opt_try, ia, (double)alpha, (int)accept, (double)mu, (double)dV1, (double)dV2, (double)Jmin, (int)flat_full);
 #endif
+    const bool roll = accept || opt_try;
     if (threadIdx.x == 0) vote[1] = 0;
     __syncthreads();
-    if (accept) vote[1] = 1;
+    if (roll) vote[1] = 1;
     __syncthreads();
     if (vote[1]) {
-      const T Jn = s.rollout_sens(cur, cur ^ 1, accept ? alpha : T(0), accept);
-      cur ^= 1;
-      need_bw = true;
+      const T Jn = s.rollout_sens(cur, cur ^ 1, opt_try ? T(1) : (accept ? alpha : T(0)), roll);
+      if (opt_try) {
+        const T flat = T(8) * Eps<T>::v() * t_abs(J);
+        const bool fin = t_finite(Jn);
+        if (fin && (J - Jn) >= T(1e-4) * (-(dV1 + dV2)) - flat && Jn < J) {
+          accept = true; ia = 0;
+        } else if (fin && mode >= 1 && t_abs(Jn - J) <= T(64) * Eps<T>::v() * t_abs(J) &&
+                   (g_flat < T(0) || gnorm < T(0.7) * g_flat)) {
+          accept = true; ia = 0; g_flat = gnorm;
+        } else {
+          optimistic = false;     // same gains, parallel line search next round
+        }
+      }
       if (accept) {
+        cur ^= 1;
+        need_bw = true;
+        optimistic = (ia == 0);
         if (ia == 0) {
           mu = (mu > T(1e-8)) ? mu * T(0.1) : T(0);
           if (mode == 0 && ham_ok && (J - Jn) < T(1e-2) * t_abs(Jn)) mode = 1;     // close: Newton-like tail
