@@ -78,11 +78,12 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world > 1:
+    use_dist = "RANK" in os.environ and "MASTER_PORT" in os.environ      # launched by torch.distributed.run
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world)       # "nccl" == RCCL on ROCm
     assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no CPU fallback)"
-    dev = torch.device("cuda", local_rank)
+    dev = torch.device("cuda", local_rank % torch.cuda.device_count())
     torch.cuda.set_device(dev)
 
     import lfsd_amd  # noqa: F401
@@ -120,7 +121,7 @@ def main():
         L._aux = oc.auxSysSolverBatch(L._sol, L.taus, L.wps, L.iface, Z_grid=L._Z, out=L._aux_out(), phase_hook=hook)
         L._Z = L._aux["Z_grid"]
         loss, grad = L._aux["loss"], L._aux["grad"]
-        if world > 1:
+        if use_dist:
             buf = torch.cat([grad.sum(dim=0), loss.sum().reshape(1)])
             dist.all_reduce(buf)                                            # summed d(theta) + loss over all ranks
         L.lib.optimizer_step(L.method, L.theta, grad, L.iter_idx, L.lr, L.mu, L.b1, L.b2, L.eps, m=L.m, v=L.v,
@@ -133,7 +134,7 @@ def main():
         return loss
 
     def sync():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -145,7 +146,7 @@ def main():
         loss = step(True)
     sync()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
@@ -193,7 +194,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(d, args.n_grid, theta0, 4)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -43,6 +43,7 @@ class COCSys:
         self.max_iter = 100
         self.tol = None
         self.exact_after = 16            # iteration from which the exact stage Hessian is forced
+        self.aux_dtype = None            # None: same as dtype; torch.float64: fp64 auxiliary (Riccati/sensitivity) pass
 
     # ---- model definition (CPDP.py:15-87) ------------------------------------------------------
     def setAuxvarVariable(self, auxvar=None):
@@ -96,11 +97,15 @@ class COCSys:
         self.steps_per_grid = steps_per_grid
 
     # ---- extensions ---------------------------------------------------------------------------
-    def setDevice(self, device=None, dtype=None):
+    def setDevice(self, device=None, dtype=None, aux_dtype=None):
+        """dtype: arithmetic of the OC solve; aux_dtype (optional): arithmetic of the differentiated-PMP pass, e.g.
+        fp32 solve + fp64 Riccati/sensitivity sweeps (BASELINE configs[4])."""
         if device is not None:
             self.device = torch.device(device)
         if dtype is not None:
             self.dtype = dtype
+        if aux_dtype is not None:
+            self.aux_dtype = aux_dtype
 
     def setSolverOptions(self, max_iter=None, tol=None, aux_substeps=None, exact_after=None):
         if max_iter is not None:
@@ -242,8 +247,12 @@ class COCSys:
             if wp.dim() == 2:
                 wp = wp.unsqueeze(0).expand(B, -1, -1).contiguous()
             ii = torch.as_tensor(list(interface_idx), dtype=torch.int32, device=self._dev())
-        return lib.aux_solve(sol["horizon"], th, sol["consts"], sol["state_grid"], sol["control_grid"],
-                             sol["costate_grid"], tt, wp, ii, substeps=self.aux_substeps, want_grids=want_grids,
+        hz, cs, X, U, Lm = sol["horizon"], sol["consts"], sol["state_grid"], sol["control_grid"], sol["costate_grid"]
+        ad = self.aux_dtype
+        if ad is not None and ad != X.dtype:          # mixed precision: promote the solved grids for the aux pass
+            cv = lambda t: None if t is None else t.to(ad).contiguous()
+            hz, th, cs, X, U, Lm, tt, wp = (cv(t) for t in (hz, th, cs, X, U, Lm, tt, wp))
+        return lib.aux_solve(hz, th, cs, X, U, Lm, tt, wp, ii, substeps=self.aux_substeps, want_grids=want_grids,
                              Z_grid=Z_grid, out=out, phase_hook=phase_hook)
 
     # ---- the reference's one-trajectory calls --------------------------------------------------------
@@ -355,7 +364,7 @@ class SparseDemoLearner:
         self._aux = self.oc.auxSysSolverBatch(self._sol, self.taus, self.wps, self.iface, Z_grid=self._Z,
                                               out=self._aux_out())
         self._Z = self._aux["Z_grid"]
-        return self._aux["loss"], self._aux["grad"]
+        return self._aux["loss"].to(self.theta.dtype), self._aux["grad"].to(self.theta.dtype)
 
     def _sol_out(self):
         if self._sol is None:

@@ -286,3 +286,72 @@ def test_rocket_newton_mode_vs_oracle(emu):
     assert rel(sol["state_grid"][0], r["X"]) < 1e-6 and rel(sol["costate_grid"][0], r["L"]) < 1e-5
     assert abs(aux["loss"][0].item() - r["loss"]) < 1e-7 * max(1.0, r["loss"])
     assert rel(aux["grad"][0], r["grad"]) < 1e-3
+
+
+def test_edge_cases_ragged_empty_and_per_trajectory_inputs(emu):
+    """Ragged batch sizes vs the lane-group packing, no waypoints, waypoint times outside [0, T] (clamped to the end
+    intervals like the interpolant's end points), per-trajectory horizons and per-trajectory constants."""
+    oc, env, d = models.pendulum(n_grid=10)
+    emu(oc)
+    oc.setDevice(dtype=torch.float64)
+    oc.setSolverOptions(aux_substeps=4)
+    rng = np.random.default_rng(7)
+    th_all = np.array([1.0, 0.5, 1.5]) + 0.2 * rng.standard_normal((17, 3))
+    th_all[:, 0] = np.abs(th_all[:, 0]) + 0.3
+    hz_all = rng.uniform(0.6, 1.4, 17)
+    taus = [0.25, 0.5]
+    wps = [[0.5], [1.0]]
+    ref = None
+    for B in (1, 7, 8, 9, 17):                        # 8 trajectories per wavefront for this model (G = 8)
+        sol = oc.cocSolverBatch(np.tile(d["ini_state"], (B, 1)), hz_all[:B], th_all[:B])
+        aux = oc.auxSysSolverBatch(sol, taus, wps, d["interface"])
+        assert sol["state_grid"].shape == (B, 11, 2) and set(sol["status"].tolist()) <= {1, 2}
+        if ref is None:
+            ref = (sol["state_grid"][0].clone(), aux["loss"][0].clone(), aux["grad"][0].clone())
+        # trajectory 0 must not depend on who shares its wavefront
+        assert torch.equal(sol["state_grid"][0], ref[0]) and torch.equal(aux["loss"][0], ref[1])
+        assert torch.equal(aux["grad"][0], ref[2])
+    # no waypoints: loss 0, gradient 0, Riccati grid still produced
+    sol = oc.cocSolverBatch(np.tile(d["ini_state"], (3, 1)), 1.0, th_all[:3])
+    aux = oc.auxSysSolverBatch(sol)
+    assert float(aux["loss"].abs().max()) == 0 and float(aux["grad"].abs().max()) == 0
+    assert torch.isfinite(aux["Z_grid"]).all()
+    # waypoint exactly at t = 0 contributes no gradient (X(0) = 0) and loss (x0 - wp)^2; t beyond T clamps to t = T
+    a0 = oc.auxSysSolverBatch(sol, [0.0], [[0.3]], d["interface"])
+    assert np.allclose(a0["loss"].numpy(), 0.09, atol=1e-12) and float(a0["grad"].abs().max()) < 1e-12
+    aT = oc.auxSysSolverBatch(sol, [1.0], [[0.3]], d["interface"])
+    aT2 = oc.auxSysSolverBatch(sol, [1.0 + 1e-9], [[0.3]], d["interface"])
+    assert torch.allclose(aT["loss"], aT2["loss"], rtol=1e-6) and torch.allclose(aT["grad"], aT2["grad"], rtol=1e-5, atol=1e-9)
+    # per-trajectory constants: a batch with different pendulum lengths equals the individual solves
+    lens = np.array([0.8, 1.0, 1.3])
+    cb = oc.consts_tensor(batch=3, overrides=dict(l=lens))
+    solb = oc.cocSolverBatch(np.tile(d["ini_state"], (3, 1)), 1.0, th_all[:3], consts=cb)
+    for b in range(3):
+        c1 = oc.consts_tensor(overrides=dict(l=float(lens[b])))
+        s1 = oc.cocSolverBatch([d["ini_state"]], 1.0, th_all[b:b + 1], consts=c1)
+        assert torch.equal(s1["state_grid"][0], solb["state_grid"][b])
+    assert not torch.equal(solb["state_grid"][0], solb["state_grid"][2])
+
+
+def test_warm_start_and_mixed_precision(emu):
+    """u_init warm start reaches the same KKT point in fewer iterations; fp32 solve + fp64 auxiliary pass
+    (BASELINE configs[4]) returns fp64-accurate sweeps on the fp32 trajectory."""
+    oc, env, d = models.robotarm(n_grid=12)
+    emu(oc)
+    th = [[3., 0.5, 2, 1.5, 0.2]]
+    oc.setDevice(dtype=torch.float64)
+    cold = oc.cocSolverBatch([d["ini_state"]], 1.0, th)
+    warm = oc.cocSolverBatch([d["ini_state"]], 1.0, th, u_init=cold["control_grid"][:, :12].contiguous())
+    assert warm["iters"].item() <= 2 and cold["iters"].item() > 10
+    assert torch.allclose(warm["state_grid"], cold["state_grid"], atol=1e-8)
+    taus, wps = [0.3], [[-np.pi / 4, 2 * np.pi / 3]]
+    a64 = oc.auxSysSolverBatch(cold, taus, wps, d["interface"])
+    oc.setDevice(dtype=torch.float32, aux_dtype=torch.float64)
+    s32 = oc.cocSolverBatch([d["ini_state"]], 1.0, th)
+    amix = oc.auxSysSolverBatch(s32, taus, wps, d["interface"])
+    assert s32["state_grid"].dtype == torch.float32 and amix["grad"].dtype == torch.float64
+    oc.aux_dtype = None
+    a32 = oc.auxSysSolverBatch(s32, taus, wps, d["interface"])
+    e_mix = rel(amix["grad"][0], a64["grad"][0].numpy())
+    e_32 = rel(a32["grad"][0], a64["grad"][0].numpy())
+    assert e_mix < 2e-2 and e_mix <= e_32 * 1.5 + 1e-6
