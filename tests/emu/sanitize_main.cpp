@@ -1,0 +1,34 @@
+// standalone sanitizer driver: exact-size heap buffers, one small solve through every entry point
+#include "lfsd_capi.cpp"   // the product C ABI translation unit, compiled with -DLFSD_EMU
+#include <vector>
+#include <cstdio>
+int main() {
+  lfsd_model_info mi; lfsd_get_model_info(&mi);
+  const int B = 5, N = 6, n = mi.n_state, m = mi.n_control, p = mi.n_auxvar, nc = mi.n_const, nw = 2, ni = 1;
+  for (int dtype = 0; dtype < 2; ++dtype) {
+    const size_t es = dtype ? 8 : 4;
+    auto buf = [&](size_t cnt) { return std::vector<char>(cnt * es); };
+    auto x0 = buf(B * n), hz = buf(B), th = buf(B * p), cs = buf(nc ? nc : 1), X = buf(B * (N + 1) * n), U = buf(B * (N + 1) * m),
+         L = buf(B * (N + 1) * n), cost = buf(B), Z = buf((size_t)B * (N + 1) * (n + p) * n), taus = buf(B * nw), wps = buf(B * nw * ni),
+         loss = buf(B), grad = buf(B * p), aX = buf((size_t)B * (N + 1) * p * n), aU = buf((size_t)B * (N + 1) * p * m),
+         mth = buf(B * p), mm = buf(B * p), mv = buf(B * p), mvh = buf(B * p), la = buf(B * p);
+    auto set = [&](std::vector<char>& v, size_t i, double val) { if (dtype) ((double*)v.data())[i] = val; else ((float*)v.data())[i] = (float)val; };
+    for (int b = 0; b < B; ++b) { set(hz, b, 1.0); for (int i = 0; i < p; ++i) set(th, b * p + i, 1.0 + 0.1 * i + 0.05 * b);
+      for (int w = 0; w < nw; ++w) { set(taus, b * nw + w, 0.3 + 0.4 * w); set(wps, b * nw + w, 0.5); } }
+    for (int i = 0; i < nc; ++i) set(cs, i, lfsd_const_default(i));
+    std::vector<int> it(B), st(B), iface = {0};
+    size_t wsb = lfsd_coc_workspace_bytes(dtype, B, N);
+    std::vector<char> ws(wsb);
+    int rc = lfsd_coc_solve(dtype, B, N, 4, x0.data(), hz.data(), th.data(), nc ? cs.data() : nullptr, 0, nullptr, X.data(), U.data(), L.data(),
+                            cost.data(), it.data(), st.data(), 40, dtype ? 1e-9 : 1e-6, 3, ws.data(), wsb, nullptr);
+    printf("dtype %d coc rc %d status %d iters %d\n", dtype, rc, st[0], it[0]);
+    rc = lfsd_aux_solve(dtype, B, N, hz.data(), th.data(), nc ? cs.data() : nullptr, 0, X.data(), U.data(), L.data(), Z.data(), nw, ni, iface.data(),
+                        taus.data(), wps.data(), loss.data(), grad.data(), aX.data(), aU.data(), 4, nullptr);
+    printf("dtype %d aux rc %d\n", dtype, rc);
+    for (int meth = 0; meth < 5; ++meth)
+      rc |= lfsd_optimizer_step(dtype, meth, B, p, 0, 0.01, 0.9, 0.9, 0.999, 1e-8, th.data(), grad.data(), mm.data(), mv.data(), mvh.data(), nullptr, nullptr);
+    rc |= lfsd_lookahead(dtype, (long long)B * p, 0.9, th.data(), mm.data(), la.data(), nullptr);
+    printf("dtype %d opt rc %d\n", dtype, rc);
+  }
+  return 0;
+}

@@ -1,0 +1,28 @@
+"""AddressSanitizer + UBSan over the kernel sources (CPU SIMT-emulator build; GPU sanitizers are not available on
+this pool).  Every C-ABI entry point is driven with exact-size heap buffers in fp32 and fp64, including the
+Newton (exact-Hessian) kernel, so any out-of-bounds access into caller memory or LDS arrays aborts the run."""
+import os
+import subprocess
+
+import lfsd_amd  # noqa: F401
+from lfsd_amd import models, runtime
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EMU = os.path.join(ROOT, "tests", "emu")
+
+
+def test_asan_ubsan_clean(tmp_path):
+    oc, _, _ = models.pendulum()
+    spec = oc.model_spec()
+    runtime.write_header(spec)
+    exe = str(tmp_path / "sanitize")
+    cmd = ["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-omit-frame-pointer", "-DLFSD_EMU",
+           "-DLFSD_G=%d" % runtime.lanes_for(spec.n, spec.m, spec.p), "-I" + EMU, "-I" + runtime.CSRC_DIR,
+           '-DLFSD_MODEL_HEADER="gen/%s.h"' % spec.hash(), os.path.join(EMU, "sanitize_main.cpp"), "-o", exe]
+    r = subprocess.run(cmd, cwd=runtime.CSRC_DIR, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    env = dict(os.environ, ASAN_OPTIONS="detect_stack_use_after_return=0:detect_leaks=0")
+    r = subprocess.run([exe], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
+    assert "ERROR: AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stderr[-4000:]
+    assert r.stdout.count("rc 0") == 6, r.stdout
