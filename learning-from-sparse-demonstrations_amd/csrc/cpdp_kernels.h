@@ -907,7 +907,10 @@ template <class M> struct AuxLayout {
   static constexpr int LDS_END = LDS_GB + 2 * NX + NU;
   static constexpr int lds_elems() { return ((LDS_END + 3) / 4) * 4; }
   // forward kernel only: per-lane parking slot for X(t_k) (row i of lane l at [i*G + l])
-  template <int G> static constexpr int lds_elems_fwd() { return ((LDS_END + NX * G + 3) / 4) * 4; }
+  // ... plus, per node and lane, the X-independent part of the right-hand side (fe - fu Huu^-1 (fu^T W + Hue)) e_j
+  template <int G> static constexpr int lds_elems_fwd() { return ((LDS_END + NX * G + NNODE * NX * G + 3) / 4) * 4; }
+  // Riccati kernel only: per node and lane, this lane's column of [Hxx Hxe] and of Huu^-1 [Hux Hue]
+  template <int G> static constexpr int lds_elems_ric() { return ((LDS_END + NNODE * (NX + NU) * G + 3) / 4) * 4; }
 };
 
 template <class M, typename T, int G> struct AuxCtx {
@@ -1016,18 +1019,36 @@ template <class M, typename T, int G> struct AuxCtx {
     }
     __syncthreads();
   }
+  // The columns of [Hxx Hxe] and Huu^-1 [Hux Hue] this lane needs do not depend on Z: once per staged node
+  // instead of once per right-hand-side evaluation (12 per unit).  Parked per lane at [(node*(NX+NU)+r)*G + lane].
+  LFSD_DEV void ric_cols() {
+    T* hc = lds + Lay::LDS_END;
+#pragma unroll
+    for (int nd = 0; nd < Lay::NNODE; ++nd) {
+      const T* L = node(nd);
+      T hx[NX], hu[NU], wq[NU];
+      M::template Hxx_mul<false>(L, ox, hx);
+      M::template Hxe_mul<true>(L, oe, hx);
+      M::template Hxu_mulT<false>(L, ox, hu);
+      M::template Hue_mul<true>(L, oe, hu);
+      matvec<NU>(L + M::OFF_IHUU, hu, wq);
+#pragma unroll
+      for (int i = 0; i < NX; ++i) hc[(nd * (NX + NU) + i) * G + lane] = hx[i];
+#pragma unroll
+      for (int a = 0; a < NU; ++a) hc[(nd * (NX + NU) + NX + a) * G + lane] = wq[a];
+    }
+  }
   // non-stiff part  dZ/dtau = [Qt qt] + A^T Z + P [A rt]   (A, Qt, rt, qt of CPDP.py:265-269)
-  LFSD_DEV void ric_rhs(const T* z, const T* L, T* y) {
+  LFSD_DEV void ric_rhs(const T* z, int nd, T* y) {
     T* ldsT = lds + Lay::LDS_T;
+    const T* L = node(nd);
+    const T* hc = lds + Lay::LDS_END + nd * (NX + NU) * G;
     const T* iH = L + M::OFF_IHUU;
-    T s[NU], v[NU], hu[NU], w[NU], nv[NU], r[NP];
+    T s[NU], v[NU], w[NU], nv[NU], r[NP];
     M::template fu_mulT<false>(L, z, s);
     matvec<NU>(iH, s, v);
-    M::template Hxu_mulT<false>(L, ox, hu);
-    M::template Hue_mul<true>(L, oe, hu);
-    matvec<NU>(iH, hu, w);
 #pragma unroll
-    for (int a = 0; a < NU; ++a) { nv[a] = -v[a]; w[a] = -(w[a] + v[a]); }
+    for (int a = 0; a < NU; ++a) { nv[a] = -v[a]; w[a] = -(hc[(NX + a) * G + lane] + v[a]); }
     M::template fx_mulT<false>(L, z, y);
     if (lane < NX) {
       T tv[NX];
@@ -1041,8 +1062,8 @@ template <class M, typename T, int G> struct AuxCtx {
 #pragma unroll
       for (int i = 0; i < NP; ++i) ldsT[lane * NZ + NX + i] = r[i];
     }
-    M::template Hxx_mul<true>(L, ox, y);
-    M::template Hxe_mul<true>(L, oe, y);
+#pragma unroll
+    for (int i = 0; i < NX; ++i) y[i] += hc[i * G + lane];
     M::template Hxu_mul<true>(L, w, y);
     __syncthreads();
     if (lane < NZ) {
@@ -1054,16 +1075,16 @@ template <class M, typename T, int G> struct AuxCtx {
   LFSD_DEV void ric_strang(T* z, int n0, int n1, int n2, T h) {
     ric_stiff(z, node(n0), h * T(0.5));
     T k[NX], acc[NX], zs[NX];
-    ric_rhs(z, node(n0), k);
+    ric_rhs(z, n0, k);
 #pragma unroll
     for (int i = 0; i < NX; ++i) { acc[i] = k[i]; zs[i] = z[i] + T(0.5) * h * k[i]; }
-    ric_rhs(zs, node(n1), k);
+    ric_rhs(zs, n1, k);
 #pragma unroll
     for (int i = 0; i < NX; ++i) { acc[i] += T(2) * k[i]; zs[i] = z[i] + T(0.5) * h * k[i]; }
-    ric_rhs(zs, node(n1), k);
+    ric_rhs(zs, n1, k);
 #pragma unroll
     for (int i = 0; i < NX; ++i) { acc[i] += T(2) * k[i]; zs[i] = z[i] + h * k[i]; }
-    ric_rhs(zs, node(n2), k);
+    ric_rhs(zs, n2, k);
 #pragma unroll
     for (int i = 0; i < NX; ++i) z[i] += h / T(6) * (acc[i] + k[i]);
     ric_stiff(z, node(n2), h * T(0.5));
@@ -1123,35 +1144,56 @@ template <class M, typename T, int G> struct AuxCtx {
     for (int a = 0; a < NU; ++a) y[a] *= -dt;
     M::template fu_mul<true>(node(2 * r), y, xa);
   }
-  // non-stiff part  X' = fx X + fe - fu Huu^-1 (Hux X + Hue + fu^T W)
-  LFSD_DEV void fwd_rhs(const T* xa, const T* wt, const T* L, T* y) {
-    const T* iH = L + M::OFF_IHUU;
+  // non-stiff part  X' = fx X + fe - fu Huu^-1 (Hux X + Hue + fu^T W).  Its X-independent part
+  //   b_j(t) = (fe - fu Huu^-1 (fu^T W(t) + Hue)) e_j
+  // is evaluated once per staged node (fwd_cols) and parked per lane; the 12 right-hand sides of a unit then cost
+  //   y = fx x - fu Huu^-1 Hux x + b_j.
+  LFSD_DEV void fwd_cols(const T* zA, const T* zB, T s0, T ds) {
+    T* bc = lds + Lay::LDS_END + NX * G;
+#pragma unroll
+    for (int nd = 0; nd < Lay::NNODE; ++nd) {
+      const T* L = node(nd);
+      const T sr = s0 + T(nd) * ds;
+      T wt[NX], sv[NU], v[NU], b[NX];
+#pragma unroll
+      for (int i = 0; i < NX; ++i) wt[i] = zA[i] + sr * (zB[i] - zA[i]);
+      M::template fu_mulT<false>(L, wt, sv);
+      M::template Hue_mul<true>(L, oe, sv);
+      matvec<NU>(L + M::OFF_IHUU, sv, v);
+#pragma unroll
+      for (int a = 0; a < NU; ++a) v[a] = -v[a];
+      M::template fe_mul<false>(L, oe, b);
+      M::template fu_mul<true>(L, v, b);
+#pragma unroll
+      for (int i = 0; i < NX; ++i) bc[(nd * NX + i) * G + lane] = b[i];
+    }
+  }
+  LFSD_DEV void fwd_rhs(const T* xa, int nd, T* y) {
+    const T* L = node(nd);
+    const T* bc = lds + Lay::LDS_END + NX * G + nd * NX * G;
     T s[NU], v[NU];
-    M::template fu_mulT<false>(L, wt, s);
-    M::template Hue_mul<true>(L, oe, s);
-    M::template Hxu_mulT<true>(L, xa, s);
-    matvec<NU>(iH, s, v);
+    M::template Hxu_mulT<false>(L, xa, s);
+    matvec<NU>(L + M::OFF_IHUU, s, v);
 #pragma unroll
     for (int a = 0; a < NU; ++a) v[a] = -v[a];
     M::template fx_mul<false>(L, xa, y);
-    M::template fe_mul<true>(L, oe, y);
     M::template fu_mul<true>(L, v, y);
+#pragma unroll
+    for (int i = 0; i < NX; ++i) y[i] += bc[i * G + lane];
   }
-  // non-stiff RK4 step of length h over nodes (n0, n1, n2); zA/zB: this lane's Z column at both interval ends
-  LFSD_DEV void fwd_rk4(T* xa, const T* zA, const T* zB, int n0, int n1, int n2, T s0, T s1, T s2, T h) {
-    T zt[NX], k[NX], acc[NX], xs[NX];
+  // non-stiff RK4 step of length h over nodes (n0, n1, n2)
+  LFSD_DEV void fwd_rk4(T* xa, int n0, int n1, int n2, T h) {
+    T k[NX], acc[NX], xs[NX];
+    fwd_rhs(xa, n0, k);
 #pragma unroll
-    for (int i = 0; i < NX; ++i) zt[i] = zA[i] + s0 * (zB[i] - zA[i]);
-    fwd_rhs(xa, zt, node(n0), k);
-#pragma unroll
-    for (int i = 0; i < NX; ++i) { acc[i] = k[i]; xs[i] = xa[i] + T(0.5) * h * k[i]; zt[i] = zA[i] + s1 * (zB[i] - zA[i]); }
-    fwd_rhs(xs, zt, node(n1), k);
+    for (int i = 0; i < NX; ++i) { acc[i] = k[i]; xs[i] = xa[i] + T(0.5) * h * k[i]; }
+    fwd_rhs(xs, n1, k);
 #pragma unroll
     for (int i = 0; i < NX; ++i) { acc[i] += T(2) * k[i]; xs[i] = xa[i] + T(0.5) * h * k[i]; }
-    fwd_rhs(xs, zt, node(n1), k);
+    fwd_rhs(xs, n1, k);
 #pragma unroll
-    for (int i = 0; i < NX; ++i) { acc[i] += T(2) * k[i]; xs[i] = xa[i] + h * k[i]; zt[i] = zA[i] + s2 * (zB[i] - zA[i]); }
-    fwd_rhs(xs, zt, node(n2), k);
+    for (int i = 0; i < NX; ++i) { acc[i] += T(2) * k[i]; xs[i] = xa[i] + h * k[i]; }
+    fwd_rhs(xs, n2, k);
 #pragma unroll
     for (int i = 0; i < NX; ++i) xa[i] += h / T(6) * (acc[i] + k[i]);
   }
@@ -1209,13 +1251,13 @@ __global__ void __launch_bounds__(64, LFSD_WAVES_PER_SIMD) aux_riccati_kernel(Au
   constexpr int NX = M::NX, NP = M::NP, NZ = NX + NP;
   constexpr int GPB = 64 / G;
   static_assert(64 % G == 0 && G >= NZ && G >= Lay::NNODE, "lane group must hold one column of [P W] per lane");
-  __shared__ T lds_all[GPB * Lay::lds_elems()];
-  poison_lds(lds_all, GPB * Lay::lds_elems());
+  __shared__ T lds_all[GPB * Lay::template lds_elems_ric<G>()];
+  poison_lds(lds_all, GPB * Lay::template lds_elems_ric<G>());
   const long long slot = (long long)blockIdx.x * GPB + threadIdx.x / G;
   const bool valid = slot < a.batch;
   const long long traj = valid ? slot : (long long)a.batch - 1;
   Ctx s;
-  aux_setup<M, T, G>(s, a, traj, lds_all);
+  aux_setup<M, T, G>(s, a, traj, lds_all, Lay::template lds_elems_ric<G>());
   const int N = a.n_grid, Sa = a.substeps;
   const int lane = s.lane;
   T* Zt = a.Z_grid + traj * (long long)(N + 1) * NZ * NX;
@@ -1247,6 +1289,7 @@ __global__ void __launch_bounds__(64, LFSD_WAVES_PER_SIMD) aux_riccati_kernel(Au
     for (int unit = 0; unit < units; ++unit) {
       const T s_hi = T(1) - T(unit) / T(units);
       s.stage_nodes(s_hi, -ds);                  // node i sits at fraction s_hi - i/(4 Sa)
+      s.ric_cols();
       T zc[NX], zf[NX];
 #pragma unroll
       for (int i = 0; i < NX; ++i) { zc[i] = z[i]; zf[i] = z[i]; }
@@ -1331,15 +1374,16 @@ __global__ void __launch_bounds__(64, LFSD_WAVES_PER_SIMD) aux_forward_kernel(Au
       for (int i = 0; i < NX; ++i) { xc[i] = xa[i]; xf[i] = xa[i]; }
       const T hq = hc * T(0.25);
       s.fwd_prep(zA, zB, s_lo, ds, hq);
+      s.fwd_cols(zA, zB, s_lo, ds);
       // coarse Strang step (stiff h/2, RK4 h, stiff h/2) and two fine ones; the two adjacent fine stiff
       // quarter-steps at the middle node compose exactly into one half-step
       s.fwd_stiff(xc, 0, true, hq);
-      s.fwd_rk4(xc, zA, zB, 0, 2, 4, s_lo, s_lo + T(2) * ds, s_lo + T(4) * ds, hc);
+      s.fwd_rk4(xc, 0, 2, 4, hc);
       s.fwd_stiff(xc, 2, true, hq);
       s.fwd_stiff(xf, 0, false, hq);
-      s.fwd_rk4(xf, zA, zB, 0, 1, 2, s_lo, s_lo + ds, s_lo + T(2) * ds, hc * T(0.5));
+      s.fwd_rk4(xf, 0, 1, 2, hc * T(0.5));
       s.fwd_stiff(xf, 1, true, hq);
-      s.fwd_rk4(xf, zA, zB, 2, 3, 4, s_lo + T(2) * ds, s_lo + T(3) * ds, s_lo + T(4) * ds, hc * T(0.5));
+      s.fwd_rk4(xf, 2, 3, 4, hc * T(0.5));
       s.fwd_stiff(xf, 2, false, hq);
       __syncthreads();      // all reads of this unit's staged coefficients are done before the next staging
 #pragma unroll

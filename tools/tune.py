@@ -13,7 +13,7 @@ def build(spec, tag, extra):
     return out
 
 if __name__ == "__main__":
-    variants = [("w1", ["-DLFSD_WAVES_PER_SIMD=1"]), ("w2", ["-DLFSD_WAVES_PER_SIMD=2"]), ("w3", ["-DLFSD_WAVES_PER_SIMD=3"])]
+    variants = [("w1", ["-DLFSD_WAVES_PER_SIMD=1"])]
     if sys.argv[1:] == ["build"]:
         oc, env, d = models.quadrotor(n_grid=50)
         spec = oc.model_spec(); runtime.write_header(spec)
