@@ -241,6 +241,7 @@ template <typename T> struct OcArgs {
   T tol;                // stop when max|dJ/du| < tol*(1+|J|)
   int exact_after;      // iteration from which the exact stage Hessian is forced (0: from the start, <0: never)
   int it_start;         // iteration counter to start from (phase 2 of a two-launch solve)
+  int max_iter_total;   // overall iteration limit of the solve (phase 1 only hands over if a phase 2 follows)
   int resume;           // 1: continue only trajectories whose status is ST_MAXITER, warm-started from control_grid
 };
 
@@ -744,6 +745,7 @@ __global__ void __launch_bounds__(64, LFSD_WAVES_PER_SIMD) oc_solve_kernel(OcArg
   int mode = 0;             // stage Hessian model: 0 Gauss-Newton, 1 Hamiltonian (cheap Newton-like), 2 exact
   bool ham_ok = true;       // the cheap Newton-like model has not failed on this trajectory yet
   bool optimistic = true;   // try the full step directly (skips the parallel line search while alpha = 1 keeps working)
+  const int it_off = (a.resume && in_batch) ? (a.iters[traj] - a.it_start) : 0;   // iterations already spent in phase 1
   int status = ST_RUNNING, it = a.it_start, my_iters = a.it_start;
   bool need_bw = true;      // costates on `lam_out` are stale
   T gnorm = T(0), dV1 = T(0), dV2 = T(0);
@@ -758,13 +760,17 @@ __global__ void __launch_bounds__(64, LFSD_WAVES_PER_SIMD) oc_solve_kernel(OcArg
     __syncthreads();
     if (!vote[0]) break;
     __syncthreads();
-    if (EXACT && mode < 2 && a.exact_after >= 0 && it >= a.exact_after) mode = 2;
+    // hand over to the exact stage Hessians at the iteration limit of the cheap models.  (Measured: handing over
+    // earlier, e.g. after three full Gauss-Newton steps, costs more regularised Newton steps than it saves.)
+    const bool want_exact = a.exact_after >= 0 && mode < 2 && it >= a.exact_after;
+    if (EXACT) { if (want_exact) mode = 2; }
+    else if (want_exact && status == ST_RUNNING && it < a.max_iter_total - 1) { status = ST_MAXITER; my_iters = it + it_off; }
     T dmin = T(0);
     const bool bw_ok = s.backward(cur, mode, mu, gnorm, dV1, dV2, dmin);
     need_bw = false;
     bool try_step = false;
     if (status == ST_RUNNING) {
-      my_iters = it + 1;
+      my_iters = it + 1 + it_off;
       if (!bw_ok) {
         // indefinite Q_uu: the cheap Newton-like model hands over to the exact one; otherwise Levenberg shift
         if (mode == 1) { mode = 0; ham_ok = false; }     // back to Gauss-Newton until the exact model takes over
@@ -852,7 +858,7 @@ __global__ void __launch_bounds__(64, LFSD_WAVES_PER_SIMD) oc_solve_kernel(OcArg
     }
     __syncthreads();
   }
-  if (status == ST_RUNNING) status = ST_MAXITER;
+  if (status == ST_RUNNING) { status = ST_MAXITER; }
   if (threadIdx.x == 0) vote[0] = 0;
   __syncthreads();
   if (need_bw) vote[0] = 1;

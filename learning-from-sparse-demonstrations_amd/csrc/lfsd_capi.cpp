@@ -72,7 +72,7 @@ static int coc_solve_t(int batch, int n_grid, int steps_per_grid, const void* in
   const size_t need = (size_t)padded_batch(batch) * (size_t)a.ws_stride * sizeof(T);
   if (workspace_bytes < need) return LFSD_ENOSPC;
   const unsigned grid = (unsigned)(padded_batch(batch) / GPB);
-  a.it_start = 0; a.resume = 0;
+  a.it_start = 0; a.resume = 0; a.max_iter_total = max_iter;
   if (exact_after < 0) {                       // Gauss-Newton / Hamiltonian models only
     LFSD_LAUNCH((lfsd::oc_solve_kernel<Model, T, G, false>), grid, 64, stream, a);
     return launch_status();
@@ -84,6 +84,7 @@ static int coc_solve_t(int batch, int n_grid, int steps_per_grid, const void* in
   // default: lean kernel for the first `exact_after` iterations, then the exact-capable kernel resumes
   // (warm-started from control_grid) the trajectories that are still at MAXITER
   a.max_iter = max_iter < exact_after ? max_iter : exact_after;
+  if (max_iter <= exact_after) a.max_iter_total = 0;      // no phase 2: never hand over
   LFSD_LAUNCH((lfsd::oc_solve_kernel<Model, T, G, false>), grid, 64, stream, a);
   int rc = launch_status();
   if (rc || max_iter <= exact_after) return rc;
