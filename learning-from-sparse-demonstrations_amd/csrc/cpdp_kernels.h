@@ -33,6 +33,23 @@
 #ifndef LFSD_WAVES_PER_SIMD
 #define LFSD_WAVES_PER_SIMD 1
 #endif
+#ifndef LFSD_WAVES_OC
+#define LFSD_WAVES_OC LFSD_WAVES_PER_SIMD
+#endif
+#ifndef LFSD_WAVES_RIC
+#define LFSD_WAVES_RIC LFSD_WAVES_PER_SIMD
+#endif
+#ifndef LFSD_WAVES_FWD
+#define LFSD_WAVES_FWD LFSD_WAVES_PER_SIMD
+#endif
+
+// LFSD_SCHED_FENCE: stop the instruction scheduler from hoisting loads across this point (bounds live ranges in
+// the fully unrolled contractions); no-op in the emulator build
+#if defined(LFSD_EMU) || !defined(LFSD_USE_SCHED_FENCE)
+#define LFSD_SCHED_FENCE()
+#else
+#define LFSD_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+#endif
 
 namespace lfsd {
 
@@ -294,14 +311,17 @@ template <class M, typename T, int G, bool EXACT> struct OcSolver {
     aq = cq; if (SENS) adq = dq;
 #pragma unroll
     for (int i = 0; i < NX; ++i) { ax[i] = f[i]; xs[i] = x[i] + hh * f[i]; if (SENS) { am[i] = d[i]; ms[i] = m[i] + hh * d[i]; } }
+    LFSD_SCHED_FENCE();
     if (SENS) M::dyn_cost_jvp(t, xs, u, e, c, ms, du, f, cq, d, dq); else M::dyn_cost(t, xs, u, e, c, f, cq);
     aq += T(2) * cq; if (SENS) adq += T(2) * dq;
 #pragma unroll
     for (int i = 0; i < NX; ++i) { ax[i] += T(2) * f[i]; xs[i] = x[i] + hh * f[i]; if (SENS) { am[i] += T(2) * d[i]; ms[i] = m[i] + hh * d[i]; } }
+    LFSD_SCHED_FENCE();
     if (SENS) M::dyn_cost_jvp(t, xs, u, e, c, ms, du, f, cq, d, dq); else M::dyn_cost(t, xs, u, e, c, f, cq);
     aq += T(2) * cq; if (SENS) adq += T(2) * dq;
 #pragma unroll
     for (int i = 0; i < NX; ++i) { ax[i] += T(2) * f[i]; xs[i] = x[i] + DT * f[i]; if (SENS) { am[i] += T(2) * d[i]; ms[i] = m[i] + DT * d[i]; } }
+    LFSD_SCHED_FENCE();
     if (SENS) M::dyn_cost_jvp(t, xs, u, e, c, ms, du, f, cq, d, dq); else M::dyn_cost(t, xs, u, e, c, f, cq);
     aq += cq; if (SENS) adq += dq;
     const T h6 = DT / T(6);
@@ -508,6 +528,7 @@ template <class M, typename T, int G, bool EXACT> struct OcSolver {
 #pragma unroll
         for (int kk = 0; kk < NX; ++kk) s += ldsV[i * NX + kk] * m[kk];
         Y[i] = s;
+        LFSD_SCHED_FENCE();
       }
 #pragma unroll
       for (int r = 0; r < NXU; ++r) {
@@ -515,6 +536,7 @@ template <class M, typename T, int G, bool EXACT> struct OcSolver {
 #pragma unroll
         for (int i = 0; i < NX; ++i) s += ldsM[r * NX + i] * Y[i];
         Qcol[r] = s;
+        LFSD_SCHED_FENCE();
       }
       if (EXACT && mode == 2) {
         T hx[NX], hu[NU];
@@ -679,7 +701,7 @@ template <class M, typename T, int G, bool EXACT> struct OcSolver {
 // EXACT = true: may switch to the exact stage Hessians.  lfsd_coc_solve runs the lean kernel for the first
 // `exact_after` iterations and resumes the unfinished trajectories in the exact-capable one.
 template <class M, typename T, int G, bool EXACT>
-__global__ void __launch_bounds__(64, LFSD_WAVES_PER_SIMD) oc_solve_kernel(OcArgs<T> a) {
+__global__ void __launch_bounds__(64, LFSD_WAVES_OC) oc_solve_kernel(OcArgs<T> a) {
   using Sol = OcSolver<M, T, G, EXACT>;
   using Lay = OcLayout<M>;
   constexpr int NX = M::NX, NU = M::NU, NP = M::NP, NC = M::NC;
@@ -1251,7 +1273,7 @@ template <class M, typename T, int G> LFSD_DEV void aux_setup(AuxCtx<M, T, G>& s
 }
 
 template <class M, typename T, int G>
-__global__ void __launch_bounds__(64, LFSD_WAVES_PER_SIMD) aux_riccati_kernel(AuxArgs<T> a) {
+__global__ void __launch_bounds__(64, LFSD_WAVES_RIC) aux_riccati_kernel(AuxArgs<T> a) {
   using Ctx = AuxCtx<M, T, G>;
   using Lay = AuxLayout<M>;
   constexpr int NX = M::NX, NP = M::NP, NZ = NX + NP;
@@ -1324,7 +1346,7 @@ __global__ void __launch_bounds__(64, LFSD_WAVES_PER_SIMD) aux_riccati_kernel(Au
 }
 
 template <class M, typename T, int G>
-__global__ void __launch_bounds__(64, LFSD_WAVES_PER_SIMD) aux_forward_kernel(AuxArgs<T> a) {
+__global__ void __launch_bounds__(64, LFSD_WAVES_FWD) aux_forward_kernel(AuxArgs<T> a) {
   using Ctx = AuxCtx<M, T, G>;
   using Lay = AuxLayout<M>;
   constexpr int NX = M::NX, NU = M::NU, NP = M::NP, NZ = NX + NP;
