@@ -73,6 +73,8 @@ def main():
     ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
     ap.add_argument("--substeps", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--warm-start", action="store_true",
+                    help="NOT the headline: start each OC solve from the previous iteration's controls")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -112,7 +114,8 @@ def main():
         th = theta_eval
         if record:
             e[0].record()
-        L._sol = oc.cocSolverBatch(L.x0, L.hz, th, consts=L.consts, workspace=L._ws, out=L._sol_out())
+        u_init = L._sol["control_grid"][:, :-1].contiguous() if (args.warm_start and L._sol is not None) else None
+        L._sol = oc.cocSolverBatch(L.x0, L.hz, th, consts=L.consts, u_init=u_init, workspace=L._ws, out=L._sol_out())
         L._ws = L._sol["workspace"]
 
         def hook(name):
@@ -178,8 +181,8 @@ def main():
             "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": "Quadrotor (JinEnv, initCost_Polynomial, beta time-warp) CPDP on the quad_example "
                                    "waypoints, n_grid(horizon) %d x 4 RK4 steps, batch %d seeds per GPU with random "
-                                   "initial guesses, Nesterov lr 0.01 mu 0.9, cold-start OC solve every iteration"
-                                   % (args.n_grid, B),
+                                   "initial guesses, Nesterov lr 0.01 mu 0.9, %s OC solve every iteration"
+                                   % (args.n_grid, B, "WARM-started (not the headline configuration)" if args.warm_start else "cold-start"),
                        "batch_per_gpu": B, "n_grid": args.n_grid, "steps_per_grid": 4, "aux_substeps": args.substeps,
                        "oc_status_hist": np.bincount(st, minlength=5).tolist(), "oc_iters_mean": float(it.mean()),
                        "loss_mean": float(loss.mean().item()),

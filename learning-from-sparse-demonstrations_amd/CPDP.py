@@ -316,7 +316,7 @@ class SparseDemoLearner:
 
     def __init__(self, oc, ini_state, horizon, taus, waypoints, interface_idx, theta0, method="Vanilla",
                  learning_rate=1e-2, mu=0.9, beta_1=0.9, beta_2=0.999, epsilon=1e-8, proj_lo=None, consts=None,
-                 mode="independent", process_group=None, true_loss_print_flag=False):
+                 mode="independent", process_group=None, true_loss_print_flag=False, warm_start=False):
         self.oc, self.method, self.lr, self.mu = oc, method, learning_rate, mu
         self.b1, self.b2, self.eps = beta_1, beta_2, epsilon
         if method not in runtime.OPT_METHODS:
@@ -350,6 +350,9 @@ class SparseDemoLearner:
         self.proj_lo = lo.to(device=self.x0.device, dtype=self.theta.dtype)
         self.iter_idx = 0
         self.true_loss = true_loss_print_flag
+        # warm_start: start every OC solve from the previous iteration's controls (theta moves little per step).
+        # The reference cold-starts IPOPT every time; the converged KKT point is the same, only the path to it is shorter.
+        self.warm_start = warm_start
         self._ws = None
         self._sol = None
         self._aux = None
@@ -358,8 +361,11 @@ class SparseDemoLearner:
     def evaluate(self, theta):
         """(loss [B], grad [B,p]) of every trajectory at parameters theta ([B,p] or [1,p])."""
         th = theta if theta.shape[0] == self.B else theta.expand(self.B, -1).contiguous()
-        self._sol = self.oc.cocSolverBatch(self.x0, self.hz, th, consts=self.consts, workspace=self._ws,
-                                           out=self._sol_out())
+        u_init = None
+        if self.warm_start and self._sol is not None:
+            u_init = self._sol["control_grid"][:, :-1].contiguous()
+        self._sol = self.oc.cocSolverBatch(self.x0, self.hz, th, consts=self.consts, u_init=u_init,
+                                           workspace=self._ws, out=self._sol_out())
         self._ws = self._sol["workspace"]
         self._aux = self.oc.auxSysSolverBatch(self._sol, self.taus, self.wps, self.iface, Z_grid=self._Z,
                                               out=self._aux_out())

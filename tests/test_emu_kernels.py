@@ -355,3 +355,19 @@ def test_warm_start_and_mixed_precision(emu):
     e_mix = rel(amix["grad"][0], a64["grad"][0].numpy())
     e_32 = rel(a32["grad"][0], a64["grad"][0].numpy())
     assert e_mix < 2e-2 and e_mix <= e_32 * 1.5 + 1e-6
+
+
+def test_learner_warm_start_same_iterates_fewer_solver_iterations(emu):
+    oc, env, d = models.pendulum(n_grid=10)
+    emu(oc)
+    oc.setDevice(dtype=torch.float64)
+    args = (oc, np.tile(d["ini_state"], (2, 1)), 1.0, [0.2, 0.5, 0.8], [[0.4], [1.5], [2.6]], [0],
+            np.array([[1.0, 0.5, 1.5], [1.4, 0.8, 1.0]]))
+    cold = CPDP.SparseDemoLearner(*args, method="Vanilla", learning_rate=1e-2)
+    warm = CPDP.SparseDemoLearner(*args, method="Vanilla", learning_rate=1e-2, warm_start=True)
+    it_c = it_w = 0
+    for _ in range(3):
+        lc, gc = cold.step(); it_c += int(cold._sol["iters"].sum())
+        lw, gw = warm.step(); it_w += int(warm._sol["iters"].sum())
+        assert torch.allclose(lc, lw, rtol=1e-8) and torch.allclose(gc, gw, rtol=1e-5, atol=1e-8)
+    assert torch.allclose(cold.theta, warm.theta, rtol=1e-7) and it_w < it_c
