@@ -50,17 +50,18 @@ def cpu_baseline(d, n_grid, thetas, n_sample):
     o.diffPMP()
     t0 = time.time()
     done = 0
+    results = []
     for b in range(n_sample):
         tg, sol = o.cocSolver(d["ini_state"], d["horizon"], thetas[b])
         aux = o.auxSysSolver(tg, sol, thetas[b])          # reference settings: BDF + RK45 at scipy defaults
-        getloss_corrections(o, d["taus"], d["waypoints"], sol, aux, d["interface"])
+        results.append(getloss_corrections(o, d["taus"], d["waypoints"], sol, aux, d["interface"]))
         done += 1
         if time.time() - t0 > 30:
             break
     dt = time.time() - t0
     return dict(value=done / dt, unit="trajectory outer-iterations/s", cores=1, kind="port",
                 sample="%d of the %d seeds, 1 outer iteration each, oracle/cpdp_oracle.py (numpy/scipy fp64, "
-                       "solve_ivp BDF+RK45 as CPDP.py:335,368) in %.1f s" % (done, len(thetas), dt))
+                       "solve_ivp BDF+RK45 as CPDP.py:335,368) in %.1f s" % (done, len(thetas), dt)), results
 
 
 def main():
@@ -103,6 +104,12 @@ def main():
     x0 = np.tile(d["ini_state"], (B, 1))
     L = CPDP.SparseDemoLearner(oc, x0, d["horizon"], d["taus"], d["waypoints"], d["interface"], theta0,
                                method="Nesterov", learning_rate=1e-2, mu=0.9)
+
+    # HIP results of the first seeds at theta_0, kept for the cross-check against the CPU baseline's oracle results
+    n_chk = 4
+    sol_c = oc.cocSolverBatch(x0[:n_chk], d["horizon"], theta0[:n_chk])
+    aux_c = oc.auxSysSolverBatch(sol_c, d["taus"], d["waypoints"], d["interface"])
+    chk_loss, chk_grad = aux_c["loss"].double().cpu().numpy(), aux_c["grad"].double().cpu().numpy()
 
     # per-kernel HIP events on the stream the kernels are launched on (torch's current stream)
     names = ("oc_solve", "aux_riccati", "aux_forward", "update")
@@ -195,7 +202,14 @@ def main():
                                  "fp32 vector work; see DESIGN.md section 4"},
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(d, args.n_grid, theta0, 4)
+            out["cpu_baseline"], ores = cpu_baseline(d, args.n_grid, theta0, n_chk)
+            # parity of the HIP path with the oracle on the benchmark's own seeds (oracle in reference mode: its
+            # solve_ivp tolerance 1e-3 limits the agreement of the gradient to ~5e-3)
+            out["parity_vs_oracle"] = {
+                "seeds": len(ores),
+                "loss_rel_err_max": max(abs(chk_loss[i] - ores[i][0]) / abs(ores[i][0]) for i in range(len(ores))),
+                "grad_rel_err_max": max(float(np.abs(chk_grad[i] - ores[i][1]).max() / np.abs(ores[i][1]).max())
+                                        for i in range(len(ores)))}
         print(json.dumps(out), flush=True)
     if use_dist:
         dist.barrier()
