@@ -868,7 +868,7 @@ __global__ void __launch_bounds__(64, LFSD_WAVES_OC) oc_solve_kernel(OcArgs<T> a
         optimistic = (ia == 0);
         if (ia == 0) {
           mu = (mu > T(1e-8)) ? mu * T(0.1) : T(0);
-          if (mode == 0 && ham_ok && (J - Jn) < T(1e-2) * t_abs(Jn)) mode = 1;     // close: Newton-like tail
+          if (mode == 0 && ham_ok && (J - Jn) < T(0.3) * t_abs(Jn)) mode = 1;      // past the first big drops: Newton-like
         }
         J = Jn;
         if (++n_acc >= 4) {
