@@ -25,7 +25,7 @@ import hashlib
 import sympy as sp
 from sympy.printing.c import C99CodePrinter
 
-CODEGEN_VERSION = 5
+CODEGEN_VERSION = 6
 
 
 class ModelSpec:
@@ -147,40 +147,56 @@ def _nz(e):
 
 
 class _Sparse:
-    """Structurally sparse matrix packed row-major into the coefficient array."""
+    """Structurally sparse matrix packed into the coefficient array, start aligned to 16 bytes.  Two packing orders
+    over the same slots: layout 0 (Riccati sweep) and layout 1 (forward sweep) each store the matrix in the order
+    ('r'ow- or 'c'olumn-major) in which that kernel's hot operator walks it, so the reads are contiguous LDS words."""
 
-    def __init__(self, name, mat, off):
-        self.name, self.mat, self.off = name, mat, off
-        self.entries = []          # (row, col, offset, expr)
-        o = off
-        for r in range(mat.shape[0]):
-            for cidx in range(mat.shape[1]):
-                if _nz(mat[r, cidx]):
-                    self.entries.append((r, cidx, o, mat[r, cidx]))
-                    o += 1
-        self.end = o
+    def __init__(self, name, mat, off, orders):
+        self.name, self.mat = name, mat
+        off = (off + 3) // 4 * 4
+        self.off = off
+        rc = [(r, c) for r in range(mat.shape[0]) for c in range(mat.shape[1]) if _nz(mat[r, c])]
+        self.lay = []
+        for o in orders:
+            seq = rc if o == 'r' else sorted(rc, key=lambda t: (t[1], t[0]))
+            self.lay.append([(r, c, off + i, mat[r, c]) for i, (r, c) in enumerate(seq)])
+        self.entries = self.lay[0]
+        self.end = off + len(rc)
+
+    def stores(self, lay):
+        return [('L[%d]' % o, ex) for (_, _, o, ex) in self.lay[lay]]
+
+    def _lines(self, lay, transposed):
+        nr, ncol = self.mat.shape
+        rows = {}
+        for (r, cc, o, _) in sorted(self.lay[lay], key=lambda t: t[2]):
+            i, k = (cc, r) if transposed else (r, cc)
+            rows.setdefault(i, []).append('L[%d]*v[%d]' % (o, k))
+        nout = ncol if transposed else nr
+        lines = []
+        for i in range(nout):
+            terms = rows.get(i)
+            if terms:
+                lines.append('      y[%d] = (ACC ? y[%d] : T(0)) + %s;' % (i, i, ' + '.join(terms)))
+            else:
+                lines.append('      if (!ACC) y[%d] = T(0);' % i)
+        return '\n'.join(lines)
 
     def emit_ops(self):
         nr, ncol = self.mat.shape
         out = []
         for suffix, transposed in (('mul', False), ('mulT', True)):
-            rows = {}
-            for (r, cc, o, _) in self.entries:
-                i, k = (cc, r) if transposed else (r, cc)
-                rows.setdefault(i, []).append('L[%d]*v[%d]' % (o, k))
             nout = ncol if transposed else nr
-            lines = []
-            for i in range(nout):
-                terms = rows.get(i)
-                if terms:
-                    lines.append('    y[%d] = (ACC ? y[%d] : T(0)) + %s;' % (i, i, ' + '.join(terms)))
-                else:
-                    lines.append('    if (!ACC) y[%d] = T(0);' % i)
-            out.append('  // y[%d] %s %s%s * v[%d]   (%d non-zeros)\n'
-                       '  template<bool ACC, class T> static LFSD_DEV void %s_%s(const T* L, const T* v, T* y) {\n%s\n  }'
-                       % (nout, '(+)=', self.name, "^T" if transposed else "", nr if transposed else ncol,
-                          len(self.entries), self.name, suffix, '\n'.join(lines)))
+            out.append('  // y[%d] (+)= %s%s * v[%d]   (%d non-zeros; LAY picks the packing the calling kernel staged)\n'
+                       '  template<bool ACC, int LAY, class T> static LFSD_DEV void %s_%s(const T* L, const T* v, T* y) {\n'
+                       '    if constexpr (LAY == 0) {\n%s\n    } else {\n%s\n    }\n  }'
+                       % (nout, self.name, "^T" if transposed else "", nr if transposed else ncol, len(self.entries),
+                          self.name, suffix, self._lines(0, transposed), self._lines(1, transposed)))
         return '\n'.join(out)
+
+
+# packing order per matrix: (layout 0 = Riccati sweep, layout 1 = forward sweep)
+_ORDERS = {'fx': 'cr', 'fu': 'cr', 'fe': 'cr', 'Hxx': 'rr', 'Hxu': 'rc', 'Hxe': 'rr', 'Hue': 'cr'}
 
 
 def emit_header(spec):
@@ -272,38 +288,45 @@ def emit_header(spec):
     mats = []
     off = 0
     for nm, mat in (('fx', fx), ('fu', fu), ('fe', fe), ('Hxx', Hxx), ('Hxu', Hxu), ('Hxe', Hxe), ('Hue', Hue)):
-        sm = _Sparse(nm, mat, off)
+        sm = _Sparse(nm, mat, off, _ORDERS[nm])
         mats.append(sm)
         off = sm.end
-    off_huu = off
-    off_ihuu = off_huu + m * m
+    off_huu = (off + 3) // 4 * 4
+    off_ihuu = (off_huu + m * m + 3) // 4 * 4
     ncoef = ((off_ihuu + m * m + 3) // 4) * 4
     S.append('  static constexpr int OFF_HUU = %d, OFF_IHUU = %d, NCOEF = %d;' % (off_huu, off_ihuu, ncoef))
-    outs = []
-    for sm in mats:
-        outs += [('L[%d]' % o, ex) for (_, _, o, ex) in sm.entries]
-    outs += [('L[%d]' % (off_huu + a * m + b), Huu[a, b]) for a in range(m) for b in range(m)]
-    S.append('  // packed: ' + ', '.join('%s[%d..%d)' % (sm.name, sm.off, sm.end) for sm in mats) +
+    S.append('  // packed (16-byte aligned starts): ' + ', '.join('%s[%d..%d)' % (sm.name, sm.off, sm.end) for sm in mats) +
              ', Huu dense, Huu^-1 dense (filled by the kernel)')
-    S.append('  template<class T> static LFSD_DEV void pmp_coeffs(%s, T* L) {' % sig_xul)
-    S.append(_body(_loads(spec, with_l=True), outs))
+    S.append('  template<int LAY, class T> static LFSD_DEV void pmp_coeffs(%s, T* L) {' % sig_xul)
+    for lay in (0, 1):
+        outs = []
+        for sm in mats:
+            outs += sm.stores(lay)
+        outs += [('L[%d]' % (off_huu + a * m + b), Huu[a, b]) for a in range(m) for b in range(m)]
+        S.append('    %s (LAY == %d) {' % ('if constexpr' if lay == 0 else '} else', lay) if lay == 0 else '    } else {')
+        S.append(_body(_loads(spec, with_l=True), outs, indent='      '))
+    S.append('    }')
     S.append('  }')
     for sm in mats:
         S.append(sm.emit_ops())
     # G[a*NU+b] (+)= sum_i S[i*NU+a] * fu[i][b]    (S = rows of B^T P gathered in LDS)
     fu_sm = mats[1]
-    cols = {}
-    for (r, cc, o, _) in fu_sm.entries:
-        cols.setdefault(cc, []).append((r, o))
-    lines = []
-    for a in range(m):
-        for b in range(m):
-            terms = ['S[%d]*L[%d]' % (r * m + a, o) for (r, o) in cols.get(b, [])]
-            lines.append('    G[%d] = (ACC ? G[%d] : T(0))%s;' % (a * m + b, a * m + b,
-                                                                  (' + ' + ' + '.join(terms)) if terms else ''))
     S.append('  // G = S^T fu  with S an NX x NU row-major matrix (e.g. S = P fu  ->  G = fu^T P fu)')
-    S.append('  template<bool ACC, class T> static LFSD_DEV void fu_gram(const T* L, const T* S, T* G) {\n%s\n  }'
-             % '\n'.join(lines))
+    S.append('  template<bool ACC, int LAY, class T> static LFSD_DEV void fu_gram(const T* L, const T* S, T* G) {')
+    for lay in (0, 1):
+        cols = {}
+        for (r, cc, o, _) in fu_sm.lay[lay]:
+            cols.setdefault(cc, []).append((r, o))
+        lines = []
+        for a in range(m):
+            for b in range(m):
+                terms = ['S[%d]*L[%d]' % (r * m + a, o) for (r, o) in sorted(cols.get(b, []))]
+                lines.append('      G[%d] = (ACC ? G[%d] : T(0))%s;' % (a * m + b, a * m + b,
+                                                                      (' + ' + ' + '.join(terms)) if terms else ''))
+        S.append('    if constexpr (LAY == %d) {' % lay if lay == 0 else '    } else {')
+        S.append('\n'.join(lines))
+    S.append('    }')
+    S.append('  }')
     S.append('};')
     S.append('}  // namespace LFSD_MODEL_NS')
     return '\n'.join(S) + '\n'

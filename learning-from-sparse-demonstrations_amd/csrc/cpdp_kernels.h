@@ -36,11 +36,13 @@
 #ifndef LFSD_WAVES_OC
 #define LFSD_WAVES_OC LFSD_WAVES_PER_SIMD
 #endif
+// fp32 aux kernels fit 256 registers (almost) without spills and are a few % faster at 2 waves/SIMD
+// (profiles/r01_tune_occupancy.txt); fp64 needs the full register file
 #ifndef LFSD_WAVES_RIC
-#define LFSD_WAVES_RIC LFSD_WAVES_PER_SIMD
+#define LFSD_WAVES_RIC 2
 #endif
 #ifndef LFSD_WAVES_FWD
-#define LFSD_WAVES_FWD LFSD_WAVES_PER_SIMD
+#define LFSD_WAVES_FWD 2
 #endif
 
 // LFSD_SCHED_FENCE: stop the instruction scheduler from hoisting loads across this point (bounds live ranges in
@@ -941,7 +943,8 @@ template <class M> struct AuxLayout {
   template <int G> static constexpr int lds_elems_ric() { return ((LDS_END + NNODE * (NX + NU) * G + 3) / 4) * 4; }
 };
 
-template <class M, typename T, int G> struct AuxCtx {
+// LAY: packing order of the staged coefficients (0: Riccati sweep, transposed operators contiguous; 1: forward sweep)
+template <class M, typename T, int G, int LAY> struct AuxCtx {
   static constexpr int NX = M::NX, NU = M::NU, NP = M::NP, NC = M::NC, NZ = NX + NP;
   using Lay = AuxLayout<M>;
   int lane;
@@ -975,7 +978,7 @@ template <class M, typename T, int G> struct AuxCtx {
 #pragma unroll
       for (int i = 0; i < NU; ++i) u[i] = ua_[i] + s * (ub_[i] - ua_[i]);
       T* L = lds + Lay::LDS_L + lane * M::NCOEF;
-      M::pmp_coeffs(t_a + s * dgrid, x, u, l, e, c, L);
+      M::template pmp_coeffs<LAY>(t_a + s * dgrid, x, u, l, e, c, L);
       T Huu[NU * NU], iH[NU * NU];
 #pragma unroll
       for (int i = 0; i < NU * NU; ++i) Huu[i] = L[M::OFF_HUU + i];
@@ -992,7 +995,7 @@ template <class M, typename T, int G> struct AuxCtx {
     T* ldsS = lds + Lay::LDS_S;
     const T* iH = L + M::OFF_IHUU;
     T s[NU], kj[NU];
-    M::template fu_mulT<false>(L, zt, s);
+    M::template fu_mulT<false, LAY>(L, zt, s);
     matvec<NU>(iH, s, kj);
     if (lane < NX) {
 #pragma unroll
@@ -1000,7 +1003,7 @@ template <class M, typename T, int G> struct AuxCtx {
     }
     __syncthreads();
     T Mx[NU * NU];
-    M::template fu_gram<false>(L, ldsS, Mx);
+    M::template fu_gram<false, LAY>(L, ldsS, Mx);
     T nrm = T(0);
 #pragma unroll
     for (int a = 0; a < NU; ++a) {
@@ -1025,7 +1028,7 @@ template <class M, typename T, int G> struct AuxCtx {
   LFSD_DEV void ric_stiff(T* z, const T* L, T dt) {
     T* ldsS = lds + Lay::LDS_S;
     T s[NU];
-    M::template fu_mulT<false>(L, z, s);
+    M::template fu_mulT<false, LAY>(L, z, s);
     if (lane < NX) {
 #pragma unroll
       for (int a = 0; a < NU; ++a) ldsS[lane * NU + a] = s[a];
@@ -1035,7 +1038,7 @@ template <class M, typename T, int G> struct AuxCtx {
     const T idt = T(1) / dt;
 #pragma unroll
     for (int i = 0; i < NU * NU; ++i) Gm[i] = L[M::OFF_HUU + i] * idt;
-    M::template fu_gram<true>(L, ldsS, Gm);
+    M::template fu_gram<true, LAY>(L, ldsS, Gm);
     lu_factor<NU>(Gm);
     lu_solve<NU>(Gm, s);
 #pragma unroll
@@ -1055,10 +1058,10 @@ template <class M, typename T, int G> struct AuxCtx {
     for (int nd = 0; nd < Lay::NNODE; ++nd) {
       const T* L = node(nd);
       T hx[NX], hu[NU], wq[NU];
-      M::template Hxx_mul<false>(L, ox, hx);
-      M::template Hxe_mul<true>(L, oe, hx);
-      M::template Hxu_mulT<false>(L, ox, hu);
-      M::template Hue_mul<true>(L, oe, hu);
+      M::template Hxx_mul<false, LAY>(L, ox, hx);
+      M::template Hxe_mul<true, LAY>(L, oe, hx);
+      M::template Hxu_mulT<false, LAY>(L, ox, hu);
+      M::template Hue_mul<true, LAY>(L, oe, hu);
       matvec<NU>(L + M::OFF_IHUU, hu, wq);
 #pragma unroll
       for (int i = 0; i < NX; ++i) hc[(nd * (NX + NU) + i) * G + lane] = hx[i];
@@ -1073,18 +1076,18 @@ template <class M, typename T, int G> struct AuxCtx {
     const T* hc = lds + Lay::LDS_END + nd * (NX + NU) * G;
     const T* iH = L + M::OFF_IHUU;
     T s[NU], v[NU], w[NU], nv[NU], r[NP];
-    M::template fu_mulT<false>(L, z, s);
+    M::template fu_mulT<false, LAY>(L, z, s);
     matvec<NU>(iH, s, v);
 #pragma unroll
     for (int a = 0; a < NU; ++a) { nv[a] = -v[a]; w[a] = -(hc[(NX + a) * G + lane] + v[a]); }
-    M::template fx_mulT<false>(L, z, y);
+    M::template fx_mulT<false, LAY>(L, z, y);
     if (lane < NX) {
       T tv[NX];
 #pragma unroll
       for (int i = 0; i < NX; ++i) tv[i] = y[i];
-      M::template Hxu_mul<true>(L, nv, tv);
-      M::template fe_mulT<false>(L, z, r);
-      M::template Hue_mulT<true>(L, nv, r);
+      M::template Hxu_mul<true, LAY>(L, nv, tv);
+      M::template fe_mulT<false, LAY>(L, z, r);
+      M::template Hue_mulT<true, LAY>(L, nv, r);
 #pragma unroll
       for (int i = 0; i < NX; ++i) ldsT[lane * NZ + i] = tv[i];
 #pragma unroll
@@ -1092,7 +1095,7 @@ template <class M, typename T, int G> struct AuxCtx {
     }
 #pragma unroll
     for (int i = 0; i < NX; ++i) y[i] += hc[i * G + lane];
-    M::template Hxu_mul<true>(L, w, y);
+    M::template Hxu_mul<true, LAY>(L, w, y);
     __syncthreads();
     if (lane < NZ) {
 #pragma unroll
@@ -1135,7 +1138,7 @@ template <class M, typename T, int G> struct AuxCtx {
       T zt[NX], sv[NU], kj[NU];
 #pragma unroll
       for (int i = 0; i < NX; ++i) zt[i] = zA[i] + sr * (zB[i] - zA[i]);
-      M::template fu_mulT<false>(L, zt, sv);
+      M::template fu_mulT<false, LAY>(L, zt, sv);
       matvec<NU>(L + M::OFF_IHUU, sv, kj);
       if (lane < NX) {
 #pragma unroll
@@ -1145,7 +1148,7 @@ template <class M, typename T, int G> struct AuxCtx {
     __syncthreads();
     if (lane < 3) {
       T Mx[NU * NU], Pq[NU * NU], Ph[NU * NU];
-      M::template fu_gram<false>(node(2 * lane), ldsK + lane * NX * NU, Mx);       // K fu
+      M::template fu_gram<false, LAY>(node(2 * lane), ldsK + lane * NX * NU, Mx);       // K fu
 #pragma unroll
       for (int i = 0; i < NU * NU; ++i) Mx[i] *= hq;
       phi1_neg<NU>(Mx, Pq, Ph);
@@ -1170,7 +1173,7 @@ template <class M, typename T, int G> struct AuxCtx {
     const T dt = half ? T(2) * hq : hq;
 #pragma unroll
     for (int a = 0; a < NU; ++a) y[a] *= -dt;
-    M::template fu_mul<true>(node(2 * r), y, xa);
+    M::template fu_mul<true, LAY>(node(2 * r), y, xa);
   }
   // non-stiff part  X' = fx X + fe - fu Huu^-1 (Hux X + Hue + fu^T W).  Its X-independent part
   //   b_j(t) = (fe - fu Huu^-1 (fu^T W(t) + Hue)) e_j
@@ -1185,13 +1188,13 @@ template <class M, typename T, int G> struct AuxCtx {
       T wt[NX], sv[NU], v[NU], b[NX];
 #pragma unroll
       for (int i = 0; i < NX; ++i) wt[i] = zA[i] + sr * (zB[i] - zA[i]);
-      M::template fu_mulT<false>(L, wt, sv);
-      M::template Hue_mul<true>(L, oe, sv);
+      M::template fu_mulT<false, LAY>(L, wt, sv);
+      M::template Hue_mul<true, LAY>(L, oe, sv);
       matvec<NU>(L + M::OFF_IHUU, sv, v);
 #pragma unroll
       for (int a = 0; a < NU; ++a) v[a] = -v[a];
-      M::template fe_mul<false>(L, oe, b);
-      M::template fu_mul<true>(L, v, b);
+      M::template fe_mul<false, LAY>(L, oe, b);
+      M::template fu_mul<true, LAY>(L, v, b);
 #pragma unroll
       for (int i = 0; i < NX; ++i) bc[(nd * NX + i) * G + lane] = b[i];
     }
@@ -1200,12 +1203,12 @@ template <class M, typename T, int G> struct AuxCtx {
     const T* L = node(nd);
     const T* bc = lds + Lay::LDS_END + NX * G + nd * NX * G;
     T s[NU], v[NU];
-    M::template Hxu_mulT<false>(L, xa, s);
+    M::template Hxu_mulT<false, LAY>(L, xa, s);
     matvec<NU>(L + M::OFF_IHUU, s, v);
 #pragma unroll
     for (int a = 0; a < NU; ++a) v[a] = -v[a];
-    M::template fx_mul<false>(L, xa, y);
-    M::template fu_mul<true>(L, v, y);
+    M::template fx_mul<false, LAY>(L, xa, y);
+    M::template fu_mul<true, LAY>(L, v, y);
 #pragma unroll
     for (int i = 0; i < NX; ++i) y[i] += bc[i * G + lane];
   }
@@ -1230,14 +1233,14 @@ template <class M, typename T, int G> struct AuxCtx {
     T* ldsS = lds + Lay::LDS_S;
     const T* iH = L + M::OFF_IHUU;
     T s[NU];
-    M::template fu_mulT<false>(L, zt, s);
+    M::template fu_mulT<false, LAY>(L, zt, s);
     if (lane < NX) {
 #pragma unroll
       for (int a = 0; a < NU; ++a) ldsS[lane * NU + a] = s[a];
     }
     __syncthreads();
-    M::template Hue_mul<true>(L, oe, s);         // X lanes: s = fu^T w_j + Hue e_j
-    M::template Hxu_mulT<true>(L, xa, s);
+    M::template Hue_mul<true, LAY>(L, oe, s);         // X lanes: s = fu^T w_j + Hue e_j
+    M::template Hxu_mulT<true, LAY>(L, xa, s);
 #pragma unroll
     for (int i = 0; i < NX; ++i) {
 #pragma unroll
@@ -1250,7 +1253,7 @@ template <class M, typename T, int G> struct AuxCtx {
   }
 };
 
-template <class M, typename T, int G> LFSD_DEV void aux_setup(AuxCtx<M, T, G>& s, const AuxArgs<T>& a, long long traj,
+template <class M, typename T, int G, int LAY> LFSD_DEV void aux_setup(AuxCtx<M, T, G, LAY>& s, const AuxArgs<T>& a, long long traj,
                                                             T* lds_all, int lds_stride = AuxLayout<M>::lds_elems()) {
   constexpr int NX = M::NX, NP = M::NP, NC = M::NC;
   using Lay = AuxLayout<M>;
@@ -1273,8 +1276,8 @@ template <class M, typename T, int G> LFSD_DEV void aux_setup(AuxCtx<M, T, G>& s
 }
 
 template <class M, typename T, int G>
-__global__ void __launch_bounds__(64, LFSD_WAVES_RIC) aux_riccati_kernel(AuxArgs<T> a) {
-  using Ctx = AuxCtx<M, T, G>;
+__global__ void __launch_bounds__(64, (sizeof(T) == 4 ? LFSD_WAVES_RIC : 1)) aux_riccati_kernel(AuxArgs<T> a) {
+  using Ctx = AuxCtx<M, T, G, 0>;
   using Lay = AuxLayout<M>;
   constexpr int NX = M::NX, NP = M::NP, NZ = NX + NP;
   constexpr int GPB = 64 / G;
@@ -1285,7 +1288,7 @@ __global__ void __launch_bounds__(64, LFSD_WAVES_RIC) aux_riccati_kernel(AuxArgs
   const bool valid = slot < a.batch;
   const long long traj = valid ? slot : (long long)a.batch - 1;
   Ctx s;
-  aux_setup<M, T, G>(s, a, traj, lds_all, Lay::template lds_elems_ric<G>());
+  aux_setup<M, T, G, 0>(s, a, traj, lds_all, Lay::template lds_elems_ric<G>());
   const int N = a.n_grid, Sa = a.substeps;
   const int lane = s.lane;
   T* Zt = a.Z_grid + traj * (long long)(N + 1) * NZ * NX;
@@ -1346,8 +1349,8 @@ __global__ void __launch_bounds__(64, LFSD_WAVES_RIC) aux_riccati_kernel(AuxArgs
 }
 
 template <class M, typename T, int G>
-__global__ void __launch_bounds__(64, LFSD_WAVES_FWD) aux_forward_kernel(AuxArgs<T> a) {
-  using Ctx = AuxCtx<M, T, G>;
+__global__ void __launch_bounds__(64, (sizeof(T) == 4 ? LFSD_WAVES_FWD : 1)) aux_forward_kernel(AuxArgs<T> a) {
+  using Ctx = AuxCtx<M, T, G, 1>;
   using Lay = AuxLayout<M>;
   constexpr int NX = M::NX, NU = M::NU, NP = M::NP, NZ = NX + NP;
   constexpr int GPB = 64 / G;
@@ -1357,7 +1360,7 @@ __global__ void __launch_bounds__(64, LFSD_WAVES_FWD) aux_forward_kernel(AuxArgs
   const bool valid = slot < a.batch;
   const long long traj = valid ? slot : (long long)a.batch - 1;
   Ctx s;
-  aux_setup<M, T, G>(s, a, traj, lds_all, Lay::template lds_elems_fwd<G>());
+  aux_setup<M, T, G, 1>(s, a, traj, lds_all, Lay::template lds_elems_fwd<G>());
   const int N = a.n_grid, Sa = a.substeps;
   const int lane = s.lane;
   const bool xlane = (lane >= NX) && (lane < NZ);

@@ -111,12 +111,20 @@ ZOO = dict(pendulum=pendulum, pendulum_poly2=pendulum_poly2, robotarm=robotarm, 
 
 def build_all(verbose=False, force=False):
     """Compile every standard model for gfx950 (in-tree .so under csrc/build/)."""
+    import glob
+    import os
     from . import runtime
-    out = {}
+    out, keep = {}, set()
     for name, fac in ZOO.items():
         oc, _, _ = fac()
         spec = oc.model_spec()
+        keep.add(spec.hash())
         out[name] = runtime.build_library(spec, force=force, verbose=verbose)
         if verbose:
             print("built", name, spec.hash(), out[name])
+    # drop generated headers / libraries of older code-generator versions (their hashes are no longer reachable)
+    for path in glob.glob(os.path.join(runtime.GEN_DIR, "*.h")) + glob.glob(os.path.join(runtime.BUILD_DIR, "liblfsd_*.so")):
+        h = os.path.basename(path).replace("liblfsd_", "").split(".")[0]
+        if h not in keep:
+            os.remove(path)
     return out

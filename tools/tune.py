@@ -13,7 +13,7 @@ def build(spec, tag, extra):
     return out
 
 if __name__ == "__main__":
-    variants = [("base", []), ("aux2", ["-DLFSD_WAVES_RIC=2", "-DLFSD_WAVES_FWD=2"]), ("oc2", ["-DLFSD_WAVES_OC=2"])]
+    variants = [("base", []), ("aux1", ["-DLFSD_WAVES_RIC=1", "-DLFSD_WAVES_FWD=1"])]
     if sys.argv[1:] == ["build"]:
         oc, env, d = models.quadrotor(n_grid=50)
         spec = oc.model_spec(); runtime.write_header(spec)
