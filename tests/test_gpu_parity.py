@@ -198,3 +198,43 @@ def test_rocket_newton_mode_vs_oracle():
     aux32 = oc32.auxSysSolverBatch(sol32, taus, wps, d["interface"])
     assert sol32["status"].item() in (1, 2)
     assert abs(aux32["loss"][0].item() - r["loss"]) < 2e-3 * max(1.0, r["loss"]) and rel(aux32["grad"][0], r["grad"]) < 2e-2
+
+
+def test_time_varying_model_vs_oracle():
+    """COCSys_TimeVarying with v(t) = b1 + 2 b2 t (Examples/pendulum_timewarping.py:35-38) on the GPU."""
+    import sympy as sp
+    from oracle import jinenv_sym as J
+    from oracle.cpdp_oracle import COCSys_TimeVarying, getloss_corrections
+    oc, d = gpu_model("pendulum_poly2", torch.float64, 10, substeps=8)
+    assert oc.compile().time_varying
+    th = [1.0, 0.8, 1.0, 1.2]
+    sol = oc.cocSolverBatch([d["ini_state"]] * 2, d["horizon"], [th] * 2)
+    aux = oc.auxSysSolverBatch(sol, d["taus"], d["waypoints"], d["interface"])
+    e2 = J.SinglePendulum(); e2.initDyn(l=1, m=1, damping_ratio=0.1); e2.initCost(wu=.01)
+    o = COCSys_TimeVarying()
+    t, b1, b2 = sp.symbols('t beta1 beta2', real=True)
+    o.setTimeVariable(t)
+    o.setAuxvarVariable([b1, b2] + e2.cost_auxvar); o.setStateVariable(e2.X); o.setControlVariable(e2.U)
+    v = b1 + 2 * b2 * t
+    o.setDyn(v * e2.f); o.setPathCost(v * e2.path_cost); o.setFinalCost(e2.final_cost); o.setIntegrator(10)
+    tg, osol, X, U, L = o.cocSolver(d["ini_state"], d["horizon"], th, return_grids=True)
+    oaux = o.auxSysSolver(tg, osol, th, riccati_method='Radau', ivp_kwargs=dict(rtol=1e-10, atol=1e-12))
+    l_o, g_o = getloss_corrections(o, d["taus"], d["waypoints"], osol, oaux, d["interface"])
+    assert rel(sol["state_grid"][1], X) < 1e-6 and rel(sol["costate_grid"][1], L) < 1e-5
+    assert abs(aux["loss"][1].item() - l_o) < 1e-7 * max(1, l_o) and rel(aux["grad"][1], g_o) < 1e-4
+
+
+def test_quadalgorithm_driver_fp32_follows_reference_run():
+    """lib/QuadAlgorithm.py mirror on the GPU in fp32 (the precision of the benchmark): the first Nesterov iterations
+    of Examples/quad_example_human_input.py must follow the reference's saved loss trace."""
+    from lfsd_amd.QuadAlgorithm import QuadAlgorithm, QuadPara, DemoSparse
+    from lfsd_amd.JinEnv import QuadStates
+    cfg = {"QUAD_AVERAGE_SPEED": 1.0, "LAB_SPACE_LIMIT": {"LIMIT_X": [-3.2, 3.2], "LIMIT_Y": [-1.6, 1.6], "LIMIT_Z": [0.0, 2.2]}}
+    S = QuadAlgorithm(cfg, QuadPara([1.0, 1.0, 1.0], 1.0, 1.0, 0.02), int(G["n_grid"]), device="cuda:0", dtype=torch.float32)
+    S.load_optimization_function({"learning_rate": 0.01, "iter_num": 10, "method": "Nesterov", "mu": 0.9,
+                                  "true_loss_print_flag": False})
+    demo = DemoSparse(waypoints=G["waypoints"].tolist(), time_list=G["taus"].tolist(), time_horizon=1.0)
+    res = S.run(QuadStates(position=[-2.0, -1.0, 0.6]), QuadStates(position=[2.5, 1.0, 1.5]), demo, ObsList=[])
+    assert res["loss_trace"].shape[0] == 10
+    assert np.allclose(res["loss_trace"][:, 0], G["loss_trace"][:10], rtol=5e-3)
+    assert np.allclose(res["parameter_trace"][10, 0], G["theta_trace"][10], rtol=1e-2, atol=2e-3)
