@@ -176,6 +176,11 @@ class ModelLibrary:
             return None
         return ctypes.c_void_p(torch.cuda.current_stream(ref.device).cuda_stream)
 
+    def _on(self, ref):
+        """Context that makes the tensors' GPU the current HIP device (kernel launches go to the current device)."""
+        import contextlib
+        return contextlib.nullcontext() if self.is_emulator else torch.cuda.device(ref.device)
+
     @staticmethod
     def _rc(rc, what):
         if rc != 0:
@@ -218,13 +223,13 @@ class ModelLibrary:
             workspace = torch.empty((need + 7) // 8, dtype=torch.int64, device=dev)
         if tol is None:
             tol = 1e-6 if dt == torch.float32 else 1e-9
-        rc = self.lib.lfsd_coc_solve(_DT[dt], B, n_grid, steps_per_grid, self._p(ini_state), self._p(horizon),
-                                     self._p(auxvar), self._p(consts), per_traj, self._p(u_init),
-                                     self._p(out["state_grid"]), self._p(out["control_grid"]),
-                                     self._p(out["costate_grid"]), self._p(out["cost"]), self._p(out["iters"]),
-                                     self._p(out["status"]), int(max_iter), float(tol), int(exact_after), self._p(workspace),
-                                     workspace.numel() * workspace.element_size(), self._stream(ini_state))
-        self._rc(rc, "lfsd_coc_solve")
+        args = (_DT[dt], B, n_grid, steps_per_grid, self._p(ini_state), self._p(horizon), self._p(auxvar),
+                self._p(consts), per_traj, self._p(u_init), self._p(out["state_grid"]), self._p(out["control_grid"]),
+                self._p(out["costate_grid"]), self._p(out["cost"]), self._p(out["iters"]), self._p(out["status"]),
+                int(max_iter), float(tol), int(exact_after), self._p(workspace),
+                workspace.numel() * workspace.element_size(), self._stream(ini_state))
+        with self._on(ini_state):
+            self._rc(self.lib.lfsd_coc_solve(*args), "lfsd_coc_solve")
         out["workspace"] = workspace
         return out
 
@@ -271,14 +276,16 @@ class ModelLibrary:
                   self._p(state_grid), self._p(control_grid), self._p(costate_grid), self._p(Z_grid))
         tail = (nw, ni, self._p(iface_idx), self._p(taus), self._p(waypoints), self._p(out["loss"]),
                 self._p(out["grad"]), self._p(auxX), self._p(auxU), int(substeps), self._stream(state_grid))
-        if phase_hook is None:
-            self._rc(self.lib.lfsd_aux_solve(*common, *tail), "lfsd_aux_solve")
-        else:
-            phase_hook("riccati")
-            self._rc(self.lib.lfsd_aux_riccati(*common, int(substeps), self._stream(state_grid)), "lfsd_aux_riccati")
-            phase_hook("forward")
-            self._rc(self.lib.lfsd_aux_forward(*common, *tail), "lfsd_aux_forward")
-            phase_hook("end")
+        with self._on(state_grid):
+            if phase_hook is None:
+                self._rc(self.lib.lfsd_aux_solve(*common, *tail), "lfsd_aux_solve")
+            else:
+                phase_hook("riccati")
+                self._rc(self.lib.lfsd_aux_riccati(*common, int(substeps), self._stream(state_grid)),
+                         "lfsd_aux_riccati")
+                phase_hook("forward")
+                self._rc(self.lib.lfsd_aux_forward(*common, *tail), "lfsd_aux_forward")
+                phase_hook("end")
         out["Z_grid"] = Z_grid
         out["auxX_grid"], out["auxU_grid"] = auxX, auxU
         return out
@@ -292,16 +299,18 @@ class ModelLibrary:
         for nm, t in (("m", m), ("v", v), ("vhat", vhat)):
             self._check(t, (B, p), dt, nm, optional=True)
         self._check(proj_lo, (p,), dt, "proj_lo", optional=True)
-        rc = self.lib.lfsd_optimizer_step(_DT[dt], OPT_METHODS[method] if isinstance(method, str) else int(method), B,
-                                          p, int(iter_idx), float(lr), float(mu), float(beta1), float(beta2),
-                                          float(eps), self._p(theta), self._p(grad), self._p(m), self._p(v),
-                                          self._p(vhat), self._p(proj_lo), self._stream(theta))
+        with self._on(theta):
+            rc = self.lib.lfsd_optimizer_step(_DT[dt], OPT_METHODS[method] if isinstance(method, str) else int(method),
+                                              B, p, int(iter_idx), float(lr), float(mu), float(beta1), float(beta2),
+                                              float(eps), self._p(theta), self._p(grad), self._p(m), self._p(v),
+                                              self._p(vhat), self._p(proj_lo), self._stream(theta))
         self._rc(rc, "lfsd_optimizer_step")
 
     def lookahead(self, theta, v, mu, out=None):
         if out is None:
             out = torch.empty_like(theta)
-        rc = self.lib.lfsd_lookahead(_DT[theta.dtype], theta.numel(), float(mu), self._p(theta), self._p(v),
-                                     self._p(out), self._stream(theta))
+        with self._on(theta):
+            rc = self.lib.lfsd_lookahead(_DT[theta.dtype], theta.numel(), float(mu), self._p(theta), self._p(v),
+                                         self._p(out), self._stream(theta))
         self._rc(rc, "lfsd_lookahead")
         return out
