@@ -172,8 +172,12 @@ def main():
         abytes = B * algorithmic_bytes(dom, n, m, p, nc, args.n_grid, nw, ni, es)
         achieved = abytes / (ktime[dom] * 1e-3) / 1e9
         traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
-        if os.path.exists(tpath):
+        # PMC passes are separate rocprofv3 runs (tools/hbm_traffic.py); the figure only applies to the workload they
+        # were collected on, so it is attached to the headline configuration and left null otherwise
+        tpath = os.path.join(ROOT, "profiles", "r01_h_hbm_traffic.json")
+        headline = (B == 4096 and args.n_grid == 50 and args.dtype == "f32" and args.substeps == 4
+                    and not args.warm_start)
+        if headline and os.path.exists(tpath):
             try:
                 traffic = json.load(open(tpath)).get(dom, {}).get("hbm_bytes_per_step")
             except Exception:
