@@ -36,13 +36,31 @@
 #ifndef LFSD_WAVES_OC
 #define LFSD_WAVES_OC LFSD_WAVES_PER_SIMD
 #endif
-// fp32 aux kernels fit 256 registers (almost) without spills and are a few % faster at 2 waves/SIMD
-// (profiles/r01_tune_occupancy.txt); fp64 needs the full register file
+// aux kernels: measured on MI355X (profiles/r01_tune_aux_occupancy.txt) 2 waves/SIMD never pays -- once the LDS footprint
+// admits a second wave the compiler holds the kernel to 256 VGPRs and spills 0.5-1.3 KB/lane (Riccati 8.8 -> 9.0 ms,
+// forward 5.8 -> 11.1 ms); VALU is busy 50-65 % of a lone wave's cycles, so there is little latency left to hide
+// tuning only: extra LDS elements per workgroup of the aux kernels, to lower their occupancy (tools/tune.py)
+#ifndef LFSD_AUX_LDS_PAD
+#define LFSD_AUX_LDS_PAD 0
+#endif
+// Riccati kernel: which Z-independent columns are parked per lane in LDS (0 none, 1 [Hxx Hxe] and Huu^-1 [Hux Hue],
+// 2 only Huu^-1 [Hux Hue]).  0 and 2 shrink LDS enough for 2 waves/SIMD but then spill: 9.0 / 10.3 ms against 8.8
+#ifndef LFSD_RIC_CACHE
+#define LFSD_RIC_CACHE 1
+#endif
+// outer per-node loop of the once-per-unit preparation: rolled is 6 % faster in the Riccati sweep (ric_cols),
+// unrolled 7 % faster in the forward sweep (fwd_prep, fwd_cols) -- measured, profiles/r01_tune_aux_occupancy.txt
+#ifndef LFSD_RIC_NODE_LOOP
+#define LFSD_RIC_NODE_LOOP _Pragma("unroll 1")
+#endif
+#ifndef LFSD_FWD_NODE_LOOP
+#define LFSD_FWD_NODE_LOOP _Pragma("unroll")
+#endif
 #ifndef LFSD_WAVES_RIC
-#define LFSD_WAVES_RIC 2
+#define LFSD_WAVES_RIC 1
 #endif
 #ifndef LFSD_WAVES_FWD
-#define LFSD_WAVES_FWD 2
+#define LFSD_WAVES_FWD 1
 #endif
 
 // LFSD_SCHED_FENCE: stop the instruction scheduler from hoisting loads across this point (bounds live ranges in
@@ -928,26 +946,43 @@ template <class M> struct AuxLayout {
   static constexpr int LDS_L = 0;
   static constexpr int LDS_S = LDS_L + NNODE * M::NCOEF;
   static constexpr int LDS_T = LDS_S + NX * NU;
-  static constexpr int LDS_KN = LDS_T + NX * NZ;              // 3 stiff nodes x (NX x NU) feedback rows K^T
+  // LDS_T (transposed exchange of the Riccati right-hand side) and LDS_KN/LDS_PSI (forward sweep) share one region:
+  // each kernel uses only its own
+  static constexpr int LDS_KN = LDS_T;                        // 3 stiff nodes x (NX x NU) feedback rows K^T
   static constexpr int LDS_PSI = LDS_KN + 3 * NX * NU;        // 3 stiff nodes x {phi1(h/4 K fu), phi1(h/2 K fu)}
-  static constexpr int LDS_E = LDS_PSI + 3 * 2 * NU * NU;     // cold per-trajectory state: auxvar, consts,
+  static constexpr int LDS_E = LDS_T + (NX * NZ > 3 * NX * NU + 6 * NU * NU ? NX * NZ : 3 * NX * NU + 6 * NU * NU);
+                                                              // cold per-trajectory state: auxvar, consts,
   static constexpr int LDS_C = LDS_E + NP;                    // and the (x,u,lambda) grid values at both interval ends
   static constexpr int LDS_GA = LDS_C + M::NC;                // [x_k u_k l_k]
   static constexpr int LDS_GB = LDS_GA + 2 * NX + NU;         // [x_k+1 u_k+1 l_k+1]
   static constexpr int LDS_END = LDS_GB + 2 * NX + NU;
   static constexpr int lds_elems() { return ((LDS_END + 3) / 4) * 4; }
-  // forward kernel only: per-lane parking slot for X(t_k) (row i of lane l at [i*G + l])
-  // ... plus, per node and lane, the X-independent part of the right-hand side (fe - fu Huu^-1 (fu^T W + Hue)) e_j
-  template <int G> static constexpr int lds_elems_fwd() { return ((LDS_END + NX * G + NNODE * NX * G + 3) / 4) * 4; }
+  // forward kernel only: parking slot for X(t_k) (row i of column j at [i*NP + j])
+  // ... plus, per node and column, the X-independent part of the right-hand side (fe - fu Huu^-1 (fu^T W + Hue)) e_j
+  template <int G> static constexpr int lds_elems_fwd() { return ((LDS_END + NX * NP + NNODE * NX * NP + 3) / 4) * 4; }
   // Riccati kernel only: per node and lane, this lane's column of [Hxx Hxe] and of Huu^-1 [Hux Hue]
-  template <int G> static constexpr int lds_elems_ric() { return ((LDS_END + NNODE * (NX + NU) * G + 3) / 4) * 4; }
+  static constexpr int RIC_ROWS = LFSD_RIC_CACHE == 1 ? NX + NU : (LFSD_RIC_CACHE == 2 ? NU : 0);
+  template <int G> static constexpr int lds_elems_ric() { return ((LDS_END + NNODE * RIC_ROWS * G + 3) / 4) * 4; }
 };
+
+// Lanes per trajectory of the forward sweep.  Only the NP columns of X = dx/dtheta advance there; the NX columns of P are
+// merely interpolated.  One lane carries P column `lane` (lane < NX) AND X / W column `lane` (lane < NP), so
+// max(NX, NP) lanes are enough (quadrotor: 16 instead of the 32 the Riccati sweep needs for its NX+NP columns).
+template <class M> constexpr int fwd_lanes() {
+  int need = M::NX > M::NP ? M::NX : M::NP;
+  if (need < AuxLayout<M>::NNODE) need = AuxLayout<M>::NNODE;
+  int g = 8;
+  while (g < need) g *= 2;
+  return g;
+}
 
 // LAY: packing order of the staged coefficients (0: Riccati sweep, transposed operators contiguous; 1: forward sweep)
 template <class M, typename T, int G, int LAY> struct AuxCtx {
   static constexpr int NX = M::NX, NU = M::NU, NP = M::NP, NC = M::NC, NZ = NX + NP;
   using Lay = AuxLayout<M>;
   int lane;
+  int xcol;                  // forward sweep: column of X = dx/dtheta (and of W) this lane carries (lanes < NP), else 0
+  bool xlane;
   const T *e, *c;            // [NP], [NC] in LDS
   const T *xa_, *ua_, *la_, *xb_, *ub_, *lb_;   // grid values at both ends of the interval, in LDS
   T t_a, dgrid;
@@ -1053,33 +1088,48 @@ template <class M, typename T, int G, int LAY> struct AuxCtx {
   // The columns of [Hxx Hxe] and Huu^-1 [Hux Hue] this lane needs do not depend on Z: once per staged node
   // instead of once per right-hand-side evaluation (12 per unit).  Parked per lane at [(node*(NX+NU)+r)*G + lane].
   LFSD_DEV void ric_cols() {
+    if (Lay::RIC_ROWS == 0) return;
+    constexpr int R = Lay::RIC_ROWS, HX = LFSD_RIC_CACHE == 1 ? NX : 0;
     T* hc = lds + Lay::LDS_END;
-#pragma unroll
+    LFSD_RIC_NODE_LOOP
     for (int nd = 0; nd < Lay::NNODE; ++nd) {
       const T* L = node(nd);
-      T hx[NX], hu[NU], wq[NU];
-      M::template Hxx_mul<false, LAY>(L, ox, hx);
-      M::template Hxe_mul<true, LAY>(L, oe, hx);
+      T hu[NU], wq[NU];
+      if (LFSD_RIC_CACHE == 1) {
+        T hx[NX];
+        M::template Hxx_mul<false, LAY>(L, ox, hx);
+        M::template Hxe_mul<true, LAY>(L, oe, hx);
+#pragma unroll
+        for (int i = 0; i < NX; ++i) hc[(nd * R + i) * G + lane] = hx[i];
+      }
       M::template Hxu_mulT<false, LAY>(L, ox, hu);
       M::template Hue_mul<true, LAY>(L, oe, hu);
       matvec<NU>(L + M::OFF_IHUU, hu, wq);
 #pragma unroll
-      for (int i = 0; i < NX; ++i) hc[(nd * (NX + NU) + i) * G + lane] = hx[i];
-#pragma unroll
-      for (int a = 0; a < NU; ++a) hc[(nd * (NX + NU) + NX + a) * G + lane] = wq[a];
+      for (int a = 0; a < NU; ++a) hc[(nd * R + HX + a) * G + lane] = wq[a];
     }
   }
   // non-stiff part  dZ/dtau = [Qt qt] + A^T Z + P [A rt]   (A, Qt, rt, qt of CPDP.py:265-269)
   LFSD_DEV void ric_rhs(const T* z, int nd, T* y) {
+    constexpr int R = Lay::RIC_ROWS, HX = LFSD_RIC_CACHE == 1 ? NX : 0;
     T* ldsT = lds + Lay::LDS_T;
     const T* L = node(nd);
-    const T* hc = lds + Lay::LDS_END + nd * (NX + NU) * G;
+    const T* hc = lds + Lay::LDS_END + nd * R * G;
     const T* iH = L + M::OFF_IHUU;
-    T s[NU], v[NU], w[NU], nv[NU], r[NP];
+    T s[NU], v[NU], w[NU], nv[NU], r[NP], wq[NU];
+    if (R == 0) {
+      T hu[NU];
+      M::template Hxu_mulT<false, LAY>(L, ox, hu);
+      M::template Hue_mul<true, LAY>(L, oe, hu);
+      matvec<NU>(iH, hu, wq);
+    } else {
+#pragma unroll
+      for (int a = 0; a < NU; ++a) wq[a] = hc[(HX + a) * G + lane];
+    }
     M::template fu_mulT<false, LAY>(L, z, s);
     matvec<NU>(iH, s, v);
 #pragma unroll
-    for (int a = 0; a < NU; ++a) { nv[a] = -v[a]; w[a] = -(hc[(NX + a) * G + lane] + v[a]); }
+    for (int a = 0; a < NU; ++a) { nv[a] = -v[a]; w[a] = -(wq[a] + v[a]); }
     M::template fx_mulT<false, LAY>(L, z, y);
     if (lane < NX) {
       T tv[NX];
@@ -1093,8 +1143,13 @@ template <class M, typename T, int G, int LAY> struct AuxCtx {
 #pragma unroll
       for (int i = 0; i < NP; ++i) ldsT[lane * NZ + NX + i] = r[i];
     }
+    if (LFSD_RIC_CACHE == 1) {
 #pragma unroll
-    for (int i = 0; i < NX; ++i) y[i] += hc[i * G + lane];
+      for (int i = 0; i < NX; ++i) y[i] += hc[i * G + lane];
+    } else {
+      M::template Hxx_mul<true, LAY>(L, ox, y);
+      M::template Hxe_mul<true, LAY>(L, oe, y);
+    }
     M::template Hxu_mul<true, LAY>(L, w, y);
     __syncthreads();
     if (lane < NZ) {
@@ -1122,7 +1177,7 @@ template <class M, typename T, int G, int LAY> struct AuxCtx {
   }
 
   // ---- forward auxiliary state -----------------------------------------------------------------
-  // lanes < NX carry P columns (interpolated), lanes NX..NX+NP carry X = dx/dtheta columns and W columns.
+  // lanes < NX carry P columns (interpolated); lanes < NP also carry one X = dx/dtheta column and its W column.
   // stiff sub-flow  X' = -fu K X,  K = Huu^-1 fu^T P (frozen over the sub-step), solved exactly:
   //   X(dt) = X - dt fu phi1(dt K fu) K X,   phi1(M) = M^-1 (I - e^-M)   (m x m matrix function).
   // (An A-stable rational step is not enough here: with a cheap control cost dt*|K fu| reaches O(10^2).)
@@ -1131,7 +1186,7 @@ template <class M, typename T, int G, int LAY> struct AuxCtx {
   LFSD_DEV void fwd_prep(const T* zA, const T* zB, T s0, T ds, T hq) {
     T* ldsK = lds + Lay::LDS_KN;
     T* ldsP = lds + Lay::LDS_PSI;
-#pragma unroll
+    LFSD_FWD_NODE_LOOP
     for (int r = 0; r < 3; ++r) {
       const T* L = node(2 * r);
       const T sr = s0 + T(2 * r) * ds;
@@ -1180,8 +1235,8 @@ template <class M, typename T, int G, int LAY> struct AuxCtx {
   // is evaluated once per staged node (fwd_cols) and parked per lane; the 12 right-hand sides of a unit then cost
   //   y = fx x - fu Huu^-1 Hux x + b_j.
   LFSD_DEV void fwd_cols(const T* zA, const T* zB, T s0, T ds) {
-    T* bc = lds + Lay::LDS_END + NX * G;
-#pragma unroll
+    T* bc = lds + Lay::LDS_END + NX * NP;
+    LFSD_FWD_NODE_LOOP
     for (int nd = 0; nd < Lay::NNODE; ++nd) {
       const T* L = node(nd);
       const T sr = s0 + T(nd) * ds;
@@ -1195,13 +1250,15 @@ template <class M, typename T, int G, int LAY> struct AuxCtx {
       for (int a = 0; a < NU; ++a) v[a] = -v[a];
       M::template fe_mul<false, LAY>(L, oe, b);
       M::template fu_mul<true, LAY>(L, v, b);
+      if (xlane) {
 #pragma unroll
-      for (int i = 0; i < NX; ++i) bc[(nd * NX + i) * G + lane] = b[i];
+        for (int i = 0; i < NX; ++i) bc[(nd * NX + i) * NP + xcol] = b[i];
+      }
     }
   }
   LFSD_DEV void fwd_rhs(const T* xa, int nd, T* y) {
     const T* L = node(nd);
-    const T* bc = lds + Lay::LDS_END + NX * G + nd * NX * G;
+    const T* bc = lds + Lay::LDS_END + NX * NP + nd * NX * NP;     // lanes without an X column read column 0; their result is dropped
     T s[NU], v[NU];
     M::template Hxu_mulT<false, LAY>(L, xa, s);
     matvec<NU>(L + M::OFF_IHUU, s, v);
@@ -1210,7 +1267,7 @@ template <class M, typename T, int G, int LAY> struct AuxCtx {
     M::template fx_mul<false, LAY>(L, xa, y);
     M::template fu_mul<true, LAY>(L, v, y);
 #pragma unroll
-    for (int i = 0; i < NX; ++i) y[i] += bc[i * G + lane];
+    for (int i = 0; i < NX; ++i) y[i] += bc[i * NP + xcol];
   }
   // non-stiff RK4 step of length h over nodes (n0, n1, n2)
   LFSD_DEV void fwd_rk4(T* xa, int n0, int n1, int n2, T h) {
@@ -1229,17 +1286,18 @@ template <class M, typename T, int G, int LAY> struct AuxCtx {
     for (int i = 0; i < NX; ++i) xa[i] += h / T(6) * (acc[i] + k[i]);
   }
   // auxiliary control at a grid point (CPDP.py:295):  U = -Huu^-1((Hux + fu^T P) X + fu^T W + Hue)
-  LFSD_DEV void aux_control(const T* xa, const T* zt, const T* L, T* uo) {
+  LFSD_DEV void aux_control(const T* xa, const T* pt, const T* wt, const T* L, T* uo) {
     T* ldsS = lds + Lay::LDS_S;
     const T* iH = L + M::OFF_IHUU;
     T s[NU];
-    M::template fu_mulT<false, LAY>(L, zt, s);
+    M::template fu_mulT<false, LAY>(L, pt, s);          // P role: row `lane` of (fu^T P)^T
     if (lane < NX) {
 #pragma unroll
       for (int a = 0; a < NU; ++a) ldsS[lane * NU + a] = s[a];
     }
     __syncthreads();
-    M::template Hue_mul<true, LAY>(L, oe, s);         // X lanes: s = fu^T w_j + Hue e_j
+    M::template fu_mulT<false, LAY>(L, wt, s);          // X role: s = fu^T w_j + Hue e_j + Hux x_j + fu^T P x_j
+    M::template Hue_mul<true, LAY>(L, oe, s);
     M::template Hxu_mulT<true, LAY>(L, xa, s);
 #pragma unroll
     for (int i = 0; i < NX; ++i) {
@@ -1259,6 +1317,8 @@ template <class M, typename T, int G, int LAY> LFSD_DEV void aux_setup(AuxCtx<M,
   using Lay = AuxLayout<M>;
   const int gib = threadIdx.x / G;
   s.lane = threadIdx.x % G;
+  s.xlane = (LAY == 1) && (s.lane < NP);
+  s.xcol = s.xlane ? s.lane : 0;
   s.lds = lds_all + gib * lds_stride;
   {
     T* le = s.lds + Lay::LDS_E;
@@ -1272,7 +1332,7 @@ template <class M, typename T, int G, int LAY> LFSD_DEV void aux_setup(AuxCtx<M,
 #pragma unroll
   for (int i = 0; i < NX; ++i) s.ox[i] = (s.lane == i) ? T(1) : T(0);
 #pragma unroll
-  for (int i = 0; i < NP; ++i) s.oe[i] = (s.lane == NX + i) ? T(1) : T(0);
+  for (int i = 0; i < NP; ++i) s.oe[i] = (LAY == 1 ? (s.xlane && s.lane == i) : (s.lane == NX + i)) ? T(1) : T(0);
 }
 
 template <class M, typename T, int G>
@@ -1282,7 +1342,7 @@ __global__ void __launch_bounds__(64, (sizeof(T) == 4 ? LFSD_WAVES_RIC : 1)) aux
   constexpr int NX = M::NX, NP = M::NP, NZ = NX + NP;
   constexpr int GPB = 64 / G;
   static_assert(64 % G == 0 && G >= NZ && G >= Lay::NNODE, "lane group must hold one column of [P W] per lane");
-  __shared__ T lds_all[GPB * Lay::template lds_elems_ric<G>()];
+  __shared__ T lds_all[GPB * Lay::template lds_elems_ric<G>() + LFSD_AUX_LDS_PAD];
   poison_lds(lds_all, GPB * Lay::template lds_elems_ric<G>());
   const long long slot = (long long)blockIdx.x * GPB + threadIdx.x / G;
   const bool valid = slot < a.batch;
@@ -1354,7 +1414,8 @@ __global__ void __launch_bounds__(64, (sizeof(T) == 4 ? LFSD_WAVES_FWD : 1)) aux
   using Lay = AuxLayout<M>;
   constexpr int NX = M::NX, NU = M::NU, NP = M::NP, NZ = NX + NP;
   constexpr int GPB = 64 / G;
-  __shared__ T lds_all[GPB * Lay::template lds_elems_fwd<G>()];
+  static_assert(64 % G == 0 && G >= NX && G >= NP && G >= Lay::NNODE, "forward lane group: one P column and one X column per lane");
+  __shared__ T lds_all[GPB * Lay::template lds_elems_fwd<G>() + LFSD_AUX_LDS_PAD];
   poison_lds(lds_all, GPB * Lay::template lds_elems_fwd<G>());
   const long long slot = (long long)blockIdx.x * GPB + threadIdx.x / G;
   const bool valid = slot < a.batch;
@@ -1363,29 +1424,35 @@ __global__ void __launch_bounds__(64, (sizeof(T) == 4 ? LFSD_WAVES_FWD : 1)) aux
   aux_setup<M, T, G, 1>(s, a, traj, lds_all, Lay::template lds_elems_fwd<G>());
   const int N = a.n_grid, Sa = a.substeps;
   const int lane = s.lane;
-  const bool xlane = (lane >= NX) && (lane < NZ);
+  const bool xlane = s.xlane;
   const T* Zt = a.Z_grid + traj * (long long)(N + 1) * NZ * NX;
-  T xa[NX], zA[NX], zB[NX];
+  T xa[NX], pA[NX], pB[NX], wA[NX], wB[NX];     // X column; P and W columns at both ends of the interval
 #pragma unroll
-  for (int i = 0; i < NX; ++i) { xa[i] = T(0); zA[i] = T(0); zB[i] = T(0); }     // X(0) = 0, CPDP.py:355
+  for (int i = 0; i < NX; ++i) { xa[i] = T(0); pA[i] = T(0); pB[i] = T(0); wA[i] = T(0); wB[i] = T(0); }     // X(0) = 0, CPDP.py:355
   T loss = T(0), gacc = T(0);
   T* Xo = a.auxX_grid ? a.auxX_grid + traj * (long long)(N + 1) * NP * NX : nullptr;
   T* Uo = a.auxU_grid ? a.auxU_grid + traj * (long long)(N + 1) * NP * NU : nullptr;
   if (valid && Xo && xlane) {
 #pragma unroll
-    for (int i = 0; i < NX; ++i) Xo[(long long)(lane - NX) * NX + i] = T(0);
+    for (int i = 0; i < NX; ++i) Xo[(long long)s.xcol * NX + i] = T(0);
   }
   for (int k = 0; k < N; ++k) {
     s.load_interval(a, traj, k, N);
-    if (lane < NZ) {
+    if (lane < NX) {
 #pragma unroll
-      for (int i = 0; i < NX; ++i) { zA[i] = Zt[((long long)k * NZ + lane) * NX + i]; zB[i] = Zt[((long long)(k + 1) * NZ + lane) * NX + i]; }
+      for (int i = 0; i < NX; ++i) { pA[i] = Zt[((long long)k * NZ + lane) * NX + i]; pB[i] = Zt[((long long)(k + 1) * NZ + lane) * NX + i]; }
+    }
+    if (xlane) {
+#pragma unroll
+      for (int i = 0; i < NX; ++i) { wA[i] = Zt[((long long)k * NZ + NX + lane) * NX + i]; wB[i] = Zt[((long long)(k + 1) * NZ + NX + lane) * NX + i]; }
     }
     T* xprev = s.lds + Lay::LDS_END;                 // this lane's X(t_k), parked in LDS until the loss needs it
+    if (xlane) {
 #pragma unroll
-    for (int i = 0; i < NX; ++i) xprev[i * G + lane] = xa[i];
+      for (int i = 0; i < NX; ++i) xprev[i * NP + s.xcol] = xa[i];
+    }
     s.stage_nodes(T(0), T(0.25));
-    const T rate = t_max(s.stiff_rate(zA, s.node(0)), s.stiff_rate(zB, s.node(4)));
+    const T rate = t_max(s.stiff_rate(pA, s.node(0)), s.stiff_rate(pB, s.node(4)));
     const int units = s.units_for(rate, Sa, a.rate_max, a.max_refine);
     const T hc = s.dgrid / T(units);
     const T ds = T(1) / T(4 * units);
@@ -1394,18 +1461,18 @@ __global__ void __launch_bounds__(64, (sizeof(T) == 4 ? LFSD_WAVES_FWD : 1)) aux
       s.stage_nodes(s_lo, ds);
       if (Uo && unit == 0) {
         T uo[NU];
-        s.aux_control(xa, zA, s.node(0), uo);
+        s.aux_control(xa, pA, wA, s.node(0), uo);
         if (valid && xlane) {
 #pragma unroll
-          for (int b = 0; b < NU; ++b) Uo[((long long)k * NP + (lane - NX)) * NU + b] = uo[b];
+          for (int b = 0; b < NU; ++b) Uo[((long long)k * NP + s.xcol) * NU + b] = uo[b];
         }
       }
       T xc[NX], xf[NX];
 #pragma unroll
       for (int i = 0; i < NX; ++i) { xc[i] = xa[i]; xf[i] = xa[i]; }
       const T hq = hc * T(0.25);
-      s.fwd_prep(zA, zB, s_lo, ds, hq);
-      s.fwd_cols(zA, zB, s_lo, ds);
+      s.fwd_prep(pA, pB, s_lo, ds, hq);
+      s.fwd_cols(wA, wB, s_lo, ds);
       // coarse Strang step (stiff h/2, RK4 h, stiff h/2) and two fine ones; the two adjacent fine stiff
       // quarter-steps at the middle node compose exactly into one half-step
       s.fwd_stiff(xc, 0, true, hq);
@@ -1421,16 +1488,16 @@ __global__ void __launch_bounds__(64, (sizeof(T) == 4 ? LFSD_WAVES_FWD : 1)) aux
       for (int i = 0; i < NX; ++i) xa[i] = xlane ? (T(4) * xf[i] - xc[i]) / T(3) : T(0);
       if (Uo && k == N - 1 && unit == units - 1) {
         T uo[NU];
-        s.aux_control(xa, zB, s.node(4), uo);
+        s.aux_control(xa, pB, wB, s.node(4), uo);
         if (valid && xlane) {
 #pragma unroll
-          for (int b = 0; b < NU; ++b) Uo[((long long)N * NP + (lane - NX)) * NU + b] = uo[b];
+          for (int b = 0; b < NU; ++b) Uo[((long long)N * NP + s.xcol) * NU + b] = uo[b];
         }
       }
     }
     if (valid && Xo && xlane) {
 #pragma unroll
-      for (int i = 0; i < NX; ++i) Xo[((long long)(k + 1) * NP + (lane - NX)) * NX + i] = xa[i];
+      for (int i = 0; i < NX; ++i) Xo[((long long)(k + 1) * NP + s.xcol) * NX + i] = xa[i];
     }
     // loss and gradient contributions of the waypoints that fall into this interval
     // (linear interpolation of the grid values, exactly what opt_sol(t)/auxsys_sol(t) do: CPDP.py:386)
@@ -1457,12 +1524,12 @@ __global__ void __launch_bounds__(64, (sizeof(T) == 4 ? LFSD_WAVES_FWD : 1)) aux
         }
       }
 #pragma unroll
-      for (int i = 0; i < NX; ++i) { const T xp = xprev[i * G + lane]; gacc += rvec[i] * (xp + sw * (xa[i] - xp)); }
+      for (int i = 0; i < NX; ++i) { const T xp = xprev[i * NP + s.xcol]; gacc += rvec[i] * (xp + sw * (xa[i] - xp)); }
     }
   }
   if (valid) {
     if (lane == 0) a.loss[traj] = loss;
-    if (xlane) a.grad[traj * NP + (lane - NX)] = gacc;
+    if (xlane) a.grad[traj * NP + s.xcol] = gacc;
   }
 }
 

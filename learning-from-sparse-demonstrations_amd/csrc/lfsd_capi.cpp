@@ -139,7 +139,11 @@ static int aux_phase_t(int phases, int batch, int n_grid, const void* horizon, c
     if (rc) return rc;
   }
   if (phases & 2) {
-    LFSD_LAUNCH((lfsd::aux_forward_kernel<Model, T, G>), grid, 64, stream, a);
+    // the forward sweep packs more trajectories into a wavefront than the Riccati sweep (lfsd::fwd_lanes)
+    constexpr int GF = lfsd::fwd_lanes<Model>() < G ? lfsd::fwd_lanes<Model>() : G;
+    constexpr int GPBF = 64 / GF;
+    const unsigned grid_f = (unsigned)(((long long)batch + GPBF - 1) / GPBF);
+    LFSD_LAUNCH((lfsd::aux_forward_kernel<Model, T, GF>), grid_f, 64, stream, a);
     return launch_status();
   }
   return 0;

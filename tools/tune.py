@@ -1,5 +1,5 @@
 """Build kernel variants (register budget / lanes per trajectory) and time them on the bench workload."""
-import os, subprocess, sys, time
+import os, re, subprocess, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 import lfsd_amd
@@ -7,13 +7,27 @@ from lfsd_amd import models, runtime
 
 def build(spec, tag, extra):
     out = os.path.join(runtime.BUILD_DIR, "tune_%s_%s.so" % (spec.hash(), tag))
-    cmd = runtime.hipcc_command(spec, out, extra)
+    cmd = runtime.hipcc_command(spec, out, list(extra) + ["-Rpass-analysis=kernel-resource-usage"])
     r = subprocess.run(cmd, cwd=runtime.CSRC_DIR, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-2000:]
+    # one line per kernel: registers, spills, LDS, occupancy
+    cur = None
+    for ln in r.stderr.splitlines():
+        m = re.search(r"remark: [^:]*:?\s*(Function Name|VGPRs|AGPRs|ScratchSize \[bytes/lane\]|Occupancy \[waves/SIMD\]|LDS Size \[bytes/block\]): (\S+)", ln)
+        if not m:
+            continue
+        if m.group(1) == "Function Name":
+            cur = m.group(2)
+            if "lfsd" in cur and ("aux_" in cur or "oc_solve" in cur) and "Id" not in cur.split("Model")[-1][:3]:
+                print("  ", re.sub(r"IN\d+lfsd_gen_[0-9a-f]+5ModelE", "", cur)[:48], end=" ")
+            else:
+                cur = None
+        elif cur:
+            print(m.group(1).split(" ")[0], m.group(2), end="  " if not m.group(1).startswith("LDS") else "\n")
     return out
 
 if __name__ == "__main__":
-    variants = [("base", []), ("aux1", ["-DLFSD_WAVES_RIC=1", "-DLFSD_WAVES_FWD=1"])]
+    variants = [("base", []), ("unr", ['-DLFSD_NODE_LOOP=_Pragma("unroll")']), ("ricw2", ["-DLFSD_WAVES_RIC=2"])]
     if sys.argv[1:] == ["build"]:
         oc, env, d = models.quadrotor(n_grid=50)
         spec = oc.model_spec(); runtime.write_header(spec)
