@@ -25,7 +25,7 @@ import hashlib
 import sympy as sp
 from sympy.printing.c import C99CodePrinter
 
-CODEGEN_VERSION = 6
+CODEGEN_VERSION = 7
 
 
 class ModelSpec:
@@ -109,9 +109,13 @@ def _pr(e):
     return _P.doprint(e)
 
 
-def _body(inputs, outputs, indent='    '):
+def _body(inputs, outputs, indent='    ', vec=(), vec_out=None):
     """inputs: list of (symbol, c_expr_to_load); outputs: list of (c_lvalue, sympy_expr).
-    Returns C statements computing all outputs with common sub-expression elimination."""
+    Returns C statements computing all outputs with common sub-expression elimination.
+
+    vec: input symbols of the tangent type `V` (a scalar `T`, or a pair of them that the packed-math kernels carry per
+    lane); every temporary that depends on one is typed `V` as well.  The expressions are linear in those symbols, so
+    only T*V, V+V and -V occur.  vec_out(lvalue) -> True marks outputs that are `V` even when identically constant."""
     exprs = [sp.sympify(e) for _, e in outputs]
     repl, red = sp.cse(exprs, symbols=sp.numbered_symbols('w_'), order='none')
     used = set()
@@ -119,14 +123,21 @@ def _body(inputs, outputs, indent='    '):
         used |= r.free_symbols
     for r in red:
         used |= r.free_symbols
+    vt = set(vec)
     lines = []
     for sym, load in inputs:
         if sym in used:
-            lines.append('%sconst T %s = %s;' % (indent, sym, load))
+            lines.append('%sconst %s %s = %s;' % (indent, 'V' if sym in vt else 'T', sym, load))
     for s, r in repl:
-        lines.append('%sconst T %s = %s;' % (indent, s, _pr(r)))
+        isv = bool(r.free_symbols & vt)
+        if isv:
+            vt.add(s)
+        lines.append('%sconst %s %s = %s;' % (indent, 'V' if isv else 'T', s, _pr(r)))
     for (lv, _), r in zip(outputs, red):
-        lines.append('%s%s = %s;' % (indent, lv, _pr(r)))
+        if vec_out is not None and vec_out(lv) and not (r.free_symbols & vt):
+            lines.append('%s%s = V(%s);' % (indent, lv, _pr(r)))
+        else:
+            lines.append('%s%s = %s;' % (indent, lv, _pr(r)))
     return '\n'.join(lines)
 
 
@@ -244,9 +255,11 @@ def emit_header(spec):
     # 2. + directional derivative
     df = fx * dX + fu * dU
     dq = (cx * dX)[0, 0] + (cu * dU)[0, 0]
-    S.append('  template<class T> static LFSD_DEV void dyn_cost_jvp(%s, const T* dx, const T* du, T* f, T& q, T* df, T& dq) {' % sig_xu)
+    # V = T: one tangent column per lane; V = lfsd::pk2<T>: two columns per lane on packed math (v_pk_fma_f32)
+    S.append('  template<class T, class V> static LFSD_DEV void dyn_cost_jvp(%s, const V* dx, const V* du, T* f, T& q, V* df, V& dq) {' % sig_xu)
     S.append(_body(_loads(spec) + tang, [('f[%d]' % i, f[i]) for i in range(n)] + [('q', c)] +
-                   [('df[%d]' % i, df[i]) for i in range(n)] + [('dq', dq)]))
+                   [('df[%d]' % i, df[i]) for i in range(n)] + [('dq', dq)],
+                   vec=[s_ for s_, _ in tang], vec_out=lambda lv: lv.startswith('df[') or lv == 'dq'))
     S.append('  }')
     # 2b. two vector-Jacobian products at one point (second-order adjoint sweep through the RK4 stages):
     #     y1x = fx^T v1 + w1*cx   (first-order stage adjoint, group-uniform)

@@ -24,9 +24,12 @@
 
 #if defined(LFSD_EMU)
 #include "simt_emu.h"
+#define LFSD_LAMBDA_INLINE
 #else
 #include <hip/hip_runtime.h>
 #define LFSD_DEV __device__ __forceinline__
+// lambdas inside kernels must be inlined as well: a real call passes their by-reference captures through scratch
+#define LFSD_LAMBDA_INLINE __attribute__((always_inline))
 #endif
 
 // register budget: measured on MI355X (tools/tune.py) 1 wave/SIMD with all 512 VGPR+AGPR beats 2-3 waves with scratch spills
@@ -86,6 +89,31 @@ template <typename T> LFSD_DEV void poison_lds(T* p, int n) {
 
 enum Status { ST_RUNNING = 0, ST_CONVERGED = 1, ST_STALLED = 2, ST_MAXITER = 3, ST_FAILED = 4 };
 enum OptMethod { OPT_VANILLA = 0, OPT_NESTEROV = 1, OPT_ADAM = 2, OPT_NADAM = 3, OPT_AMSGRAD = 4 };
+
+// Two values per lane, for the kernels that carry two tangent columns on one lane: native 2-vectors on the GPU (the
+// tangent code is linear, so it compiles to v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 at the scalar issue rate), a plain
+// struct in the CPU emulator build.
+#if defined(LFSD_EMU)
+template <typename T> struct pk2 {
+  T x, y;
+  pk2() = default;
+  pk2(T s) : x(s), y(s) {}
+  pk2(T a, T b) : x(a), y(b) {}
+};
+template <typename T> inline pk2<T> operator+(pk2<T> a, pk2<T> b) { return pk2<T>(a.x + b.x, a.y + b.y); }
+template <typename T> inline pk2<T> operator-(pk2<T> a, pk2<T> b) { return pk2<T>(a.x - b.x, a.y - b.y); }
+template <typename T> inline pk2<T> operator-(pk2<T> a) { return pk2<T>(-a.x, -a.y); }
+template <typename T> inline pk2<T> operator*(pk2<T> a, pk2<T> b) { return pk2<T>(a.x * b.x, a.y * b.y); }
+template <typename T> inline pk2<T> operator*(T a, pk2<T> b) { return pk2<T>(a * b.x, a * b.y); }
+template <typename T> inline pk2<T> operator*(pk2<T> a, T b) { return pk2<T>(a.x * b, a.y * b); }
+template <typename T> inline pk2<T> operator+(T a, pk2<T> b) { return pk2<T>(a + b.x, a + b.y); }
+template <typename T> inline pk2<T> operator+(pk2<T> a, T b) { return pk2<T>(a.x + b, a.y + b); }
+template <typename T> inline pk2<T>& operator+=(pk2<T>& a, pk2<T> b) { a.x += b.x; a.y += b.y; return a; }
+template <typename T> inline pk2<T>& operator-=(pk2<T>& a, pk2<T> b) { a.x -= b.x; a.y -= b.y; return a; }
+#else
+template <typename T> using pk2 = T __attribute__((ext_vector_type(2)));
+#endif
+template <typename T> LFSD_DEV pk2<T> mk2(T a, T b) { pk2<T> v; v.x = a; v.y = b; return v; }
 
 template <typename T> struct Eps;
 template <> struct Eps<float> { static LFSD_DEV float v() { return 1.1920929e-07f; } };
@@ -323,9 +351,11 @@ template <class M, typename T, int G, bool EXACT> struct OcSolver {
   LFSD_DEV T tk(int k) const { return M::TIME_VARYING ? dgrid * T(k) : T(0); }
 
   // One RK4 step of (x, q) with frozen control; optionally with the per-lane tangent (m, mq).
-  template <bool SENS>
-  LFSD_DEV void rk4_step(T t, T* x, T& q, const T* u, T* m, T& mq, const T* du) const {
-    T xs[NX], ms[NX], ax[NX], am[NX], f[NX], d[NX], cq, dq, aq, adq;
+  // V: tangent type -- T (one column per lane) or pk2<T> (two columns per lane, packed math)
+  template <bool SENS, class V = T>
+  LFSD_DEV void rk4_step(T t, T* x, T& q, const T* u, V* m, V& mq, const V* du) const {
+    T xs[NX], ax[NX], f[NX], cq, aq;
+    V ms[NX], am[NX], d[NX], dq, adq;
     const T hh = DT * T(0.5);
     if (SENS) M::dyn_cost_jvp(t, x, u, e, c, m, du, f, cq, d, dq); else M::dyn_cost(t, x, u, e, c, f, cq);
     aq = cq; if (SENS) adq = dq;
@@ -397,6 +427,52 @@ template <class M, typename T, int G, bool EXACT> struct OcSolver {
 #pragma unroll
         for (int i = 0; i < NX; ++i) col[i] = m[i];
         col[NX] = mq;
+      }
+    }
+    if (lane == 0) {
+#pragma unroll
+      for (int i = 0; i < NX; ++i) xb[nxt][N * NX + i] = x[i];
+    }
+    J += M::final_cost(tk(N), x, e, c);
+    return J;
+  }
+
+  // The same sweep with two columns per lane: lane l < (NX+NU+1)/2 propagates columns 2l and 2l+1 as one packed
+  // tangent, so a trajectory needs half the lanes (quadrotor: 9 of a 16-lane group, four trajectories per wavefront).
+  LFSD_DEV T rollout_sens_pk(int cur, int nxt, T alpha, bool gains) {
+    using V = pk2<T>;
+    T x[NX], u[NU], J = T(0);
+#pragma unroll
+    for (int i = 0; i < NX; ++i) x[i] = x0[i];
+    const int c0 = 2 * lane, c1 = 2 * lane + 1;
+    for (int k = 0; k < N; ++k) {
+      control(cur, k, x, alpha, gains, u);
+      if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < NX; ++i) xb[nxt][k * NX + i] = x[i];
+#pragma unroll
+        for (int a = 0; a < NU; ++a) ub[nxt][k * NU + a] = u[a];
+      }
+      V m[NX], du[NU], mq = V(T(0));
+      T q = T(0);
+#pragma unroll
+      for (int i = 0; i < NX; ++i) m[i] = mk2<T>((c0 == i) ? T(1) : T(0), (c1 == i) ? T(1) : T(0));
+#pragma unroll
+      for (int a = 0; a < NU; ++a) du[a] = mk2<T>((c0 == NX + a) ? T(1) : T(0), (c1 == NX + a) ? T(1) : T(0));
+      const T t = tk(k);
+      for (int s = 0; s < S; ++s) rk4_step<true, V>(t, x, q, u, m, mq, du);
+      J += q;
+      if (c0 < NXU) {
+        T* col = Mws[nxt] + ((long long)k * NXU + c0) * (NX + 1);
+#pragma unroll
+        for (int i = 0; i < NX; ++i) col[i] = m[i].x;
+        col[NX] = mq.x;
+      }
+      if (c1 < NXU) {
+        T* col = Mws[nxt] + ((long long)k * NXU + c1) * (NX + 1);
+#pragma unroll
+        for (int i = 0; i < NX; ++i) col[i] = m[i].y;
+        col[NX] = mq.y;
       }
     }
     if (lane == 0) {
@@ -717,22 +793,62 @@ template <class M, typename T, int G, bool EXACT> struct OcSolver {
   }
 };
 
+// Point a solver view at one trajectory: its LDS region, its scratch slot and its costate rows.  GL is the lane-group
+// size the LDS / workspace layouts were sized for (the Riccati-style "one column per lane" mapping).
+template <class M, typename T, int GL, class Sol>
+LFSD_DEV void oc_bind(Sol& s, const OcArgs<T>& a, T* region, long long slot, bool valid, long long traj) {
+  using Lay = OcLayout<M>;
+  constexpr int NX = M::NX, NU = M::NU;
+  s.N = a.n_grid; s.S = a.steps_per_grid;
+  s.lds = region;
+  s.e = region + Lay::template lds_e<GL>();
+  s.c = region + Lay::template lds_c<GL>();
+  s.x0 = region + Lay::template lds_x0<GL>();
+  s.horizon = a.horizon[traj];
+  s.dgrid = s.horizon / T(s.N);
+  s.DT = s.dgrid / T(s.S);
+  const int N = s.N;
+  T* w = a.ws + slot * a.ws_stride;
+  s.xb[0] = w; w += (N + 1) * NX;
+  s.xb[1] = w; w += (N + 1) * NX;
+  s.ub[0] = w; w += N * NU;
+  s.ub[1] = w; w += N * NU;
+  s.Mws[0] = w; w += (long long)N * (NX + NU) * (NX + 1);
+  s.Mws[1] = w; w += (long long)N * (NX + NU) * (NX + 1);
+  s.Kws = w; w += (long long)N * NX * NU;
+  s.kws = w; w += N * NU;
+  s.exws = w; w += (long long)Lay::SMAX * NX * (1 + GL);
+  // padding groups (slot >= batch) clone the last trajectory and keep their costates in scratch
+  s.lam_out = valid ? a.costate_grid + traj * (N + 1) * NX : w;
+}
+
 // EXACT = false: lean instantiation without the exact-Hessian code (Gauss-Newton / Hamiltonian models only);
 // EXACT = true: may switch to the exact stage Hessians.  lfsd_coc_solve runs the lean kernel for the first
 // `exact_after` iterations and resumes the unfinished trajectories in the exact-capable one.
-template <class M, typename T, int G, bool EXACT>
+// PK = true (lean kernel of the 32-lane models only): the roll-out + linearisation and the line search run on
+// 16-lane groups -- two tangent columns per lane on packed math (rollout_sens_pk) -- so a wavefront carries four
+// trajectories instead of two; the backward sweep keeps its one-column-per-lane mapping on 32-lane groups and is run
+// in two passes.  The phases already meet in the per-trajectory scratch ([A B q], gains, nominal), so only the
+// few scalars of the step control cross between the mappings, through an LDS mailbox.
+template <class M, typename T, int G, bool EXACT, bool PK = false>
 __global__ void __launch_bounds__(64, LFSD_WAVES_OC) oc_solve_kernel(OcArgs<T> a) {
-  using Sol = OcSolver<M, T, G, EXACT>;
+  constexpr int GR = PK ? 16 : G;                 // lanes per trajectory of the roll-out / line-search mapping
+  using Sol = OcSolver<M, T, GR, EXACT>;
+  using SolB = OcSolver<M, T, G, EXACT>;          // backward-sweep mapping
   using Lay = OcLayout<M>;
   constexpr int NX = M::NX, NU = M::NU, NP = M::NP, NC = M::NC;
-  constexpr int GPB = 64 / G;
+  constexpr int GPB = 64 / GR;
+  constexpr int RS = EXACT ? Lay::template lds_elems<G>() : ((Lay::template lds_ex<G>() + 3) / 4) * 4;
+  constexpr int MB = 12;                          // mailbox floats per trajectory
   static_assert(64 % G == 0 && G >= NX + NU, "lane group must hold one column of [A B] per lane");
-  __shared__ T lds_all[GPB * Lay::template lds_elems<G>()];
+  static_assert(!PK || (!EXACT && G == 32 && 2 * GR >= NX + NU), "packed roll-out: lean kernel of a 32-lane model");
+  __shared__ T lds_all[GPB * RS];
+  __shared__ T mbox[PK ? GPB * MB : 1];
   __shared__ int vote[2];
-  poison_lds(lds_all, GPB * Lay::template lds_elems<G>());
+  poison_lds(lds_all, GPB * RS);
   Sol s;
-  const int gib = threadIdx.x / G;
-  s.lane = threadIdx.x % G;
+  const int gib = threadIdx.x / GR;
+  s.lane = threadIdx.x % GR;
   const long long slot = (long long)blockIdx.x * GPB + gib;      // scratch slot (padded batch)
   const bool in_batch = slot < a.batch;
   const long long traj = in_batch ? slot : (long long)a.batch - 1;
@@ -747,41 +863,65 @@ __global__ void __launch_bounds__(64, LFSD_WAVES_OC) oc_solve_kernel(OcArgs<T> a
     if (!vote[0]) return;              // nothing to do in this workgroup
     __syncthreads();
   }
-  s.N = a.n_grid; s.S = a.steps_per_grid;
-  s.lds = lds_all + gib * Lay::template lds_elems<G>();
+  oc_bind<M, T, G>(s, a, lds_all + gib * RS, slot, valid, traj);
   {
     T* le = s.lds + Lay::template lds_e<G>();
     T* lc = s.lds + Lay::template lds_c<G>();
     T* lx = s.lds + Lay::template lds_x0<G>();
-    for (int i = s.lane; i < NP; i += G) le[i] = a.auxvar[traj * NP + i];
-    for (int i = s.lane; i < NC; i += G) lc[i] = a.consts[traj * a.const_stride + i];
-    for (int i = s.lane; i < NX; i += G) lx[i] = a.ini_state[traj * NX + i];
-    s.e = le; s.c = lc; s.x0 = lx;
+    for (int i = s.lane; i < NP; i += GR) le[i] = a.auxvar[traj * NP + i];
+    for (int i = s.lane; i < NC; i += GR) lc[i] = a.consts[traj * a.const_stride + i];
+    for (int i = s.lane; i < NX; i += GR) lx[i] = a.ini_state[traj * NX + i];
   }
   __syncthreads();
-  s.horizon = a.horizon[traj];
-  s.dgrid = s.horizon / T(s.N);
-  s.DT = s.dgrid / T(s.S);
   const int N = s.N;
-  T* w = a.ws + slot * a.ws_stride;
-  s.xb[0] = w; w += (N + 1) * NX;
-  s.xb[1] = w; w += (N + 1) * NX;
-  s.ub[0] = w; w += N * NU;
-  s.ub[1] = w; w += N * NU;
-  s.Mws[0] = w; w += (long long)N * (NX + NU) * (NX + 1);
-  s.Mws[1] = w; w += (long long)N * (NX + NU) * (NX + 1);
-  s.Kws = w; w += (long long)N * NX * NU;
-  s.kws = w; w += N * NU;
-  s.exws = w; w += (long long)Lay::SMAX * NX * (1 + G);
-  // padding groups (slot >= batch) clone the last trajectory and keep their costates in scratch
-  s.lam_out = valid ? a.costate_grid + traj * (N + 1) * NX : w;
+
+  // backward sweep of this lane's trajectory; `force`: also when the trajectory is no longer running (final refresh
+  // of the costates).  Returns whether the sweep ran (PK skips a pass none of whose trajectories wants it).
+  auto do_backward = [&](int cur_, int mode_, T mu_, bool want_, T& gnorm_, T& dV1_, T& dV2_, T& dmin_, bool& ok_) LFSD_LAMBDA_INLINE -> bool {
+    if constexpr (!PK) {
+      ok_ = s.backward(cur_, mode_, mu_, gnorm_, dV1_, dV2_, dmin_);
+      return true;
+    } else {
+      T* mb = mbox + gib * MB;
+      if (s.lane == 0) { mb[0] = T(cur_); mb[1] = T(mode_); mb[2] = mu_; mb[3] = want_ ? T(1) : T(0); }
+      __syncthreads();
+      SolB sb;
+      sb.lane = threadIdx.x % G;
+      for (int pass = 0; pass < GPB * G / 64; ++pass) {
+        const int t0 = pass * (64 / G);
+        bool want_pass = false;
+        for (int j = 0; j < 64 / G; ++j) want_pass = want_pass || (mbox[(t0 + j) * MB + 3] != T(0));
+        const int tb = t0 + threadIdx.x / G;
+        T* mo = mbox + tb * MB;
+        if (want_pass) {
+          const long long slot_b = (long long)blockIdx.x * GPB + tb;
+          const bool valid_b = slot_b < a.batch;
+          oc_bind<M, T, G>(sb, a, lds_all + tb * RS, slot_b, valid_b, valid_b ? slot_b : (long long)a.batch - 1);
+          T g_, d1_, d2_, dm_;
+          const bool okb = sb.backward((int)mo[0], (int)mo[1], mo[2], g_, d1_, d2_, dm_);
+          if (sb.lane == 0) { mo[4] = okb ? T(1) : T(0); mo[5] = g_; mo[6] = d1_; mo[7] = d2_; mo[8] = dm_; mo[9] = T(1); }
+        } else if (sb.lane == 0) {
+          mo[9] = T(0);
+        }
+        __syncthreads();
+      }
+      const bool ran = mb[9] != T(0);
+      if (ran) { ok_ = mb[4] != T(0); gnorm_ = mb[5]; dV1_ = mb[6]; dV2_ = mb[7]; dmin_ = mb[8]; }
+      __syncthreads();
+      return ran;
+    }
+  };
+  auto do_rollout = [&](int cur_, int nxt_, T alpha_, bool gains_) LFSD_LAMBDA_INLINE -> T {
+    if constexpr (PK) return s.rollout_sens_pk(cur_, nxt_, alpha_, gains_);
+    else return s.rollout_sens(cur_, nxt_, alpha_, gains_);
+  };
 
   // initial guess into buffer 1, then "roll out" 1 -> 0 without gains
-  for (int i = s.lane; i < N * NU; i += G)
+  for (int i = s.lane; i < N * NU; i += GR)
     s.ub[1][i] = a.resume ? a.control_grid[traj * (N + 1) * NU + i] : (a.u_init ? a.u_init[traj * N * NU + i] : T(0));
   __syncthreads();
   int cur = 0;
-  T J = s.rollout_sens(1, 0, T(0), false);
+  T J = do_rollout(1, 0, T(0), false);
   __syncthreads();
   T mu = T(0);
   int mode = 0;             // stage Hessian model: 0 Gauss-Newton, 1 Hamiltonian (cheap Newton-like), 2 exact
@@ -808,8 +948,8 @@ __global__ void __launch_bounds__(64, LFSD_WAVES_OC) oc_solve_kernel(OcArgs<T> a
     if (EXACT) { if (want_exact) mode = 2; }
     else if (want_exact && status == ST_RUNNING && it < a.max_iter_total - 1) { status = ST_MAXITER; my_iters = it + it_off; }
     T dmin = T(0);
-    const bool bw_ok = s.backward(cur, mode, mu, gnorm, dV1, dV2, dmin);
-    need_bw = false;
+    bool bw_ok = false;
+    if (do_backward(cur, mode, mu, status == ST_RUNNING, gnorm, dV1, dV2, dmin, bw_ok)) need_bw = false;
     bool try_step = false;
     if (status == ST_RUNNING) {
       my_iters = it + 1 + it_off;
@@ -869,7 +1009,7 @@ __global__ void __launch_bounds__(64, LFSD_WAVES_OC) oc_solve_kernel(OcArgs<T> a
     if (roll) vote[1] = 1;
     __syncthreads();
     if (vote[1]) {
-      const T Jn = s.rollout_sens(cur, cur ^ 1, opt_try ? T(1) : (accept ? alpha : T(0)), roll);
+      const T Jn = do_rollout(cur, cur ^ 1, opt_try ? T(1) : (accept ? alpha : T(0)), roll);
       if (opt_try) {
         const T flat = T(8) * Eps<T>::v() * t_abs(J);
         const bool fin = t_finite(Jn);
@@ -905,13 +1045,13 @@ __global__ void __launch_bounds__(64, LFSD_WAVES_OC) oc_solve_kernel(OcArgs<T> a
   __syncthreads();
   if (need_bw) vote[0] = 1;
   __syncthreads();
-  { T dmin = T(0); if (vote[0]) s.backward(cur, 0, T(0), gnorm, dV1, dV2, dmin); }   // refresh costates on the final nominal
+  { T dmin = T(0); bool okf = false; if (vote[0]) do_backward(cur, 0, T(0), need_bw, gnorm, dV1, dV2, dmin, okf); }   // refresh costates on the final nominal
   __syncthreads();
   if (valid) {
     T* xo = a.state_grid + traj * (N + 1) * NX;
     T* uo = a.control_grid + traj * (N + 1) * NU;
-    for (int i = s.lane; i < (N + 1) * NX; i += G) xo[i] = s.xb[cur][i];
-    for (int i = s.lane; i < (N + 1) * NU; i += G) uo[i] = s.ub[cur][(i < N * NU) ? i : i - NU];
+    for (int i = s.lane; i < (N + 1) * NX; i += GR) xo[i] = s.xb[cur][i];
+    for (int i = s.lane; i < (N + 1) * NU; i += GR) uo[i] = s.ub[cur][(i < N * NU) ? i : i - NU];
     if (s.lane == 0) { a.cost[traj] = J; a.iters[traj] = my_iters; a.status[traj] = status; }
   }
 }

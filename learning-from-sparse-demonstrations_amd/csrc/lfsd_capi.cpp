@@ -44,7 +44,10 @@ LFSD_API double lfsd_const_default(int i) {
   return Model::const_default(i);
 }
 
-static long long padded_batch(int batch) { return ((long long)(batch + GPB - 1) / GPB) * GPB; }
+// fp32 lean OC kernel of the 32-lane models: packed roll-out, four trajectories per wavefront (cpdp_kernels.h, PK)
+static constexpr bool OC_PK = (G == 32) && (Model::NX + Model::NU + 1) / 2 <= 16;
+static constexpr int OC_GPB = OC_PK ? 4 : GPB;      // scratch slots are padded to whole workgroups of either mapping
+static long long padded_batch(int batch) { return ((long long)(batch + OC_GPB - 1) / OC_GPB) * OC_GPB; }
 
 LFSD_API size_t lfsd_coc_workspace_bytes(int dtype, int batch, int n_grid) {
   if (batch <= 0 || n_grid <= 0 || (dtype != LFSD_F32 && dtype != LFSD_F64)) return 0;
@@ -73,8 +76,10 @@ static int coc_solve_t(int batch, int n_grid, int steps_per_grid, const void* in
   if (workspace_bytes < need) return LFSD_ENOSPC;
   const unsigned grid = (unsigned)(padded_batch(batch) / GPB);
   a.it_start = 0; a.resume = 0; a.max_iter_total = max_iter;
+  constexpr bool PK = OC_PK && sizeof(T) == 4;
+  const unsigned grid_lean = PK ? (unsigned)(padded_batch(batch) / OC_GPB) : grid;
   if (exact_after < 0) {                       // Gauss-Newton / Hamiltonian models only
-    LFSD_LAUNCH((lfsd::oc_solve_kernel<Model, T, G, false>), grid, 64, stream, a);
+    LFSD_LAUNCH((lfsd::oc_solve_kernel<Model, T, G, false, PK>), grid_lean, 64, stream, a);
     return launch_status();
   }
   if (exact_after == 0) {                      // Newton from the first iteration
@@ -85,7 +90,7 @@ static int coc_solve_t(int batch, int n_grid, int steps_per_grid, const void* in
   // (warm-started from control_grid) the trajectories that are still at MAXITER
   a.max_iter = max_iter < exact_after ? max_iter : exact_after;
   if (max_iter <= exact_after) a.max_iter_total = 0;      // no phase 2: never hand over
-  LFSD_LAUNCH((lfsd::oc_solve_kernel<Model, T, G, false>), grid, 64, stream, a);
+  LFSD_LAUNCH((lfsd::oc_solve_kernel<Model, T, G, false, PK>), grid_lean, 64, stream, a);
   int rc = launch_status();
   if (rc || max_iter <= exact_after) return rc;
   a.max_iter = max_iter; a.it_start = exact_after; a.resume = 1;
@@ -132,7 +137,7 @@ static int aux_phase_t(int phases, int batch, int n_grid, const void* horizon, c
   a.n_waypoints = n_waypoints; a.n_iface = n_iface; a.iface_idx = iface_idx;
   a.taus = (const T*)taus; a.waypoints = (const T*)waypoints;
   a.loss = (T*)loss; a.grad = (T*)grad; a.auxX_grid = (T*)auxX_grid; a.auxU_grid = (T*)auxU_grid;
-  const unsigned grid = (unsigned)(padded_batch(batch) / GPB);
+  const unsigned grid = (unsigned)(((long long)batch + GPB - 1) / GPB);
   if (phases & 1) {
     LFSD_LAUNCH((lfsd::aux_riccati_kernel<Model, T, G>), grid, 64, stream, a);
     const int rc = launch_status();

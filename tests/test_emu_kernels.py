@@ -117,6 +117,32 @@ def test_quadrotor_against_reference_golden_run(emu):
     assert np.abs(tr[:, 13:17] - G["opt_control_traj"]).max() < 1e-6
 
 
+def test_quadrotor_fp32_packed_rollout_matches_fp64(emu):
+    """The fp32 lean OC kernel of the 32-lane models rolls out on 16-lane groups with two tangent columns per lane
+    (oc_solve_kernel<..., PK=true>, four trajectories per workgroup, backward sweep relayed in two passes); fp64 keeps the
+    one-column-per-lane mapping.  Same inputs, ragged batch of 5 (one full workgroup + one partial), stated fp32
+    tolerances: loss 5e-4, gradient 2e-2, grids 5e-3."""
+    oc, env, d = models.quadrotor(n_grid=int(G["n_grid"]))
+    emu(oc)
+    consts = oc.consts_tensor(overrides=dict(goal_r0=G["goal_r"][0], goal_r1=G["goal_r"][1], goal_r2=G["goal_r"][2]))
+    idx = [0, 20, 40, 60, 99]
+    out = {}
+    for dt in (torch.float64, torch.float32):
+        oc.setDevice(dtype=dt)
+        sol = oc.cocSolverBatch(np.tile(G["ini_state"], (len(idx), 1)), float(G["horizon"]), G["lookahead_theta"][idx],
+                                consts=consts.to(dt))
+        aux = oc.auxSysSolverBatch(sol, G["taus"], G["waypoints"], [0, 1, 2])
+        out[dt] = (sol, aux)
+    s64, a64 = out[torch.float64]
+    s32, a32 = out[torch.float32]
+    assert (s32["status"] != 4).all() and (s32["status"] != 3).all(), s32["status"]      # neither failed nor at the limit
+    assert rel(s32["state_grid"], s64["state_grid"]) < 5e-3
+    assert rel(s32["costate_grid"], s64["costate_grid"]) < 5e-3
+    for k, j in enumerate(idx):
+        assert abs(a32["loss"][k].item() - G["loss_trace"][j]) < 5e-4 * G["loss_trace"][j]
+        assert rel(a32["grad"][k], a64["grad"][k]) < 2e-2
+
+
 def test_reference_shaped_single_trajectory_api(emu):
     """cocSolver / auxSysSolver with the reference's signatures and return types (CPDP.py:92,301)."""
     oc, env, d = models.pendulum(n_grid=10)

@@ -4,6 +4,8 @@ Newton (exact-Hessian) kernel, so any out-of-bounds access into caller memory or
 import os
 import subprocess
 
+import pytest
+
 import lfsd_amd  # noqa: F401
 from lfsd_amd import models, runtime
 
@@ -11,8 +13,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 EMU = os.path.join(ROOT, "tests", "emu")
 
 
-def test_asan_ubsan_clean(tmp_path):
-    oc, _, _ = models.pendulum()
+# pendulum: 8-lane groups; robot arm: 16-lane groups, 8-lane forward sweep; quadrotor: 32-lane groups, packed fp32
+# roll-out on 16-lane groups with the relayed backward sweep, 16-lane forward sweep.  Batch 5 leaves a partial workgroup.
+@pytest.mark.parametrize("kind", ["pendulum", "robotarm", "quadrotor"])
+def test_asan_ubsan_clean(tmp_path, kind):
+    oc, _, _ = models.ZOO[kind]()
     spec = oc.model_spec()
     runtime.write_header(spec)
     exe = str(tmp_path / "sanitize")

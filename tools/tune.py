@@ -27,7 +27,7 @@ def build(spec, tag, extra):
     return out
 
 if __name__ == "__main__":
-    variants = [("base", []), ("unr", ['-DLFSD_NODE_LOOP=_Pragma("unroll")']), ("ricw2", ["-DLFSD_WAVES_RIC=2"])]
+    variants = [("base", [])]
     if sys.argv[1:] == ["build"]:
         oc, env, d = models.quadrotor(n_grid=50)
         spec = oc.model_spec(); runtime.write_header(spec)
