@@ -29,7 +29,12 @@
 #include <hip/hip_runtime.h>
 #define LFSD_DEV __device__ __forceinline__
 // lambdas inside kernels must be inlined as well: a real call passes their by-reference captures through scratch
+// (experiment knob LFSD_PHASE_CALLS=1: keep them as calls, so every phase gets its own register allocation)
+#if defined(LFSD_PHASE_CALLS) && LFSD_PHASE_CALLS
+#define LFSD_LAMBDA_INLINE __attribute__((noinline))
+#else
 #define LFSD_LAMBDA_INLINE __attribute__((always_inline))
+#endif
 #endif
 
 // register budget: measured on MI355X (tools/tune.py) 1 wave/SIMD with all 512 VGPR+AGPR beats 2-3 waves with scratch spills

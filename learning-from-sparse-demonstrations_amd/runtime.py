@@ -76,7 +76,8 @@ def hipcc_command(spec, out, extra=()):
     return [find_hipcc(), "-x", "hip", "--offload-arch=gfx950", "-std=c++17", "-O3", "-fPIC", "-shared",
             "-fno-signed-zeros", "-fvisibility=hidden",
             "-DLFSD_G=%d" % g, '-DLFSD_MODEL_HEADER="gen/%s.h"' % spec.hash(),
-            "-I" + CSRC_DIR, os.path.join(CSRC_DIR, "lfsd_capi.cpp"), "-o", out] + list(extra)
+            "-I" + CSRC_DIR, os.path.join(CSRC_DIR, "lfsd_capi.cpp"), "-o", out] + list(extra) + \
+        os.environ.get("LFSD_EXTRA_HIPCC_FLAGS", "").split()       # tuning experiments (tools/tune.py)
 
 
 def build_library(spec, force=False, verbose=False):
