@@ -130,7 +130,7 @@ def main():
                 {"riccati": e[1], "forward": e[2], "end": e[3]}[name].record()
         L._aux = oc.auxSysSolverBatch(L._sol, L.taus, L.wps, L.iface, Z_grid=L._Z, out=L._aux_out(), phase_hook=hook)
         L._Z = L._aux["Z_grid"]
-        loss, grad = L._aux["loss"], L._aux["grad"]
+        loss, grad = L.mask_unconverged(L._sol["status"], L._aux["loss"], L._aux["grad"])    # as SparseDemoLearner.step
         if use_dist:
             buf = torch.cat([grad.sum(dim=0), loss.sum().reshape(1)])
             dist.all_reduce(buf)                                            # summed d(theta) + loss over all ranks
@@ -174,7 +174,7 @@ def main():
         traffic = None
         # PMC passes are separate rocprofv3 runs (tools/hbm_traffic.py); the figure only applies to the workload they
         # were collected on, so it is attached to the headline configuration and left null otherwise
-        tpath = os.path.join(ROOT, "profiles", "r01_h_hbm_traffic.json")
+        tpath = os.path.join(ROOT, "profiles", "r01_i_hbm_traffic.json")
         headline = (B == 4096 and args.n_grid == 50 and args.dtype == "f32" and args.substeps == 4
                     and not args.warm_start)
         if headline and os.path.exists(tpath):

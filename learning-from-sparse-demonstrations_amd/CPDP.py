@@ -312,11 +312,18 @@ class SparseDemoLearner:
     ``mode='independent'``: every trajectory (seed) owns its theta and optimizer state.
     ``mode='shared'``: one theta for all demonstrations; the gradient is summed over the batch and
     all-reduced over ``process_group`` (RCCL) before a single update.
+
+    ``skip_unconverged`` (default on; not in the reference, which has a single trajectory and would simply show IPOPT's
+    failure): a trajectory whose optimal-control solve ended at the iteration limit or failed has a meaningless
+    sensitivity, and one such gradient at the examples' learning rates sends its parameters to infinity.  Its gradient
+    (and, in shared sums, its loss) is zeroed for that step; ``n_unconverged`` counts them.  At the next outer iteration
+    such a solve is continued from the controls it stopped at; every other trajectory cold-starts as in the reference.
     """
 
     def __init__(self, oc, ini_state, horizon, taus, waypoints, interface_idx, theta0, method="Vanilla",
                  learning_rate=1e-2, mu=0.9, beta_1=0.9, beta_2=0.999, epsilon=1e-8, proj_lo=None, consts=None,
-                 mode="independent", process_group=None, true_loss_print_flag=False, warm_start=False):
+                 mode="independent", process_group=None, true_loss_print_flag=False, warm_start=False,
+                 skip_unconverged=True):
         self.oc, self.method, self.lr, self.mu = oc, method, learning_rate, mu
         self.b1, self.b2, self.eps = beta_1, beta_2, epsilon
         if method not in runtime.OPT_METHODS:
@@ -353,6 +360,9 @@ class SparseDemoLearner:
         # warm_start: start every OC solve from the previous iteration's controls (theta moves little per step).
         # The reference cold-starts IPOPT every time; the converged KKT point is the same, only the path to it is shorter.
         self.warm_start = warm_start
+        self.skip_unconverged = skip_unconverged
+        self.count_unconverged = True      # one small device->host read per step; switch off inside timed loops
+        self.n_unconverged = 0
         self._ws = None
         self._sol = None
         self._aux = None
@@ -364,13 +374,32 @@ class SparseDemoLearner:
         u_init = None
         if self.warm_start and self._sol is not None:
             u_init = self._sol["control_grid"][:, :-1].contiguous()
+        elif self.skip_unconverged and self._sol is not None:
+            # a solve that ran out of iterations is continued from where it stopped instead of restarted (its parameters
+            # did not move, a cold start would fail the same way); all others start from zero controls = cold start
+            cont = (self._sol["status"] == 3).reshape(-1, 1, 1)
+            prev = self._sol["control_grid"][:, :-1]
+            u_init = torch.where(cont & torch.isfinite(prev), prev, torch.zeros_like(prev)).contiguous()
         self._sol = self.oc.cocSolverBatch(self.x0, self.hz, th, consts=self.consts, u_init=u_init,
                                            workspace=self._ws, out=self._sol_out())
         self._ws = self._sol["workspace"]
         self._aux = self.oc.auxSysSolverBatch(self._sol, self.taus, self.wps, self.iface, Z_grid=self._Z,
                                               out=self._aux_out())
         self._Z = self._aux["Z_grid"]
-        return self._aux["loss"].to(self.theta.dtype), self._aux["grad"].to(self.theta.dtype)
+        loss, grad = self._aux["loss"].to(self.theta.dtype), self._aux["grad"].to(self.theta.dtype)
+        if self.skip_unconverged:
+            loss, grad = self.mask_unconverged(self._sol["status"], loss, grad)
+        return loss, grad
+
+    def mask_unconverged(self, status, loss, grad):
+        """Zero the gradient of trajectories whose OC solve neither converged (1) nor stalled at working precision (2);
+        in shared mode also their loss, which enters a sum."""
+        ok = (status == 1) | (status == 2)
+        self._ok = ok
+        grad = torch.where(ok.unsqueeze(1), grad, torch.zeros_like(grad))
+        if self.mode == "shared":
+            loss = torch.where(ok, loss, torch.zeros_like(loss))
+        return loss, grad
 
     def _sol_out(self):
         if self._sol is None:
@@ -401,6 +430,8 @@ class SparseDemoLearner:
         self.lib.optimizer_step(self.method, self.theta, grad_used, self.iter_idx, self.lr, self.mu, self.b1,
                                 self.b2, self.eps, m=self.m, v=self.v, vhat=self.vhat, proj_lo=self.proj_lo)
         self.iter_idx += 1
+        if self.skip_unconverged:
+            self.n_unconverged = int(self.B - self._ok.sum().item()) if self.count_unconverged else self.n_unconverged
         if self.method == "Nesterov" and self.true_loss:
             loss_out, grad_used = self.evaluate(self.theta)                   # QuadAlgorithm.py:487-492
             if self.mode == "shared":

@@ -71,6 +71,29 @@
 #define LFSD_WAVES_FWD 1
 #endif
 
+// Levenberg shift ladder of the OC solve: factor up after a failed backward sweep / line search, factor down after an
+// accepted full step, and how many accepted full steps to hold before the shift returns to a level that has just failed.
+// Measured on BASELINE configs[1] (robot arm, 1024 seeds, tools/tune_arm.py, profiles/r01_tune_step_control.txt): with
+// x10 / x0.1 the accepted steps land on shifts up to 10x larger than necessary (over-damped) and every other backward
+// sweep fails; sqrt(10) rungs + a one-step hold cut the slowest seed from 87 to 65 iterations and the seeds that run
+// out of iterations at the step-1 parameters from 98 to 65 of 1024.  Handing over to the exact model as soon as
+// Gauss-Newton crawls (the oracle's rule, LFSD_GN_CRAWL) costs iterations here (27 -> 40 on average) and stays off.
+#ifndef LFSD_MU_UP
+#define LFSD_MU_UP 3.1623
+#endif
+#ifndef LFSD_MU_DOWN
+#define LFSD_MU_DOWN 0.31623
+#endif
+#ifndef LFSD_MU_HOLD
+#define LFSD_MU_HOLD 1
+#endif
+#ifndef LFSD_MU_HOLD_BACKOFF
+#define LFSD_MU_HOLD_BACKOFF 0
+#endif
+#ifndef LFSD_GN_CRAWL
+#define LFSD_GN_CRAWL 0
+#endif
+
 // LFSD_SCHED_FENCE: stop the instruction scheduler from hoisting loads across this point (bounds live ranges in
 // the fully unrolled contractions); no-op in the emulator build
 #if defined(LFSD_EMU) || !defined(LFSD_USE_SCHED_FENCE)
@@ -939,6 +962,9 @@ __global__ void __launch_bounds__(64, LFSD_WAVES_OC) oc_solve_kernel(OcArgs<T> a
   T g_flat = T(-1);         // gradient norm at the last accepted noise-level ("flat") step; <0: none yet
   T J_ref = J;              // cost 4 accepted steps ago (stagnation window)
   int n_acc = 0;
+  bool gn_crawl = false;    // Gauss-Newton is all that is left (Hamiltonian model failed) and its full steps gain < 1 %
+  T mu_bad = T(-1);         // largest Levenberg shift that failed recently (<0: none)
+  int mu_hold = 0, mu_hold_need = LFSD_MU_HOLD;   // accepted full steps to wait before the shift returns to a level <= mu_bad
   if (!t_finite(J)) status = ST_FAILED;
   for (; it < a.max_iter; ++it) {
     if (threadIdx.x == 0) vote[0] = 0;
@@ -949,7 +975,8 @@ __global__ void __launch_bounds__(64, LFSD_WAVES_OC) oc_solve_kernel(OcArgs<T> a
     __syncthreads();
     // hand over to the exact stage Hessians at the iteration limit of the cheap models.  (Measured: handing over
     // earlier, e.g. after three full Gauss-Newton steps, costs more regularised Newton steps than it saves.)
-    const bool want_exact = a.exact_after >= 0 && mode < 2 && it >= a.exact_after;
+    // ... or as soon as Gauss-Newton is reduced to crawling (the oracle's "close: switch to Newton" rule)
+    const bool want_exact = a.exact_after >= 0 && mode < 2 && (it >= a.exact_after || gn_crawl);
     if (EXACT) { if (want_exact) mode = 2; }
     else if (want_exact && status == ST_RUNNING && it < a.max_iter_total - 1) { status = ST_MAXITER; my_iters = it + it_off; }
     T dmin = T(0);
@@ -962,10 +989,11 @@ __global__ void __launch_bounds__(64, LFSD_WAVES_OC) oc_solve_kernel(OcArgs<T> a
         // indefinite Q_uu: the cheap Newton-like model hands over to the exact one; otherwise Levenberg shift
         if (mode == 1) { mode = 0; ham_ok = false; }     // back to Gauss-Newton until the exact model takes over
         else {
+          mu_bad = mu; mu_hold = 0;
           if (mu == T(0) && mode == 2 && t_finite(dmin))
             mu = t_min(t_max(T(-2) * dmin, T(1e-4)), T(1e6));     // first shift: the size of the negative pivot
           else
-            mu = t_max(mu * T(10), mode == 2 ? T(1e-4) : T(1e-6));
+            mu = t_max(mu * T(LFSD_MU_UP), mode == 2 ? T(1e-4) : T(1e-6));
           if (mu > T(1e12)) status = ST_FAILED;
         }
       } else if (gnorm < a.tol * (T(1) + t_abs(J))) {
@@ -1002,7 +1030,8 @@ __global__ void __launch_bounds__(64, LFSD_WAVES_OC) oc_solve_kernel(OcArgs<T> a
                  ((J - Jmin) <= T(8) * Eps<T>::v() * t_abs(J) && (mode == 0 || flat_full || mu > T(1e6)))) {
         status = ST_STALLED;      // no step length gains more than rounding noise
       } else {                    // (exact model far from the optimum: indefinite direction -> larger shift)
-        mu = t_max(mu * T(10), mode == 2 ? T(1e-4) : T(1e-6));
+        mu_bad = mu; mu_hold = 0;
+        mu = t_max(mu * T(LFSD_MU_UP), mode == 2 ? T(1e-4) : T(1e-6));
       }
     }
 #if defined(LFSD_TRACE)
@@ -1032,8 +1061,18 @@ __global__ void __launch_bounds__(64, LFSD_WAVES_OC) oc_solve_kernel(OcArgs<T> a
         need_bw = true;
         optimistic = (ia == 0);
         if (ia == 0) {
-          mu = (mu > T(1e-8)) ? mu * T(0.1) : T(0);
+          // relax the shift after a full step -- but not straight back to a level that has just failed: hold for
+          // mu_hold_need accepted steps first, and twice as long after every failed return (a shift that bounces
+          // between a failing and a working level wastes every other backward sweep)
+          const T mu_next = (mu > T(1e-8)) ? mu * T(LFSD_MU_DOWN) : T(0);
+          if (mu > T(0) && mu_bad >= T(0) && mu_next <= mu_bad && mu_hold < mu_hold_need) {
+            ++mu_hold;
+          } else {
+            if (LFSD_MU_HOLD_BACKOFF && mu > T(0) && mu_bad >= T(0) && mu_next <= mu_bad) mu_hold_need = mu_hold_need < 16 ? 2 * mu_hold_need : 16;
+            mu = mu_next; mu_hold = 0;
+          }
           if (mode == 0 && ham_ok && (J - Jn) < T(0.3) * t_abs(Jn)) mode = 1;      // past the first big drops: Newton-like
+          else if (LFSD_GN_CRAWL && mode == 0 && !ham_ok && (J - Jn) < T(1e-2) * t_abs(Jn)) gn_crawl = true;
         }
         J = Jn;
         if (++n_acc >= 4) {

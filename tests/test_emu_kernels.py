@@ -397,3 +397,38 @@ def test_learner_warm_start_same_iterates_fewer_solver_iterations(emu):
         lw, gw = warm.step(); it_w += int(warm._sol["iters"].sum())
         assert torch.allclose(lc, lw, rtol=1e-8) and torch.allclose(gc, gw, rtol=1e-5, atol=1e-8)
     assert torch.allclose(cold.theta, warm.theta, rtol=1e-7) and it_w < it_c
+
+
+def test_learner_skips_unconverged_trajectories(emu):
+    """A trajectory whose OC solve ran out of iterations has a meaningless sensitivity: by default the learner zeroes its
+    gradient for that step (and counts it) instead of letting it throw the parameters away; skip_unconverged=False keeps
+    the reference's unguarded behaviour."""
+    from lfsd_amd import CPDP
+    oc, env, d = models.ZOO["pendulum"](n_grid=10)
+    emu(oc)
+    oc.setDevice(dtype=torch.float64)
+    th = np.array([[1.0, 0.5, 1.5], [2.0, 1.0, 1.0]])
+    args = (np.tile(d["ini_state"], (2, 1)), d["horizon"], [0.3, 0.6], [[0.5], [1.0]], d["interface"], th)
+    oc.setSolverOptions(max_iter=3)                       # every solve stops at the limit
+    L = CPDP.SparseDemoLearner(oc, *args, learning_rate=0.1)
+    th0 = L.theta.clone()
+    loss, grad = L.step()
+    assert (L._sol["status"] == 3).all() and L.n_unconverged == 2
+    assert (grad == 0).all() and torch.equal(L.theta, th0)
+    # ... and the solve is continued at the next outer iteration rather than restarted: with 3 iterations per step a cold
+    # start could never finish, the continued solves converge after a few steps and the update then goes ahead
+    converged_once = False
+    for _ in range(15):
+        L.step()
+        converged_once = converged_once or bool((L._sol["status"] == 1).any())
+        if not torch.equal(L.theta[0], th0[0]):
+            break
+    assert converged_once and not torch.equal(L.theta[0], th0[0])
+    L2 = CPDP.SparseDemoLearner(oc, *args, learning_rate=0.1, skip_unconverged=False)
+    L2.step()
+    assert not torch.equal(L2.theta, th0)
+    oc.setSolverOptions(max_iter=100)                     # converged solves are untouched by the guard
+    L3 = CPDP.SparseDemoLearner(oc, *args, learning_rate=0.1)
+    L4 = CPDP.SparseDemoLearner(oc, *args, learning_rate=0.1, skip_unconverged=False)
+    L3.step(); L4.step()
+    assert L3.n_unconverged == 0 and torch.equal(L3.theta, L4.theta)
