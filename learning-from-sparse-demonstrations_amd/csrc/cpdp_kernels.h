@@ -1143,7 +1143,10 @@ template <class M> struct AuxLayout {
   static constexpr int lds_elems() { return ((LDS_END + 3) / 4) * 4; }
   // forward kernel only: parking slot for X(t_k) (row i of column j at [i*NP + j])
   // ... plus, per node and column, the X-independent part of the right-hand side (fe - fu Huu^-1 (fu^T W + Hue)) e_j
-  template <int G> static constexpr int lds_elems_fwd() { return ((LDS_END + NX * NP + NNODE * NX * NP + 3) / 4) * 4; }
+  // ... plus the P columns at both ends of the interval ([end][column][row], and one zero row that lanes without a P
+  // column point at): they are needed three times per unit only, too cold for 2*NX registers per lane
+  static constexpr int FWD_P = NX * NP + NNODE * NX * NP;                 // offset of that block behind LDS_END
+  template <int G> static constexpr int lds_elems_fwd() { return ((LDS_END + FWD_P + 2 * NX * NX + NX + 3) / 4) * 4; }
   // Riccati kernel only: per node and lane, this lane's column of [Hxx Hxe] and of Huu^-1 [Hux Hue]
   static constexpr int RIC_ROWS = LFSD_RIC_CACHE == 1 ? NX + NU : (LFSD_RIC_CACHE == 2 ? NU : 0);
   template <int G> static constexpr int lds_elems_ric() { return ((LDS_END + NNODE * RIC_ROWS * G + 3) / 4) * 4; }
@@ -1342,8 +1345,8 @@ template <class M, typename T, int G, int LAY> struct AuxCtx {
     }
     __syncthreads();
   }
-  LFSD_DEV void ric_strang(T* z, int n0, int n1, int n2, T h) {
-    ric_stiff(z, node(n0), h * T(0.5));
+  // non-stiff RK4 step of length h over nodes (n0, n1, n2)
+  LFSD_DEV void ric_rk4(T* z, int n0, int n1, int n2, T h) {
     T k[NX], acc[NX], zs[NX];
     ric_rhs(z, n0, k);
 #pragma unroll
@@ -1357,7 +1360,21 @@ template <class M, typename T, int G, int LAY> struct AuxCtx {
     ric_rhs(zs, n2, k);
 #pragma unroll
     for (int i = 0; i < NX; ++i) z[i] += h / T(6) * (acc[i] + k[i]);
+  }
+  // Strang step: stiff h/2, non-stiff h, stiff h/2
+  LFSD_DEV void ric_strang(T* z, int n0, int n1, int n2, T h) {
+    ric_stiff(z, node(n0), h * T(0.5));
+    ric_rk4(z, n0, n1, n2, h);
     ric_stiff(z, node(n2), h * T(0.5));
+  }
+  // two Strang steps of length h/2 over nodes (0,1,2) and (2,3,4): the two adjacent stiff quarter-steps at the middle
+  // node are the exact flow of the same frozen system, so they compose exactly into one half-step
+  LFSD_DEV void ric_strang2(T* z, T h) {
+    ric_stiff(z, node(0), h * T(0.25));
+    ric_rk4(z, 0, 1, 2, h * T(0.5));
+    ric_stiff(z, node(2), h * T(0.5));
+    ric_rk4(z, 2, 3, 4, h * T(0.5));
+    ric_stiff(z, node(4), h * T(0.25));
   }
 
   // ---- forward auxiliary state -----------------------------------------------------------------
@@ -1569,8 +1586,7 @@ __global__ void __launch_bounds__(64, (sizeof(T) == 4 ? LFSD_WAVES_RIC : 1)) aux
 #pragma unroll
       for (int i = 0; i < NX; ++i) { zc[i] = z[i]; zf[i] = z[i]; }
       s.ric_strang(zc, 0, 2, 4, hc);
-      s.ric_strang(zf, 0, 1, 2, hc * T(0.5));
-      s.ric_strang(zf, 2, 3, 4, hc * T(0.5));
+      s.ric_strang2(zf, hc);
 #pragma unroll
       for (int i = 0; i < NX; ++i) z[i] = (T(4) * zf[i] - zc[i]) / T(3);     // Richardson (Strang is O(h^2), symmetric)
     }
@@ -1610,9 +1626,15 @@ __global__ void __launch_bounds__(64, (sizeof(T) == 4 ? LFSD_WAVES_FWD : 1)) aux
   const int lane = s.lane;
   const bool xlane = s.xlane;
   const T* Zt = a.Z_grid + traj * (long long)(N + 1) * NZ * NX;
-  T xa[NX], pA[NX], pB[NX], wA[NX], wB[NX];     // X column; P and W columns at both ends of the interval
+  T xa[NX], wA[NX], wB[NX];     // X column; W column at both ends of the interval (the P columns live in LDS)
 #pragma unroll
-  for (int i = 0; i < NX; ++i) { xa[i] = T(0); pA[i] = T(0); pB[i] = T(0); wA[i] = T(0); wB[i] = T(0); }     // X(0) = 0, CPDP.py:355
+  for (int i = 0; i < NX; ++i) { xa[i] = T(0); wA[i] = T(0); wB[i] = T(0); }     // X(0) = 0, CPDP.py:355
+  T* ldsPA = s.lds + Lay::LDS_END + Lay::FWD_P;
+  T* ldsPB = ldsPA + NX * NX;
+  T* ldsP0 = ldsPB + NX * NX;                                  // zero row
+  for (int i = lane; i < NX; i += G) ldsP0[i] = T(0);
+  const T* pA = (lane < NX) ? ldsPA + lane * NX : ldsP0;
+  const T* pB = (lane < NX) ? ldsPB + lane * NX : ldsP0;
   T loss = T(0), gacc = T(0);
   T* Xo = a.auxX_grid ? a.auxX_grid + traj * (long long)(N + 1) * NP * NX : nullptr;
   T* Uo = a.auxU_grid ? a.auxU_grid + traj * (long long)(N + 1) * NP * NU : nullptr;
@@ -1622,9 +1644,9 @@ __global__ void __launch_bounds__(64, (sizeof(T) == 4 ? LFSD_WAVES_FWD : 1)) aux
   }
   for (int k = 0; k < N; ++k) {
     s.load_interval(a, traj, k, N);
-    if (lane < NX) {
+    if (lane < NX) {           // (load_interval's barriers fence the previous interval's readers; stage_nodes' the writers)
 #pragma unroll
-      for (int i = 0; i < NX; ++i) { pA[i] = Zt[((long long)k * NZ + lane) * NX + i]; pB[i] = Zt[((long long)(k + 1) * NZ + lane) * NX + i]; }
+      for (int i = 0; i < NX; ++i) { ldsPA[lane * NX + i] = Zt[((long long)k * NZ + lane) * NX + i]; ldsPB[lane * NX + i] = Zt[((long long)(k + 1) * NZ + lane) * NX + i]; }
     }
     if (xlane) {
 #pragma unroll
