@@ -238,3 +238,36 @@ def test_quadalgorithm_driver_fp32_follows_reference_run():
     assert res["loss_trace"].shape[0] == 10
     assert np.allclose(res["loss_trace"][:, 0], G["loss_trace"][:10], rtol=5e-3)
     assert np.allclose(res["parameter_trace"][10, 0], G["theta_trace"][10], rtol=1e-2, atol=2e-3)
+
+
+def test_robotarm_batch1024_random_seeds_configs1():
+    """BASELINE configs[1]: robot arm, n_grid 50, 1024 random seeds, fp32.  At the perturbed initial guesses every cold-started
+    solve has to finish (converged, or stalled at fp32 working precision) and the fp32 loss / gradient have to agree with the
+    fp64 kernels on every seed (stated fp32 tolerances for the flat-cost arm: loss 2e-3, gradient 2e-2; measured 4e-4).
+    Then five plain gradient steps at the example's learning rate (Examples/robotarm_random.py): no trajectory may be lost
+    to a non-finite parameter -- an unconverged solve is skipped and continued, not applied."""
+    from lfsd_amd import CPDP
+    B = 1024
+    rng = np.random.default_rng(0)
+    th = np.array([5.0, 1, 1, 1, 1])[None, :] * (1 + 0.05 * rng.standard_normal((B, 5)))     # around the example's initial guess
+    th[:, 0] = np.abs(th[:, 0]) + 0.1
+    res = {}
+    for dt in (torch.float32, torch.float64):
+        oc, d = gpu_model("robotarm", dt, 50, substeps=4)
+        sol = oc.cocSolverBatch(np.tile(d["ini_state"], (B, 1)), d["horizon"], th)
+        aux = oc.auxSysSolverBatch(sol, d["taus"], d["waypoints"], d["interface"])
+        st = sol["status"].cpu().numpy()
+        assert np.isin(st, (1, 2)).all(), (dt, np.bincount(st, minlength=5))
+        res[dt] = (aux["loss"].double().cpu().numpy(), aux["grad"].double().cpu().numpy())
+    l32, g32 = res[torch.float32]
+    l64, g64 = res[torch.float64]
+    assert (np.abs(l32 - l64) < 2e-3 * np.maximum(1.0, l64)).all()
+    assert (np.abs(g32 - g64).max(1) < 2e-2 * np.abs(g64).max(1)).all()
+    oc, d = gpu_model("robotarm", torch.float32, 50, substeps=4)
+    L = CPDP.SparseDemoLearner(oc, np.tile(d["ini_state"], (B, 1)), d["horizon"], d["taus"], d["waypoints"], d["interface"], th,
+                               method="Vanilla", learning_rate=d["lr"])
+    for _ in range(5):
+        loss, grad = L.step()
+    assert torch.isfinite(L.theta).all() and torch.isfinite(grad).all()
+    st = L._sol["status"].cpu().numpy()
+    assert (st == 4).sum() == 0 and np.isin(st, (1, 2)).mean() > 0.85, np.bincount(st, minlength=5)
