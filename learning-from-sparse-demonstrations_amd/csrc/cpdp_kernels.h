@@ -344,7 +344,8 @@ template <class M> struct OcLayout {
   static constexpr int SMAX = 8;       // RK4 sub-steps per grid interval supported by the exact-Hessian sweep
   template <int G> static long long ws_elems(int N) {
     return 2LL * (N + 1) * NX + 2LL * N * NU + 2LL * N * NXU * (NX + 1) + 1LL * N * NX * NU + 1LL * N * NU +
-           1LL * (N + 1) * NX + 1LL * SMAX * NX * (1 + G);      // + sub-step start states (uniform | per lane)
+           1LL * (N + 1) * NX + 1LL * SMAX * NX * (1 + G) +     // + sub-step start states (uniform | per lane)
+           1LL * N * NXU * NXU;                                  // + exact stage Hessians of the current nominal
   }
   // LDS per group (elements)
   static constexpr int LDS_V = 0;
@@ -373,7 +374,8 @@ template <class M, typename T, int G, bool EXACT> struct OcSolver {
   int lane, N, S;
   const T *e, *c, *x0;      // [NP], [NC], [NX] in LDS
   T horizon, dgrid, DT;
-  T *xb[2], *ub[2], *Mws[2], *Kws, *kws, *lds, *exws;
+  T *xb[2], *ub[2], *Mws[2], *Kws, *kws, *lds, *exws, *Hws;
+  bool reuse_hess = false;   // exact stage Hessians in Hws belong to the nominal being swept (a retry with another shift)
   T* lam_out;   // costate grid of this trajectory (or scratch when invalid)
 
   LFSD_DEV T tk(int k) const { return M::TIME_VARYING ? dgrid * T(k) : T(0); }
@@ -663,8 +665,24 @@ template <class M, typename T, int G, bool EXACT> struct OcSolver {
         LFSD_SCHED_FENCE();
       }
       if (EXACT && mode == 2) {
+        // column `lane` of the exact stage Hessian depends on the nominal and its costates only, not on the shift: a
+        // retry of the sweep with a larger shift reads it back instead of repeating the second-order adjoint
         T hx[NX], hu[NU];
-        stage_hessian_col(k, xk, uk, lam, hx, hu);
+        T* hcol = Hws + ((long long)k * NXU + (lane < NXU ? lane : 0)) * NXU;
+        if (reuse_hess) {
+#pragma unroll
+          for (int i = 0; i < NX; ++i) hx[i] = hcol[i];
+#pragma unroll
+          for (int a = 0; a < NU; ++a) hu[a] = hcol[NX + a];
+        } else {
+          stage_hessian_col(k, xk, uk, lam, hx, hu);
+          if (lane < NXU) {
+#pragma unroll
+            for (int i = 0; i < NX; ++i) hcol[i] = hx[i];
+#pragma unroll
+            for (int a = 0; a < NU; ++a) hcol[NX + a] = hu[a];
+          }
+        }
 #if defined(LFSD_TRACE)
         if (lane < NXU && blockIdx.x == 0 && threadIdx.x < G) {
           printf("HCOL k %d lane %d x", k, lane); for (int i = 0; i < NX; ++i) printf(" %.17g", (double)xk[i]);
@@ -846,6 +864,7 @@ LFSD_DEV void oc_bind(Sol& s, const OcArgs<T>& a, T* region, long long slot, boo
   s.Kws = w; w += (long long)N * NX * NU;
   s.kws = w; w += N * NU;
   s.exws = w; w += (long long)Lay::SMAX * NX * (1 + GL);
+  s.Hws = w; w += (long long)N * (NX + NU) * (NX + NU);
   // padding groups (slot >= batch) clone the last trajectory and keep their costates in scratch
   s.lam_out = valid ? a.costate_grid + traj * (N + 1) * NX : w;
 }
@@ -962,6 +981,7 @@ __global__ void __launch_bounds__(64, LFSD_WAVES_OC) oc_solve_kernel(OcArgs<T> a
   T g_flat = T(-1);         // gradient norm at the last accepted noise-level ("flat") step; <0: none yet
   T J_ref = J;              // cost 4 accepted steps ago (stagnation window)
   int n_acc = 0;
+  bool hess_ok = false;     // Hws holds the exact stage Hessians of nominal `cur`
   bool gn_crawl = false;    // Gauss-Newton is all that is left (Hamiltonian model failed) and its full steps gain < 1 %
   T mu_bad = T(-1);         // largest Levenberg shift that failed recently (<0: none)
   int mu_hold = 0, mu_hold_need = LFSD_MU_HOLD;   // accepted full steps to wait before the shift returns to a level <= mu_bad
@@ -981,7 +1001,8 @@ __global__ void __launch_bounds__(64, LFSD_WAVES_OC) oc_solve_kernel(OcArgs<T> a
     else if (want_exact && status == ST_RUNNING && it < a.max_iter_total - 1) { status = ST_MAXITER; my_iters = it + it_off; }
     T dmin = T(0);
     bool bw_ok = false;
-    if (do_backward(cur, mode, mu, status == ST_RUNNING, gnorm, dV1, dV2, dmin, bw_ok)) need_bw = false;
+    s.reuse_hess = EXACT && mode == 2 && hess_ok;
+    if (do_backward(cur, mode, mu, status == ST_RUNNING, gnorm, dV1, dV2, dmin, bw_ok)) { need_bw = false; hess_ok = EXACT && mode == 2; }
     bool try_step = false;
     if (status == ST_RUNNING) {
       my_iters = it + 1 + it_off;
@@ -1059,6 +1080,7 @@ __global__ void __launch_bounds__(64, LFSD_WAVES_OC) oc_solve_kernel(OcArgs<T> a
       if (accept) {
         cur ^= 1;
         need_bw = true;
+        hess_ok = false;
         optimistic = (ia == 0);
         if (ia == 0) {
           // relax the shift after a full step -- but not straight back to a level that has just failed: hold for
