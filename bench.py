@@ -74,6 +74,7 @@ def main():
     ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
     ap.add_argument("--substeps", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--library", default=None, help="tuning only: path of an alternative build of the model library")
     ap.add_argument("--warm-start", action="store_true",
                     help="NOT the headline: start each OC solve from the previous iteration's controls")
     args = ap.parse_args()
@@ -93,6 +94,8 @@ def main():
     from lfsd_amd import CPDP, models
     dtype = torch.float32 if args.dtype == "f32" else torch.float64
     oc, env, d = models.quadrotor(n_grid=args.n_grid)
+    if args.library:
+        oc.use_library(args.library)
     oc.setDevice(dev, dtype)
     oc.setSolverOptions(aux_substeps=args.substeps)
     lib = oc.compile()
@@ -176,7 +179,7 @@ def main():
         # were collected on, so it is attached to the headline configuration and left null otherwise
         tpath = os.path.join(ROOT, "profiles", "r01_j_hbm_traffic.json")
         headline = (B == 4096 and args.n_grid == 50 and args.dtype == "f32" and args.substeps == 4
-                    and not args.warm_start)
+                    and not args.warm_start and not args.library)
         if headline and os.path.exists(tpath):
             try:
                 traffic = json.load(open(tpath)).get(dom, {}).get("hbm_bytes_per_step")

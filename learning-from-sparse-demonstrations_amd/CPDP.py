@@ -392,9 +392,10 @@ class SparseDemoLearner:
         return loss, grad
 
     def mask_unconverged(self, status, loss, grad):
-        """Zero the gradient of trajectories whose OC solve neither converged (1) nor stalled at working precision (2);
-        in shared mode also their loss, which enters a sum."""
-        ok = (status == 1) | (status == 2)
+        """Zero the gradient of trajectories whose OC solve neither converged (1) nor stalled at working precision (2), or
+        whose loss / gradient is not finite (parameters that have left the region where the problem is well posed, e.g. a
+        cost weight driven negative); in shared mode also their loss, which enters a sum."""
+        ok = ((status == 1) | (status == 2)) & torch.isfinite(loss) & torch.isfinite(grad).all(dim=1)
         self._ok = ok
         grad = torch.where(ok.unsqueeze(1), grad, torch.zeros_like(grad))
         if self.mode == "shared":

@@ -1,26 +1,10 @@
 // C ABI (include/lfsd_cpdp.h) over the kernels of cpdp_kernels.h for ONE model.
-// Build:  hipcc -x hip --offload-arch=gfx950 -DLFSD_MODEL_HEADER='"gen/<hash>.h"' -DLFSD_G=<lanes> ...
+// Build:  runtime.build_library (two translation units, see lfsd_internal.h), or as a single one:
+//         hipcc -x hip --offload-arch=gfx950 -DLFSD_MODEL_HEADER='"gen/<hash>.h"' -DLFSD_G=<lanes> ...
 // (tests/emu builds the same file with g++ -DLFSD_EMU for the CPU SIMT emulator.)
-#include "cpdp_kernels.h"
-#include LFSD_MODEL_HEADER
-#define LFSD_API extern "C" __attribute__((visibility("default")))
-#include "../../include/lfsd_cpdp.h"
-
-#ifndef LFSD_G
-#error "LFSD_G (lanes per trajectory) must be defined by the build"
-#endif
-
-using Model = LFSD_MODEL_NS::Model;
-static constexpr int G = LFSD_G;
-static constexpr int GPB = 64 / G;
-
-#if defined(LFSD_EMU)
-#define LFSD_LAUNCH(kern, grid, block, stream, args) emu::launch(dim3(grid), dim3(block), [&] { kern(args); })
-static int launch_status() { return 0; }
-#else
-#define LFSD_LAUNCH(kern, grid, block, stream, args) \
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(block), 0, (hipStream_t)(stream), args)
-static int launch_status() { return (int)hipGetLastError(); }
+#include "lfsd_internal.h"
+#if !defined(LFSD_SPLIT_RICCATI)
+#include "lfsd_riccati.inc"
 #endif
 
 LFSD_API int lfsd_get_model_info(lfsd_model_info* out) {
@@ -139,8 +123,9 @@ static int aux_phase_t(int phases, int batch, int n_grid, const void* horizon, c
   a.loss = (T*)loss; a.grad = (T*)grad; a.auxX_grid = (T*)auxX_grid; a.auxU_grid = (T*)auxU_grid;
   const unsigned grid = (unsigned)(((long long)batch + GPB - 1) / GPB);
   if (phases & 1) {
-    LFSD_LAUNCH((lfsd::aux_riccati_kernel<Model, T, G>), grid, 64, stream, a);
-    const int rc = launch_status();
+    int rc;
+    if constexpr (sizeof(T) == 4) rc = lfsd_detail::launch_riccati_f32(grid, stream, a);
+    else rc = lfsd_detail::launch_riccati_f64(grid, stream, a);
     if (rc) return rc;
   }
   if (phases & 2) {

@@ -71,13 +71,27 @@ def write_header(spec, force=False):
     return hp
 
 
-def hipcc_command(spec, out, extra=()):
+def _hipcc_flags(spec, extra=()):
     g = lanes_for(spec.n, spec.m, spec.p)
-    return [find_hipcc(), "-x", "hip", "--offload-arch=gfx950", "-std=c++17", "-O3", "-fPIC", "-shared",
+    return [find_hipcc(), "-x", "hip", "--offload-arch=gfx950", "-std=c++17", "-O3", "-fPIC",
             "-fno-signed-zeros", "-fvisibility=hidden",
-            "-DLFSD_G=%d" % g, '-DLFSD_MODEL_HEADER="gen/%s.h"' % spec.hash(),
-            "-I" + CSRC_DIR, os.path.join(CSRC_DIR, "lfsd_capi.cpp"), "-o", out] + list(extra) + \
+            "-DLFSD_G=%d" % g, '-DLFSD_MODEL_HEADER="gen/%s.h"' % spec.hash(), "-I" + CSRC_DIR] + list(extra) + \
         os.environ.get("LFSD_EXTRA_HIPCC_FLAGS", "").split()       # tuning experiments (tools/tune.py)
+
+
+def hipcc_command(spec, out, extra=()):
+    """The library as ONE translation unit (tuning tools; the product build is hipcc_commands)."""
+    return _hipcc_flags(spec, extra) + ["-shared", os.path.join(CSRC_DIR, "lfsd_capi.cpp"), "-o", out]
+
+
+def hipcc_commands(spec, out, extra=()):
+    """Product build: the Riccati sweep in its own translation unit with clang's SLP vectoriser on, everything else
+    with -fno-slp-vectorize (csrc/lfsd_internal.h, profiles/r01_tune_compiler_flags.txt), then the link."""
+    flags = _hipcc_flags(spec, extra)
+    o1, o2 = out + ".capi.o", out + ".riccati.o"
+    return ([flags + ["-c", "-DLFSD_SPLIT_RICCATI", "-fno-slp-vectorize", os.path.join(CSRC_DIR, "lfsd_capi.cpp"), "-o", o1],
+             flags + ["-c", os.path.join(CSRC_DIR, "lfsd_riccati.cpp"), "-o", o2],
+             [find_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", o1, o2, "-o", out]], [o1, o2])
 
 
 def build_library(spec, force=False, verbose=False):
@@ -85,17 +99,24 @@ def build_library(spec, force=False, verbose=False):
     os.makedirs(BUILD_DIR, exist_ok=True)
     out = library_path(spec.hash())
     write_header(spec, force=force)
-    deps = [header_path(spec.hash()), os.path.join(CSRC_DIR, "cpdp_kernels.h"), os.path.join(CSRC_DIR, "lfsd_capi.cpp"),
-            os.path.join(INCLUDE_DIR, "lfsd_cpdp.h")]
+    deps = [header_path(spec.hash()), os.path.join(INCLUDE_DIR, "lfsd_cpdp.h")] + \
+        [os.path.join(CSRC_DIR, f) for f in ("cpdp_kernels.h", "lfsd_capi.cpp", "lfsd_internal.h", "lfsd_riccati.inc",
+                                             "lfsd_riccati.cpp")]
     if not force and os.path.exists(out) and all(os.path.getmtime(out) >= os.path.getmtime(d) for d in deps):
         return out
     tmp = out + ".tmp%d" % os.getpid()
-    cmd = hipcc_command(spec, tmp)
-    if verbose:
-        print(" ".join(cmd))
-    r = subprocess.run(cmd, cwd=CSRC_DIR, capture_output=True, text=True)
-    if r.returncode != 0:
-        raise LfsdError("hipcc failed for model %s:\n%s\n%s" % (spec.name, r.stdout[-4000:], r.stderr[-4000:]))
+    cmds, objs = hipcc_commands(spec, tmp)
+    try:
+        for cmd in cmds:
+            if verbose:
+                print(" ".join(cmd))
+            r = subprocess.run(cmd, cwd=CSRC_DIR, capture_output=True, text=True)
+            if r.returncode != 0:
+                raise LfsdError("hipcc failed for model %s:\n%s\n%s" % (spec.name, r.stdout[-4000:], r.stderr[-4000:]))
+    finally:
+        for o in objs:
+            if os.path.exists(o):
+                os.remove(o)
     os.replace(tmp, out)
     return out
 
