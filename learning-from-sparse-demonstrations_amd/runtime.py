@@ -84,13 +84,20 @@ def hipcc_command(spec, out, extra=()):
     return _hipcc_flags(spec, extra) + ["-shared", os.path.join(CSRC_DIR, "lfsd_capi.cpp"), "-o", out]
 
 
-def hipcc_commands(spec, out, extra=()):
+# measured per translation unit (profiles/r01_tune_compiler_flags.txt): max-ILP scheduling takes 5 % off oc_solve, a
+# slightly raised SLP profitability threshold 2.5 % off the Riccati sweep; together 208.9k -> 214.9k outer iterations/s
+TUNED_CAPI = ("-mllvm", "-amdgpu-sched-strategy=max-ilp")
+TUNED_RICCATI = ("-mllvm", "-slp-threshold=4")
+
+
+def hipcc_commands(spec, out, extra=(), extra_capi=TUNED_CAPI, extra_riccati=TUNED_RICCATI):
     """Product build: the Riccati sweep in its own translation unit with clang's SLP vectoriser on, everything else
     with -fno-slp-vectorize (csrc/lfsd_internal.h, profiles/r01_tune_compiler_flags.txt), then the link."""
     flags = _hipcc_flags(spec, extra)
     o1, o2 = out + ".capi.o", out + ".riccati.o"
-    return ([flags + ["-c", "-DLFSD_SPLIT_RICCATI", "-fno-slp-vectorize", os.path.join(CSRC_DIR, "lfsd_capi.cpp"), "-o", o1],
-             flags + ["-c", os.path.join(CSRC_DIR, "lfsd_riccati.cpp"), "-o", o2],
+    return ([flags + ["-c", "-DLFSD_SPLIT_RICCATI", "-fno-slp-vectorize", os.path.join(CSRC_DIR, "lfsd_capi.cpp"), "-o", o1] +
+             list(extra_capi),
+             flags + ["-c", os.path.join(CSRC_DIR, "lfsd_riccati.cpp"), "-o", o2] + list(extra_riccati),
              [find_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", o1, o2, "-o", out]], [o1, o2])
 
 
@@ -105,18 +112,25 @@ def build_library(spec, force=False, verbose=False):
     if not force and os.path.exists(out) and all(os.path.getmtime(out) >= os.path.getmtime(d) for d in deps):
         return out
     tmp = out + ".tmp%d" % os.getpid()
-    cmds, objs = hipcc_commands(spec, tmp)
-    try:
-        for cmd in cmds:
-            if verbose:
-                print(" ".join(cmd))
-            r = subprocess.run(cmd, cwd=CSRC_DIR, capture_output=True, text=True)
-            if r.returncode != 0:
-                raise LfsdError("hipcc failed for model %s:\n%s\n%s" % (spec.name, r.stdout[-4000:], r.stderr[-4000:]))
-    finally:
-        for o in objs:
-            if os.path.exists(o):
-                os.remove(o)
+    def run(cmds, objs):
+        try:
+            for cmd in cmds:
+                if verbose:
+                    print(" ".join(cmd))
+                r = subprocess.run(cmd, cwd=CSRC_DIR, capture_output=True, text=True)
+                if r.returncode != 0:
+                    return "%s\n%s" % (r.stdout[-4000:], r.stderr[-4000:])
+            return None
+        finally:
+            for o in objs:
+                if os.path.exists(o):
+                    os.remove(o)
+
+    err = run(*hipcc_commands(spec, tmp))
+    if err is not None:        # a toolchain that does not know the tuned -mllvm options: same sources, plain flags
+        err2 = run(*hipcc_commands(spec, tmp, extra_capi=(), extra_riccati=()))
+        if err2 is not None:
+            raise LfsdError("hipcc failed for model %s:\n%s" % (spec.name, err))
     os.replace(tmp, out)
     return out
 
