@@ -44,28 +44,31 @@
 #ifndef LFSD_WAVES_OC
 #define LFSD_WAVES_OC LFSD_WAVES_PER_SIMD
 #endif
-// aux kernels: measured on MI355X (profiles/r01_tune_aux_occupancy.txt) 2 waves/SIMD never pays -- once the LDS footprint
-// admits a second wave the compiler holds the kernel to 256 VGPRs and spills 0.5-1.3 KB/lane (Riccati 8.8 -> 9.0 ms,
-// forward 5.8 -> 11.1 ms); VALU is busy 50-65 % of a lone wave's cycles, so there is little latency left to hide
+// aux kernels and occupancy, measured on MI355X.  Compiled with clang's SLP vectoriser (profiles/r01_tune_aux_occupancy.txt)
+// a second wave per SIMD never paid: held to 256 VGPRs the kernels spilled 0.5-1.3 KB/lane (Riccati 8.8 -> 9.0 ms, forward
+// 5.8 -> 11.1 ms).  Without SLP (profiles/r01_tune_compiler_flags.txt) the fp32 Riccati sweep needs 256 + 84 registers: with
+// the small column cache (LFSD_RIC_CACHE 2) it runs two waves per SIMD with 0.4 KB/lane of spills -- the 2048 waves of the
+// benchmark batch in one round instead of two, 8.2 -> 7.1 ms.  The forward sweep stays at one wave (256 + 256 registers).
 // tuning only: extra LDS elements per workgroup of the aux kernels, to lower their occupancy (tools/tune.py)
 #ifndef LFSD_AUX_LDS_PAD
 #define LFSD_AUX_LDS_PAD 0
 #endif
 // Riccati kernel: which Z-independent columns are parked per lane in LDS (0 none, 1 [Hxx Hxe] and Huu^-1 [Hux Hue],
-// 2 only Huu^-1 [Hux Hue]).  0 and 2 shrink LDS enough for 2 waves/SIMD but then spill: 9.0 / 10.3 ms against 8.8
+// 2 only Huu^-1 [Hux Hue]).  Mode 2 leaves 16 KB of LDS per workgroup, which admits the second wave per SIMD below.
 #ifndef LFSD_RIC_CACHE
-#define LFSD_RIC_CACHE 1
+#define LFSD_RIC_CACHE 2
 #endif
-// outer per-node loop of the once-per-unit preparation: rolled is 6 % faster in the Riccati sweep (ric_cols),
-// unrolled 7 % faster in the forward sweep (fwd_prep, fwd_cols) -- measured, profiles/r01_tune_aux_occupancy.txt
+// outer per-node loops of the once-per-unit preparation (ric_cols; fwd_prep, fwd_cols): rolled.  Measured: 6 % faster in
+// the Riccati sweep; the forward sweep preferred them unrolled (7 %) until it was compiled with the max-ILP scheduler,
+// since then rolled is 5 % faster there too (profiles/r01_tune_aux_occupancy.txt, r01_tune_compiler_flags.txt)
 #ifndef LFSD_RIC_NODE_LOOP
 #define LFSD_RIC_NODE_LOOP _Pragma("unroll 1")
 #endif
 #ifndef LFSD_FWD_NODE_LOOP
-#define LFSD_FWD_NODE_LOOP _Pragma("unroll")
+#define LFSD_FWD_NODE_LOOP _Pragma("unroll 1")
 #endif
 #ifndef LFSD_WAVES_RIC
-#define LFSD_WAVES_RIC 1
+#define LFSD_WAVES_RIC 2
 #endif
 #ifndef LFSD_WAVES_FWD
 #define LFSD_WAVES_FWD 1

@@ -23,11 +23,13 @@ static int launch_status() { return (int)hipGetLastError(); }
 #endif
 
 
-// The Riccati sweep is the one kernel that gains from clang's SLP vectoriser (it pairs 44 % of the kernel's scalar math
-// into v_pk_* ops: 8.6 vs 9.7 ms); every other kernel loses to the register pressure and operand shuffling the pairing
-// costs (oc_solve 11.4 -> 8.3 ms, aux_forward 3.35 -> 2.97 ms without it; profiles/r01_tune_compiler_flags.txt).  The
-// product build therefore compiles it in its own translation unit with SLP on and the rest with -fno-slp-vectorize
-// (runtime.build_library, -DLFSD_SPLIT_RICCATI); single-TU builds (emulator, sanitizer, tuning tools) include the launcher.
+// Compiler settings are chosen per kernel (profiles/r01_tune_compiler_flags.txt).  clang's SLP vectoriser pairs scalar fp32
+// operations into v_pk_* instructions at the price of adjacent-register constraints: every kernel of this library is
+// faster without it (oc_solve 11.4 -> 8.2 ms, aux_forward 3.35 -> 2.97 ms; the Riccati sweep, the one kernel that gained
+// from it at one wave per SIMD, needs so few registers without it that it runs two waves per SIMD: 8.5 -> 7.1 ms).  The
+// max-ILP instruction scheduler takes another 5 % off oc_solve but costs the Riccati sweep 25 %, so the product build
+// (runtime.hipcc_commands, -DLFSD_SPLIT_RICCATI) compiles the Riccati sweep in its own translation unit; single-unit builds
+// (emulator, sanitizer, tuning tools) include the launcher below instead.
 namespace lfsd_detail {
 int launch_riccati_f32(unsigned grid, void* stream, const lfsd::AuxArgs<float>& a);
 int launch_riccati_f64(unsigned grid, void* stream, const lfsd::AuxArgs<double>& a);

@@ -84,19 +84,19 @@ def hipcc_command(spec, out, extra=()):
     return _hipcc_flags(spec, extra) + ["-shared", os.path.join(CSRC_DIR, "lfsd_capi.cpp"), "-o", out]
 
 
-# measured per translation unit (profiles/r01_tune_compiler_flags.txt): max-ILP scheduling takes 5 % off oc_solve, a
-# slightly raised SLP profitability threshold 2.5 % off the Riccati sweep; together 208.9k -> 214.9k outer iterations/s
+# measured per translation unit (profiles/r01_tune_compiler_flags.txt): max-ILP scheduling takes 5 % off oc_solve but
+# costs the Riccati sweep 25 %, which is why the latter keeps its own unit with the default scheduler
 TUNED_CAPI = ("-mllvm", "-amdgpu-sched-strategy=max-ilp")
-TUNED_RICCATI = ("-mllvm", "-slp-threshold=4")
+TUNED_RICCATI = ()
 
 
 def hipcc_commands(spec, out, extra=(), extra_capi=TUNED_CAPI, extra_riccati=TUNED_RICCATI):
-    """Product build: the Riccati sweep in its own translation unit with clang's SLP vectoriser on, everything else
-    with -fno-slp-vectorize (csrc/lfsd_internal.h, profiles/r01_tune_compiler_flags.txt), then the link."""
-    flags = _hipcc_flags(spec, extra)
+    """Product build: two translation units -- the Riccati sweep apart from everything else -- so that each gets the
+    compiler settings it measured best with (csrc/lfsd_internal.h, profiles/r01_tune_compiler_flags.txt), then the link.
+    Both are compiled without clang's SLP vectoriser."""
+    flags = _hipcc_flags(spec, extra) + ["-fno-slp-vectorize"]
     o1, o2 = out + ".capi.o", out + ".riccati.o"
-    return ([flags + ["-c", "-DLFSD_SPLIT_RICCATI", "-fno-slp-vectorize", os.path.join(CSRC_DIR, "lfsd_capi.cpp"), "-o", o1] +
-             list(extra_capi),
+    return ([flags + ["-c", "-DLFSD_SPLIT_RICCATI", os.path.join(CSRC_DIR, "lfsd_capi.cpp"), "-o", o1] + list(extra_capi),
              flags + ["-c", os.path.join(CSRC_DIR, "lfsd_riccati.cpp"), "-o", o2] + list(extra_riccati),
              [find_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", o1, o2, "-o", out]], [o1, o2])
 

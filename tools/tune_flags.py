@@ -5,13 +5,15 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import lfsd_amd
 from lfsd_amd import models, runtime
 # tag, flags for lfsd_capi.cpp (everything but the Riccati sweep), flags for lfsd_riccati.cpp
+T1, T2 = list(runtime.TUNED_CAPI), list(runtime.TUNED_RICCATI)
+NS = ["-fno-slp-vectorize"]
+R2 = ["-DLFSD_RIC_CACHE=2", "-DLFSD_WAVES_RIC=2"]
 ILP = ["-mllvm", "-amdgpu-sched-strategy=max-ilp"]
-VARIANTS = [("plain", [], []),          # (the shipped flags are runtime.TUNED_CAPI / TUNED_RICCATI = variant ilp_p4)
-            ("ilp_p4", ILP, ["-mllvm", "-slp-threshold=4"]),
-            ("ilp_p8", ILP, ["-mllvm", "-slp-threshold=8"]),
-            ("p8", [], ["-mllvm", "-slp-threshold=8"]),
-            ("p16", [], ["-mllvm", "-slp-threshold=16"]),
-            ("p2", [], ["-mllvm", "-slp-threshold=2"])]
+VARIANTS = [("r2_ns", T1, NS + R2),
+            ("r2_slp4", T1, T2 + R2),
+            ("r2_ns_ilp", T1, NS + ILP + R2),
+            ("r2_ns_unr", T1, NS + R2 + ['-DLFSD_RIC_NODE_LOOP=_Pragma("unroll")']),
+            ("r2_ns_memcl", T1, NS + ["-mllvm", "-amdgpu-sched-strategy=max-memory-clause"] + R2)]
 oc, _, _ = models.quadrotor()
 spec = oc.model_spec(); runtime.write_header(spec)
 for tag, e1, e2 in VARIANTS:
