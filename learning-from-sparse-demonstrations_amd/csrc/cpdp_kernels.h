@@ -47,8 +47,10 @@
 // aux kernels and occupancy, measured on MI355X.  Compiled with clang's SLP vectoriser (profiles/r01_tune_aux_occupancy.txt)
 // a second wave per SIMD never paid: held to 256 VGPRs the kernels spilled 0.5-1.3 KB/lane (Riccati 8.8 -> 9.0 ms, forward
 // 5.8 -> 11.1 ms).  Without SLP (profiles/r01_tune_compiler_flags.txt) the fp32 Riccati sweep needs 256 + 84 registers: with
-// the small column cache (LFSD_RIC_CACHE 2) it runs two waves per SIMD with 0.4 KB/lane of spills -- the 2048 waves of the
-// benchmark batch in one round instead of two, 8.2 -> 7.1 ms.  The forward sweep stays at one wave (256 + 256 registers).
+// the small column cache (LFSD_RIC_CACHE 2) it runs two waves per SIMD -- the 2048 waves of the benchmark batch in one
+// round instead of two, 8.2 -> 7.1 ms with 0.4 KB/lane of spills, and 5.7 ms with none (246 VGPRs) once the coarse and the
+// fine Richardson chain run in place with the other column parked in LDS.  The forward sweep stays at one wave per SIMD
+// (256 + 256 registers) and keeps its two chains as independent instruction streams: in place it is 20 % slower.
 // tuning only: extra LDS elements per workgroup of the aux kernels, to lower their occupancy (tools/tune.py)
 #ifndef LFSD_AUX_LDS_PAD
 #define LFSD_AUX_LDS_PAD 0
@@ -1174,7 +1176,10 @@ template <class M> struct AuxLayout {
   template <int G> static constexpr int lds_elems_fwd() { return ((LDS_END + FWD_P + 2 * NX * NX + NX + 3) / 4) * 4; }
   // Riccati kernel only: per node and lane, this lane's column of [Hxx Hxe] and of Huu^-1 [Hux Hue]
   static constexpr int RIC_ROWS = LFSD_RIC_CACHE == 1 ? NX + NU : (LFSD_RIC_CACHE == 2 ? NU : 0);
-  template <int G> static constexpr int lds_elems_ric() { return ((LDS_END + NNODE * RIC_ROWS * G + 3) / 4) * 4; }
+  // ... plus one parking slot per lane for a column of Z (row i of lane l at [i*G + l]): of the unit's start value and
+  // the coarse Richardson result only one has to be in registers at a time
+  template <int G> static constexpr int ric_park() { return LDS_END + NNODE * RIC_ROWS * G; }
+  template <int G> static constexpr int lds_elems_ric() { return ((ric_park<G>() + NX * G + 3) / 4) * 4; }
 };
 
 // Lanes per trajectory of the forward sweep.  Only the NP columns of X = dx/dtheta advance there; the NX columns of P are
@@ -1607,13 +1612,17 @@ __global__ void __launch_bounds__(64, (sizeof(T) == 4 ? LFSD_WAVES_RIC : 1)) aux
       const T s_hi = T(1) - T(unit) / T(units);
       s.stage_nodes(s_hi, -ds);                  // node i sits at fraction s_hi - i/(4 Sa)
       s.ric_cols();
-      T zc[NX], zf[NX];
+      // coarse chain in place, then the fine chain in place from the parked start value (the barriers inside the chains
+      // keep the compiler from carrying the parked column in registers)
+      T* zpark = s.lds + Lay::template ric_park<G>();
 #pragma unroll
-      for (int i = 0; i < NX; ++i) { zc[i] = z[i]; zf[i] = z[i]; }
-      s.ric_strang(zc, 0, 2, 4, hc);
-      s.ric_strang2(zf, hc);
+      for (int i = 0; i < NX; ++i) zpark[i * G + lane] = z[i];
+      s.ric_strang(z, 0, 2, 4, hc);
 #pragma unroll
-      for (int i = 0; i < NX; ++i) z[i] = (T(4) * zf[i] - zc[i]) / T(3);     // Richardson (Strang is O(h^2), symmetric)
+      for (int i = 0; i < NX; ++i) { const T z0 = zpark[i * G + lane]; zpark[i * G + lane] = z[i]; z[i] = z0; }
+      s.ric_strang2(z, hc);
+#pragma unroll
+      for (int i = 0; i < NX; ++i) z[i] = (T(4) * z[i] - zpark[i * G + lane]) / T(3);     // Richardson (Strang is O(h^2), symmetric)
     }
     // keep P symmetric (the closed-form stiff update relies on it) and store the grid value
     if (lane < NX) {
@@ -1705,7 +1714,9 @@ __global__ void __launch_bounds__(64, (sizeof(T) == 4 ? LFSD_WAVES_FWD : 1)) aux
       s.fwd_prep(pA, pB, s_lo, ds, hq);
       s.fwd_cols(wA, wB, s_lo, ds);
       // coarse Strang step (stiff h/2, RK4 h, stiff h/2) and two fine ones; the two adjacent fine stiff
-      // quarter-steps at the middle node compose exactly into one half-step
+      // quarter-steps at the middle node compose exactly into one half-step.  (Unlike the Riccati sweep, which runs its
+      // two chains in place with the other value parked in LDS, this one-wave-per-SIMD kernel is 20 % faster with both
+      // chains as independent instruction streams the compiler can interleave.)
       s.fwd_stiff(xc, 0, true, hq);
       s.fwd_rk4(xc, 0, 2, 4, hc);
       s.fwd_stiff(xc, 2, true, hq);
