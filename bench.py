@@ -177,7 +177,7 @@ def main():
         traffic = None
         # PMC passes are separate rocprofv3 runs (tools/hbm_traffic.py); the figure only applies to the workload they
         # were collected on, so it is attached to the headline configuration and left null otherwise
-        tpath = os.path.join(ROOT, "profiles", "r01_n_hbm_traffic.json")
+        tpath = os.path.join(ROOT, "profiles", "r01_o_hbm_traffic.json")
         headline = (B == 4096 and args.n_grid == 50 and args.dtype == "f32" and args.substeps == 4
                     and not args.warm_start and not args.library)
         if headline and os.path.exists(tpath):
