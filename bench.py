@@ -1,32 +1,73 @@
 #!/usr/bin/env python3
 """Headline benchmark: CPDP outer iterations/sec over a batch of trajectories (BASELINE.json metric).
 
-Workload (BASELINE.json configs[2]): Quadrotor CPDP with time-warping on the quad_example waypoints
-(Examples/quad_example.py), n_grid ("horizon") 50, 4 RK4 steps per grid interval, batch 4096 seeds per GPU,
-each seed with its own random initial guess theta_0 and its own optimizer state.  One "step" = one complete
-outer iteration for every seed (lib/QuadAlgorithm.py:469-486, Nesterov, lr 0.01, mu 0.9):
+One "step" = one complete outer iteration of ``SparseDemoLearner.step`` (the product's own iteration, bracketed with
+HIP events through its ``event_hook``) for every trajectory of the batch (lib/QuadAlgorithm.py:469-486, Nesterov,
+lr 0.01, mu 0.9):
     look-ahead point -> optimal-control solve (cold start, as the reference) -> differentiated PMP
-    (Riccati + sensitivity sweeps) -> waypoint loss and d(theta) -> parameter update + projection,
-plus, for N > 1 GPUs, the all-reduce (RCCL) of the summed parameter gradient and loss.
-`value` = seeds * N * K / wall seconds  (trajectory outer-iterations per second, whole job).
+    (Riccati + sensitivity sweeps) -> waypoint loss and d(theta) -> parameter update + projection.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--dtype f32|f64]
+Workloads (Quadrotor CPDP with time-warping, n_grid "horizon" 50, 4 RK4 steps per grid interval, 4096 per GPU):
+  --mode independent (default at N=1; BASELINE configs[2]): 4096 random initial-guess seeds on the quad_example
+      waypoints, every seed with its own theta and optimizer state.
+  --mode shared (default at N>1; BASELINE configs[3]): ONE theta for all ranks, 4096 random demonstrations per GPU
+      (start position, goal and waypoints drawn around the quad_example's); per outer iteration the summed d(theta)
+      and loss are all-reduced over the ranks (RCCL over xGMI) and the all-reduced gradient drives the single update.
+`value` = trajectories * K / wall seconds over all ranks (trajectory outer-iterations per second, whole job).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--dtype f32|f64] [--mode independent|shared]
+
+`--gpus N` with N > 1 and no torch.distributed.run environment: this process touches no GPU, starts
+`python -m torch.distributed.run --nproc-per-node N bench.py ...` as a child, relays rank 0's JSON line and exits
+with the child's code.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import numpy as np
-import torch
-import torch.distributed as dist
-
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
 VALU_PEAK_TFLOPS = {"f32": 157.3, "f64": 78.6}
+PROFILE_TAG = "r02"            # profiles/<tag>_hbm_traffic.json, <tag>_issue_counters.json feed the roofline object
+
+
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=4096)
+    ap.add_argument("--n-grid", type=int, default=50)
+    ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
+    ap.add_argument("--substeps", type=int, default=4)
+    ap.add_argument("--mode", default=None, choices=["independent", "shared"],
+                    help="default: independent seeds at N=1 (configs[2]), shared theta + gradient all-reduce at N>1 (configs[3])")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seeds", type=int, default=0, help="seeds of the CPU baseline sample (0: max(64, 2 x cores))")
+    ap.add_argument("--library", default=None, help="tuning only: path of an alternative build of the model library")
+    ap.add_argument("--warm-start", action="store_true",
+                    help="NOT the headline: start each OC solve from the previous iteration's controls")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl == RCCL on ROCm)")
+    return ap.parse_args(argv)
+
+
+def spawn_ranks(args, argv):
+    """N > 1 without a launcher: become the launcher.  Nothing in this process has touched a GPU."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    r = subprocess.run(cmd, env=env)
+    sys.exit(r.returncode)
 
 
 def algorithmic_bytes(kernel, n, m, p, nc, N, nw, ni, es):
@@ -41,58 +82,111 @@ def algorithmic_bytes(kernel, n, m, p, nc, N, nw, ni, es):
     raise KeyError(kernel)
 
 
-def cpu_baseline(d, n_grid, thetas, n_sample):
-    """The oracle (fp64 port of the reference pipeline, 1 host core) on a bounded sample of the same seeds."""
+# ---- CPU baseline: the oracle (port of the reference pipeline) on ALL host cores -----------------------------------
+_ORACLE = None
+
+
+def _cpu_init(n_grid):
+    global _ORACLE
+    sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from conftest import make_oracle
+    _ORACLE = make_oracle("quadrotor", n_grid)
+    _ORACLE.diffPMP()
+
+
+def _cpu_task(job):
     from oracle.cpdp_oracle import getloss_corrections
-    o = make_oracle("quadrotor", n_grid)
-    o.diffPMP()
-    t0 = time.time()
-    done = 0
-    results = []
-    for b in range(n_sample):
-        tg, sol = o.cocSolver(d["ini_state"], d["horizon"], thetas[b])
-        aux = o.auxSysSolver(tg, sol, thetas[b])          # reference settings: BDF + RK45 at scipy defaults
-        results.append(getloss_corrections(o, d["taus"], d["waypoints"], sol, aux, d["interface"]))
-        done += 1
-        if time.time() - t0 > 30:
-            break
-    dt = time.time() - t0
-    return dict(value=done / dt, unit="trajectory outer-iterations/s", cores=1, kind="port",
-                sample="%d of the %d seeds, 1 outer iteration each, oracle/cpdp_oracle.py (numpy/scipy fp64, "
-                       "solve_ivp BDF+RK45 as CPDP.py:335,368) in %.1f s" % (done, len(thetas), dt)), results
+    if job is None:
+        return None                                    # start-up barrier: the worker has built its oracle
+    ini, hz, taus, wps, iface, theta = job
+    tg, sol = _ORACLE.cocSolver(ini, hz, theta)
+    aux = _ORACLE.auxSysSolver(tg, sol, theta)          # reference settings: BDF + RK45 at scipy defaults
+    l, g = getloss_corrections(_ORACLE, taus, wps, sol, aux, iface)
+    return float(l), [float(x) for x in g]
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=4096)
-    ap.add_argument("--n-grid", type=int, default=50)
-    ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
-    ap.add_argument("--substeps", type=int, default=4)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--library", default=None, help="tuning only: path of an alternative build of the model library")
-    ap.add_argument("--warm-start", action="store_true",
-                    help="NOT the headline: start each OC solve from the previous iteration's controls")
-    args = ap.parse_args()
+def cpu_baseline(d, n_grid, thetas, n_sample):
+    """The oracle (fp64 numpy/scipy port of the reference pipeline; CasADi/IPOPT cannot be installed here) on a
+    bounded sample of the benchmark's own seeds, one worker process per host core.  Workers are started with `spawn`
+    (this process holds a GPU context) and build their oracle before the clock starts."""
+    import multiprocessing as mp
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    n_sample = min(len(thetas), n_sample if n_sample > 0 else max(64, 2 * cores))
+    ctx = mp.get_context("spawn")
+    jobs = [(list(d["ini_state"]), float(d["horizon"]), list(d["taus"]), [list(w) for w in d["waypoints"]],
+             list(d["interface"]), [float(x) for x in thetas[b]]) for b in range(n_sample)]
+    with ctx.Pool(cores, initializer=_cpu_init, initargs=(n_grid,)) as pool:
+        pool.map(_cpu_task, [None] * (4 * cores), chunksize=1)     # every worker imported + lambdified its model
+        t0 = time.time()
+        results = pool.map(_cpu_task, jobs, chunksize=1)
+        dt = time.time() - t0
+    return dict(value=n_sample / dt, unit="trajectory outer-iterations/s", cores=cores, kind="port",
+                sample="%d of the %d seeds of rank 0, 1 outer iteration each, oracle/cpdp_oracle.py (numpy/scipy fp64, "
+                       "solve_ivp BDF+RK45 as CPDP.py:335,368) on %d worker processes = all host cores, %.1f s; the "
+                       "reference itself needs CasADi 3.5.5 + IPOPT 3.11.9, which are not installed and cannot be "
+                       "(no network)" % (n_sample, len(thetas), cores, dt)), results
 
+
+def build_learner(args, oc, d, lib, rank, world, mode, pg=None):
+    """The benchmark's problem set: rank r draws its own 4096 trajectories (weak scaling)."""
+    import numpy as np
+    from lfsd_amd import CPDP
+    B = args.batch
+    rng = np.random.default_rng(1234 + rank)
+    if mode == "independent":
+        theta0 = np.array(d["theta0"])[None, :] + 0.05 * rng.standard_normal((B, lib.n_auxvar))
+        theta0[:, 0] = np.abs(theta0[:, 0]) + 0.5
+        x0 = np.tile(d["ini_state"], (B, 1))
+        L = CPDP.SparseDemoLearner(oc, x0, d["horizon"], d["taus"], d["waypoints"], d["interface"], theta0,
+                                   method="Nesterov", learning_rate=1e-2, mu=0.9, warm_start=args.warm_start)
+        return L, theta0, x0
+    # shared theta, random demonstrations: start position, goal and waypoints perturbed per trajectory
+    x0 = np.tile(d["ini_state"], (B, 1))
+    x0[:, 0:3] += 0.2 * rng.standard_normal((B, 3))
+    goal = np.array([3.0, 3.0, 1.5])[None, :] + 0.2 * rng.standard_normal((B, 3))
+    wps = np.array(d["waypoints"])[None, :, :] + 0.1 * rng.standard_normal((B, len(d["waypoints"]), 3))
+    consts = oc.consts_tensor(batch=B, overrides=dict(goal_r0=goal[:, 0], goal_r1=goal[:, 1], goal_r2=goal[:, 2]))
+    theta0 = np.array(d["theta0"], dtype=np.float64)
+    # lr 1e-2 is the example's rate for ONE demonstration; the summed gradient of B*world demonstrations is scaled back
+    L = CPDP.SparseDemoLearner(oc, x0, d["horizon"], np.tile(d["taus"], (B, 1)), wps, d["interface"], theta0,
+                               method="Nesterov", learning_rate=1e-2 / (B * world), mu=0.9, consts=consts,
+                               mode="shared", process_group=pg, warm_start=args.warm_start)
+    return L, theta0[None, :], x0
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    args = parse_args(argv)
+    in_launcher = "RANK" in os.environ and "MASTER_PORT" in os.environ      # started by torch.distributed.run
+    if args.gpus > 1 and not in_launcher:
+        spawn_ranks(args, argv)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    use_dist = "RANK" in os.environ and "MASTER_PORT" in os.environ      # launched by torch.distributed.run
-    if use_dist:
+    world = int(os.environ.get("WORLD_SIZE", "1")) if in_launcher else 1
+    if world != args.gpus:
+        print("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world), file=sys.stderr)
+        sys.exit(2)
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    use_dist = in_launcher and world > 1
+    if in_launcher:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)       # "nccl" == RCCL on ROCm
+        dist.init_process_group(args.backend, rank=rank, world_size=world)       # "nccl" == RCCL on ROCm
     assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no CPU fallback)"
     dev = torch.device("cuda", local_rank % torch.cuda.device_count())
     torch.cuda.set_device(dev)
 
     import lfsd_amd  # noqa: F401
-    from lfsd_amd import CPDP, models
+    from lfsd_amd import models, perf_model
     dtype = torch.float32 if args.dtype == "f32" else torch.float64
+    mode = args.mode or ("shared" if world > 1 else "independent")
     oc, env, d = models.quadrotor(n_grid=args.n_grid)
     if args.library:
         oc.use_library(args.library)
@@ -101,50 +195,28 @@ def main():
     lib = oc.compile()
     assert not lib.is_emulator
     B = args.batch
-    rng = np.random.default_rng(1234 + rank)                                # different seeds on every rank (weak scaling)
-    theta0 = np.array(d["theta0"])[None, :] + 0.05 * rng.standard_normal((B, lib.n_auxvar))
-    theta0[:, 0] = np.abs(theta0[:, 0]) + 0.5
-    x0 = np.tile(d["ini_state"], (B, 1))
-    L = CPDP.SparseDemoLearner(oc, x0, d["horizon"], d["taus"], d["waypoints"], d["interface"], theta0,
-                               method="Nesterov", learning_rate=1e-2, mu=0.9)
+    L, theta0, x0 = build_learner(args, oc, d, lib, rank, world, mode)
+    L.count_unconverged = False                       # no device->host read inside the timed loop
 
     # HIP results of the first seeds at theta_0, kept for the cross-check against the CPU baseline's oracle results
     n_chk = 4
-    sol_c = oc.cocSolverBatch(x0[:n_chk], d["horizon"], theta0[:n_chk])
-    aux_c = oc.auxSysSolverBatch(sol_c, d["taus"], d["waypoints"], d["interface"])
-    chk_loss, chk_grad = aux_c["loss"].double().cpu().numpy(), aux_c["grad"].double().cpu().numpy()
+    chk_loss = chk_grad = None
+    if mode == "independent" and rank == 0:
+        sol_c = oc.cocSolverBatch(x0[:n_chk], d["horizon"], theta0[:n_chk])
+        aux_c = oc.auxSysSolverBatch(sol_c, d["taus"], d["waypoints"], d["interface"])
+        chk_loss, chk_grad = aux_c["loss"].double().cpu().numpy(), aux_c["grad"].double().cpu().numpy()
 
     # per-kernel HIP events on the stream the kernels are launched on (torch's current stream)
     names = ("oc_solve", "aux_riccati", "aux_forward", "update")
     ev = {k: [] for k in names}
+    cur = {}
 
-    def step(record):
-        e = [torch.cuda.Event(enable_timing=True) for _ in range(5)] if record else None
-        theta_eval = L.lib.lookahead(L.theta, L.m, L.mu)
-        th = theta_eval
-        if record:
-            e[0].record()
-        u_init = L._sol["control_grid"][:, :-1].contiguous() if (args.warm_start and L._sol is not None) else None
-        L._sol = oc.cocSolverBatch(L.x0, L.hz, th, consts=L.consts, u_init=u_init, workspace=L._ws, out=L._sol_out())
-        L._ws = L._sol["workspace"]
-
-        def hook(name):
-            if record:
-                {"riccati": e[1], "forward": e[2], "end": e[3]}[name].record()
-        L._aux = oc.auxSysSolverBatch(L._sol, L.taus, L.wps, L.iface, Z_grid=L._Z, out=L._aux_out(), phase_hook=hook)
-        L._Z = L._aux["Z_grid"]
-        loss, grad = L.mask_unconverged(L._sol["status"], L._aux["loss"], L._aux["grad"])    # as SparseDemoLearner.step
-        if use_dist:
-            buf = torch.cat([grad.sum(dim=0), loss.sum().reshape(1)])
-            dist.all_reduce(buf)                                            # summed d(theta) + loss over all ranks
-        L.lib.optimizer_step(L.method, L.theta, grad, L.iter_idx, L.lr, L.mu, L.b1, L.b2, L.eps, m=L.m, v=L.v,
-                             vhat=L.vhat, proj_lo=L.proj_lo)
-        L.iter_idx += 1
-        if record:
-            e[4].record()
-            for k, (a, b) in zip(names, ((e[0], e[1]), (e[1], e[2]), (e[2], e[3]), (e[3], e[4]))):
-                ev[k].append((a, b))
-        return loss
+    def hook(name):
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        if cur.get("prev"):
+            ev[cur["prev"][0]].append((cur["prev"][1], e))
+        cur["prev"] = None if name == "end" else (name, e)
 
     def sync():
         if use_dist:
@@ -152,19 +224,21 @@ def main():
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
-        step(False)
+        L.step()
     sync()
+    L.event_hook = hook
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        loss = step(True)
+        loss, _g = L.step()
     sync()
     elapsed = time.perf_counter() - t0
+    L.event_hook = None
     if use_dist:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
-    ktime = {k: float(np.mean([a.elapsed_time(b) for a, b in v])) for k, v in ev.items()}    # ms per launch
+    ktime = {k: float(np.mean([a.elapsed_time(b) for a, b in v])) for k, v in ev.items()}    # ms per step
     st = L._sol["status"].cpu().numpy()
     it = L._sol["iters"].cpu().numpy()
     if rank == 0:
@@ -174,17 +248,26 @@ def main():
         nw, ni = L.taus.shape[1], len(d["interface"])
         abytes = B * algorithmic_bytes(dom, n, m, p, nc, args.n_grid, nw, ni, es)
         achieved = abytes / (ktime[dom] * 1e-3) / 1e9
-        traffic = None
-        # PMC passes are separate rocprofv3 runs (tools/hbm_traffic.py); the figure only applies to the workload they
-        # were collected on, so it is attached to the headline configuration and left null otherwise
-        tpath = os.path.join(ROOT, "profiles", "r01_o_hbm_traffic.json")
+        # PMC passes are separate rocprofv3 runs (tools/hbm_traffic.py, tools/issue_counters.py); the figures only apply
+        # to the workload they were collected on, so they are attached to the headline configuration and null otherwise
         headline = (B == 4096 and args.n_grid == 50 and args.dtype == "f32" and args.substeps == 4
-                    and not args.warm_start and not args.library)
-        if headline and os.path.exists(tpath):
+                    and mode == "independent" and not args.warm_start and not args.library)
+
+        def profile(name):
+            path = os.path.join(ROOT, "profiles", "%s_%s.json" % (PROFILE_TAG, name))
+            if not (headline and os.path.exists(path)):
+                return {}
             try:
-                traffic = json.load(open(tpath)).get(dom, {}).get("hbm_bytes_per_step")
+                return json.load(open(path)).get(dom, {})
             except Exception:
-                traffic = None
+                return {}
+        traffic = profile("hbm_traffic").get("hbm_bytes_per_step")
+        issue = profile("issue_counters")
+        # useful flops of the dominant kernel: operation counts of the generated model code x calls x active columns
+        # (perf_model.py), times the solver iterations the batch actually ran
+        flops = perf_model.kernel_flops(oc.model_spec(), dom, args.n_grid, 4, args.substeps,
+                                        mean_iters=float(it.mean())) * B
+        useful_tflops = flops / (ktime[dom] * 1e-3) / 1e12
         out = {
             "metric": "CPDP outer iterations/sec (batch trajectories)",
             "value": B * world * args.steps / elapsed,
@@ -193,32 +276,46 @@ def main():
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": "Quadrotor (JinEnv, initCost_Polynomial, beta time-warp) CPDP on the quad_example "
-                                   "waypoints, n_grid(horizon) %d x 4 RK4 steps, batch %d seeds per GPU with random "
-                                   "initial guesses, Nesterov lr 0.01 mu 0.9, %s OC solve every iteration"
-                                   % (args.n_grid, B, "WARM-started (not the headline configuration)" if args.warm_start else "cold-start"),
-                       "batch_per_gpu": B, "n_grid": args.n_grid, "steps_per_grid": 4, "aux_substeps": args.substeps,
+            "config": {"workload": ("Quadrotor (JinEnv, initCost_Polynomial, beta time-warp) CPDP, n_grid(horizon) %d x 4 RK4 "
+                                    "steps, batch %d per GPU, Nesterov mu 0.9, %s OC solve every iteration; " %
+                                    (args.n_grid, B, "WARM-started (not the headline configuration)" if args.warm_start
+                                     else "cold-start")) +
+                                   ("BASELINE configs[2]: random initial-guess seeds on the quad_example waypoints, one theta "
+                                    "and optimizer state per seed, lr 0.01" if mode == "independent" else
+                                    "BASELINE configs[3] at 4096 per GPU: random demonstrations (start, goal, waypoints), ONE "
+                                    "shared theta, summed d(theta)+loss all-reduced over the ranks every iteration and "
+                                    "driving the update (SparseDemoLearner mode='shared')"),
+                       "mode": mode, "batch_per_gpu": B, "n_grid": args.n_grid, "steps_per_grid": 4,
+                       "aux_substeps": args.substeps,
                        "oc_status_hist": np.bincount(st, minlength=5).tolist(), "oc_iters_mean": float(it.mean()),
-                       "loss_mean": float(loss.mean().item()),
+                       "oc_iters_max": int(it.max()), "loss_mean": float(loss.mean().item()) / (1 if mode == "independent" else B * world),
                        "kernel_ms": {k: round(v, 3) for k, v in ktime.items()}},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": abytes, "avg_launch_ms": ktime[dom],
+                         # the fraction that actually bounds this path: fp32 vector issue, not HBM
+                         "valu_useful_tflops": useful_tflops,
+                         "valu_frac": useful_tflops / VALU_PEAK_TFLOPS[args.dtype],
+                         "valu_issue_util": issue.get("valu_issue_util"),
+                         "mfma_busy": issue.get("mfma_busy"),
                          "note": "the per-trajectory recursions are latency/VALU-issue bound, not HBM bound: "
-                                 "algorithmic bytes are O(10 KB) per trajectory against O(10^8) FLOP of sequential "
-                                 "fp32 vector work; see DESIGN.md section 4"},
+                                 "algorithmic bytes are O(10 KB) per trajectory against O(10^7) FLOP of sequential "
+                                 "fp32 vector work per solve; valu_frac = useful flops (perf_model.py) / 157.3 TFLOP/s, "
+                                 "valu_issue_util and mfma_busy from the SQ counters of profiles/%s_issue_counters.json; "
+                                 "see DESIGN.md section 4" % PROFILE_TAG},
         }
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"], ores = cpu_baseline(d, args.n_grid, theta0, n_chk)
+        if world == 1 and mode == "independent" and not args.no_cpu_baseline:
+            out["cpu_baseline"], ores = cpu_baseline(d, args.n_grid, theta0, args.cpu_seeds)
             # parity of the HIP path with the oracle on the benchmark's own seeds (oracle in reference mode: its
             # solve_ivp tolerance 1e-3 limits the agreement of the gradient to ~5e-3)
+            k = min(n_chk, len(ores))
             out["parity_vs_oracle"] = {
-                "seeds": len(ores),
-                "loss_rel_err_max": max(abs(chk_loss[i] - ores[i][0]) / abs(ores[i][0]) for i in range(len(ores))),
-                "grad_rel_err_max": max(float(np.abs(chk_grad[i] - ores[i][1]).max() / np.abs(ores[i][1]).max())
-                                        for i in range(len(ores)))}
+                "seeds": k,
+                "loss_rel_err_max": max(abs(chk_loss[i] - ores[i][0]) / abs(ores[i][0]) for i in range(k)),
+                "grad_rel_err_max": max(float(np.abs(chk_grad[i] - np.array(ores[i][1])).max() / np.abs(ores[i][1]).max())
+                                        for i in range(k))}
         print(json.dumps(out), flush=True)
-    if use_dist:
+    if in_launcher:
         dist.barrier()
         dist.destroy_process_group()
 

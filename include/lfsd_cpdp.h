@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define LFSD_ABI_VERSION 1
+#define LFSD_ABI_VERSION 2
 #define LFSD_F32 0
 #define LFSD_F64 1
 #define LFSD_EINVAL (-1)   /* bad argument (null pointer, non-positive size, unknown enum) */
@@ -121,11 +121,13 @@ int lfsd_aux_forward(int dtype, int batch, int n_grid,
 /* theta <- update(theta, grad) for every trajectory; m/v/vhat are optimizer state [B][n_param]
  * (m: Nesterov velocity or first moment; v: second moment; vhat: AMSGrad max; unused ones may be NULL).
  * proj_lo [n_param] or NULL: theta <- max(theta, proj_lo) after the step (the examples' projection
- * current_parameter[0] = fmax(current_parameter[0], 1e-8)).  iter_idx counts from 0.                */
+ * current_parameter[0] = fmax(current_parameter[0], 1e-8)).  iter_idx counts from 0.
+ * row_active [B] int32 or NULL: rows with 0 are frozen for this step -- theta and m/v/vhat stay untouched (a
+ * learner that skips trajectories whose solve did not converge; the reference has no such case, pass NULL).  */
 int lfsd_optimizer_step(int dtype, int method, int batch, int n_param, int iter_idx,
                         double lr, double mu, double beta1, double beta2, double eps,
                         void* theta, const void* grad, void* m, void* v, void* vhat,
-                        const void* proj_lo, void* stream);
+                        const void* proj_lo, const int* row_active, void* stream);
 
 /* out = theta + mu * v   (Nesterov look-ahead, [B][n_param]) */
 int lfsd_lookahead(int dtype, long long n, double mu, const void* theta, const void* v, void* out, void* stream);

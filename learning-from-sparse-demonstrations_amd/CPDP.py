@@ -232,8 +232,22 @@ class COCSys:
         sol.update(horizon=hz, auxvar=th, consts=consts, ini_state=x0, n_grid=self.n_grid)
         return sol
 
+    def check_waypoints(self, taus, horizon, interface_idx):
+        """Host-side validation the kernels do not repeat.  The reference's opt_sol(t) is scipy's interp1d (CPDP.py:386),
+        which raises ValueError for t outside [0, horizon]; its interface functions are arbitrary CasADi expressions,
+        ours select state components only."""
+        lib = self.compile()
+        idx = [int(i) for i in interface_idx]
+        if any(i < 0 or i >= lib.n_state for i in idx):
+            raise LfsdError("interface_idx %s outside [0, n_state=%d)" % (idx, lib.n_state))
+        tt = torch.as_tensor(taus, dtype=torch.float64).cpu() if not isinstance(taus, torch.Tensor) else taus.double().cpu()
+        hz = torch.as_tensor(horizon, dtype=torch.float64).cpu() if not isinstance(horizon, torch.Tensor) else horizon.double().cpu()
+        hz = hz.reshape(-1, 1) if (hz.dim() >= 1 and tt.dim() == 2 and hz.numel() == tt.shape[0]) else hz.min()
+        if tt.numel() and (bool((tt < 0).any()) or bool((tt > hz * (1 + 1e-12)).any())):
+            raise ValueError("A value in taus is outside the interpolation range [0, horizon].")
+
     def auxSysSolverBatch(self, sol, taus=None, waypoints=None, interface_idx=None, auxvar=None, want_grids=False,
-                          Z_grid=None, out=None, phase_hook=None):
+                          Z_grid=None, out=None, phase_hook=None, validate=True):
         """Differentiate the PMP along ``sol`` and (optionally) evaluate the sparse-waypoint loss + gradient."""
         lib = self.compile()
         B = sol["state_grid"].shape[0]
@@ -247,6 +261,8 @@ class COCSys:
             if wp.dim() == 2:
                 wp = wp.unsqueeze(0).expand(B, -1, -1).contiguous()
             ii = torch.as_tensor(list(interface_idx), dtype=torch.int32, device=self._dev())
+            if validate:          # (a device->host read: callers that validated at setup switch it off)
+                self.check_waypoints(tt, sol["horizon"], interface_idx)
         hz, cs, X, U, Lm = sol["horizon"], sol["consts"], sol["state_grid"], sol["control_grid"], sol["costate_grid"]
         ad = self.aux_dtype
         if ad is not None and ad != X.dtype:          # mixed precision: promote the solved grids for the aux pass
@@ -313,17 +329,23 @@ class SparseDemoLearner:
     ``mode='shared'``: one theta for all demonstrations; the gradient is summed over the batch and
     all-reduced over ``process_group`` (RCCL) before a single update.
 
-    ``skip_unconverged`` (default on; not in the reference, which has a single trajectory and would simply show IPOPT's
-    failure): a trajectory whose optimal-control solve ended at the iteration limit or failed has a meaningless
-    sensitivity, and one such gradient at the examples' learning rates sends its parameters to infinity.  Its gradient
-    (and, in shared sums, its loss) is zeroed for that step; ``n_unconverged`` counts them.  At the next outer iteration
-    such a solve is continued from the controls it stopped at; every other trajectory cold-starts as in the reference.
+    ``skip_unconverged`` (default OFF = the reference's behaviour: every gradient is applied; since round 2 the OC
+    solve converges on every seed of the BASELINE configurations, tests/test_gpu_parity.py).  When switched on, a
+    trajectory whose optimal-control solve ended at the iteration limit or failed, or whose loss / gradient is not
+    finite, is frozen for that step: its row is masked out of the update kernel (parameters AND optimizer state stay
+    untouched, for every update rule), in shared mode it is left out of the summed loss / gradient, and the number of
+    dropped demonstrations is all-reduced and reported as ``n_unconverged``.  At the next outer iteration such a solve
+    is continued from the controls it stopped at; every other trajectory cold-starts as in the reference.
+
+    ``event_hook(name)``, if set, is called right before each device phase of ``step`` ("oc_solve", "aux_riccati",
+    "aux_forward", "update") and once after the last one ("end"), so a caller can bracket the kernels with HIP events
+    (bench.py) without re-implementing the iteration.
     """
 
     def __init__(self, oc, ini_state, horizon, taus, waypoints, interface_idx, theta0, method="Vanilla",
                  learning_rate=1e-2, mu=0.9, beta_1=0.9, beta_2=0.999, epsilon=1e-8, proj_lo=None, consts=None,
                  mode="independent", process_group=None, true_loss_print_flag=False, warm_start=False,
-                 skip_unconverged=True):
+                 skip_unconverged=False):
         self.oc, self.method, self.lr, self.mu = oc, method, learning_rate, mu
         self.b1, self.b2, self.eps = beta_1, beta_2, epsilon
         if method not in runtime.OPT_METHODS:
@@ -341,6 +363,7 @@ class SparseDemoLearner:
         wp = oc._t(waypoints)
         self.wps = wp.unsqueeze(0).expand(B, -1, -1).contiguous() if wp.dim() == 2 else wp
         self.iface = torch.as_tensor(list(interface_idx), dtype=torch.int32, device=self.x0.device)
+        oc.check_waypoints(self.taus, self.hz, interface_idx)
         th = oc._t(theta0)
         th = th.unsqueeze(0) if th.dim() == 1 else th
         if mode == "shared":
@@ -363,6 +386,8 @@ class SparseDemoLearner:
         self.skip_unconverged = skip_unconverged
         self.count_unconverged = True      # one small device->host read per step; switch off inside timed loops
         self.n_unconverged = 0
+        self.event_hook = None
+        self._ok = None
         self._ws = None
         self._sol = None
         self._aux = None
@@ -380,11 +405,15 @@ class SparseDemoLearner:
             cont = (self._sol["status"] == 3).reshape(-1, 1, 1)
             prev = self._sol["control_grid"][:, :-1]
             u_init = torch.where(cont & torch.isfinite(prev), prev, torch.zeros_like(prev)).contiguous()
+        hook = self.event_hook
+        if hook is not None:
+            hook("oc_solve")
         self._sol = self.oc.cocSolverBatch(self.x0, self.hz, th, consts=self.consts, u_init=u_init,
                                            workspace=self._ws, out=self._sol_out())
         self._ws = self._sol["workspace"]
+        phase = None if hook is None else (lambda nm: hook("aux_" + nm) if nm != "end" else None)
         self._aux = self.oc.auxSysSolverBatch(self._sol, self.taus, self.wps, self.iface, Z_grid=self._Z,
-                                              out=self._aux_out())
+                                              out=self._aux_out(), phase_hook=phase, validate=False)
         self._Z = self._aux["Z_grid"]
         loss, grad = self._aux["loss"].to(self.theta.dtype), self._aux["grad"].to(self.theta.dtype)
         if self.skip_unconverged:
@@ -392,9 +421,10 @@ class SparseDemoLearner:
         return loss, grad
 
     def mask_unconverged(self, status, loss, grad):
-        """Zero the gradient of trajectories whose OC solve neither converged (1) nor stalled at working precision (2), or
-        whose loss / gradient is not finite (parameters that have left the region where the problem is well posed, e.g. a
-        cost weight driven negative); in shared mode also their loss, which enters a sum."""
+        """Rows whose OC solve neither converged (1) nor stalled at working precision (2), or whose loss / gradient is
+        not finite (parameters that have left the region where the problem is well posed, e.g. a cost weight driven
+        negative) are frozen for this step: ``self._ok`` masks them out of the update kernel; their gradient (and, in
+        shared mode, their loss, which enters a sum) is zeroed."""
         ok = ((status == 1) | (status == 2)) & torch.isfinite(loss) & torch.isfinite(grad).all(dim=1)
         self._ok = ok
         grad = torch.where(ok.unsqueeze(1), grad, torch.zeros_like(grad))
@@ -417,22 +447,35 @@ class SparseDemoLearner:
         theta_eval = self.theta
         if self.method == "Nesterov":
             theta_eval = self.lib.lookahead(self.theta, self.m, self.mu)      # QuadAlgorithm.py:478
+        self._ok = None
         loss, grad = self.evaluate(theta_eval)
+        hook = self.event_hook
+        if hook is not None:
+            hook("update")
+        row_active = None
         if self.mode == "shared":
             g = grad.sum(dim=0, keepdim=True)
             l = loss.sum().reshape(1)
+            n_bad = (self.B - self._ok.sum()).to(g.dtype).reshape(1) if self._ok is not None else torch.zeros_like(l)
             if self.pg is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()):
-                buf = torch.cat([g.reshape(-1), l])
+                buf = torch.cat([g.reshape(-1), l, n_bad])
                 torch.distributed.all_reduce(buf, group=self.pg)              # RCCL over xGMI on the GPU
-                g, l = buf[:-1].reshape(1, -1), buf[-1:]
+                g, l, n_bad = buf[:-2].reshape(1, -1), buf[-2:-1], buf[-1:]
             grad_used, loss_out = g.contiguous(), l
+            if self.skip_unconverged and self.count_unconverged:
+                self.n_unconverged = int(round(n_bad.item()))                 # over all ranks
         else:
             grad_used, loss_out = grad, loss
+            if self._ok is not None:
+                row_active = self._ok.to(torch.int32)
+                if self.count_unconverged:
+                    self.n_unconverged = int(self.B - self._ok.sum().item())
         self.lib.optimizer_step(self.method, self.theta, grad_used, self.iter_idx, self.lr, self.mu, self.b1,
-                                self.b2, self.eps, m=self.m, v=self.v, vhat=self.vhat, proj_lo=self.proj_lo)
+                                self.b2, self.eps, m=self.m, v=self.v, vhat=self.vhat, proj_lo=self.proj_lo,
+                                row_active=row_active)
         self.iter_idx += 1
-        if self.skip_unconverged:
-            self.n_unconverged = int(self.B - self._ok.sum().item()) if self.count_unconverged else self.n_unconverged
+        if hook is not None:
+            hook("end")
         if self.method == "Nesterov" and self.true_loss:
             loss_out, grad_used = self.evaluate(self.theta)                   # QuadAlgorithm.py:487-492
             if self.mode == "shared":

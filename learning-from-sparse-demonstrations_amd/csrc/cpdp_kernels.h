@@ -96,7 +96,20 @@
 #define LFSD_MU_HOLD_BACKOFF 0
 #endif
 #ifndef LFSD_GN_CRAWL
-#define LFSD_GN_CRAWL 0
+#define LFSD_GN_CRAWL 1
+#endif
+// Levenberg shift of the Newton modes, measured on BASELINE configs[1] (robot arm, 1024 seeds, emulator + MI355X,
+// profiles/r02_arm_step_control.txt).  LFSD_REG_CONSISTENT: the value recursion continues with the SHIFTED Q_uu, i.e. the
+// sweep is the block LDL^T factorisation of (Lagrangian Hessian + mu I_u) -- the model the step actually minimises, and
+// what IPOPT's inertia correction delta_w does to the KKT matrix (CPDP.py:177-184).  With the unshifted Q_uu in the
+// recursion (Tassa's form) an indefinite Q_uu feeds -mu K^T K into V_xx, the sweep needs shifts 30x larger, and 64 of
+// 1024 seeds ran out of 100 iterations.  LFSD_HAM_SHIFT: shift the cheap Hamiltonian model as well instead of falling
+// back to Gauss-Newton (measured: no gain).
+#ifndef LFSD_REG_CONSISTENT
+#define LFSD_REG_CONSISTENT 1
+#endif
+#ifndef LFSD_HAM_SHIFT
+#define LFSD_HAM_SHIFT 0
 #endif
 
 // LFSD_SCHED_FENCE: stop the instruction scheduler from hoisting loads across this point (bounds live ranges in
@@ -172,7 +185,7 @@ template <int n, typename T> LFSD_DEV bool chol_factor(T* A, T& dmin) {
     T d = A[j * n + j];
 #pragma unroll
     for (int k = 0; k < j; ++k) d -= A[j * n + k] * A[j * n + k];
-    if (!(d > T(0))) { ok = false; if (d < dmin) dmin = d; d = T(1); }
+    if (!(d > T(0))) { if (ok && d < dmin) dmin = d; ok = false; d = T(1); }    // only the first failing pivot is meaningful
     d = t_sqrt(d);
     A[j * n + j] = d;
     const T inv = T(1) / d;
@@ -743,6 +756,10 @@ template <class M, typename T, int G, bool EXACT> struct OcSolver {
 #pragma unroll
       for (int a = 0; a < NU; ++a) Lc[a * NU + a] += mu;
       if (ok) ok = chol_factor<NU>(Lc, dmin); else { T dd = T(0); chol_factor<NU>(Lc, dd); }   // first failing pivot sizes the shift
+      if (LFSD_REG_CONSISTENT) {
+#pragma unroll
+        for (int a = 0; a < NU; ++a) Quu0[a * NU + a] += mu;
+      }
 #pragma unroll
       for (int a = 0; a < NU; ++a) { kff[a] = -Qu[a]; Kj[a] = -Quxj[a]; }
       chol_solve<NU>(Lc, kff);
@@ -1013,10 +1030,10 @@ __global__ void __launch_bounds__(64, LFSD_WAVES_OC) oc_solve_kernel(OcArgs<T> a
       my_iters = it + 1 + it_off;
       if (!bw_ok) {
         // indefinite Q_uu: the cheap Newton-like model hands over to the exact one; otherwise Levenberg shift
-        if (mode == 1) { mode = 0; ham_ok = false; }     // back to Gauss-Newton until the exact model takes over
+        if (mode == 1 && !LFSD_HAM_SHIFT) { mode = 0; ham_ok = false; }     // back to Gauss-Newton until the exact model takes over
         else {
           mu_bad = mu; mu_hold = 0;
-          if (mu == T(0) && mode == 2 && t_finite(dmin))
+          if (mu == T(0) && mode >= 1 && t_finite(dmin))
             mu = t_min(t_max(T(-2) * dmin, T(1e-4)), T(1e6));     // first shift: the size of the negative pivot
           else
             mu = t_max(mu * T(LFSD_MU_UP), mode == 2 ? T(1e-4) : T(1e-6));
@@ -1050,7 +1067,7 @@ __global__ void __launch_bounds__(64, LFSD_WAVES_OC) oc_solve_kernel(OcArgs<T> a
         // Newton-like step whose cost change is below rounding noise: take it as long as the
         // gradient norm keeps contracting (this is what lets fp32 reach its gradient floor)
         accept = true; ia = 0; alpha = T(1); g_flat = gnorm;
-      } else if (mode == 1) {
+      } else if (mode == 1 && !LFSD_HAM_SHIFT) {
         mode = 0; ham_ok = false;
       } else if (mu > T(1e10) ||
                  ((J - Jmin) <= T(8) * Eps<T>::v() * t_abs(J) && (mode == 0 || flat_full || mu > T(1e6)))) {
@@ -1787,11 +1804,13 @@ template <typename T> struct OptArgs {
   T* v;                // [B][p]  second moment
   T* vhat;             // [B][p]  AMSGrad running max
   const T* proj_lo;    // [p] lower bound applied after the step (-inf = none); examples clamp theta[0] >= 1e-8
+  const int* row_active;   // [B] or nullptr: rows with 0 keep theta AND their optimizer state (a frozen trajectory)
 };
 
 template <typename T> __global__ void optimizer_kernel(OptArgs<T> a) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (long long)a.batch * a.n_param) return;
+  if (a.row_active && !a.row_active[i / a.n_param]) return;
   const int j = (int)(i % a.n_param);
   const T g = a.grad[i];
   T th = a.theta[i];

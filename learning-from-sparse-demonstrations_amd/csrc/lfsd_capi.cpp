@@ -192,12 +192,12 @@ LFSD_API int lfsd_aux_forward(int dtype, int batch, int n_grid, const void* hori
 template <typename T>
 static int opt_step_t(int method, int batch, int n_param, int iter_idx, double lr, double mu, double beta1,
                       double beta2, double eps, void* theta, const void* grad, void* m, void* v, void* vhat,
-                      const void* proj_lo, void* stream) {
+                      const void* proj_lo, const int* row_active, void* stream) {
   lfsd::OptArgs<T> a;
   a.batch = batch; a.n_param = n_param; a.method = method; a.iter_idx = iter_idx;
   a.lr = (T)lr; a.mu = (T)mu; a.beta1 = (T)beta1; a.beta2 = (T)beta2; a.eps = (T)eps;
   a.theta = (T*)theta; a.grad = (const T*)grad; a.m = (T*)m; a.v = (T*)v; a.vhat = (T*)vhat;
-  a.proj_lo = (const T*)proj_lo;
+  a.proj_lo = (const T*)proj_lo; a.row_active = row_active;
   const long long n = (long long)batch * n_param;
   const unsigned grid = (unsigned)((n + 63) / 64);
   LFSD_LAUNCH((lfsd::optimizer_kernel<T>), grid, 64, stream, a);
@@ -206,7 +206,7 @@ static int opt_step_t(int method, int batch, int n_param, int iter_idx, double l
 
 LFSD_API int lfsd_optimizer_step(int dtype, int method, int batch, int n_param, int iter_idx, double lr, double mu,
                                    double beta1, double beta2, double eps, void* theta, const void* grad, void* m,
-                                   void* v, void* vhat, const void* proj_lo, void* stream) {
+                                   void* v, void* vhat, const void* proj_lo, const int* row_active, void* stream) {
   if (batch <= 0 || n_param <= 0 || iter_idx < 0 || !theta || !grad) return LFSD_EINVAL;
   if (method < LFSD_OPT_VANILLA || method > LFSD_OPT_AMSGRAD) return LFSD_EINVAL;
   if (method == LFSD_OPT_NESTEROV && !m) return LFSD_EINVAL;
@@ -214,10 +214,10 @@ LFSD_API int lfsd_optimizer_step(int dtype, int method, int batch, int n_param, 
   if (method == LFSD_OPT_AMSGRAD && !vhat) return LFSD_EINVAL;
   if (dtype == LFSD_F32)
     return opt_step_t<float>(method, batch, n_param, iter_idx, lr, mu, beta1, beta2, eps, theta, grad, m, v, vhat,
-                             proj_lo, stream);
+                             proj_lo, row_active, stream);
   if (dtype == LFSD_F64)
     return opt_step_t<double>(method, batch, n_param, iter_idx, lr, mu, beta1, beta2, eps, theta, grad, m, v, vhat,
-                              proj_lo, stream);
+                              proj_lo, row_active, stream);
   return LFSD_EINVAL;
 }
 

@@ -167,11 +167,11 @@ class ModelLibrary:
         L.lfsd_aux_riccati.argtypes = [ci, ci, ci, vp, vp, vp, ci, vp, vp, vp, vp, ci, vp]
         L.lfsd_aux_forward.argtypes = [ci, ci, ci, vp, vp, vp, ci, vp, vp, vp, vp, ci, ci, vp, vp, vp, vp, vp, vp, vp,
                                        ci, vp]
-        L.lfsd_optimizer_step.argtypes = [ci, ci, ci, ci, ci, cd, cd, cd, cd, cd, vp, vp, vp, vp, vp, vp, vp]
+        L.lfsd_optimizer_step.argtypes = [ci, ci, ci, ci, ci, cd, cd, cd, cd, cd, vp, vp, vp, vp, vp, vp, vp, vp]
         L.lfsd_lookahead.argtypes = [ci, ctypes.c_longlong, cd, vp, vp, vp, vp]
         info = _ModelInfo()
         rc = L.lfsd_get_model_info(ctypes.byref(info))
-        if rc != 0 or info.abi_version != 1:
+        if rc != 0 or info.abi_version != 2:
             raise LfsdError("ABI mismatch in %s" % path)
         self.n_state, self.n_control, self.n_auxvar, self.n_const = (info.n_state, info.n_control, info.n_auxvar,
                                                                       info.n_const)
@@ -327,7 +327,7 @@ class ModelLibrary:
         return out
 
     def optimizer_step(self, method, theta, grad, iter_idx, lr, mu=0.9, beta1=0.9, beta2=0.999, eps=1e-8, m=None,
-                       v=None, vhat=None, proj_lo=None):
+                       v=None, vhat=None, proj_lo=None, row_active=None):
         dt = theta.dtype
         B, p = theta.shape
         for nm, t in (("theta", theta), ("grad", grad)):
@@ -335,11 +335,13 @@ class ModelLibrary:
         for nm, t in (("m", m), ("v", v), ("vhat", vhat)):
             self._check(t, (B, p), dt, nm, optional=True)
         self._check(proj_lo, (p,), dt, "proj_lo", optional=True)
+        self._check(row_active, (B,), torch.int32, "row_active", optional=True)
         with self._on(theta):
             rc = self.lib.lfsd_optimizer_step(_DT[dt], OPT_METHODS[method] if isinstance(method, str) else int(method),
                                               B, p, int(iter_idx), float(lr), float(mu), float(beta1), float(beta2),
                                               float(eps), self._p(theta), self._p(grad), self._p(m), self._p(v),
-                                              self._p(vhat), self._p(proj_lo), self._stream(theta))
+                                              self._p(vhat), self._p(proj_lo), self._p(row_active),
+                                              self._stream(theta))
         self._rc(rc, "lfsd_optimizer_step")
 
     def lookahead(self, theta, v, mu, out=None):

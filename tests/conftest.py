@@ -87,3 +87,20 @@ def oracle_loss_grad(oc, ini_state, horizon, theta, taus, wps, iface, tight=True
     aux, PW, vX, vU = oc.auxSysSolver(tg, sol, theta, return_grids=True, **(TIGHT if tight else {}))
     loss, grad = getloss_corrections(oc, taus, wps, sol, aux, iface)
     return dict(loss=loss, grad=grad, X=X, U=U, L=L, PW=PW, vX=vX, vU=vU, info=oc.last_info)
+
+
+def oracle_check_solution(oc, ini_state, horizon, theta, X, U, L, taus, wps, iface, tight=True):
+    """Basin-independent parity check for problems with several local minima (rocket, cart-pole swing-up): the oracle
+    does not solve -- it (1) certifies with complex-step arithmetic that the given grids ARE a KKT point of the
+    reference's NLP (CPDP.py:126-179) and (2) differentiates the PMP along exactly these grids (CPDP.py:301-381) and
+    evaluates the loss / gradient.  X, U, L: [N+1][n], [N+1][m], [N+1][n] numpy arrays."""
+    import numpy as np
+    from oracle.cpdp_oracle import getloss_corrections
+    oc.diffPMP()
+    X, U, L = (np.asarray(a, dtype=np.float64) for a in (X, U, L))
+    defect, gmax, lmax = oc.kkt_certificate(ini_state, horizon, theta, X, U, L)
+    tg = np.linspace(0, horizon, oc.n_grid + 1)
+    sol = oc.interpolation(tg, np.concatenate((X, U, L), axis=1))
+    aux, PW, vX, vU = oc.auxSysSolver(tg, sol, theta, return_grids=True, **(TIGHT if tight else {}))
+    loss, grad = getloss_corrections(oc, taus, wps, sol, aux, iface)
+    return dict(defect=defect, gmax=gmax, lmax=lmax, loss=loss, grad=grad, PW=PW, vX=vX, vU=vU)

@@ -26,7 +26,7 @@ int main() {
                         taus.data(), wps.data(), loss.data(), grad.data(), aX.data(), aU.data(), 4, nullptr);
     printf("dtype %d aux rc %d\n", dtype, rc);
     for (int meth = 0; meth < 5; ++meth)
-      rc |= lfsd_optimizer_step(dtype, meth, B, p, 0, 0.01, 0.9, 0.9, 0.999, 1e-8, th.data(), grad.data(), mm.data(), mv.data(), mvh.data(), nullptr, nullptr);
+      rc |= lfsd_optimizer_step(dtype, meth, B, p, 0, 0.01, 0.9, 0.9, 0.999, 1e-8, th.data(), grad.data(), mm.data(), mv.data(), mvh.data(), nullptr, nullptr, nullptr);
     rc |= lfsd_lookahead(dtype, (long long)B * p, 0.9, th.data(), mm.data(), la.data(), nullptr);
     printf("dtype %d opt rc %d\n", dtype, rc);
   }

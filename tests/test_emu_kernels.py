@@ -293,7 +293,11 @@ def test_quadalgorithm_driver_replays_reference_run_start(emu):
 
 def test_rocket_newton_mode_vs_oracle(emu):
     """Examples/rocket_groundtruth.py (6-DoF powered landing, T=3): needs the exact stage Hessians (second-order
-    adjoint through the RK4 stages) from the first iteration; kernel and oracle must reach the same KKT point."""
+    adjoint through the RK4 stages) from the first iteration.  The problem has several local minima and which one a
+    cold start reaches depends on the globalisation (IPOPT's would differ from both ours and the oracle's), so parity is
+    checked basin-independently: the oracle certifies the kernel's cold-start answer as a KKT point of the reference's
+    NLP and differentiates the PMP along it; and the oracle's own KKT point is a fixed point of the kernel."""
+    from conftest import oracle_check_solution
     oc, env, d = models.rocket(n_grid=15)
     emu(oc)
     oc.setDevice(dtype=torch.float64)
@@ -304,14 +308,19 @@ def test_rocket_newton_mode_vs_oracle(emu):
     o = make_oracle("rocket", 15)
     tg = np.linspace(0, d["horizon"], 16)
     taus = tg[[1, 3, 6, 10, 13]]                                    # rocket_groundtruth.py:78
-    r0 = o.cocSolver(d["ini_state"], d["horizon"], th, return_grids=True, exact_after=0, max_iter=400)
-    assert o.last_info["converged"] and abs(o.last_cost - sol["cost"][0].item()) < 1e-8 * abs(o.last_cost)
-    wps = [np.concatenate([r0[1](t)[0:3], r0[1](t)[6:10]]) + 0.05 for t in taus]
-    r = oracle_loss_grad(o, d["ini_state"], d["horizon"], th, taus, wps, d["interface"], exact_after=0, max_iter=400)
+    X, U, Lm = (sol[k][0].numpy() for k in ("state_grid", "control_grid", "costate_grid"))
+    wps = [np.concatenate([X[k, 0:3], X[k, 6:10]]) + 0.05 for k in (1, 3, 6, 10, 13)]
+    r = oracle_check_solution(o, d["ini_state"], d["horizon"], th, X, U, Lm, taus, wps, d["interface"])
+    assert r["defect"] < 1e-9 and r["gmax"] < 1e-6 and r["lmax"] < 1e-6 * np.abs(Lm).max(), (r["defect"], r["gmax"], r["lmax"])
     aux = oc.auxSysSolverBatch(sol, taus, wps, d["interface"])
-    assert rel(sol["state_grid"][0], r["X"]) < 1e-6 and rel(sol["costate_grid"][0], r["L"]) < 1e-5
     assert abs(aux["loss"][0].item() - r["loss"]) < 1e-7 * max(1.0, r["loss"])
     assert rel(aux["grad"][0], r["grad"]) < 1e-3
+    # the oracle's cold-start KKT point, handed over as the initial guess, is where the kernel stays
+    r0 = o.cocSolver(d["ini_state"], d["horizon"], th, return_grids=True, exact_after=0, max_iter=400)
+    assert o.last_info["converged"]
+    sol2 = oc.cocSolverBatch([d["ini_state"]], d["horizon"], [th], u_init=torch.as_tensor(r0[3][None, :-1].copy()))
+    assert sol2["status"].tolist() == [1] and abs(o.last_cost - sol2["cost"][0].item()) < 1e-8 * abs(o.last_cost)
+    assert rel(sol2["state_grid"][0], r0[2]) < 1e-6 and rel(sol2["costate_grid"][0], r0[4]) < 1e-5
 
 
 def test_edge_cases_ragged_empty_and_per_trajectory_inputs(emu):
@@ -346,7 +355,9 @@ def test_edge_cases_ragged_empty_and_per_trajectory_inputs(emu):
     a0 = oc.auxSysSolverBatch(sol, [0.0], [[0.3]], d["interface"])
     assert np.allclose(a0["loss"].numpy(), 0.09, atol=1e-12) and float(a0["grad"].abs().max()) < 1e-12
     aT = oc.auxSysSolverBatch(sol, [1.0], [[0.3]], d["interface"])
-    aT2 = oc.auxSysSolverBatch(sol, [1.0 + 1e-9], [[0.3]], d["interface"])
+    with pytest.raises(ValueError):                   # scipy's interp1d (CPDP.py:386) refuses t > T; so does the host check
+        oc.auxSysSolverBatch(sol, [1.0 + 1e-9], [[0.3]], d["interface"])
+    aT2 = oc.auxSysSolverBatch(sol, [1.0 + 1e-9], [[0.3]], d["interface"], validate=False)      # the kernel itself clamps
     assert torch.allclose(aT["loss"], aT2["loss"], rtol=1e-6) and torch.allclose(aT["grad"], aT2["grad"], rtol=1e-5, atol=1e-9)
     # per-trajectory constants: a batch with different pendulum lengths equals the individual solves
     lens = np.array([0.8, 1.0, 1.3])
@@ -400,9 +411,9 @@ def test_learner_warm_start_same_iterates_fewer_solver_iterations(emu):
 
 
 def test_learner_skips_unconverged_trajectories(emu):
-    """A trajectory whose OC solve ran out of iterations has a meaningless sensitivity: by default the learner zeroes its
-    gradient for that step (and counts it) instead of letting it throw the parameters away; skip_unconverged=False keeps
-    the reference's unguarded behaviour."""
+    """skip_unconverged=True (opt-in; the default is the reference's unguarded behaviour): a trajectory whose OC solve ran
+    out of iterations has a meaningless sensitivity, so its row is frozen for that step -- parameters AND optimizer state,
+    for every update rule (lfsd_optimizer_step's row_active mask) -- and counted."""
     from lfsd_amd import CPDP
     oc, env, d = models.ZOO["pendulum"](n_grid=10)
     emu(oc)
@@ -410,11 +421,16 @@ def test_learner_skips_unconverged_trajectories(emu):
     th = np.array([[1.0, 0.5, 1.5], [2.0, 1.0, 1.0]])
     args = (np.tile(d["ini_state"], (2, 1)), d["horizon"], [0.3, 0.6], [[0.5], [1.0]], d["interface"], th)
     oc.setSolverOptions(max_iter=3)                       # every solve stops at the limit
-    L = CPDP.SparseDemoLearner(oc, *args, learning_rate=0.1)
+    for method in ("Vanilla", "Nesterov", "Adam", "Nadam", "AMSGrad"):
+        L = CPDP.SparseDemoLearner(oc, *args, method=method, learning_rate=0.1, skip_unconverged=True)
+        L.m += 0.25; L.v += 0.5; L.vhat += 0.75        # state a masked update must leave alone (it would decay / move it)
+        th0 = L.theta.clone()
+        loss, grad = L.step()
+        assert (L._sol["status"] == 3).all() and L.n_unconverged == 2
+        assert (grad == 0).all() and torch.equal(L.theta, th0), method
+        assert (L.m == 0.25).all() and (L.v == 0.5).all() and (L.vhat == 0.75).all(), method
+    L = CPDP.SparseDemoLearner(oc, *args, learning_rate=0.1, skip_unconverged=True)
     th0 = L.theta.clone()
-    loss, grad = L.step()
-    assert (L._sol["status"] == 3).all() and L.n_unconverged == 2
-    assert (grad == 0).all() and torch.equal(L.theta, th0)
     # ... and the solve is continued at the next outer iteration rather than restarted: with 3 iterations per step a cold
     # start could never finish, the continued solves converge after a few steps and the update then goes ahead
     converged_once = False
@@ -424,11 +440,31 @@ def test_learner_skips_unconverged_trajectories(emu):
         if not torch.equal(L.theta[0], th0[0]):
             break
     assert converged_once and not torch.equal(L.theta[0], th0[0])
-    L2 = CPDP.SparseDemoLearner(oc, *args, learning_rate=0.1, skip_unconverged=False)
+    L2 = CPDP.SparseDemoLearner(oc, *args, learning_rate=0.1)          # default: every gradient is applied
+    assert L2.skip_unconverged is False
     L2.step()
     assert not torch.equal(L2.theta, th0)
     oc.setSolverOptions(max_iter=100)                     # converged solves are untouched by the guard
-    L3 = CPDP.SparseDemoLearner(oc, *args, learning_rate=0.1)
-    L4 = CPDP.SparseDemoLearner(oc, *args, learning_rate=0.1, skip_unconverged=False)
+    L3 = CPDP.SparseDemoLearner(oc, *args, learning_rate=0.1, skip_unconverged=True)
+    L4 = CPDP.SparseDemoLearner(oc, *args, learning_rate=0.1)
     L3.step(); L4.step()
     assert L3.n_unconverged == 0 and torch.equal(L3.theta, L4.theta)
+
+
+def test_waypoints_outside_the_horizon_raise_like_interp1d(emu):
+    """The reference's opt_sol(t) is scipy's interp1d (CPDP.py:386): a tau outside [0, horizon] raises ValueError there;
+    the kernels would extrapolate silently, so the host checks.  Same for an interface index that selects no state."""
+    from lfsd_amd import CPDP, runtime
+    oc, env, d = models.ZOO["pendulum"](n_grid=10)
+    emu(oc)
+    oc.setDevice(dtype=torch.float64)
+    sol = oc.cocSolverBatch([d["ini_state"]], d["horizon"], [[1.0, 0.5, 1.5]])
+    with pytest.raises(ValueError):
+        oc.auxSysSolverBatch(sol, [0.3, 1.2], [[0.5], [1.0]], d["interface"])
+    with pytest.raises(ValueError):
+        oc.auxSysSolverBatch(sol, [-0.1], [[0.5]], d["interface"])
+    with pytest.raises(runtime.LfsdError):
+        oc.auxSysSolverBatch(sol, [0.3], [[0.5]], [2])
+    with pytest.raises(ValueError):
+        CPDP.SparseDemoLearner(oc, [d["ini_state"]], d["horizon"], [0.3, 1.5], [[0.5], [1.0]], d["interface"], [1.0, 0.5, 1.5])
+    oc.auxSysSolverBatch(sol, [0.0, 1.0], [[0.5], [1.0]], d["interface"])           # both ends are inside
