@@ -48,7 +48,7 @@ def parse_args(argv=None):
     ap.add_argument("--mode", default=None, choices=["independent", "shared"],
                     help="default: independent seeds at N=1 (configs[2]), shared theta + gradient all-reduce at N>1 (configs[3])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seeds", type=int, default=0, help="seeds of the CPU baseline sample (0: max(64, 2 x cores))")
+    ap.add_argument("--cpu-seeds", type=int, default=0, help="seeds of the CPU baseline sample (default 64)")
     ap.add_argument("--library", default=None, help="tuning only: path of an alternative build of the model library")
     ap.add_argument("--warm-start", action="store_true",
                     help="NOT the headline: start each OC solve from the previous iteration's controls")
@@ -83,53 +83,86 @@ def algorithmic_bytes(kernel, n, m, p, nc, N, nw, ni, es):
 
 
 # ---- CPU baseline: the oracle (port of the reference pipeline) on ALL host cores -----------------------------------
-_ORACLE = None
-
-
-def _cpu_init(n_grid):
-    global _ORACLE
-    sys.path.insert(0, ROOT)
+def cpu_worker(n_grid):
+    """`bench.py --cpu-worker N_GRID`: build the oracle, say READY, read one JSON line of jobs, answer one JSON line."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from conftest import make_oracle
-    _ORACLE = make_oracle("quadrotor", n_grid)
-    _ORACLE.diffPMP()
-
-
-def _cpu_task(job):
     from oracle.cpdp_oracle import getloss_corrections
-    if job is None:
-        return None                                    # start-up barrier: the worker has built its oracle
-    ini, hz, taus, wps, iface, theta = job
-    tg, sol = _ORACLE.cocSolver(ini, hz, theta)
-    aux = _ORACLE.auxSysSolver(tg, sol, theta)          # reference settings: BDF + RK45 at scipy defaults
-    l, g = getloss_corrections(_ORACLE, taus, wps, sol, aux, iface)
-    return float(l), [float(x) for x in g]
+    o = make_oracle("quadrotor", n_grid)
+    o.diffPMP()
+    print("READY", flush=True)
+    jobs = json.loads(sys.stdin.readline())
+    out = []
+    for ini, hz, taus, wps, iface, theta in jobs:
+        tg, sol = o.cocSolver(ini, hz, theta)
+        aux = o.auxSysSolver(tg, sol, theta)            # reference settings: BDF + RK45 at scipy defaults
+        l, g = getloss_corrections(o, taus, wps, sol, aux, iface)
+        out.append([float(l), [float(x) for x in g]])
+    print(json.dumps(out), flush=True)
 
 
-def cpu_baseline(d, n_grid, thetas, n_sample):
+def cpu_baseline(d, n_grid, thetas, n_sample, timeout=240.0):
     """The oracle (fp64 numpy/scipy port of the reference pipeline; CasADi/IPOPT cannot be installed here) on a
-    bounded sample of the benchmark's own seeds, one worker process per host core.  Workers are started with `spawn`
-    (this process holds a GPU context) and build their oracle before the clock starts."""
-    import multiprocessing as mp
-    cores = os.cpu_count() or 1
+    bounded sample of the benchmark's own seeds, one worker PROCESS per host core (plain child processes of this
+    script: nothing is forked from the process that holds the GPU context).  Every worker has imported and lambdified
+    its model before the clock starts; seeds are dealt round-robin; a worker that does not answer in time is killed."""
+    import threading
     try:
         cores = len(os.sched_getaffinity(0))
     except Exception:
-        pass
-    n_sample = min(len(thetas), n_sample if n_sample > 0 else max(64, 2 * cores))
-    ctx = mp.get_context("spawn")
-    jobs = [(list(d["ini_state"]), float(d["horizon"]), list(d["taus"]), [list(w) for w in d["waypoints"]],
-             list(d["interface"]), [float(x) for x in thetas[b]]) for b in range(n_sample)]
-    with ctx.Pool(cores, initializer=_cpu_init, initargs=(n_grid,)) as pool:
-        pool.map(_cpu_task, [None] * (4 * cores), chunksize=1)     # every worker imported + lambdified its model
+        cores = os.cpu_count() or 1
+    # 64 seeds on at most 64 workers: one seed costs 2.5-6 s of one core, so the leg stays inside ~10-30 s on any host
+    # (on the 256-core GPU box 256 workers x 2 seeds took 154 s: the processes fight over memory bandwidth)
+    n_sample = min(len(thetas), n_sample if n_sample > 0 else 64)
+    workers = min(cores, n_sample, 64)
+    jobs = [(list(map(float, d["ini_state"])), float(d["horizon"]), list(map(float, d["taus"])),
+             [list(map(float, w)) for w in d["waypoints"]], list(map(int, d["interface"])),
+             [float(x) for x in thetas[b]]) for b in range(n_sample)]
+    env = dict(os.environ, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1")   # the processes are the parallelism
+    procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", str(n_grid)], env=env,
+                              stdin=subprocess.PIPE, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
+             for _ in range(workers)]
+    ready, go = [threading.Event() for _ in procs], threading.Event()
+    answers = [None] * workers
+
+    def serve(w):
+        if procs[w].stdout.readline().strip() != "READY":
+            return
+        ready[w].set()
+        go.wait()
+        procs[w].stdin.write(json.dumps(jobs[w::workers]) + "\n")
+        procs[w].stdin.flush()
+        line = procs[w].stdout.readline()
+        answers[w] = json.loads(line) if line.strip() else None
+    threads = [threading.Thread(target=serve, args=(w,), daemon=True) for w in range(workers)]
+    try:
+        for t in threads:
+            t.start()
+        deadline = time.time() + timeout
+        for e in ready:
+            if not e.wait(max(0.0, deadline - time.time())):
+                raise RuntimeError("a CPU-baseline worker did not start within %.0f s" % timeout)
         t0 = time.time()
-        results = pool.map(_cpu_task, jobs, chunksize=1)
+        go.set()
+        deadline = t0 + timeout
+        for t in threads:
+            t.join(max(0.0, deadline - time.time()))
         dt = time.time() - t0
-    return dict(value=n_sample / dt, unit="trajectory outer-iterations/s", cores=cores, kind="port",
+        if any(a is None for a in answers):
+            raise RuntimeError("a CPU-baseline worker did not answer within %.0f s" % timeout)
+    finally:
+        go.set()
+        for pr in procs:
+            if pr.poll() is None:
+                pr.kill()
+    results = [None] * n_sample
+    for w in range(workers):
+        results[w::workers] = [(a[0], a[1]) for a in answers[w]]
+    return dict(value=n_sample / dt, unit="trajectory outer-iterations/s", cores=workers, kind="port",
                 sample="%d of the %d seeds of rank 0, 1 outer iteration each, oracle/cpdp_oracle.py (numpy/scipy fp64, "
-                       "solve_ivp BDF+RK45 as CPDP.py:335,368) on %d worker processes = all host cores, %.1f s; the "
-                       "reference itself needs CasADi 3.5.5 + IPOPT 3.11.9, which are not installed and cannot be "
-                       "(no network)" % (n_sample, len(thetas), cores, dt)), results
+                       "solve_ivp BDF+RK45 as CPDP.py:335,368) on %d single-threaded worker processes (host has %d "
+                       "cores), %.1f s; the reference itself needs CasADi 3.5.5 + IPOPT 3.11.9, which are not installed "
+                       "and cannot be (no network)" % (n_sample, len(thetas), workers, cores, dt)), results
 
 
 def build_learner(args, oc, d, lib, rank, world, mode, pg=None):
@@ -161,6 +194,8 @@ def build_learner(args, oc, d, lib, rank, world, mode, pg=None):
 
 def main(argv=None):
     argv = sys.argv[1:] if argv is None else argv
+    if len(argv) == 2 and argv[0] == "--cpu-worker":
+        return cpu_worker(int(argv[1]))
     args = parse_args(argv)
     in_launcher = "RANK" in os.environ and "MASTER_PORT" in os.environ      # started by torch.distributed.run
     if args.gpus > 1 and not in_launcher:
@@ -305,11 +340,15 @@ def main(argv=None):
                                  "see DESIGN.md section 4" % PROFILE_TAG},
         }
         if world == 1 and mode == "independent" and not args.no_cpu_baseline:
-            out["cpu_baseline"], ores = cpu_baseline(d, args.n_grid, theta0, args.cpu_seeds)
+            try:
+                out["cpu_baseline"], ores = cpu_baseline(d, args.n_grid, theta0, args.cpu_seeds)
+            except Exception as exc:          # the GPU measurement must not be lost to a host-side problem
+                out["cpu_baseline"], ores = dict(value=None, unit="trajectory outer-iterations/s", cores=0, kind="port",
+                                                 sample="failed: %r" % (exc,)), []
             # parity of the HIP path with the oracle on the benchmark's own seeds (oracle in reference mode: its
             # solve_ivp tolerance 1e-3 limits the agreement of the gradient to ~5e-3)
             k = min(n_chk, len(ores))
-            out["parity_vs_oracle"] = {
+            out["parity_vs_oracle"] = None if k == 0 else {
                 "seeds": k,
                 "loss_rel_err_max": max(abs(chk_loss[i] - ores[i][0]) / abs(ores[i][0]) for i in range(k)),
                 "grad_rel_err_max": max(float(np.abs(chk_grad[i] - np.array(ores[i][1])).max() / np.abs(ores[i][1]).max())

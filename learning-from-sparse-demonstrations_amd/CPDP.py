@@ -40,7 +40,7 @@ class COCSys:
         self._lib = None
         self._lib_override = None
         self.aux_substeps = 0           # 0 = library default
-        self.max_iter = 100
+        self.max_iter = 300              # (IPOPT's default is 3000; an iteration here is one DDP sweep)
         self.tol = None
         self.exact_after = 16            # iteration from which the exact stage Hessian is forced
         self.aux_dtype = None            # None: same as dtype; torch.float64: fp64 auxiliary (Riccati/sensitivity) pass

@@ -105,6 +105,10 @@
 // recursion (Tassa's form) an indefinite Q_uu feeds -mu K^T K into V_xx, the sweep needs shifts 30x larger, and 64 of
 // 1024 seeds ran out of 100 iterations.  LFSD_HAM_SHIFT: shift the cheap Hamiltonian model as well instead of falling
 // back to Gauss-Newton (measured: no gain).
+// backward sweep: issue the loads of interval k-1 while interval k is processed (costs NX+1 + NX+NU registers)
+#ifndef LFSD_BW_PREFETCH
+#define LFSD_BW_PREFETCH 1
+#endif
 #ifndef LFSD_REG_CONSISTENT
 #define LFSD_REG_CONSISTENT 1
 #endif
@@ -360,10 +364,19 @@ template <class M> struct OcLayout {
   static constexpr int NX = M::NX, NU = M::NU, NXU = NX + NU;
   // scratch per trajectory (elements)
   static constexpr int SMAX = 8;       // RK4 sub-steps per grid interval supported by the exact-Hessian sweep
+  // The linearisation [A B; q] of interval k and its exact stage Hessian are stored ROW-major with the column index
+  // fastest ([k][row][column], rows padded to an even length): lane j owns column j, so one store / load instruction of
+  // the tangent sweep (writer) and of the backward sweep (reader) touches NXU consecutive words -- one or two cache lines
+  // -- where the column-major layout of round 1 touched NXU lines at a 56-byte stride (83x the algorithmic traffic in
+  // the round-1 profile).  An even row length keeps the two-column stores of the packed roll-out 8-byte aligned.
+  static constexpr int NXUP = (NXU + 1) / 2 * 2;
+  static constexpr int M_ELEMS = (NX + 1) * NXUP;                // [A B] rows + the cost-gradient row q, per interval
+  static constexpr int H_ELEMS = NXU * NXUP;
   template <int G> static long long ws_elems(int N) {
-    return 2LL * (N + 1) * NX + 2LL * N * NU + 2LL * N * NXU * (NX + 1) + 1LL * N * NX * NU + 1LL * N * NU +
+    const long long n = 2LL * (N + 1) * NX + 2LL * N * NU + 2LL * N * M_ELEMS + 1LL * N * NX * NU + 1LL * N * NU +
            1LL * (N + 1) * NX + 1LL * SMAX * NX * (1 + G) +     // + sub-step start states (uniform | per lane)
-           1LL * N * NXU * NXU;                                  // + exact stage Hessians of the current nominal
+           1LL * N * H_ELEMS;                                    // + exact stage Hessians of the current nominal
+    return (n + 1) / 2 * 2;
   }
   // LDS per group (elements)
   static constexpr int LDS_V = 0;
@@ -471,10 +484,10 @@ template <class M, typename T, int G, bool EXACT> struct OcSolver {
       for (int s = 0; s < S; ++s) rk4_step<true>(t, x, q, u, m, mq, du);
       J += q;
       if (lane < NXU) {
-        T* col = Mws[nxt] + ((long long)k * NXU + lane) * (NX + 1);
+        T* Mk = Mws[nxt] + (long long)k * Lay::M_ELEMS + lane;
 #pragma unroll
-        for (int i = 0; i < NX; ++i) col[i] = m[i];
-        col[NX] = mq;
+        for (int i = 0; i < NX; ++i) Mk[i * Lay::NXUP] = m[i];
+        Mk[NX * Lay::NXUP] = mq;
       }
     }
     if (lane == 0) {
@@ -510,17 +523,11 @@ template <class M, typename T, int G, bool EXACT> struct OcSolver {
       const T t = tk(k);
       for (int s = 0; s < S; ++s) rk4_step<true, V>(t, x, q, u, m, mq, du);
       J += q;
-      if (c0 < NXU) {
-        T* col = Mws[nxt] + ((long long)k * NXU + c0) * (NX + 1);
+      if (c0 < NXU) {          // columns c0, c0+1 of every row as one 8-byte store (c1 < NXUP: the pad column of an odd NXU)
+        V* Mk = reinterpret_cast<V*>(Mws[nxt] + (long long)k * Lay::M_ELEMS + c0);
 #pragma unroll
-        for (int i = 0; i < NX; ++i) col[i] = m[i].x;
-        col[NX] = mq.x;
-      }
-      if (c1 < NXU) {
-        T* col = Mws[nxt] + ((long long)k * NXU + c1) * (NX + 1);
-#pragma unroll
-        for (int i = 0; i < NX; ++i) col[i] = m[i].y;
-        col[NX] = mq.y;
+        for (int i = 0; i < NX; ++i) Mk[i * (Lay::NXUP / 2)] = m[i];
+        Mk[NX * (Lay::NXUP / 2)] = mq;
       }
     }
     if (lane == 0) {
@@ -637,24 +644,28 @@ template <class M, typename T, int G, bool EXACT> struct OcSolver {
         for (int i = 0; i < NX; ++i) lam_out[N * NX + i] = lam[i];
       }
     }
-    for (int k = N - 1; k >= 0; --k) {
-      T m[NX], mq = T(0);
+    // this lane's column of [A B; q] and the nominal (x_k, u_k) of one interval.  The loads of interval k-1 are issued
+    // while interval k is being processed (one wave per SIMD: nothing else would hide their latency)
+    auto load_stage = [&](int k_, T* m_, T& mq_, T* xk_, T* uk_) LFSD_LAMBDA_INLINE {
       if (lane < NXU) {
-        const T* col = Mws[cur] + ((long long)k * NXU + lane) * (NX + 1);
+        const T* Mk = Mws[cur] + (long long)k_ * Lay::M_ELEMS + lane;
 #pragma unroll
-        for (int i = 0; i < NX; ++i) m[i] = col[i];
-        mq = col[NX];
+        for (int i = 0; i < NX; ++i) m_[i] = Mk[i * Lay::NXUP];
+        mq_ = Mk[NX * Lay::NXUP];
       } else {
 #pragma unroll
-        for (int i = 0; i < NX; ++i) m[i] = T(0);
+        for (int i = 0; i < NX; ++i) m_[i] = T(0);
+        mq_ = T(0);
       }
-      {
-        const T* xp = xb[cur] + k * NX;  const T* up = ub[cur] + k * NU;
+      const T* xp = xb[cur] + k_ * NX;  const T* up = ub[cur] + k_ * NU;
 #pragma unroll
-        for (int i = 0; i < NX; ++i) xk[i] = xp[i];
+      for (int i = 0; i < NX; ++i) xk_[i] = xp[i];
 #pragma unroll
-        for (int a = 0; a < NU; ++a) uk[a] = up[a];
-      }
+      for (int a = 0; a < NU; ++a) uk_[a] = up[a];
+    };
+    T m[NX], mq = T(0), mN[NX], mqN = T(0), xkN[NX], ukN[NU];
+    load_stage(N - 1, m, mq, xk, uk);
+    for (int k = N - 1; k >= 0; --k) {
       if (lane < NX) {
 #pragma unroll
         for (int i = 0; i < NX; ++i) ldsV[lane * NX + i] = vcol[i];
@@ -664,6 +675,7 @@ template <class M, typename T, int G, bool EXACT> struct OcSolver {
         for (int i = 0; i < NX; ++i) ldsM[lane * NX + i] = m[i];
       }
       __syncthreads();
+      if (LFSD_BW_PREFETCH && k > 0) load_stage(k - 1, mN, mqN, xkN, ukN);
       // Y = Vxx' m_j ;  Qcol = [A B]^T Y
       T Y[NX], Qcol[NXU];
 #pragma unroll
@@ -686,19 +698,19 @@ template <class M, typename T, int G, bool EXACT> struct OcSolver {
         // column `lane` of the exact stage Hessian depends on the nominal and its costates only, not on the shift: a
         // retry of the sweep with a larger shift reads it back instead of repeating the second-order adjoint
         T hx[NX], hu[NU];
-        T* hcol = Hws + ((long long)k * NXU + (lane < NXU ? lane : 0)) * NXU;
+        T* hcol = Hws + (long long)k * Lay::H_ELEMS + (lane < NXU ? lane : 0);      // [row][column], column = lane
         if (reuse_hess) {
 #pragma unroll
-          for (int i = 0; i < NX; ++i) hx[i] = hcol[i];
+          for (int i = 0; i < NX; ++i) hx[i] = hcol[i * Lay::NXUP];
 #pragma unroll
-          for (int a = 0; a < NU; ++a) hu[a] = hcol[NX + a];
+          for (int a = 0; a < NU; ++a) hu[a] = hcol[(NX + a) * Lay::NXUP];
         } else {
           stage_hessian_col(k, xk, uk, lam, hx, hu);
           if (lane < NXU) {
 #pragma unroll
-            for (int i = 0; i < NX; ++i) hcol[i] = hx[i];
+            for (int i = 0; i < NX; ++i) hcol[i * Lay::NXUP] = hx[i];
 #pragma unroll
-            for (int a = 0; a < NU; ++a) hcol[NX + a] = hu[a];
+            for (int a = 0; a < NU; ++a) hcol[(NX + a) * Lay::NXUP] = hu[a];
           }
         }
 #if defined(LFSD_TRACE)
@@ -812,6 +824,17 @@ template <class M, typename T, int G, bool EXACT> struct OcSolver {
         for (int i = 0; i < NX; ++i) vcol[i] = T(0.5) * (vcol[i] + ldsV[i * NX + lane]);
       }
       __syncthreads();
+      if (k > 0) {
+        if (LFSD_BW_PREFETCH) {
+#pragma unroll
+          for (int i = 0; i < NX; ++i) { m[i] = mN[i]; xk[i] = xkN[i]; }
+#pragma unroll
+          for (int a = 0; a < NU; ++a) uk[a] = ukN[a];
+          mq = mqN;
+        } else {
+          load_stage(k - 1, m, mq, xk, uk);
+        }
+      }
     }
     ldsRed[lane] = gl_max;
     __syncthreads();
@@ -881,12 +904,12 @@ LFSD_DEV void oc_bind(Sol& s, const OcArgs<T>& a, T* region, long long slot, boo
   s.xb[1] = w; w += (N + 1) * NX;
   s.ub[0] = w; w += N * NU;
   s.ub[1] = w; w += N * NU;
-  s.Mws[0] = w; w += (long long)N * (NX + NU) * (NX + 1);
-  s.Mws[1] = w; w += (long long)N * (NX + NU) * (NX + 1);
+  s.Mws[0] = w; w += (long long)N * Lay::M_ELEMS;
+  s.Mws[1] = w; w += (long long)N * Lay::M_ELEMS;
   s.Kws = w; w += (long long)N * NX * NU;
   s.kws = w; w += N * NU;
   s.exws = w; w += (long long)Lay::SMAX * NX * (1 + GL);
-  s.Hws = w; w += (long long)N * (NX + NU) * (NX + NU);
+  s.Hws = w; w += (long long)N * Lay::H_ELEMS;
   // padding groups (slot >= batch) clone the last trajectory and keep their costates in scratch
   s.lam_out = valid ? a.costate_grid + traj * (N + 1) * NX : w;
 }

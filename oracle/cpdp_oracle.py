@@ -455,6 +455,8 @@ class COCSys:
         for k in range(N, 0, -1):
             t_span = [time_grid[k], time_grid[k - 1]]
             sol = solve_ivp(vec_PW_ode, t_span, vec_PW_grid[k, :], t_eval=[t_span[1]], method=riccati_method, **kw)
+            if not sol.success:        # finite escape of the Riccati solution (a conjugate point): the reference would crash here too
+                raise RuntimeError("Riccati sweep failed on interval %d: %s" % (k, sol.message))
             vec_PW_grid[k - 1, :] = sol.y.ravel()
         vec_PW_sol = self.interpolation(time_grid, vec_PW_grid)
 

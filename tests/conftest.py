@@ -104,3 +104,91 @@ def oracle_check_solution(oc, ini_state, horizon, theta, X, U, L, taus, wps, ifa
     aux, PW, vX, vU = oc.auxSysSolver(tg, sol, theta, return_grids=True, **(TIGHT if tight else {}))
     loss, grad = getloss_corrections(oc, taus, wps, sol, aux, iface)
     return dict(defect=defect, gmax=gmax, lmax=lmax, loss=loss, grad=grad, PW=PW, vX=vX, vU=vU)
+
+
+# ---- the slow fp64 oracle, fanned out over the host cores (plain child processes, one BLAS thread each) -------------
+_ORACLES = {}
+
+
+def oracle_job(job):
+    """job: dict(kind, n_grid, ini_state, horizon, theta, taus, wps, iface, tight=True, solver_kw={}, make_kw={},
+    check=None).  check = (X, U, L): do not solve, certify + differentiate these grids (oracle_check_solution)."""
+    key = (job["kind"], job["n_grid"], tuple(sorted(job.get("make_kw", {}).items())))
+    if key not in _ORACLES:
+        _ORACLES[key] = make_oracle(job["kind"], job["n_grid"], **job.get("make_kw", {}))
+    o = _ORACLES[key]
+    if job.get("check") is not None:
+        X, U, L = job["check"]
+        return oracle_check_solution(o, job["ini_state"], job["horizon"], job["theta"], X, U, L, job["taus"], job["wps"],
+                                     job["iface"], tight=job.get("tight", True))
+    try:
+        r = oracle_loss_grad(o, job["ini_state"], job["horizon"], job["theta"], job["taus"], job["wps"], job["iface"],
+                             tight=job.get("tight", True), **job.get("solver_kw", {}))
+    except RuntimeError as exc:          # e.g. finite escape of the Riccati solution (conjugate point) under the tight integrator
+        if job.get("allow_fail"):
+            return dict(error=str(exc))
+        raise
+    r["cost"] = o.last_cost
+    return r
+
+
+def oracle_parallel(jobs, timeout=1500.0):
+    """Results of oracle_job for every job, computed by min(len(jobs), cores) child processes."""
+    import pickle
+    import tempfile
+    import time
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        cores = os.cpu_count() or 1
+    w = max(1, min(len(jobs), cores))
+    if w == 1:
+        return [oracle_job(j) for j in jobs]
+    env = dict(os.environ, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1")
+    with tempfile.TemporaryDirectory() as td:
+        procs = []
+        for i in range(w):
+            jp, op = os.path.join(td, "j%d.pkl" % i), os.path.join(td, "o%d.pkl" % i)
+            with open(jp, "wb") as f:
+                pickle.dump(jobs[i::w], f)
+            procs.append((subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "oracle_worker.py"), jp, op], env=env), op))
+        deadline = time.time() + timeout
+        try:
+            for pr, _ in procs:
+                pr.wait(max(1.0, deadline - time.time()))
+                assert pr.returncode == 0, "oracle worker failed"
+        finally:
+            for pr, _ in procs:
+                if pr.poll() is None:
+                    pr.kill()
+        out = [None] * len(jobs)
+        for i, (_, op) in enumerate(procs):
+            out[i::w] = pickle.load(open(op, "rb"))
+    return out
+
+
+def assert_grids_match(sol, aux, b, r, n, m, p, tol, what=""):
+    """Every output of the path vs the oracle: state / control / costate grids (CPDP.py:186-196), Riccati pair [P W]
+    (CPDP.py:329-338), dx/dtheta and du/dtheta (CPDP.py:352-381), loss and gradient.  tol: dict(grid, costate, aux, loss, grad)."""
+    import numpy as np
+
+    def rel(a, ref):
+        a = a.detach().double().cpu().numpy() if hasattr(a, "detach") else np.asarray(a, dtype=np.float64)
+        ref = np.asarray(ref, dtype=np.float64)
+        return np.abs(a - ref).max() / max(np.abs(ref).max(), 1e-300)
+    assert rel(sol["state_grid"][b], r["X"]) < tol["grid"], (what, "state", rel(sol["state_grid"][b], r["X"]))
+    assert rel(sol["control_grid"][b], r["U"]) < tol["grid"], (what, "control", rel(sol["control_grid"][b], r["U"]))
+    assert rel(sol["costate_grid"][b], r["L"]) < tol["costate"], (what, "costate", rel(sol["costate_grid"][b], r["L"]))
+    N1 = r["PW"].shape[0]
+    Zo = np.concatenate([r["PW"][:, :n * n].reshape(N1, n, n), r["PW"][:, n * n:].reshape(N1, n, p)], axis=2)
+    e = rel(aux["Z_grid"][b].permute(0, 2, 1), Zo)
+    assert e < tol["aux"], (what, "Z_grid", e)
+    e = rel(aux["auxX_grid"][b].permute(0, 2, 1).reshape(N1, n * p), r["vX"])
+    assert e < tol["aux"], (what, "auxX_grid", e)
+    # du/dtheta(T) = -Huu^-1 (fu^T h_xx) dx/dtheta(T) + ...  amplifies the error of dx/dtheta by |Huu^-1 fu^T h_xx| (10^3 for the
+    # arm's final-cost weight 100), hence its own tolerance
+    e = rel(aux["auxU_grid"][b].permute(0, 2, 1).reshape(N1, m * p), r["vU"])
+    assert e < tol.get("auxU", tol["aux"]), (what, "auxU_grid", e)
+    assert abs(float(aux["loss"][b]) - r["loss"]) < tol["loss"] * max(1.0, r["loss"]), (what, "loss", float(aux["loss"][b]), r["loss"])
+    e = rel(aux["grad"][b], r["grad"])
+    assert e < tol["grad"], (what, "grad", e)

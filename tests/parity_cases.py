@@ -1,0 +1,128 @@
+"""Parity cases shared by the CPU tier (kernels through the SIMT emulator) and the -m gpu tier (gfx950 libraries): the same
+comparison code runs on both, so a case that is green on the emulator and red on the GPU isolates a device-side
+problem.  `prepare(oc, dtype)` binds the model to its backend (emulator library / cuda:0) and returns it.
+
+Stated tolerances (relative to the largest component of the compared array):
+
+                       fp64                                   fp32 (fp64 -> fp32 tolerance of the pipeline)
+  state/control grids  1e-6                                   5e-3
+  costate grid         1e-5                                   2e-2  (flat-cost problems: arm, cart-pole)
+  Z = [P W], dx/dth,   2e-3 at 16 sub-steps                   2e-2
+  du/dth               (4th-order split-step sweeps vs Radau rtol 1e-10); du/dth 2e-2 / 5e-2: its value at t = T is
+                       -Huu^-1 fu^T h_xx dx/dth(T), which multiplies the error of dx/dth by ~10^3 on the robot arm
+  loss                 1e-6                                   2e-3
+  gradient             1e-4                                   2e-2
+"""
+import numpy as np
+import torch
+
+import lfsd_amd  # noqa: F401
+from lfsd_amd import models
+from conftest import oracle_parallel, assert_grids_match
+
+TOL = {torch.float64: dict(grid=1e-6, costate=1e-5, aux=2e-3, auxU=2e-2, loss=1e-6, grad=1e-4),
+       torch.float32: dict(grid=5e-3, costate=2e-2, aux=2e-2, auxU=5e-2, loss=2e-3, grad=2e-2)}
+
+G_CASES = {
+    "pendulum": dict(n_grid=10, thetas=[[1.0, 0.5, 1.5], [2.0, 1.0, 1.0], [0.7, 1.3, 0.6]],
+                     taus=[0.0, 0.3, 0.6, 0.7, 1.0], wps=[[0.0], [1.2], [2.1], [2.4], [2.9]]),
+    "robotarm": dict(n_grid=12, thetas=[[5., 1, 1, 1, 1], [3., 0.5, 2, 1.5, 0.2]], taus=[0.3],
+                     wps=[[-np.pi / 4, 2 * np.pi / 3]]),
+    "cartpole": dict(n_grid=10, thetas=[[1.0, 0.5, 0.5, 0.5, 0.5], [0.8, 2, 0.3, 1, 1]], taus=[0.25, 0.8],
+                     wps=[[0.1, 0.5], [0.0, 2.5]]),
+    "quadrotor": dict(n_grid=10, thetas=[[1, 0.1, 0.1, 0.1, 0.1, 0.1, -1], [1.4, 0.3, 0.05, 0.2, 0.1, 0.15, -0.8]],
+                      taus=None, wps=None),
+}
+
+
+def all_grids_vs_oracle(prepare, kind, dtype, substeps=16, tol=None):
+    """Every output array of cocSolver + auxSysSolver (state, control, costate, [P W], dx/dtheta, du/dtheta, loss,
+    gradient) against the tight oracle."""
+    c = G_CASES[kind]
+    oc, env, d = models.ZOO[kind](n_grid=c["n_grid"])
+    prepare(oc, dtype)
+    oc.setSolverOptions(aux_substeps=substeps)
+    taus = c["taus"] if c["taus"] is not None else d["taus"]
+    wps = c["wps"] if c["wps"] is not None else d["waypoints"]
+    th = np.asarray(c["thetas"], dtype=np.float64)
+    B = len(th)
+    sol = oc.cocSolverBatch(np.tile(d["ini_state"], (B, 1)), d["horizon"], th)
+    aux = oc.auxSysSolverBatch(sol, taus, wps, d["interface"], want_grids=True)
+    assert set(sol["status"].tolist()) <= {1, 2}, sol["status"]
+    refs = oracle_parallel([dict(kind=kind, n_grid=c["n_grid"], ini_state=d["ini_state"], horizon=d["horizon"],
+                                 theta=list(t), taus=taus, wps=wps, iface=d["interface"]) for t in th])
+    lib = oc.compile()
+    for b in range(B):
+        assert_grids_match(sol, aux, b, refs[b], lib.n_state, lib.n_control, lib.n_auxvar, tol or TOL[dtype],
+                           what="%s %s seed %d" % (kind, dtype, b))
+    return oc, d, sol, aux, refs
+
+
+def single_trajectory_api(prepare, kind="robotarm", dtype=torch.float64):
+    """The reference-shaped calls oc.cocSolver(ini_state, horizon, theta) -> (time_grid, opt_sol) and
+    oc.auxSysSolver(time_grid, opt_sol, theta) -> auxsys_sol (CPDP.py:92, 301): return types, shapes, values."""
+    c = G_CASES[kind]
+    oc, env, d = models.ZOO[kind](n_grid=c["n_grid"])
+    prepare(oc, dtype)
+    oc.setSolverOptions(aux_substeps=16)
+    th = c["thetas"][1]
+    time_grid, opt_sol = oc.cocSolver(d["ini_state"], d["horizon"], th)
+    auxsys_sol = oc.auxSysSolver(time_grid, opt_sol, th)
+    lib = oc.compile()
+    n, m, p = lib.n_state, lib.n_control, lib.n_auxvar
+    N = c["n_grid"]
+    assert time_grid.shape == (N + 1,) and opt_sol(0.37 * d["horizon"]).shape == (2 * n + m,)
+    assert auxsys_sol(0.37 * d["horizon"]).shape == (n * p + m * p,)
+    taus = c["taus"] if c["taus"] is not None else d["taus"]
+    wps = c["wps"] if c["wps"] is not None else d["waypoints"]
+    r = oracle_parallel([dict(kind=kind, n_grid=N, ini_state=d["ini_state"], horizon=d["horizon"], theta=th, taus=taus,
+                              wps=wps, iface=d["interface"])])[0]
+    t = TOL[dtype]
+    g = opt_sol(time_grid)
+    ref = np.concatenate((r["X"], r["U"], r["L"]), axis=1)
+    assert np.abs(g - ref).max() < 10 * t["grid"] * np.abs(ref).max()
+    a = auxsys_sol(time_grid)                       # [vec(dx/dtheta) row-major n x p | vec(du/dtheta) m x p]
+    aref = np.concatenate((r["vX"], r["vU"]), axis=1)
+    assert np.abs(a[:, :n * p] - r["vX"]).max() < t["aux"] * np.abs(r["vX"]).max()
+    assert np.abs(a[:, n * p:] - r["vU"]).max() < t["auxU"] * np.abs(r["vU"]).max()
+    # between grid points both are linear interpolants of the grid values (CPDP.py:386)
+    tm = 0.5 * (time_grid[3] + time_grid[4])
+    assert np.allclose(opt_sol(tm), 0.5 * (g[3] + g[4]), rtol=1e-12, atol=1e-14)
+    assert np.allclose(auxsys_sol(tm), 0.5 * (a[3] + a[4]), rtol=1e-12, atol=1e-14)
+
+
+def rocket_mixed_precision(prepare, n_grid=15):
+    """BASELINE configs[4]'s arithmetic: fp32 optimal-control solve + fp64 auxiliary (Riccati / sensitivity) pass
+    (COCSys.setDevice(aux_dtype=float64)).  The rocket has several local minima, so the check is basin-independent: the
+    oracle certifies the solved grids as a KKT point of the reference's NLP (to fp32 accuracy) and differentiates the
+    PMP along exactly those grids -- which is what the fp64 auxiliary pass computes, so loss and gradient must agree to
+    fp64 tolerances although the solve ran in fp32."""
+    oc, env, d = models.rocket(n_grid=n_grid)
+    prepare(oc, torch.float32)
+    oc.setDevice(aux_dtype=torch.float64)
+    oc.setSolverOptions(aux_substeps=16)
+    th = d["true_theta"]
+    sol = oc.cocSolverBatch([d["ini_state"]] * 2, d["horizon"], [th] * 2)
+    assert set(sol["status"].tolist()) <= {1, 2}, sol["status"]
+    X, U, Lm = (sol[k][1].double().cpu().numpy() for k in ("state_grid", "control_grid", "costate_grid"))
+    idx = [1, 3, 6, 10, 13]
+    taus = np.linspace(0, d["horizon"], n_grid + 1)[idx]           # rocket_groundtruth.py:78
+    wps = [np.concatenate([X[k, 0:3], X[k, 6:10]]) + 0.05 for k in idx]
+    aux = oc.auxSysSolverBatch(sol, taus, wps, d["interface"], want_grids=True)
+    assert aux["loss"].dtype == torch.float64 and aux["Z_grid"].dtype == torch.float64
+    r = oracle_parallel([dict(kind="rocket", n_grid=n_grid, ini_state=d["ini_state"], horizon=d["horizon"], theta=th,
+                              taus=list(taus), wps=wps, iface=d["interface"], check=(X, U, Lm))])[0]
+    # KKT point to fp32 accuracy: feasibility exact (single shooting), stationarity / costates at the fp32 floor
+    J = float(sol["cost"][1])
+    assert r["defect"] < 1e-4 * np.abs(X).max() and r["gmax"] < 2e-4 * (1 + abs(J)) and r["lmax"] < 5e-3 * np.abs(Lm).max(), \
+        (r["defect"], r["gmax"], r["lmax"], J, np.abs(Lm).max())
+    n, m, p = 13, 3, 12
+    N1 = n_grid + 1
+    Zo = np.concatenate([r["PW"][:, :n * n].reshape(N1, n, n), r["PW"][:, n * n:].reshape(N1, n, p)], axis=2)
+    rel = lambda a, b: np.abs(a - b).max() / np.abs(b).max()
+    assert rel(aux["Z_grid"][1].permute(0, 2, 1).cpu().numpy(), Zo) < 2e-3
+    assert rel(aux["auxX_grid"][1].permute(0, 2, 1).reshape(N1, n * p).cpu().numpy(), r["vX"]) < 2e-3
+    assert rel(aux["auxU_grid"][1].permute(0, 2, 1).reshape(N1, m * p).cpu().numpy(), r["vU"]) < 2e-3
+    assert abs(aux["loss"][1].item() - r["loss"]) < 1e-6 * max(1.0, r["loss"])
+    assert rel(aux["grad"][1].cpu().numpy(), r["grad"]) < 1e-3
+    return sol, aux

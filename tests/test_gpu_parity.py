@@ -7,7 +7,8 @@ import torch
 
 import lfsd_amd  # noqa: F401
 from lfsd_amd import CPDP, models, runtime
-from conftest import make_oracle, oracle_loss_grad
+from conftest import make_oracle, oracle_loss_grad, oracle_parallel, oracle_check_solution, assert_grids_match
+import parity_cases as pc
 
 pytestmark = pytest.mark.gpu
 G = np.load(os.path.join(os.path.dirname(__file__), "golden", "uav_golden.npz"))
@@ -28,41 +29,45 @@ def gpu_model(kind, dtype, n_grid, substeps=8):
     return oc, d
 
 
-# stated tolerances: fp64 (loss 1e-7, grad 1e-4 at 8-16 substeps); fp32 = fp64->fp32 tolerance of the
-# pipeline (loss 1e-4 well-conditioned / 2e-3 flat-cost problems, gradient 5e-3 / 2e-2)
-@pytest.mark.parametrize("dtype,ltol,gtol", [(torch.float64, 1e-7, 1e-4), (torch.float32, 1e-4, 5e-3)])
-def test_pendulum_vs_oracle(dtype, ltol, gtol):
-    oc, d = gpu_model("pendulum", dtype, 10, substeps=16)
-    thetas = np.array([[1.0, 0.5, 1.5], [2.0, 1.0, 1.0], [0.7, 1.3, 0.6]])
-    taus, wps = [0.0, 0.3, 0.6, 0.7, 1.0], [[0.0], [1.2], [2.1], [2.4], [2.9]]
-    sol = oc.cocSolverBatch(np.tile(d["ini_state"], (3, 1)), d["horizon"], thetas)
-    aux = oc.auxSysSolverBatch(sol, taus, wps, d["interface"], want_grids=True)
-    o = make_oracle("pendulum", 10)
+def gpu_prepare(oc, dtype):
+    oc.setDevice("cuda:0", dtype)
+    assert not oc.compile().is_emulator, "the GPU tier must run the HIP library"
+    return oc
+
+
+@pytest.mark.parametrize("kind", ["pendulum", "robotarm", "cartpole", "quadrotor"])
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+def test_every_output_grid_vs_oracle(kind, dtype):
+    """state / control / costate grids, Z = [P W], dx/dtheta, du/dtheta, loss, gradient -- all of them, on the GPU, against
+    the tight oracle (tolerances: parity_cases.TOL)."""
+    pc.all_grids_vs_oracle(gpu_prepare, kind, dtype)
+
+
+@pytest.mark.parametrize("kind", ["pendulum", "robotarm"])
+def test_reference_shaped_single_trajectory_api(kind):
+    """oc.cocSolver(ini_state, horizon, theta) / oc.auxSysSolver(time_grid, opt_sol, theta) with the reference's signatures
+    and return types (CPDP.py:92, 301), through the HIP library."""
+    pc.single_trajectory_api(gpu_prepare, kind)
+
+
+@pytest.mark.parametrize("dtype,ltol,gtol,xtol", [(torch.float64, 1e-6, 1e-3, 1e-6), (torch.float32, 5e-4, 1e-2, 5e-3)])
+def test_quadrotor_bench_seeds_vs_tight_oracle(dtype, ltol, gtol, xtol):
+    """The headline configuration itself (n_grid 50, the first seeds bench.py draws, aux_substeps 4) against the TIGHT oracle
+    (Radau, rtol 1e-10), so the floor of the shipped fp32 path is known apart from the reference integrator's own 5e-3:
+    fp64 isolates the discretisation error of the 4-sub-step sweeps, fp32 adds the arithmetic."""
+    oc, d = gpu_model("quadrotor", dtype, 50, substeps=4)
+    rng = np.random.default_rng(1234)
+    th = np.array(d["theta0"])[None, :] + 0.05 * rng.standard_normal((4096, 7))
+    th[:, 0] = np.abs(th[:, 0]) + 0.5
+    th = th[:4]
+    sol = oc.cocSolverBatch(np.tile(d["ini_state"], (4, 1)), d["horizon"], th)
+    aux = oc.auxSysSolverBatch(sol, d["taus"], d["waypoints"], d["interface"], want_grids=True)
     assert set(sol["status"].tolist()) <= {1, 2}
-    for b in range(3):
-        r = oracle_loss_grad(o, d["ini_state"], d["horizon"], thetas[b], taus, wps, d["interface"])
-        assert rel(sol["state_grid"][b], r["X"]) < (1e-6 if dtype == torch.float64 else 5e-3)
-        assert abs(aux["loss"][b].item() - r["loss"]) < ltol * max(1.0, r["loss"])
-        assert rel(aux["grad"][b], r["grad"]) < gtol
-        n, p = 2, 3
-        assert rel(aux["auxX_grid"][b].permute(0, 2, 1).reshape(-1, n * p), r["vX"]) < (1e-3 if dtype == torch.float64 else 1e-2)
-
-
-@pytest.mark.parametrize("kind,n_grid,thetas,taus,wps", [
-    ("robotarm", 12, [[5., 1, 1, 1, 1], [3., 0.5, 2, 1.5, 0.2]], [0.3], [[-np.pi / 4, 2 * np.pi / 3]]),
-    ("cartpole", 10, [[1.0, 0.5, 0.5, 0.5, 0.5], [0.8, 2, 0.3, 1, 1]], [0.25, 0.8], [[0.1, 0.5], [0.0, 2.5]])])
-def test_robotarm_cartpole_vs_oracle(kind, n_grid, thetas, taus, wps):
-    o = make_oracle(kind, n_grid)
-    refs = None
-    for dtype, ltol, gtol in ((torch.float64, 1e-6, 1e-4), (torch.float32, 2e-3, 2e-2)):
-        oc, d = gpu_model(kind, dtype, n_grid, substeps=16)
-        refs = refs or [oracle_loss_grad(o, d["ini_state"], d["horizon"], th, taus, wps, d["interface"]) for th in thetas]
-        B = len(thetas)
-        sol = oc.cocSolverBatch(np.tile(d["ini_state"], (B, 1)), d["horizon"], np.array(thetas))
-        aux = oc.auxSysSolverBatch(sol, taus, wps, d["interface"])
-        for b in range(B):
-            assert abs(aux["loss"][b].item() - refs[b]["loss"]) < ltol * max(1.0, refs[b]["loss"]), (kind, dtype)
-            assert rel(aux["grad"][b], refs[b]["grad"]) < gtol, (kind, dtype)
+    refs = oracle_parallel([dict(kind="quadrotor", n_grid=50, ini_state=d["ini_state"], horizon=d["horizon"], theta=list(t),
+                                 taus=d["taus"], wps=d["waypoints"], iface=d["interface"]) for t in th])
+    tol = dict(grid=xtol, costate=10 * xtol, aux=10 * gtol, auxU=10 * gtol, loss=ltol, grad=gtol)
+    for b in range(4):
+        assert_grids_match(sol, aux, b, refs[b], 13, 4, 7, tol, what="bench seed %d %s" % (b, dtype))
 
 
 @pytest.mark.parametrize("dtype,ltol", [(torch.float64, 1e-6), (torch.float32, 5e-4)])
@@ -179,25 +184,35 @@ def test_optimizer_kernels(method):
 
 
 def test_rocket_newton_mode_vs_oracle():
-    """BASELINE configs[4] robot (Examples/rocket_groundtruth.py): exact stage Hessians from the first iteration."""
+    """BASELINE configs[4] robot (Examples/rocket_groundtruth.py): exact stage Hessians from the first iteration.  Several
+    local minima: which one a cold start reaches depends on the globalisation (IPOPT's would differ from ours and from the
+    oracle's), so parity is basin-independent -- the oracle certifies the kernel's cold-start answer as a KKT point of the
+    reference's NLP with complex-step arithmetic and differentiates the PMP along it; and the oracle's own KKT point,
+    handed over as the initial guess, is where the kernel stays."""
     o = make_oracle("rocket", 15)
     oc, d = gpu_model("rocket", torch.float64, 15, substeps=8)
     th = d["true_theta"]
-    taus = np.linspace(0, d["horizon"], 16)[[1, 3, 6, 10, 13]]
-    r0 = o.cocSolver(d["ini_state"], d["horizon"], th, return_grids=True, exact_after=0, max_iter=400)
-    wps = [np.concatenate([r0[1](t)[0:3], r0[1](t)[6:10]]) + 0.05 for t in taus]
-    r = oracle_loss_grad(o, d["ini_state"], d["horizon"], th, taus, wps, d["interface"], exact_after=0, max_iter=400)
+    idx = [1, 3, 6, 10, 13]
+    taus = np.linspace(0, d["horizon"], 16)[idx]
     sol = oc.cocSolverBatch([d["ini_state"]] * 3, d["horizon"], [th] * 3)
-    aux = oc.auxSysSolverBatch(sol, taus, wps, d["interface"])
     assert sol["status"].tolist() == [1, 1, 1]
-    assert abs(sol["cost"][0].item() - o.last_cost) < 1e-8 * abs(o.last_cost)
-    assert rel(sol["state_grid"][2], r["X"]) < 1e-6
+    X, U, Lm = (sol[k][2].cpu().numpy() for k in ("state_grid", "control_grid", "costate_grid"))
+    wps = [np.concatenate([X[k, 0:3], X[k, 6:10]]) + 0.05 for k in idx]
+    aux = oc.auxSysSolverBatch(sol, taus, wps, d["interface"])
+    r = oracle_check_solution(o, d["ini_state"], d["horizon"], th, X, U, Lm, taus, wps, d["interface"])
+    assert r["defect"] < 1e-9 and r["gmax"] < 1e-6 and r["lmax"] < 1e-6 * np.abs(Lm).max(), (r["defect"], r["gmax"], r["lmax"])
     assert abs(aux["loss"][1].item() - r["loss"]) < 1e-7 * max(1.0, r["loss"]) and rel(aux["grad"][1], r["grad"]) < 1e-3
-    oc32, _ = gpu_model("rocket", torch.float32, 15, substeps=8)
-    sol32 = oc32.cocSolverBatch([d["ini_state"]], d["horizon"], [th])
-    aux32 = oc32.auxSysSolverBatch(sol32, taus, wps, d["interface"])
-    assert sol32["status"].item() in (1, 2)
-    assert abs(aux32["loss"][0].item() - r["loss"]) < 2e-3 * max(1.0, r["loss"]) and rel(aux32["grad"][0], r["grad"]) < 2e-2
+    r0 = o.cocSolver(d["ini_state"], d["horizon"], th, return_grids=True, exact_after=0, max_iter=400)
+    assert o.last_info["converged"]
+    u0 = torch.as_tensor(r0[3][None, :-1].copy(), device="cuda:0")
+    sol2 = oc.cocSolverBatch([d["ini_state"]], d["horizon"], [th], u_init=u0)
+    assert sol2["status"].tolist() == [1] and abs(sol2["cost"][0].item() - o.last_cost) < 1e-8 * abs(o.last_cost)
+    assert rel(sol2["state_grid"][0], r0[2]) < 1e-6 and rel(sol2["costate_grid"][0], r0[4]) < 1e-5
+
+
+def test_rocket_fp32_solve_fp64_aux_vs_oracle():
+    """The mixed-precision path of BASELINE configs[4] (setDevice(aux_dtype=float64), CPDP.py:247-250 of this package)."""
+    pc.rocket_mixed_precision(gpu_prepare)
 
 
 def test_time_varying_model_vs_oracle():
@@ -240,34 +255,192 @@ def test_quadalgorithm_driver_fp32_follows_reference_run():
     assert np.allclose(res["parameter_trace"][10, 0], G["theta_trace"][10], rtol=1e-2, atol=2e-3)
 
 
-def test_robotarm_batch1024_random_seeds_configs1():
-    """BASELINE configs[1]: robot arm, n_grid 50, 1024 random seeds, fp32.  At the perturbed initial guesses every cold-started
-    solve has to finish (converged, or stalled at fp32 working precision) and the fp32 loss / gradient have to agree with the
-    fp64 kernels on every seed (stated fp32 tolerances for the flat-cost arm: loss 2e-3, gradient 2e-2; measured 4e-4).
-    Then five plain gradient steps at the example's learning rate (Examples/robotarm_random.py): no trajectory may be lost
-    to a non-finite parameter -- an unconverged solve is skipped and continued, not applied."""
-    from lfsd_amd import CPDP
-    B = 1024
+def _arm_seeds(B=1024):
     rng = np.random.default_rng(0)
     th = np.array([5.0, 1, 1, 1, 1])[None, :] * (1 + 0.05 * rng.standard_normal((B, 5)))     # around the example's initial guess
     th[:, 0] = np.abs(th[:, 0]) + 0.1
+    return th
+
+
+def test_robotarm_batch1024_random_seeds_configs1():
+    """BASELINE configs[1]: robot arm, n_grid 50, 1024 random seeds.  EVERY cold-started solve has to end converged (or
+    stalled at fp32 working precision) -- at the perturbed initial guesses theta_0 and at theta_1 = theta_0 - lr*grad_0
+    (Examples/robotarm_random.py:67-73), where the round-1 step control left 64 of 1024 at the iteration limit -- in
+    fp32 and in fp64, with the fp32 loss within 2e-3 of fp64 on every seed and the fp32 gradient within 2e-2 (flat-cost
+    arm) on every seed at theta_0 and on >= 98 % of them at theta_1 (see below)."""
+    B = 1024
+    th0 = _arm_seeds(B)
     res = {}
-    for dt in (torch.float32, torch.float64):
-        oc, d = gpu_model("robotarm", dt, 50, substeps=4)
-        sol = oc.cocSolverBatch(np.tile(d["ini_state"], (B, 1)), d["horizon"], th)
-        aux = oc.auxSysSolverBatch(sol, d["taus"], d["waypoints"], d["interface"])
-        st = sol["status"].cpu().numpy()
-        assert np.isin(st, (1, 2)).all(), (dt, np.bincount(st, minlength=5))
-        res[dt] = (aux["loss"].double().cpu().numpy(), aux["grad"].double().cpu().numpy())
-    l32, g32 = res[torch.float32]
-    l64, g64 = res[torch.float64]
-    assert (np.abs(l32 - l64) < 2e-3 * np.maximum(1.0, l64)).all()
-    assert (np.abs(g32 - g64).max(1) < 2e-2 * np.abs(g64).max(1)).all()
+    thetas = {"theta0": th0}
+    for name in ("theta0", "theta1"):
+        for dt in (torch.float64, torch.float32):
+            oc, d = gpu_model("robotarm", dt, 50, substeps=4)
+            sol = oc.cocSolverBatch(np.tile(d["ini_state"], (B, 1)), d["horizon"], thetas[name])
+            aux = oc.auxSysSolverBatch(sol, d["taus"], d["waypoints"], d["interface"])
+            st = sol["status"].cpu().numpy()
+            assert np.isin(st, (1, 2)).mean() == 1.0, (dt, name, np.bincount(st, minlength=5))
+            res[(dt, name)] = (aux["loss"].double().cpu().numpy(), aux["grad"].double().cpu().numpy())
+        if name == "theta0":
+            th1 = th0 - d["lr"] * res[(torch.float64, "theta0")][1]
+            th1[:, 0] = np.maximum(th1[:, 0], 1e-8)
+            thetas["theta1"] = th1
+        l32, g32 = res[(torch.float32, name)]
+        l64, g64 = res[(torch.float64, name)]
+        assert (np.abs(l32 - l64) < 2e-3 * np.maximum(1.0, l64)).all(), name
+        gerr = np.abs(g32 - g64).max(1) / np.abs(g64).max(1)
+        if name == "theta0":
+            assert (gerr < 2e-2).all(), (name, gerr.max())
+        else:
+            # theta_1: about 1 % of the seeds sit next to a conjugate point of the optimal-control problem (the tight oracle's
+            # Riccati integration has a finite escape there, next test); the same KKT point is found (loss above), but its
+            # sensitivity is ill-conditioned with respect to the trajectory itself: fp32 round-off of the SOLVE moves it by
+            # O(1), whichever precision the auxiliary pass runs in.  Stated: >= 98 % of the seeds within 2e-2.
+            assert (gerr < 2e-2).mean() >= 0.98, (name, (gerr < 2e-2).mean())
+
+
+def test_robotarm_theta1_vs_oracle_16_seeds():
+    """HIP vs the tight oracle at theta_1 on >= 16 of the 1024 seeds: 12 drawn at random and the 12 with the largest
+    gradients below 100x the typical one (sensitivities of 10-100x: these parameters sit next to a conjugate point of the
+    optimal-control problem; the oracle confirms the numbers).  Where the tight Riccati integration itself runs into the
+    pole (finite escape: scipy gives up, as the reference's BDF call would or would step across) there is no number to
+    compare with and the seed is skipped; at least 16 comparisons must remain."""
+    B = 1024
+    th0 = _arm_seeds(B)
+    oc, d = gpu_model("robotarm", torch.float64, 50, substeps=8)
+    x0 = np.tile(d["ini_state"], (B, 1))
+    sol = oc.cocSolverBatch(x0, d["horizon"], th0)
+    aux = oc.auxSysSolverBatch(sol, d["taus"], d["waypoints"], d["interface"])
+    th1 = th0 - d["lr"] * aux["grad"].cpu().numpy()
+    th1[:, 0] = np.maximum(th1[:, 0], 1e-8)
+    sol = oc.cocSolverBatch(x0, d["horizon"], th1)
+    aux = oc.auxSysSolverBatch(sol, d["taus"], d["waypoints"], d["interface"])
+    g = aux["grad"].cpu().numpy()
+    gmax = np.abs(g).max(1)
+    cand = np.where(gmax < 100 * np.median(gmax))[0]
+    pick = list(cand[np.argsort(-gmax[cand])[:12]]) + list(np.random.default_rng(1).choice(B, 12, replace=False))
+    refs = oracle_parallel([dict(kind="robotarm", n_grid=50, ini_state=d["ini_state"], horizon=d["horizon"],
+                                 theta=list(th1[b]), taus=d["taus"], wps=d["waypoints"], iface=d["interface"],
+                                 allow_fail=True) for b in pick])
+    oc32, _ = gpu_model("robotarm", torch.float32, 50, substeps=8)
+    sol32 = oc32.cocSolverBatch(x0[pick], d["horizon"], th1[pick])
+    aux32 = oc32.auxSysSolverBatch(sol32, d["taus"], d["waypoints"], d["interface"])
+    compared = 0
+    for k, b in enumerate(pick):
+        r = refs[k]
+        if "error" in r:
+            assert "Riccati" in r["error"], r["error"]
+            continue
+        compared += 1
+        big = np.abs(r["grad"]).max() > 10 * np.median(gmax)
+        assert rel(sol["state_grid"][b], r["X"]) < 1e-6 and rel(sol["costate_grid"][b], r["L"]) < 1e-5, b
+        assert abs(aux["loss"][b].item() - r["loss"]) < 1e-6 * max(1.0, r["loss"]), b
+        assert rel(aux["grad"][b], r["grad"]) < (1e-3 if big else 1e-4), (b, g[b], r["grad"])
+        assert abs(aux32["loss"][k].item() - r["loss"]) < 2e-3 * max(1.0, r["loss"]), b
+        assert rel(aux32["grad"][k], r["grad"]) < (2e-1 if big else 2e-2), (b, aux32["grad"][k], r["grad"])
+    assert compared >= 16, compared
+
+
+def test_robotarm_12_vanilla_steps_every_gradient_applied():
+    """Twelve plain gradient steps at the example's learning rate 0.1 with skip_unconverged=False (the reference's loop,
+    Examples/robotarm_random.py:60-73), 1024 seeds, fp32.  The fixed learning rate throws the few large-sensitivity seeds
+    (previous test) out of the region where the problem is well posed -- negative quadratic state weights make the
+    running cost non-convex; no solver has a KKT point to return there (J runs to -10^3 ... -10^4) -- so the assertion
+    is on the admissible seeds: finite parameters, beta > 0, both quadratic weights > 0.05.  Every one of them has to
+    converge at every step."""
+    from lfsd_amd import CPDP
+    B = 1024
+    th0 = _arm_seeds(B)
     oc, d = gpu_model("robotarm", torch.float32, 50, substeps=4)
-    L = CPDP.SparseDemoLearner(oc, np.tile(d["ini_state"], (B, 1)), d["horizon"], d["taus"], d["waypoints"], d["interface"], th,
-                               method="Vanilla", learning_rate=d["lr"])
-    for _ in range(5):
-        loss, grad = L.step()
-    assert torch.isfinite(L.theta).all() and torch.isfinite(grad).all()
-    st = L._sol["status"].cpu().numpy()
-    assert (st == 4).mean() < 0.01 and np.isin(st, (1, 2)).mean() > 0.85, np.bincount(st, minlength=5)
+    L = CPDP.SparseDemoLearner(oc, np.tile(d["ini_state"], (B, 1)), d["horizon"], d["taus"], d["waypoints"], d["interface"], th0,
+                               method="Vanilla", learning_rate=d["lr"], skip_unconverged=False)
+    for k in range(13):
+        th = L.theta.double().cpu().numpy()
+        adm = np.isfinite(th).all(1) & (th[:, 0] > 0) & (th[:, 1] > 0.05) & (th[:, 3] > 0.05)
+        L.step()
+        st = L._sol["status"].cpu().numpy()
+        assert np.isin(st[adm], (1, 2)).mean() == 1.0, (k, np.bincount(st[adm], minlength=5))
+        assert adm.mean() > 0.97, (k, adm.sum())
+        if k <= 1:
+            assert adm.all(), k
+
+
+
+
+def test_full_size_properties_quadrotor_batch32768():
+    """BASELINE configs[3]'s per-node batch (32768 random demonstrations) on one GPU: size-independent properties."""
+    oc, d = gpu_model("quadrotor", torch.float32, 50, substeps=4)
+    B = 32768
+    rng = np.random.default_rng(3)
+    x0 = np.tile(d["ini_state"], (B, 1))
+    x0[:, 0:3] += 0.2 * rng.standard_normal((B, 3))
+    goal = np.array([3.0, 3.0, 1.5])[None, :] + 0.2 * rng.standard_normal((B, 3))
+    wps = np.array(d["waypoints"])[None, :, :] + 0.1 * rng.standard_normal((B, 5, 3))
+    th = np.array(d["theta0"])[None, :] + 0.03 * rng.standard_normal((B, 7))
+    for a in (x0, goal, wps, th):
+        a[B // 2:] = a[:B // 2]                       # duplicated demonstrations must give identical results
+    consts = oc.consts_tensor(batch=B, overrides=dict(goal_r0=goal[:, 0], goal_r1=goal[:, 1], goal_r2=goal[:, 2]))
+    sol = oc.cocSolverBatch(x0, d["horizon"], th, consts=consts)
+    aux = oc.auxSysSolverBatch(sol, np.tile(d["taus"], (B, 1)), wps, d["interface"])
+    st = sol["status"].cpu().numpy()
+    assert np.isin(st, (1, 2)).all(), np.bincount(st, minlength=5)
+    assert torch.isfinite(aux["loss"]).all() and torch.isfinite(aux["grad"]).all()
+    h = B // 2
+    assert torch.equal(aux["loss"][:h], aux["loss"][h:]) and torch.equal(aux["grad"][:h], aux["grad"][h:])
+    assert torch.equal(sol["state_grid"][:h], sol["state_grid"][h:])
+    assert torch.allclose(sol["state_grid"][:, 0], torch.as_tensor(x0, dtype=torch.float32, device="cuda:0"))
+    assert torch.equal(sol["control_grid"][:, -1], sol["control_grid"][:, -2])                     # CPDP.py:191
+    Z = aux["Z_grid"]
+    P = Z[:, :, :13, :]
+    assert (P - P.transpose(2, 3)).abs().max() < 1e-3 * P.abs().max()
+    # shared-theta gradient of the whole node batch == sum over the demonstrations (what the ranks all-reduce)
+    sub = rng.choice(h, 32, replace=False)
+    oc64, _ = gpu_model("quadrotor", torch.float64, 50, substeps=4)
+    c64 = oc64.consts_tensor(batch=32, overrides=dict(goal_r0=goal[sub, 0], goal_r1=goal[sub, 1], goal_r2=goal[sub, 2]))
+    s64 = oc64.cocSolverBatch(x0[sub], d["horizon"], th[sub], consts=c64)
+    a64 = oc64.auxSysSolverBatch(s64, np.tile(d["taus"], (32, 1)), wps[sub], d["interface"])
+    l32, l64 = aux["loss"][sub].double().cpu().numpy(), a64["loss"].cpu().numpy()
+    g32, g64 = aux["grad"][sub].double().cpu().numpy(), a64["grad"].cpu().numpy()
+    assert np.all(np.abs(l32 - l64) < 1e-3 * np.maximum(1.0, l64))
+    assert np.all(np.abs(g32 - g64).max(axis=1) < 2e-2 * np.abs(g64).max(axis=1))
+
+
+def test_full_size_properties_rocket_n100_mixed_precision():
+    """BASELINE configs[4]: Rocket (6-DoF), horizon (n_grid) 100, fp32 solve + fp64 auxiliary Riccati / sensitivity pass,
+    1024 seeds on one GPU (8192 over 8).  No solve may end at the iteration limit or fail; duplicates bit-identical;
+    P symmetric; and one trajectory certified by the oracle as a KKT point of the reference's NLP (fp32 floor) with the
+    fp64 auxiliary pass along it reproduced to fp64 tolerance."""
+    oc, env, d = models.rocket(n_grid=100)
+    oc.setDevice("cuda:0", torch.float32, aux_dtype=torch.float64)
+    oc.setSolverOptions(aux_substeps=4)
+    assert not oc.compile().is_emulator
+    B = 1024
+    rng = np.random.default_rng(0)
+    th = np.array(d["theta0"])[None, :] * (1 + 0.05 * rng.standard_normal((B, 12)))
+    th[:, 0] = np.abs(th[:, 0]) + 0.1
+    th[B // 2:] = th[:B // 2]
+    x0 = np.tile(d["ini_state"], (B, 1))
+    sol = oc.cocSolverBatch(x0, d["horizon"], th)
+    st = sol["status"].cpu().numpy()
+    assert np.isin(st, (1, 2)).all(), np.bincount(st, minlength=5)
+    idx = [7, 20, 40, 67, 87]
+    taus = np.linspace(0, d["horizon"], 101)[idx]
+    X0 = sol["state_grid"][0].double().cpu().numpy()
+    wps = [np.concatenate([X0[k, 0:3], X0[k, 6:10]]) + 0.05 for k in idx]
+    aux = oc.auxSysSolverBatch(sol, taus, wps, d["interface"])
+    assert aux["loss"].dtype == torch.float64
+    assert torch.isfinite(aux["loss"]).all() and torch.isfinite(aux["grad"]).all()
+    h = B // 2
+    assert torch.equal(aux["loss"][:h], aux["loss"][h:]) and torch.equal(aux["grad"][:h], aux["grad"][h:])
+    assert torch.equal(sol["control_grid"][:, -1], sol["control_grid"][:, -2])
+    Z = aux["Z_grid"]
+    P = Z[:, :, :13, :]
+    assert (P - P.transpose(2, 3)).abs().max() < 1e-6 * P.abs().max()
+    b = 5
+    X, U, Lm = (sol[k][b].double().cpu().numpy() for k in ("state_grid", "control_grid", "costate_grid"))
+    r = oracle_parallel([dict(kind="rocket", n_grid=100, ini_state=d["ini_state"], horizon=d["horizon"], theta=list(th[b]),
+                              taus=list(taus), wps=wps, iface=d["interface"], check=(X, U, Lm), tight=True)] * 1)[0]
+    J = float(sol["cost"][b])
+    assert r["defect"] < 1e-4 * np.abs(X).max() and r["gmax"] < 2e-4 * (1 + abs(J)) and r["lmax"] < 5e-3 * np.abs(Lm).max(), \
+        (r["defect"], r["gmax"], r["lmax"], J)
+    assert abs(aux["loss"][b].item() - r["loss"]) < 1e-5 * max(1.0, r["loss"])
+    assert rel(aux["grad"][b], r["grad"]) < 5e-3
