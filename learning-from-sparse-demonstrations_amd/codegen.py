@@ -14,6 +14,7 @@ Emitted per model (``struct Model`` in namespace ``lfsd_gen``):
                       tangent (dx,du): the RK4 sensitivity sweep of the shooting map
 * ``final_cost / final_grad / final_hess_mul``
 * ``ham_hess_mul``    [Hxx Hxu; Hux Huu] applied to a per-lane vector (DDP backward)
+* ``ham_huu``         the dense control block Huu alone (MFMA backward sweep)
 * ``pmp_coeffs``      every structurally non-zero entry of fx, fu, fe, Hxx, Hxu,
                       Hxe, Hue (+ dense Huu) packed into one array that is staged
                       in LDS, and ``<mat>_mul / <mat>_mulT`` operators that apply
@@ -25,7 +26,7 @@ import hashlib
 import sympy as sp
 from sympy.printing.c import C99CodePrinter
 
-CODEGEN_VERSION = 7
+CODEGEN_VERSION = 8
 
 
 class ModelSpec:
@@ -66,8 +67,11 @@ class ModelSpec:
         self.n, self.m, self.p, self.nc = n, m, p, nc
 
     def hash(self):
-        key = "v%d|%d %d %d %d %d|%s|%s|%s" % (CODEGEN_VERSION, self.n, self.m, self.p, self.nc, self.time_varying,
-                                               sp.srepr(self.f), sp.srepr(self.c), sp.srepr(self.h))
+        # everything the generated header bakes in: structure, expressions, AND the name / constant defaults the C ABI
+        # reports (lfsd_get_model_info, lfsd_const_default) -- two models that differ only there must not share a library
+        key = "v%d|%d %d %d %d %d|%s|%s|%s|%s|%r" % (CODEGEN_VERSION, self.n, self.m, self.p, self.nc, self.time_varying,
+                                                     sp.srepr(self.f), sp.srepr(self.c), sp.srepr(self.h), self.name,
+                                                     [float(v) for v in self.const_defaults])
         return hashlib.sha1(key.encode()).hexdigest()[:16]
 
 
@@ -296,6 +300,11 @@ def emit_header(spec):
     S.append('  template<class T> static LFSD_DEV void ham_hess_mul(%s, const T* dx, const T* du, T* yx, T* yu) {' % sig_xul)
     S.append(_body(_loads(spec, with_l=True) + tang, [('yx[%d]' % i, yx[i]) for i in range(n)] +
                    [('yu[%d]' % i, yu[i]) for i in range(m)]))
+    S.append('  }')
+    # 4b. the control block of the Hamiltonian Hessian alone (dense, row-major): the MFMA backward sweep of the 16-lane
+    #     mapping gets the columns no lane owns from the symmetry of H and needs only their diagonal block on top
+    S.append('  template<class T> static LFSD_DEV void ham_huu(%s, T* Huu_out) {' % sig_xul)
+    S.append(_body(_loads(spec, with_l=True), [('Huu_out[%d]' % (a * m + b), Huu[a, b]) for a in range(m) for b in range(m)]))
     S.append('  }')
     # 5. packed PMP coefficients
     mats = []

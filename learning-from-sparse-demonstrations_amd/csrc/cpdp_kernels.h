@@ -109,6 +109,10 @@
 #ifndef LFSD_BW_PREFETCH
 #define LFSD_BW_PREFETCH 1
 #endif
+// lean fp32 kernel of the 32-lane models: backward sweep on the matrix cores (1) or relayed on the vector pipe (0)
+#ifndef LFSD_MFMA_BACKWARD
+#define LFSD_MFMA_BACKWARD 1
+#endif
 #ifndef LFSD_REG_CONSISTENT
 #define LFSD_REG_CONSISTENT 1
 #endif
@@ -164,6 +168,70 @@ template <typename T> inline pk2<T>& operator-=(pk2<T>& a, pk2<T> b) { a.x -= b.
 template <typename T> using pk2 = T __attribute__((ext_vector_type(2)));
 #endif
 template <typename T> LFSD_DEV pk2<T> mk2(T a, T b) { pk2<T> v; v.x = a; v.y = b; return v; }
+
+// ---- wave-level matrix helpers of the MFMA backward sweep (fp32, four 16-lane trajectories per wavefront) --------------
+// mfma4b: v_mfma_f32_16x16x1_4b_f32 -- four independent 16x16 rank-1 updates, block b fed by the lanes of 16-lane group b:
+//   D_b[i][j] += a(lane 16b+i) * b(lane 16b+j);  D_b[i][j] lives in register 4b + i%4 of lane 16(i/4) + j.
+// tile_transpose: afterwards lane 16b+j holds D_b[i][j] in register i (column j of ITS block: the column-per-lane layout
+//   of the rest of the kernel), by 8 v_permlane32_swap + 8 v_permlane16_swap.
+// Both must be reached by all 64 lanes.  The emulator build restates them with an exchange buffer.
+#if defined(LFSD_EMU)
+struct f32x16 {
+  float v[16];
+  float& operator[](int i) { return v[i]; }
+  const float& operator[](int i) const { return v[i]; }
+};
+inline void mfma4b(float a, float b, f32x16& acc) {
+  static float sa[64], sb[64];
+  const int l = threadIdx.x;
+  sa[l] = a; sb[l] = b;
+  __syncthreads();
+  for (int r = 0; r < 16; ++r) {
+    const int blk = r / 4, i = 4 * (l >> 4) + r % 4, j = l & 15;
+    acc[r] = std::fmaf(sa[16 * blk + i], sb[16 * blk + j], acc[r]);      // the hardware's k-ordered fmaf chain
+  }
+  __syncthreads();
+}
+inline void tile_transpose(f32x16& acc) {
+  static float sx[64][16];
+  const int l = threadIdx.x, b = l >> 4, j = l & 15;
+  for (int r = 0; r < 16; ++r) sx[l][r] = acc[r];
+  __syncthreads();
+  for (int q = 0; q < 4; ++q)
+    for (int r = 0; r < 4; ++r) acc[4 * q + r] = sx[16 * q + j][4 * b + r];
+  __syncthreads();
+}
+#else
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+LFSD_DEV void mfma4b(float a, float b, f32x16& acc) { acc = __builtin_amdgcn_mfma_f32_16x16x1f32(a, b, acc, 0, 0, 0); }
+LFSD_DEV void tile_transpose(f32x16& acc) {
+  // exchange the block index (register group 4R..4R+3) with the lane-group index, one bit per stage
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+#pragma unroll
+    for (int R0 = 0; R0 < 2; ++R0) {        // bit 1: register groups R0 / R0+2  <->  lane halves
+      const float lo = acc[4 * R0 + r], hi = acc[4 * (R0 + 2) + r];      // (scalars first: __builtin_bit_cast applied to a
+      const auto v = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, lo),      //  vector ELEMENT reads element 0)
+                                                      __builtin_bit_cast(unsigned, hi), false, false);
+      const unsigned v0 = v[0], v1 = v[1];
+      acc[4 * R0 + r] = __builtin_bit_cast(float, v0);
+      acc[4 * (R0 + 2) + r] = __builtin_bit_cast(float, v1);
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+#pragma unroll
+    for (int R1 = 0; R1 < 2; ++R1) {        // bit 0: register groups 2R1 / 2R1+1  <->  odd / even 16-lane rows
+      const float lo = acc[8 * R1 + r], hi = acc[8 * R1 + 4 + r];
+      const auto v = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, lo),
+                                                      __builtin_bit_cast(unsigned, hi), false, false);
+      const unsigned v0 = v[0], v1 = v[1];
+      acc[8 * R1 + r] = __builtin_bit_cast(float, v0);
+      acc[8 * R1 + 4 + r] = __builtin_bit_cast(float, v1);
+    }
+  }
+}
+#endif
 
 template <typename T> struct Eps;
 template <> struct Eps<float> { static LFSD_DEV float v() { return 1.1920929e-07f; } };
@@ -846,6 +914,220 @@ template <class M, typename T, int G, bool EXACT> struct OcSolver {
     return ok;
   }
 
+  // ---- the backward sweep on the matrix cores (fp32, 16-lane groups: four trajectories per wavefront, ONE pass) -------
+  // The two dense products of a stage,  Y = V_xx [A B]  and  Q = [A B]^T Y,  run as rank-1 updates of the 4-block MFMA
+  // v_mfma_f32_16x16x1_4b_f32 (mfma4b): block b = trajectory b of the wavefront, operands straight from the registers
+  // of the column-per-lane layout (lane i of a group owns column i of V_xx -- symmetric, so also row i -- and column i
+  // of [A B]); the result comes back column-per-lane after one register/lane-group transposition (tile_transpose).
+  // 2 x NX MFMAs per stage for FOUR trajectories replace 2 x (NX*NX + NXU*NX) LDS-fed FMAs per lane for two of them.
+  // The 16 lanes carry columns 0..15; a 17th column (quadrotor: NX + NU = 17) is carried as a row-per-lane vector in LDS
+  // and enters through NX-term dot products; its rows of Q and of the stage Hessian follow from symmetry, its diagonal
+  // element from M::ham_huu.  Stage-Hessian models 0 / 1 only (lean kernel); the exact model keeps the 32-lane sweep.
+  static constexpr int NCL = (NXU < 16) ? NXU : 16;      // columns carried by lanes
+  static constexpr int NUL = NCL - NX;                   // ... of them control columns
+  static constexpr int NEXT = NXU - NCL;                 // columns carried in LDS (0 or 1)
+  LFSD_DEV bool backward_mf(int cur, int mode, T mu, bool live, T& gnorm, T& dV1, T& dV2, T& dmin) {
+    static_assert(G == 16 && NX <= 16 && NEXT <= 1, "MFMA backward sweep: 16-lane groups, at most one column beyond 16");
+    T* ldsV = lds + Lay::LDS_V;  T* ldsK = lds + Lay::LDS_K;
+    T* ldsQux = lds + Lay::LDS_QUX;  T* ldsQuu = lds + Lay::LDS_QUU;  T* ldsQu = lds + Lay::LDS_QU;
+    T* ldsVx = lds + Lay::LDS_VX;  T* ldsLam = lds + Lay::LDS_LAM;  T* ldsRed = lds + Lay::LDS_RED;
+    T* ldsME = lds + Lay::LDS_M;              // [NX] extra column of [A B], [NX] its q entry   (LDS_M region: NXU*NX words)
+    T* ldsYE = ldsME + NX + 1;                // [NX] V_xx times that column
+    T Vx[NX], lam[NX], vcol[NX], xk[NX], uk[NU];
+    bool ok = true;
+    T gl_max = T(0);
+    dV1 = T(0); dV2 = T(0); dmin = T(0);
+    {
+      const T* xN = xb[cur] + N * NX;
+#pragma unroll
+      for (int i = 0; i < NX; ++i) xk[i] = xN[i];
+      M::final_grad(tk(N), xk, e, c, Vx);
+      T ox[NX], oe[NP];
+#pragma unroll
+      for (int i = 0; i < NX; ++i) { ox[i] = (lane == i) ? T(1) : T(0); lam[i] = Vx[i]; }
+#pragma unroll
+      for (int i = 0; i < NP; ++i) oe[i] = T(0);
+      M::final_hess_mul(tk(N), xk, e, c, ox, oe, vcol);      // lanes >= NX: ox = 0  ->  vcol = 0
+      if (lane == 0 && live) {
+#pragma unroll
+        for (int i = 0; i < NX; ++i) lam_out[N * NX + i] = lam[i];
+      }
+    }
+    for (int k = N - 1; k >= 0; --k) {
+      T m[NX], mq = T(0);
+      const T* Mk = Mws[cur] + (long long)k * Lay::M_ELEMS;
+      if (lane < NCL) {
+#pragma unroll
+        for (int i = 0; i < NX; ++i) m[i] = Mk[i * Lay::NXUP + lane];
+        mq = Mk[NX * Lay::NXUP + lane];
+      } else {
+#pragma unroll
+        for (int i = 0; i < NX; ++i) m[i] = T(0);
+      }
+      if (NEXT) {                                  // column NCL of [A B; q]: row `lane` of it, parked in LDS
+        if (lane <= NX) ldsME[lane] = Mk[lane * Lay::NXUP + NCL];
+      }
+      {
+        const T* xp = xb[cur] + k * NX;  const T* up = ub[cur] + k * NU;
+#pragma unroll
+        for (int i = 0; i < NX; ++i) xk[i] = xp[i];
+#pragma unroll
+        for (int a = 0; a < NU; ++a) uk[a] = up[a];
+      }
+      // Y = V_xx [A B](:, 0..15)
+      f32x16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+      for (int kk = 0; kk < NX; ++kk) mfma4b(vcol[kk], m[kk], acc);
+      // stage-Hessian column of this lane (vector pipe; independent of the products in flight on the matrix pipe)
+      T hx[NX], hu[NU], huu[NU * NU];
+      {
+        T ox[NX], ou[NU], ls[NX];
+        const T HL = (mode == 1) ? T(1) : T(0);
+#pragma unroll
+        for (int i = 0; i < NX; ++i) { ox[i] = (lane == i) ? T(1) : T(0); ls[i] = HL * lam[i]; }
+#pragma unroll
+        for (int a = 0; a < NU; ++a) ou[a] = (lane == NX + a) ? T(1) : T(0);
+        M::ham_hess_mul(tk(k), xk, uk, ls, e, c, ox, ou, hx, hu);
+        if (NEXT) M::ham_huu(tk(k), xk, uk, ls, e, c, huu);
+      }
+      tile_transpose(acc);
+      T ycol[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) ycol[r] = acc[r];
+      __syncthreads();                             // ldsME visible
+      T q_e = T(0), q_ee = T(0), Qg_e = T(0), gl_e = T(0);      // row NCL of Q at this lane's column; its diagonal; gradient terms
+      if (NEXT) {
+        T ye = T(0);
+#pragma unroll
+        for (int kk = 0; kk < NX; ++kk) { ye += vcol[kk] * ldsME[kk]; q_e += ldsME[kk] * ycol[kk]; }
+        if (lane < NX) ldsYE[lane] = ye;           // (V_xx m_e)_lane : V_xx row `lane` == this lane's column
+      }
+      // Q(0..15, 0..15) = [A B]^T Y
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+      for (int kk = 0; kk < NX; ++kk) mfma4b(m[kk], ycol[kk], acc);
+      T Qg = mq, gl = mq;
+#pragma unroll
+      for (int i = 0; i < NX; ++i) { Qg += m[i] * Vx[i]; gl += m[i] * lam[i]; }
+      tile_transpose(acc);
+      T Qcol[NXU];
+#pragma unroll
+      for (int r = 0; r < NCL; ++r) Qcol[r] = acc[r];
+      __syncthreads();                             // ldsYE visible
+      if (NEXT) {
+        Qg_e = ldsME[NX]; gl_e = ldsME[NX];
+#pragma unroll
+        for (int kk = 0; kk < NX; ++kk) { q_ee += ldsME[kk] * ldsYE[kk]; Qg_e += ldsME[kk] * Vx[kk]; gl_e += ldsME[kk] * lam[kk]; }
+        // symmetry of the stage Hessian: row NCL of column j is the last control entry of column j's own product
+        q_e += dgrid * hu[NU - 1];
+        q_ee += dgrid * huu[NU * NU - 1];
+        Qcol[NCL] = q_e;
+      }
+#pragma unroll
+      for (int i = 0; i < NX; ++i) Qcol[i] += dgrid * hx[i];
+#pragma unroll
+      for (int a = 0; a < NUL; ++a) Qcol[NX + a] += dgrid * hu[a];
+      T Quxj[NU];
+#pragma unroll
+      for (int a = 0; a < NU; ++a) Quxj[a] = Qcol[NX + a];
+      if (lane < NX) {
+#pragma unroll
+        for (int a = 0; a < NU; ++a) ldsQux[lane * NU + a] = Quxj[a];
+      } else if (lane < NCL) {
+        const int b = lane - NX;
+#pragma unroll
+        for (int a = 0; a < NU; ++a) ldsQuu[b * NU + a] = Quxj[a];
+        ldsQu[b] = Qg;
+        gl_max = t_max(gl_max, t_abs(gl));
+        if (NEXT) ldsQuu[(NU - 1) * NU + b] = q_e;           // column NCL of Q_uu from its row (symmetric)
+      }
+      if (NEXT) {
+        if (lane == 0) { ldsQuu[NU * NU - 1] = q_ee; ldsQu[NU - 1] = Qg_e; }
+        gl_max = t_max(gl_max, (lane == NX) ? t_abs(gl_e) : T(0));
+      }
+      __syncthreads();
+      T Quu0[NU * NU], Lc[NU * NU], Qu[NU], kff[NU], Kj[NU], t1[NU];
+#pragma unroll
+      for (int a = 0; a < NU; ++a) {
+        Qu[a] = ldsQu[a];
+#pragma unroll
+        for (int b = 0; b < NU; ++b) Quu0[a * NU + b] = T(0.5) * (ldsQuu[b * NU + a] + ldsQuu[a * NU + b]);
+      }
+#pragma unroll
+      for (int i = 0; i < NU * NU; ++i) Lc[i] = Quu0[i];
+#pragma unroll
+      for (int a = 0; a < NU; ++a) Lc[a * NU + a] += mu;
+      if (ok) ok = chol_factor<NU>(Lc, dmin); else { T dd = T(0); chol_factor<NU>(Lc, dd); }
+      if (LFSD_REG_CONSISTENT) {
+#pragma unroll
+        for (int a = 0; a < NU; ++a) Quu0[a * NU + a] += mu;
+      }
+#pragma unroll
+      for (int a = 0; a < NU; ++a) { kff[a] = -Qu[a]; Kj[a] = -Quxj[a]; }
+      chol_solve<NU>(Lc, kff);
+      chol_solve<NU>(Lc, Kj);
+      T qk[NU];
+      matvec<NU>(Quu0, kff, qk);
+#pragma unroll
+      for (int a = 0; a < NU; ++a) { dV1 += kff[a] * Qu[a]; dV2 += T(0.5) * kff[a] * qk[a]; }
+      T Vxj = Qg;
+#pragma unroll
+      for (int a = 0; a < NU; ++a) Vxj += Kj[a] * (qk[a] + Qu[a]) + Quxj[a] * kff[a];
+      if (lane < NX) {
+#pragma unroll
+        for (int a = 0; a < NU; ++a) ldsK[lane * NU + a] = Kj[a];
+        ldsVx[lane] = Vxj;
+        ldsLam[lane] = gl;
+        if (live) {
+          T* Kout = Kws + ((long long)k * NX + lane) * NU;
+#pragma unroll
+          for (int a = 0; a < NU; ++a) Kout[a] = Kj[a];
+        }
+      }
+      if (lane == 0 && live) {
+#pragma unroll
+        for (int a = 0; a < NU; ++a) kws[k * NU + a] = kff[a];
+      }
+      __syncthreads();
+      matvec<NU>(Quu0, Kj, t1);
+#pragma unroll
+      for (int a = 0; a < NU; ++a) t1[a] += Quxj[a];
+#pragma unroll
+      for (int i = 0; i < NX; ++i) {
+        T sacc = Qcol[i];
+#pragma unroll
+        for (int a = 0; a < NU; ++a) sacc += ldsK[i * NU + a] * t1[a] + ldsQux[i * NU + a] * Kj[a];
+        vcol[i] = sacc;
+        Vx[i] = ldsVx[i];
+        lam[i] = ldsLam[i];
+      }
+      if (lane == 0 && live) {
+#pragma unroll
+        for (int i = 0; i < NX; ++i) lam_out[k * NX + i] = lam[i];
+      }
+      // symmetrise V_xx through LDS (the rank-1 feeds above rely on row i == column i); lanes >= NX carry no column
+      if (lane < NX) {
+#pragma unroll
+        for (int i = 0; i < NX; ++i) ldsV[lane * NX + i] = vcol[i];
+      }
+      __syncthreads();
+#pragma unroll
+      for (int i = 0; i < NX; ++i) vcol[i] = (lane < NX) ? T(0.5) * (vcol[i] + ldsV[i * NX + lane]) : T(0);
+      __syncthreads();
+    }
+    ldsRed[lane] = gl_max;
+    __syncthreads();
+    gnorm = T(0);
+#pragma unroll
+    for (int a = 0; a < NUL; ++a) gnorm = t_max(gnorm, ldsRed[NX + a]);      // (lane NX also carries the LDS column's entry)
+    __syncthreads();
+    if (!t_finite(gnorm) || !t_finite(dV1) || !t_finite(dV2)) ok = false;
+    return ok;
+  }
+
   // Lane l tries step length 2^-l (all candidate roll-outs run concurrently in the group).
   // Returns the index of the largest accepted step (or -1) and the best cost seen.
   LFSD_DEV int linesearch(int cur, T J, T dV1, T dV2, T& alpha_out, T& Jmin, bool& flat_full) {
@@ -930,13 +1212,15 @@ __global__ void __launch_bounds__(64, LFSD_WAVES_OC) oc_solve_kernel(OcArgs<T> a
   using Lay = OcLayout<M>;
   constexpr int NX = M::NX, NU = M::NU, NP = M::NP, NC = M::NC;
   constexpr int GPB = 64 / GR;
+  // backward sweep of the packed kernel on the matrix cores (OcSolver::backward_mf) where the model fits 16-lane groups
+  constexpr bool MF = PK && (LFSD_MFMA_BACKWARD != 0) && sizeof(T) == 4 && NX <= 16 && NX + NU <= 17;
   constexpr int RS = EXACT ? Lay::template lds_elems<G>() : ((Lay::template lds_ex<G>() + 3) / 4) * 4;
   constexpr int MB = 12;                          // mailbox floats per trajectory
   static_assert(64 % G == 0 && G >= NX + NU, "lane group must hold one column of [A B] per lane");
   static_assert(!PK || (!EXACT && G == 32 && 2 * GR >= NX + NU), "packed roll-out: lean kernel of a 32-lane model");
   __shared__ T lds_all[GPB * RS];
   __shared__ T mbox[PK ? GPB * MB : 1];
-  __shared__ int vote[2];
+  __shared__ int vote[3];
   poison_lds(lds_all, GPB * RS);
   Sol s;
   const int gib = threadIdx.x / GR;
@@ -970,7 +1254,21 @@ __global__ void __launch_bounds__(64, LFSD_WAVES_OC) oc_solve_kernel(OcArgs<T> a
   // backward sweep of this lane's trajectory; `force`: also when the trajectory is no longer running (final refresh
   // of the costates).  Returns whether the sweep ran (PK skips a pass none of whose trajectories wants it).
   auto do_backward = [&](int cur_, int mode_, T mu_, bool want_, T& gnorm_, T& dV1_, T& dV2_, T& dmin_, bool& ok_) LFSD_LAMBDA_INLINE -> bool {
-    if constexpr (!PK) {
+    if constexpr (MF) {
+      // all four trajectories of the wavefront sweep together on the matrix cores; a group that does not want the sweep
+      // rides along without writing anything (the MFMAs need every lane)
+      if (threadIdx.x == 0) vote[2] = 0;
+      __syncthreads();
+      if (want_) vote[2] = 1;
+      __syncthreads();
+      const bool any = vote[2] != 0;
+      __syncthreads();
+      if (!any) return false;
+      T g_, d1_, d2_, dm_;
+      const bool okb = s.backward_mf(cur_, mode_, mu_, want_, g_, d1_, d2_, dm_);
+      if (want_) { ok_ = okb; gnorm_ = g_; dV1_ = d1_; dV2_ = d2_; dmin_ = dm_; }
+      return want_;
+    } else if constexpr (!PK) {
       ok_ = s.backward(cur_, mode_, mu_, gnorm_, dV1_, dV2_, dmin_);
       return true;
     } else {
@@ -1606,8 +1904,15 @@ template <class M, typename T, int G, int LAY> LFSD_DEV void aux_setup(AuxCtx<M,
   for (int i = 0; i < NP; ++i) s.oe[i] = (LAY == 1 ? (s.xlane && s.lane == i) : (s.lane == NX + i)) ? T(1) : T(0);
 }
 
+// Barriers in the two auxiliary sweeps: the number of split units per interval (`units`) follows each trajectory's own
+// stiffness, so lane groups of one workgroup pass different numbers of __syncthreads().  That is well defined here --
+// and only here -- because a workgroup is exactly ONE wavefront (launched with 64 threads, checked below): s_barrier is
+// a scalar instruction the wavefront executes as a whole whatever its EXEC mask, it has nobody to wait for, and what
+// remains of __syncthreads() is the LDS fence (s_waitcnt lgkmcnt(0)) every group needs for its own private LDS slice.
+// A port to multi-wave workgroups would have to make `units` block-uniform first (as oc_solve_kernel does with its votes).
 template <class M, typename T, int G>
 __global__ void __launch_bounds__(64, (sizeof(T) == 4 ? LFSD_WAVES_RIC : 1)) aux_riccati_kernel(AuxArgs<T> a) {
+  if (blockDim.x != 64) return;                   // one wavefront per workgroup: see the note on barriers above
   using Ctx = AuxCtx<M, T, G, 0>;
   using Lay = AuxLayout<M>;
   constexpr int NX = M::NX, NP = M::NP, NZ = NX + NP;
@@ -1684,6 +1989,7 @@ __global__ void __launch_bounds__(64, (sizeof(T) == 4 ? LFSD_WAVES_RIC : 1)) aux
 
 template <class M, typename T, int G>
 __global__ void __launch_bounds__(64, (sizeof(T) == 4 ? LFSD_WAVES_FWD : 1)) aux_forward_kernel(AuxArgs<T> a) {
+  if (blockDim.x != 64) return;                   // one wavefront per workgroup: see the note above aux_riccati_kernel
   using Ctx = AuxCtx<M, T, G, 1>;
   using Lay = AuxLayout<M>;
   constexpr int NX = M::NX, NU = M::NU, NP = M::NP, NZ = NX + NP;

@@ -110,8 +110,11 @@ ZOO = dict(pendulum=pendulum, pendulum_poly2=pendulum_poly2, robotarm=robotarm, 
 
 
 def build_all(verbose=False, force=False):
-    """Compile every standard model for gfx950 (in-tree .so under csrc/build/)."""
-    import glob
+    """Compile every standard model for gfx950 (in-tree .so under csrc/build/).  Generated headers / libraries that an
+    EARLIER build_all produced for the zoo and that are no longer reachable (code-generator version bump) are removed;
+    files of models a user compiled through COCSys.compile() are never touched (csrc/gen/ZOO_MANIFEST.json records
+    which hashes belong to the zoo)."""
+    import json
     import os
     from . import runtime
     out, keep = {}, set()
@@ -122,9 +125,17 @@ def build_all(verbose=False, force=False):
         out[name] = runtime.build_library(spec, force=force, verbose=verbose)
         if verbose:
             print("built", name, spec.hash(), out[name])
-    # drop generated headers / libraries of older code-generator versions (their hashes are no longer reachable)
-    for path in glob.glob(os.path.join(runtime.GEN_DIR, "*.h")) + glob.glob(os.path.join(runtime.BUILD_DIR, "liblfsd_*.so")):
-        h = os.path.basename(path).replace("liblfsd_", "").split(".")[0]
-        if h not in keep:
-            os.remove(path)
+    manifest = os.path.join(runtime.GEN_DIR, "ZOO_MANIFEST.json")
+    old = set()
+    if os.path.exists(manifest):
+        try:
+            old = set(json.load(open(manifest)).get("hashes", []))
+        except Exception:
+            old = set()
+    for h in old - keep:
+        for path in (runtime.header_path(h), runtime.library_path(h)):
+            if os.path.exists(path):
+                os.remove(path)
+    with open(manifest, "w") as f:
+        json.dump({"hashes": sorted(keep)}, f, indent=1)
     return out

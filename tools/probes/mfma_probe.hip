@@ -2,6 +2,9 @@
 // integer data.  build: hipcc --offload-arch=gfx950 -O2 mfma_probe.hip -o mfma_probe
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstdlib>
+#include <cmath>
+#include "../../learning-from-sparse-demonstrations_amd/csrc/cpdp_kernels.h"
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 __global__ void probe(float* out) {
@@ -19,7 +22,38 @@ __global__ void probe(float* out) {
   out[2048 + l * 4 + 0] = (float)r32[0]; out[2048 + l * 4 + 1] = (float)r32[1];
   out[2048 + l * 4 + 2] = (float)r16[0]; out[2048 + l * 4 + 3] = (float)r16[1];
 }
+// the helpers of the MFMA backward sweep exactly as the kernels use them: K rank-1 updates per block, then the transposition
+__global__ void chain(const float* a, const float* b, float* out) {
+  lfsd::f32x16 acc;
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  float av[13], bv[13];
+  for (int i = 0; i < 13; ++i) { av[i] = a[threadIdx.x * 13 + i]; bv[i] = b[threadIdx.x * 13 + i]; }
+#pragma unroll
+  for (int kk = 0; kk < 13; ++kk) lfsd::mfma4b(av[kk], bv[kk], acc);
+  lfsd::tile_transpose(acc);
+  for (int r = 0; r < 16; ++r) out[threadIdx.x * 16 + r] = acc[r];
+}
+static int check_chain() {
+  static float ha[64 * 13], hb[64 * 13], ho[64 * 16];
+  srand(7);
+  for (int i = 0; i < 64 * 13; ++i) { ha[i] = (float)(rand() % 17 - 8); hb[i] = (float)(rand() % 13 - 6); }      // exact in fp32
+  float *da, *db, *dout;
+  hipMalloc(&da, sizeof(ha)); hipMalloc(&db, sizeof(hb)); hipMalloc(&dout, sizeof(ho));
+  hipMemcpy(da, ha, sizeof(ha), hipMemcpyHostToDevice); hipMemcpy(db, hb, sizeof(hb), hipMemcpyHostToDevice);
+  hipLaunchKernelGGL(chain, dim3(1), dim3(64), 0, 0, da, db, dout);
+  hipMemcpy(ho, dout, sizeof(ho), hipMemcpyDeviceToHost);
+  int bad = 0;
+  for (int blk = 0; blk < 4; ++blk) for (int j = 0; j < 16; ++j) for (int i = 0; i < 16; ++i) {
+    float ref = 0.f;                                  // D_blk[i][j] = sum_k a(lane 16 blk + i)[k] * b(lane 16 blk + j)[k]
+    for (int k = 0; k < 13; ++k) ref += ha[(16 * blk + i) * 13 + k] * hb[(16 * blk + j) * 13 + k];
+    const float got = ho[(16 * blk + j) * 16 + i];    // after tile_transpose: lane 16 blk + j, register i
+    if (got != ref) { if (bad < 8) printf("chain block %d i %d j %d: got %g expected %g\n", blk, i, j, got, ref); ++bad; }
+  }
+  printf("lfsd::mfma4b x13 + lfsd::tile_transpose vs host: %s (%d mismatches of 1024)\n", bad ? "WRONG" : "CONFIRMED", bad);
+  return bad;
+}
 int main() {
+  check_chain();
   float* d; hipMalloc(&d, 4096 * 4); hipMemset(d, 0, 4096 * 4);
   hipLaunchKernelGGL(probe, dim3(1), dim3(64), 0, 0, d);
   static float h[4096]; hipMemcpy(h, d, 4096 * 4, hipMemcpyDeviceToHost);
