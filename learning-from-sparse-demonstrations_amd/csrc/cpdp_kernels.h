@@ -474,6 +474,7 @@ template <class M, typename T, int G, bool EXACT> struct OcSolver {
   const T *e, *c, *x0;      // [NP], [NC], [NX] in LDS
   T horizon, dgrid, DT;
   T *xb[2], *ub[2], *Mws[2], *Kws, *kws, *lds, *exws, *Hws;
+  T *xa = nullptr, *ua = nullptr, *exwu = nullptr;      // wide mapping only: per-step-length roll-outs, per-lane sub-step states
   bool reuse_hess = false;   // exact stage Hessians in Hws belong to the nominal being swept (a retry with another shift)
   T* lam_out;   // costate grid of this trajectory (or scratch when invalid)
 
@@ -610,21 +611,26 @@ template <class M, typename T, int G, bool EXACT> struct OcSolver {
   // second-order adjoint sweep through the S x 4 RK4 stages (tangent forward, adjoint + its tangent backward).
   // No cross-lane traffic: every lane recomputes the group-uniform stage states and parks them, with its own
   // tangents, in its private LDS slots (index (slot)*G + lane), so the routine may run under a divergent branch.
-  LFSD_DEV void stage_hessian_col(int k, const T* xk, const T* uk, const T* lam_next, T* hx, T* hu) {
+  // WIDE (one trajectory per wavefront, lanes work on different intervals): `col` is the column, `lane` only names the
+  // private slots, and the sub-step start states are per lane too (exwu).
+  template <bool WIDE = false>
+  LFSD_DEV void stage_hessian_col(int k, const T* xk, const T* uk, const T* lam_next, T* hx, T* hu, int col = -1) {
     constexpr int SMAX = Lay::SMAX;
+    if (!WIDE) col = lane;
     T* ex = lds + Lay::template lds_ex<G>();
-    T* exu = exws;                           // [S][NX] uniform (all lanes store the same value)
+    T* exu = WIDE ? exwu + lane : exws;      // [S][NX] uniform (all lanes store the same value) | [S][NX][G] per lane
+    constexpr int XS = WIDE ? G : 1;
     T* exl = exws + SMAX * NX;               // [S][NX][G] per lane
     const T t = tk(k);
     const T h = DT;
     T x[NX], m[NX], du[NU], q = T(0), mq = T(0);
 #pragma unroll
-    for (int i = 0; i < NX; ++i) { x[i] = xk[i]; m[i] = (lane == i) ? T(1) : T(0); }
+    for (int i = 0; i < NX; ++i) { x[i] = xk[i]; m[i] = (col == i) ? T(1) : T(0); }
 #pragma unroll
-    for (int a = 0; a < NU; ++a) du[a] = (lane == NX + a) ? T(1) : T(0);
+    for (int a = 0; a < NU; ++a) du[a] = (col == NX + a) ? T(1) : T(0);
     for (int s = 0; s < S; ++s) {
 #pragma unroll
-      for (int i = 0; i < NX; ++i) { exu[s * NX + i] = x[i]; exl[(s * NX + i) * G + lane] = m[i]; }
+      for (int i = 0; i < NX; ++i) { exu[(s * NX + i) * XS] = x[i]; exl[(s * NX + i) * G + lane] = m[i]; }
       rk4_step<true>(t, x, q, uk, m, mq, du);
     }
     T lam[NX], dlam[NX];
@@ -639,7 +645,7 @@ template <class M, typename T, int G, bool EXACT> struct OcSolver {
       // recompute the four stage points of this sub-step and park them
       T x0s[NX], m0s[NX];
 #pragma unroll
-      for (int i = 0; i < NX; ++i) { x0s[i] = exu[s * NX + i]; m0s[i] = exl[(s * NX + i) * G + lane]; }
+      for (int i = 0; i < NX; ++i) { x0s[i] = exu[(s * NX + i) * XS]; m0s[i] = exl[(s * NX + i) * G + lane]; }
 #pragma unroll
       for (int i = 0; i < NX; ++i) { x[i] = x0s[i]; m[i] = m0s[i]; }
       for (int st = 0; st < 4; ++st) {
