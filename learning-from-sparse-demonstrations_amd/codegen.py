@@ -67,11 +67,13 @@ class ModelSpec:
         self.n, self.m, self.p, self.nc = n, m, p, nc
 
     def hash(self):
-        # everything the generated header bakes in: structure, expressions, AND the name / constant defaults the C ABI
-        # reports (lfsd_get_model_info, lfsd_const_default) -- two models that differ only there must not share a library
-        key = "v%d|%d %d %d %d %d|%s|%s|%s|%s|%r" % (CODEGEN_VERSION, self.n, self.m, self.p, self.nc, self.time_varying,
-                                                     sp.srepr(self.f), sp.srepr(self.c), sp.srepr(self.h), self.name,
-                                                     [float(v) for v in self.const_defaults])
+        # structure and expressions only.  Name and constant DEFAULTS are deliberately left out: a driver such as
+        # lib/QuadAlgorithm.py builds the same model with another goal (a constant's default) for every run, and that must
+        # not cost a recompilation.  Consequently lfsd_get_model_info().name and lfsd_const_default() report the values of
+        # whichever instance generated the header first -- informational only: COCSys always passes its own instance's
+        # constant values to the kernels (COCSys.const_values / consts_tensor), never the library's defaults.
+        key = "v%d|%d %d %d %d %d|%s|%s|%s" % (CODEGEN_VERSION, self.n, self.m, self.p, self.nc, self.time_varying,
+                                               sp.srepr(self.f), sp.srepr(self.c), sp.srepr(self.h))
         return hashlib.sha1(key.encode()).hexdigest()[:16]
 
 

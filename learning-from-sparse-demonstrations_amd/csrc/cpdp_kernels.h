@@ -25,15 +25,26 @@
 #if defined(LFSD_EMU)
 #include "simt_emu.h"
 #define LFSD_LAMBDA_INLINE
+#define LFSD_LAMBDA_BW
+#define LFSD_LAMBDA_RO
+#define LFSD_HD
 #else
 #include <hip/hip_runtime.h>
 #define LFSD_DEV __device__ __forceinline__
+#define LFSD_HD __host__ __device__
 // lambdas inside kernels must be inlined as well: a real call passes their by-reference captures through scratch
-// (experiment knob LFSD_PHASE_CALLS=1: keep them as calls, so every phase gets its own register allocation)
-#if defined(LFSD_PHASE_CALLS) && LFSD_PHASE_CALLS
-#define LFSD_LAMBDA_INLINE __attribute__((noinline))
-#else
+// (experiment knob LFSD_PHASE_CALLS: bit 0 keeps the backward sweep of oc_solve_kernel a real call, bit 1 the roll-out, so
+// that each phase gets its own register allocation; profiles/r02_e_phase_calls.txt)
 #define LFSD_LAMBDA_INLINE __attribute__((always_inline))
+#if defined(LFSD_PHASE_CALLS) && (LFSD_PHASE_CALLS & 1)
+#define LFSD_LAMBDA_BW __attribute__((noinline))
+#else
+#define LFSD_LAMBDA_BW __attribute__((always_inline))
+#endif
+#if defined(LFSD_PHASE_CALLS) && (LFSD_PHASE_CALLS & 2)
+#define LFSD_LAMBDA_RO __attribute__((noinline))
+#else
+#define LFSD_LAMBDA_RO __attribute__((always_inline))
 #endif
 #endif
 
@@ -162,6 +173,10 @@ template <typename T> inline pk2<T> operator*(T a, pk2<T> b) { return pk2<T>(a *
 template <typename T> inline pk2<T> operator*(pk2<T> a, T b) { return pk2<T>(a.x * b, a.y * b); }
 template <typename T> inline pk2<T> operator+(T a, pk2<T> b) { return pk2<T>(a + b.x, a + b.y); }
 template <typename T> inline pk2<T> operator+(pk2<T> a, T b) { return pk2<T>(a.x + b, a.y + b); }
+template <typename T> inline pk2<T> operator/(pk2<T> a, T b) { return pk2<T>(a.x / b, a.y / b); }
+template <typename T> inline pk2<T> operator/(pk2<T> a, pk2<T> b) { return pk2<T>(a.x / b.x, a.y / b.y); }
+template <typename T> inline pk2<T> operator-(pk2<T> a, T b) { return pk2<T>(a.x - b, a.y - b); }
+template <typename T> inline pk2<T> operator-(T a, pk2<T> b) { return pk2<T>(a - b.x, a - b.y); }
 template <typename T> inline pk2<T>& operator+=(pk2<T>& a, pk2<T> b) { a.x += b.x; a.y += b.y; return a; }
 template <typename T> inline pk2<T>& operator-=(pk2<T>& a, pk2<T> b) { a.x -= b.x; a.y -= b.y; return a; }
 #else
@@ -440,10 +455,17 @@ template <class M> struct OcLayout {
   static constexpr int NXUP = (NXU + 1) / 2 * 2;
   static constexpr int M_ELEMS = (NX + 1) * NXUP;                // [A B] rows + the cost-gradient row q, per interval
   static constexpr int H_ELEMS = NXU * NXUP;
-  template <int G> static long long ws_elems(int N) {
+  template <int G> LFSD_HD static long long ws_elems(int N) {
     const long long n = 2LL * (N + 1) * NX + 2LL * N * NU + 2LL * N * M_ELEMS + 1LL * N * NX * NU + 1LL * N * NU +
            1LL * (N + 1) * NX + 1LL * SMAX * NX * (1 + G) +     // + sub-step start states (uniform | per lane)
            1LL * N * H_ELEMS;                                    // + exact stage Hessians of the current nominal
+    return (n + 1) / 2 * 2;
+  }
+  // wide mapping (one trajectory per wavefront): the above for 64 lanes + the parked roll-outs of the 16 step lengths
+  // + per-lane sub-step start states of the exact-Hessian sweeps
+  static constexpr int WIDE_NAL = 16;
+  LFSD_HD static long long ws_elems_wide(int N) {
+    const long long n = ws_elems<64>(N) + 1LL * WIDE_NAL * ((N + 1) * NX + N * NU) + 1LL * SMAX * NX * 64;
     return (n + 1) / 2 * 2;
   }
   // LDS per group (elements)
@@ -1172,6 +1194,150 @@ template <class M, typename T, int G, bool EXACT> struct OcSolver {
   }
 };
 
+// The same steps for the WIDE mapping -- one trajectory per wavefront (OcSolver<M, T, 64, EXACT>), for batches that leave most
+// of the machine idle under the lock-step mapping (robot arm / rocket at 1024 trajectories per GPU: 256-512 wavefronts
+// for 1024 SIMDs, and an iteration as long as N sequential intervals).  What depends only on the nominal of ONE interval
+// is done for all intervals at once, spread over the 64 lanes:
+//   rollout_alphas      the closed-loop roll-outs of 16 step lengths, one per lane (the line search IS the roll-out)
+//   linearise_parallel  [A_k B_k; q_k] for every interval k: lane <- (k, column pair), N*ceil(NXU/2)/64 rounds
+//   costate_sweep       lambda_k = q_x + A_k^T lambda_k+1 (sequential, NX FMAs per interval)
+//   hessians_parallel   exact stage Hessian columns for every (k, column): second-order adjoint sweeps, N*NXU/64 rounds
+// which leaves only the cheap Riccati-type recursion of OcSolver::backward sequential in k.
+template <class M, typename T, bool EXACT> struct OcWide : OcSolver<M, T, 64, EXACT> {
+  using Base = OcSolver<M, T, 64, EXACT>;
+  using Lay = OcLayout<M>;
+  static constexpr int NX = M::NX, NU = M::NU, NP = M::NP, NXU = NX + NU;
+  static constexpr int NAL = 16;                       // step lengths 2^0 .. 2^-15
+  using Base::lane; using Base::N; using Base::S; using Base::e; using Base::c; using Base::x0; using Base::xb; using Base::ub;
+  using Base::Mws; using Base::Hws; using Base::lds; using Base::xa; using Base::ua; using Base::lam_out; using Base::DT;
+
+  // lane l < NAL rolls the closed loop out with step length 2^-l and parks states / controls at [k][component][l]
+  LFSD_DEV T rollout_alphas(int cur, bool gains, T& alpha) {
+    alpha = T(0);
+    if (lane < NAL) { alpha = T(1); for (int i = 0; i < lane; ++i) alpha *= T(0.5); }
+    T x[NX], u[NU], Ja = T(0), dummy = T(0);
+#pragma unroll
+    for (int i = 0; i < NX; ++i) x[i] = x0[i];
+    for (int k = 0; k < N; ++k) {
+      this->control(cur, k, x, alpha, gains, u);
+      if (lane < NAL) {
+#pragma unroll
+        for (int i = 0; i < NX; ++i) xa[(k * NX + i) * NAL + lane] = x[i];
+#pragma unroll
+        for (int a = 0; a < NU; ++a) ua[(k * NU + a) * NAL + lane] = u[a];
+      }
+      T q = T(0);
+      const T t = this->tk(k);
+      for (int s = 0; s < S; ++s) this->template rk4_step<false>(t, x, q, u, x, dummy, u);
+      Ja += q;
+    }
+    if (lane < NAL) {
+#pragma unroll
+      for (int i = 0; i < NX; ++i) xa[(N * NX + i) * NAL + lane] = x[i];
+    }
+    Ja += M::final_cost(this->tk(N), x, e, c);
+    return Ja;
+  }
+  // the roll-out of step length index ia becomes nominal `nxt`
+  LFSD_DEV void adopt_alpha(int ia, int nxt) {
+    __syncthreads();
+    for (int i = lane; i < (N + 1) * NX; i += 64) xb[nxt][i] = xa[i * NAL + ia];
+    for (int i = lane; i < N * NU; i += 64) ub[nxt][i] = ua[i * NAL + ia];
+    __syncthreads();
+  }
+  // linearise the shooting map along nominal `nxt`, all intervals at once
+  LFSD_DEV void linearise_parallel(int nxt) {
+    if constexpr (sizeof(T) == 4) {
+      using V = pk2<T>;
+      constexpr int NCT = (NXU + 1) / 2;
+      for (int t = lane; t < N * NCT; t += 64) {
+        const int k = t / NCT, c0 = 2 * (t % NCT), c1 = c0 + 1;
+        T x[NX], u[NU], q = T(0);
+        V m[NX], du[NU], mq = V(T(0));
+#pragma unroll
+        for (int i = 0; i < NX; ++i) { x[i] = xb[nxt][k * NX + i]; m[i] = mk2<T>((c0 == i) ? T(1) : T(0), (c1 == i) ? T(1) : T(0)); }
+#pragma unroll
+        for (int a = 0; a < NU; ++a) { u[a] = ub[nxt][k * NU + a]; du[a] = mk2<T>((c0 == NX + a) ? T(1) : T(0), (c1 == NX + a) ? T(1) : T(0)); }
+        const T tt = this->tk(k);
+        for (int s = 0; s < S; ++s) this->template rk4_step<true, V>(tt, x, q, u, m, mq, du);
+        V* Mk = reinterpret_cast<V*>(Mws[nxt] + (long long)k * Lay::M_ELEMS + c0);
+#pragma unroll
+        for (int i = 0; i < NX; ++i) Mk[i * (Lay::NXUP / 2)] = m[i];
+        Mk[NX * (Lay::NXUP / 2)] = mq;
+      }
+    } else {
+      for (int t = lane; t < N * NXU; t += 64) {
+        const int k = t / NXU, col = t % NXU;
+        T x[NX], u[NU], m[NX], du[NU], q = T(0), mq = T(0);
+#pragma unroll
+        for (int i = 0; i < NX; ++i) { x[i] = xb[nxt][k * NX + i]; m[i] = (col == i) ? T(1) : T(0); }
+#pragma unroll
+        for (int a = 0; a < NU; ++a) { u[a] = ub[nxt][k * NU + a]; du[a] = (col == NX + a) ? T(1) : T(0); }
+        const T tt = this->tk(k);
+        for (int s = 0; s < S; ++s) this->template rk4_step<true>(tt, x, q, u, m, mq, du);
+        T* Mk = Mws[nxt] + (long long)k * Lay::M_ELEMS + col;
+#pragma unroll
+        for (int i = 0; i < NX; ++i) Mk[i * Lay::NXUP] = m[i];
+        Mk[NX * Lay::NXUP] = mq;
+      }
+    }
+    __syncthreads();
+  }
+  // exact discrete costates (== IPOPT's lam_g) of nominal `cur` into lam_out; returns max |dJ/du|
+  LFSD_DEV T costate_sweep(int cur) {
+    T* ldsLam = lds + Lay::LDS_LAM;  T* ldsRed = lds + Lay::LDS_RED;
+    T lam[NX], xN[NX];
+#pragma unroll
+    for (int i = 0; i < NX; ++i) xN[i] = xb[cur][N * NX + i];
+    M::final_grad(this->tk(N), xN, e, c, lam);
+    if (lane == 0) {
+#pragma unroll
+      for (int i = 0; i < NX; ++i) lam_out[N * NX + i] = lam[i];
+    }
+    T gl_max = T(0);
+    for (int k = N - 1; k >= 0; --k) {
+      T gl = T(0);
+      if (lane < NXU) {
+        const T* Mk = Mws[cur] + (long long)k * Lay::M_ELEMS + lane;
+        gl = Mk[NX * Lay::NXUP];
+#pragma unroll
+        for (int i = 0; i < NX; ++i) gl += Mk[i * Lay::NXUP] * lam[i];
+        if (lane < NX) { ldsLam[lane] = gl; lam_out[k * NX + lane] = gl; }
+        else gl_max = t_max(gl_max, t_abs(gl));
+      }
+      __syncthreads();
+#pragma unroll
+      for (int i = 0; i < NX; ++i) lam[i] = ldsLam[i];
+      __syncthreads();
+    }
+    ldsRed[lane] = gl_max;
+    __syncthreads();
+    T g = T(0);
+#pragma unroll
+    for (int a = 0; a < NU; ++a) g = t_max(g, ldsRed[NX + a]);
+    __syncthreads();
+    return g;
+  }
+  // exact stage Hessians of nominal `cur` (costates must be on lam_out), every (interval, column) at once
+  LFSD_DEV void hessians_parallel(int cur) {
+    for (int t = lane; t < N * NXU; t += 64) {
+      const int k = t / NXU, col = t % NXU;
+      T xk[NX], uk[NU], ln[NX], hx[NX], hu[NU];
+#pragma unroll
+      for (int i = 0; i < NX; ++i) { xk[i] = xb[cur][k * NX + i]; ln[i] = lam_out[(k + 1) * NX + i]; }
+#pragma unroll
+      for (int a = 0; a < NU; ++a) uk[a] = ub[cur][k * NU + a];
+      this->template stage_hessian_col<true>(k, xk, uk, ln, hx, hu, col);
+      T* hcol = Hws + (long long)k * Lay::H_ELEMS + col;
+#pragma unroll
+      for (int i = 0; i < NX; ++i) hcol[i * Lay::NXUP] = hx[i];
+#pragma unroll
+      for (int a = 0; a < NU; ++a) hcol[(NX + a) * Lay::NXUP] = hu[a];
+    }
+    __syncthreads();
+  }
+};
+
 // Point a solver view at one trajectory: its LDS region, its scratch slot and its costate rows.  GL is the lane-group
 // size the LDS / workspace layouts were sized for (the Riccati-style "one column per lane" mapping).
 template <class M, typename T, int GL, class Sol>
@@ -1259,7 +1425,7 @@ __global__ void __launch_bounds__(64, LFSD_WAVES_OC) oc_solve_kernel(OcArgs<T> a
 
   // backward sweep of this lane's trajectory; `force`: also when the trajectory is no longer running (final refresh
   // of the costates).  Returns whether the sweep ran (PK skips a pass none of whose trajectories wants it).
-  auto do_backward = [&](int cur_, int mode_, T mu_, bool want_, T& gnorm_, T& dV1_, T& dV2_, T& dmin_, bool& ok_) LFSD_LAMBDA_INLINE -> bool {
+  auto do_backward = [&](int cur_, int mode_, T mu_, bool want_, T& gnorm_, T& dV1_, T& dV2_, T& dmin_, bool& ok_) LFSD_LAMBDA_BW -> bool {
     if constexpr (MF) {
       // all four trajectories of the wavefront sweep together on the matrix cores; a group that does not want the sweep
       // rides along without writing anything (the MFMAs need every lane)
@@ -1307,7 +1473,7 @@ __global__ void __launch_bounds__(64, LFSD_WAVES_OC) oc_solve_kernel(OcArgs<T> a
       return ran;
     }
   };
-  auto do_rollout = [&](int cur_, int nxt_, T alpha_, bool gains_) LFSD_LAMBDA_INLINE -> T {
+  auto do_rollout = [&](int cur_, int nxt_, T alpha_, bool gains_) LFSD_LAMBDA_RO -> T {
     if constexpr (PK) return s.rollout_sens_pk(cur_, nxt_, alpha_, gains_);
     else return s.rollout_sens(cur_, nxt_, alpha_, gains_);
   };
@@ -1468,6 +1634,140 @@ __global__ void __launch_bounds__(64, LFSD_WAVES_OC) oc_solve_kernel(OcArgs<T> a
     for (int i = s.lane; i < (N + 1) * NX; i += GR) xo[i] = s.xb[cur][i];
     for (int i = s.lane; i < (N + 1) * NU; i += GR) uo[i] = s.ub[cur][(i < N * NU) ? i : i - NU];
     if (s.lane == 0) { a.cost[traj] = J; a.iters[traj] = my_iters; a.status[traj] = status; }
+  }
+}
+
+// The WIDE solver: one trajectory per wavefront (grid = batch), same discretisation, same stage-Hessian models and the same
+// step control as oc_solve_kernel (one backward sweep = one iteration; the step lengths 2^0..2^-15 are all rolled out at
+// once, so "optimistic full step, then line search" is a single phase: the largest step length that passes the Armijo
+// test is taken).  Control flow is uniform per workgroup -- no votes, no lock-step partners.  lfsd_coc_solve picks this
+// kernel when the lock-step mapping would leave most SIMDs without a wavefront (LFSD_OC_WIDE overrides).
+template <class M, typename T, bool EXACT>
+__global__ void __launch_bounds__(64, 1) oc_solve_wide_kernel(OcArgs<T> a) {
+  using Sol = OcWide<M, T, EXACT>;
+  using Lay = OcLayout<M>;
+  constexpr int NX = M::NX, NU = M::NU, NP = M::NP, NC = M::NC, NAL = Sol::NAL;
+  constexpr int RS = EXACT ? Lay::template lds_elems<64>() : ((Lay::template lds_ex<64>() + 3) / 4) * 4;
+  __shared__ T lds_all[RS];
+  if (blockDim.x != 64) return;
+  poison_lds(lds_all, RS);
+  Sol s;
+  s.lane = threadIdx.x;
+  const long long traj = blockIdx.x;
+  oc_bind<M, T, 64>(s, a, lds_all, traj, true, traj);
+  const int N = s.N;
+  {
+    T* w2 = a.ws + traj * a.ws_stride + Lay::template ws_elems<64>(N);
+    s.xa = w2; s.ua = s.xa + (long long)NAL * (N + 1) * NX; s.exwu = s.ua + (long long)NAL * N * NU;
+    T* le = s.lds + Lay::template lds_e<64>();
+    T* lc = s.lds + Lay::template lds_c<64>();
+    T* lx = s.lds + Lay::template lds_x0<64>();
+    for (int i = s.lane; i < NP; i += 64) le[i] = a.auxvar[traj * NP + i];
+    for (int i = s.lane; i < NC; i += 64) lc[i] = a.consts[traj * a.const_stride + i];
+    for (int i = s.lane; i < NX; i += 64) lx[i] = a.ini_state[traj * NX + i];
+  }
+  T* ldsRed = s.lds + Lay::LDS_RED;
+  // initial guess into buffer 1, rolled out without gains into buffer 0, linearised
+  for (int i = s.lane; i < N * NU; i += 64) s.ub[1][i] = a.u_init ? a.u_init[traj * N * NU + i] : T(0);
+  __syncthreads();
+  int cur = 0;
+  T alpha_l = T(0);
+  T J = s.rollout_alphas(1, false, alpha_l);             // (every lane rolls the same controls out; lane 0's copy is adopted)
+  ldsRed[s.lane] = J;
+  __syncthreads();
+  J = ldsRed[0];
+  s.adopt_alpha(0, 0);
+  s.linearise_parallel(0);
+  T mu = T(0);
+  int mode = (EXACT && a.exact_after == 0) ? 2 : 0;
+  bool ham_ok = true, hess_ok = false, gn_crawl = false, costates_ok = false;
+  int status = t_finite(J) ? ST_RUNNING : ST_FAILED, it = 0;
+  T gnorm = T(0), dV1 = T(0), dV2 = T(0), g_flat = T(-1), J_ref = J, mu_bad = T(-1);
+  int n_acc = 0, mu_hold = 0;
+  const int mu_hold_need = LFSD_MU_HOLD;
+  for (; it < a.max_iter && status == ST_RUNNING; ++it) {
+    if (EXACT && a.exact_after >= 0 && mode < 2 && (it >= a.exact_after || gn_crawl)) mode = 2;
+    if (EXACT && mode == 2 && !hess_ok) {
+      s.costate_sweep(cur);
+      s.hessians_parallel(cur);
+      hess_ok = true;
+    }
+    s.reuse_hess = EXACT && mode == 2;
+    T dmin = T(0);
+    const bool bw_ok = s.backward(cur, mode, mu, gnorm, dV1, dV2, dmin);
+    costates_ok = true;
+    if (!bw_ok) {
+      if (mode == 1 && !LFSD_HAM_SHIFT) { mode = 0; ham_ok = false; }
+      else {
+        mu_bad = mu; mu_hold = 0;
+        if (mu == T(0) && mode >= 1 && t_finite(dmin)) mu = t_min(t_max(T(-2) * dmin, T(1e-4)), T(1e6));
+        else mu = t_max(mu * T(LFSD_MU_UP), mode == 2 ? T(1e-4) : T(1e-6));
+        if (mu > T(1e12)) status = ST_FAILED;
+      }
+      continue;
+    }
+    if (gnorm < a.tol * (T(1) + t_abs(J))) { status = ST_CONVERGED; break; }
+    // all step lengths at once; the largest one that passes the Armijo test is taken
+    const T Ja = s.rollout_alphas(cur, true, alpha_l);
+    ldsRed[s.lane] = Ja;
+    __syncthreads();
+    int ia = -1;
+    T Jmin = J, Jn = J, aa = T(1);
+    const T flat = T(8) * Eps<T>::v() * t_abs(J);
+    const bool flat_full = t_finite(ldsRed[0]) && t_abs(ldsRed[0] - J) <= T(64) * Eps<T>::v() * t_abs(J);
+    for (int l = 0; l < NAL; ++l) {
+      const T Jl = ldsRed[l];
+      const T expected = -(aa * dV1 + aa * aa * dV2);
+      const bool okl = t_finite(Jl) && ((J - Jl) >= T(1e-4) * expected - flat) && (Jl < J);
+      if (okl && ia < 0) { ia = l; Jn = Jl; }
+      if (t_finite(Jl)) Jmin = t_min(Jmin, Jl);
+      aa *= T(0.5);
+    }
+    __syncthreads();
+    bool accept = ia >= 0;
+    if (!accept) {
+      if (mode >= 1 && flat_full && (g_flat < T(0) || gnorm < T(0.7) * g_flat)) {
+        accept = true; ia = 0; Jn = ldsRed[0]; g_flat = gnorm;      // Newton-like step below rounding noise, gradient still contracting
+      } else if (mode == 1 && !LFSD_HAM_SHIFT) {
+        mode = 0; ham_ok = false;
+      } else if (mu > T(1e10) || ((J - Jmin) <= T(8) * Eps<T>::v() * t_abs(J) && (mode == 0 || flat_full || mu > T(1e6)))) {
+        status = ST_STALLED;
+      } else {
+        mu_bad = mu; mu_hold = 0;
+        mu = t_max(mu * T(LFSD_MU_UP), mode == 2 ? T(1e-4) : T(1e-6));
+      }
+    }
+#if defined(LFSD_TRACE)
+    if (s.lane == 0 && traj == 0) printf("wide it %d st %d mode %d g %.6e J %.12e ia %d accept %d mu %g dV1 %.4e dV2 %.4e Jmin %.12e\n", it, status, mode, (double)gnorm, (double)J, ia, (int)accept, (double)mu, (double)dV1, (double)dV2, (double)Jmin);
+#endif
+    if (accept) {
+      s.adopt_alpha(ia, cur ^ 1);
+      s.linearise_parallel(cur ^ 1);
+      cur ^= 1;
+      hess_ok = false; costates_ok = false;
+      if (ia == 0) {
+        const T mu_next = (mu > T(1e-8)) ? mu * T(LFSD_MU_DOWN) : T(0);
+        if (mu > T(0) && mu_bad >= T(0) && mu_next <= mu_bad && mu_hold < mu_hold_need) ++mu_hold;
+        else { mu = mu_next; mu_hold = 0; }
+        if (mode == 0 && ham_ok && (J - Jn) < T(0.3) * t_abs(Jn)) mode = 1;
+        else if (LFSD_GN_CRAWL && mode == 0 && !ham_ok && (J - Jn) < T(1e-2) * t_abs(Jn)) gn_crawl = true;
+      }
+      J = Jn;
+      if (++n_acc >= 4) {
+        if (J_ref - J <= T(16) * Eps<T>::v() * t_abs(J)) status = ST_STALLED;
+        J_ref = J; n_acc = 0;
+      }
+    }
+  }
+  if (status == ST_RUNNING) status = ST_MAXITER;
+  if (!costates_ok) s.costate_sweep(cur);                 // costates of the final nominal
+  __syncthreads();
+  {
+    T* xo = a.state_grid + traj * (N + 1) * NX;
+    T* uo = a.control_grid + traj * (N + 1) * NU;
+    for (int i = s.lane; i < (N + 1) * NX; i += 64) xo[i] = s.xb[cur][i];
+    for (int i = s.lane; i < (N + 1) * NU; i += 64) uo[i] = s.ub[cur][(i < N * NU) ? i : i - NU];
+    if (s.lane == 0) { a.cost[traj] = J; a.iters[traj] = (status == ST_CONVERGED) ? it + 1 : it; a.status[traj] = status; }
   }
 }
 

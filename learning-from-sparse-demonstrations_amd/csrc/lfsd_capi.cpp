@@ -3,6 +3,10 @@
 //         hipcc -x hip --offload-arch=gfx950 -DLFSD_MODEL_HEADER='"gen/<hash>.h"' -DLFSD_G=<lanes> ...
 // (tests/emu builds the same file with g++ -DLFSD_EMU for the CPU SIMT emulator.)
 #include "lfsd_internal.h"
+#include <cstdlib>
+#ifndef LFSD_WIDE_MAX_BATCH
+#define LFSD_WIDE_MAX_BATCH 1536
+#endif
 #if !defined(LFSD_SPLIT_RICCATI)
 #include "lfsd_riccati.inc"
 #endif
@@ -33,10 +37,30 @@ static constexpr bool OC_PK = (G == 32) && (Model::NX + Model::NU + 1) / 2 <= 16
 static constexpr int OC_GPB = OC_PK ? 4 : GPB;      // scratch slots are padded to whole workgroups of either mapping
 static long long padded_batch(int batch) { return ((long long)(batch + OC_GPB - 1) / OC_GPB) * OC_GPB; }
 
+// Which mapping solves a batch.  The lock-step kernels (several trajectories per wavefront, intervals in sequence) fill the
+// machine from ~4096 trajectories up; below ~1500 most of the 1024 SIMDs would have no wavefront, and where an iteration is
+// expensive -- exact stage Hessians: robot arm, rocket -- the WIDE kernel (one trajectory per wavefront, intervals in
+// parallel: oc_solve_wide_kernel) is 3.5-6x faster (robot arm 1024 seeds 108 -> 18.6 ms, rocket n_grid 100 763 -> 215 ms).
+// The fp32 models with the packed / MFMA lean kernel that converge in a handful of cheap iterations (quadrotor: 5) stay
+// on the lock-step mapping, which is faster for them at every batch size (profiles/r02_d_wide_vs_lockstep.txt).
+// LFSD_OC_WIDE=0/1 in the environment overrides.
+template <typename T> static bool use_wide(int batch, int exact_after) {
+  if (const char* ev = getenv("LFSD_OC_WIDE")) return atoi(ev) != 0;
+  const bool lean_mfma = OC_PK && sizeof(T) == 4 && exact_after != 0;
+  return batch <= LFSD_WIDE_MAX_BATCH && !lean_mfma;
+}
+// (the workspace query does not know exact_after: it returns the larger of the two layouts where wide is possible)
+static bool wide_possible(int batch) {
+  if (const char* ev = getenv("LFSD_OC_WIDE")) return atoi(ev) != 0;
+  return batch <= LFSD_WIDE_MAX_BATCH;
+}
+
 LFSD_API size_t lfsd_coc_workspace_bytes(int dtype, int batch, int n_grid) {
   if (batch <= 0 || n_grid <= 0 || (dtype != LFSD_F32 && dtype != LFSD_F64)) return 0;
   const size_t es = dtype == LFSD_F32 ? 4 : 8;
-  return (size_t)padded_batch(batch) * (size_t)lfsd::OcLayout<Model>::template ws_elems<G>(n_grid) * es;
+  const size_t lock = (size_t)padded_batch(batch) * (size_t)lfsd::OcLayout<Model>::template ws_elems<G>(n_grid) * es;
+  const size_t wide = (size_t)batch * (size_t)lfsd::OcLayout<Model>::ws_elems_wide(n_grid) * es;
+  return (wide_possible(batch) && wide > lock) ? wide : lock;
 }
 
 template <typename T>
@@ -56,6 +80,14 @@ static int coc_solve_t(int batch, int n_grid, int steps_per_grid, const void* in
   a.ws = (T*)workspace; a.ws_stride = lfsd::OcLayout<Model>::template ws_elems<G>(n_grid);
   a.tol = (T)tol;
   a.exact_after = exact_after;
+  if (use_wide<T>(batch, exact_after)) {
+    a.ws_stride = lfsd::OcLayout<Model>::ws_elems_wide(n_grid);
+    if (workspace_bytes < (size_t)batch * (size_t)a.ws_stride * sizeof(T)) return LFSD_ENOSPC;
+    a.it_start = 0; a.resume = 0; a.max_iter_total = max_iter;
+    if (exact_after < 0) { LFSD_LAUNCH((lfsd::oc_solve_wide_kernel<Model, T, false>), (unsigned)batch, 64, stream, a); }
+    else { LFSD_LAUNCH((lfsd::oc_solve_wide_kernel<Model, T, true>), (unsigned)batch, 64, stream, a); }
+    return launch_status();
+  }
   const size_t need = (size_t)padded_batch(batch) * (size_t)a.ws_stride * sizeof(T);
   if (workspace_bytes < need) return LFSD_ENOSPC;
   const unsigned grid = (unsigned)(padded_batch(batch) / GPB);

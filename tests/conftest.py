@@ -41,6 +41,15 @@ def build_emu_library(oc):
     return out
 
 
+@pytest.fixture(params=["lockstep", "wide"])
+def oc_mapping(request, monkeypatch):
+    """Both mappings of the OC solve: several trajectories per wavefront with the intervals in sequence (lfsd_coc_solve's
+    choice from a few thousand trajectories up) and one trajectory per wavefront with the intervals in parallel (its choice
+    below that).  LFSD_OC_WIDE forces one or the other whatever the batch size."""
+    monkeypatch.setenv("LFSD_OC_WIDE", "1" if request.param == "wide" else "0")
+    return request.param
+
+
 @pytest.fixture(scope="session")
 def emu():
     def bind(oc):

@@ -2,10 +2,13 @@
 #include "lfsd_capi.cpp"   // the product C ABI translation unit, compiled with -DLFSD_EMU
 #include <vector>
 #include <cstdio>
+#include <cstdlib>
 int main() {
   lfsd_model_info mi; lfsd_get_model_info(&mi);
   const int B = 5, N = 6, n = mi.n_state, m = mi.n_control, p = mi.n_auxvar, nc = mi.n_const, nw = 2, ni = 1;
-  for (int dtype = 0; dtype < 2; ++dtype) {
+  for (int pass = 0; pass < 4; ++pass) {         // both arithmetic types x both mappings of the OC solve (lock-step, wide)
+    const int dtype = pass & 1;
+    setenv("LFSD_OC_WIDE", (pass & 2) ? "1" : "0", 1);
     const size_t es = dtype ? 8 : 4;
     auto buf = [&](size_t cnt) { return std::vector<char>(cnt * es); };
     auto x0 = buf(B * n), hz = buf(B), th = buf(B * p), cs = buf(nc ? nc : 1), X = buf(B * (N + 1) * n), U = buf(B * (N + 1) * m),

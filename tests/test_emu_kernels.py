@@ -42,7 +42,7 @@ def run_case(emu, kind, dtype, thetas, taus, wps, n_grid, batch_pad=0, substeps=
 
 
 @pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
-def test_pendulum_full_pipeline_vs_oracle(emu, dtype):
+def test_pendulum_full_pipeline_vs_oracle(emu, dtype, oc_mapping):
     thetas = [[1.0, 0.5, 1.5], [2.0, 1.0, 1.0], [0.7, 1.3, 0.6]]      # B=3: ragged vs 8 groups per block
     taus, wps = [0.0, 0.3, 0.6, 0.7, 1.0], [[0.0], [1.2], [2.1], [2.4], [2.9]]   # endpoints + a grid point
     oc, d, sol, aux = run_case(emu, "pendulum", dtype, thetas, taus, wps, 10, substeps=16)
@@ -117,11 +117,12 @@ def test_quadrotor_against_reference_golden_run(emu):
     assert np.abs(tr[:, 13:17] - G["opt_control_traj"]).max() < 1e-6
 
 
-def test_quadrotor_fp32_packed_rollout_matches_fp64(emu):
+def test_quadrotor_fp32_packed_rollout_matches_fp64(emu, monkeypatch):
     """The fp32 lean OC kernel of the 32-lane models rolls out on 16-lane groups with two tangent columns per lane
-    (oc_solve_kernel<..., PK=true>, four trajectories per workgroup, backward sweep relayed in two passes); fp64 keeps the
+    (oc_solve_kernel<..., PK=true>, four trajectories per workgroup, backward sweep on the (emulated) matrix cores); fp64 keeps the
     one-column-per-lane mapping.  Same inputs, ragged batch of 5 (one full workgroup + one partial), stated fp32
     tolerances: loss 5e-4, gradient 2e-2, grids 5e-3."""
+    monkeypatch.setenv("LFSD_OC_WIDE", "0")          # this test is about the lock-step kernels
     oc, env, d = models.quadrotor(n_grid=int(G["n_grid"]))
     emu(oc)
     consts = oc.consts_tensor(overrides=dict(goal_r0=G["goal_r"][0], goal_r1=G["goal_r"][1], goal_r2=G["goal_r"][2]))
@@ -323,7 +324,7 @@ def test_rocket_newton_mode_vs_oracle(emu):
     assert rel(sol2["state_grid"][0], r0[2]) < 1e-6 and rel(sol2["costate_grid"][0], r0[4]) < 1e-5
 
 
-def test_edge_cases_ragged_empty_and_per_trajectory_inputs(emu):
+def test_edge_cases_ragged_empty_and_per_trajectory_inputs(emu, oc_mapping):
     """Ragged batch sizes vs the lane-group packing, no waypoints, waypoint times outside [0, T] (clamped to the end
     intervals like the interpolant's end points), per-trajectory horizons and per-trajectory constants."""
     oc, env, d = models.pendulum(n_grid=10)
@@ -370,9 +371,11 @@ def test_edge_cases_ragged_empty_and_per_trajectory_inputs(emu):
     assert not torch.equal(solb["state_grid"][0], solb["state_grid"][2])
 
 
-def test_warm_start_and_mixed_precision(emu):
+def test_warm_start_and_mixed_precision(emu, monkeypatch):
     """u_init warm start reaches the same KKT point in fewer iterations; fp32 solve + fp64 auxiliary pass
-    (BASELINE configs[4]) returns fp64-accurate sweeps on the fp32 trajectory."""
+    (BASELINE configs[4]) returns fp64-accurate sweeps on the fp32 trajectory.  Robot arm on the lock-step kernels (the other
+    robot-arm tests run the wide mapping, lfsd_coc_solve's choice for small batches)."""
+    monkeypatch.setenv("LFSD_OC_WIDE", "0")
     oc, env, d = models.robotarm(n_grid=12)
     emu(oc)
     th = [[3., 0.5, 2, 1.5, 0.2]]

@@ -37,7 +37,7 @@ def gpu_prepare(oc, dtype):
 
 @pytest.mark.parametrize("kind", ["pendulum", "robotarm", "cartpole", "quadrotor"])
 @pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
-def test_every_output_grid_vs_oracle(kind, dtype):
+def test_every_output_grid_vs_oracle(kind, dtype, oc_mapping):
     """state / control / costate grids, Z = [P W], dx/dtheta, du/dtheta, loss, gradient -- all of them, on the GPU, against
     the tight oracle (tolerances: parity_cases.TOL)."""
     pc.all_grids_vs_oracle(gpu_prepare, kind, dtype)
@@ -71,7 +71,7 @@ def test_quadrotor_bench_seeds_vs_tight_oracle(dtype, ltol, gtol, xtol):
 
 
 @pytest.mark.parametrize("dtype,ltol", [(torch.float64, 1e-6), (torch.float32, 5e-4)])
-def test_quadrotor_vs_reference_golden_run(dtype, ltol):
+def test_quadrotor_vs_reference_golden_run(dtype, ltol, oc_mapping):
     """(theta, loss, dtheta) triples produced by the reference's own CasADi+IPOPT+solve_ivp run.
     Gradient tolerance 1e-2: the reference's solve_ivp (rtol 1e-3) is itself 5e-4..5e-3 off the exact ODE."""
     oc, d = gpu_model("quadrotor", dtype, int(G["n_grid"]), substeps=4)
@@ -183,7 +183,7 @@ def test_optimizer_kernels(method):
         assert np.allclose(theta.cpu().numpy(), th_ref, rtol=1e-12, atol=1e-13)
 
 
-def test_rocket_newton_mode_vs_oracle():
+def test_rocket_newton_mode_vs_oracle(oc_mapping):
     """BASELINE configs[4] robot (Examples/rocket_groundtruth.py): exact stage Hessians from the first iteration.  Several
     local minima: which one a cold start reaches depends on the globalisation (IPOPT's would differ from ours and from the
     oracle's), so parity is basin-independent -- the oracle certifies the kernel's cold-start answer as a KKT point of the
@@ -210,7 +210,7 @@ def test_rocket_newton_mode_vs_oracle():
     assert rel(sol2["state_grid"][0], r0[2]) < 1e-6 and rel(sol2["costate_grid"][0], r0[4]) < 1e-5
 
 
-def test_rocket_fp32_solve_fp64_aux_vs_oracle():
+def test_rocket_fp32_solve_fp64_aux_vs_oracle(oc_mapping):
     """The mixed-precision path of BASELINE configs[4] (setDevice(aux_dtype=float64), CPDP.py:247-250 of this package)."""
     pc.rocket_mixed_precision(gpu_prepare)
 
@@ -345,8 +345,8 @@ def test_robotarm_12_vanilla_steps_every_gradient_applied():
     Examples/robotarm_random.py:60-73), 1024 seeds, fp32.  The fixed learning rate throws the few large-sensitivity seeds
     (previous test) out of the region where the problem is well posed -- negative quadratic state weights make the
     running cost non-convex; no solver has a KKT point to return there (J runs to -10^3 ... -10^4) -- so the assertion
-    is on the admissible seeds: finite parameters, beta > 0, both quadratic weights > 0.05.  Every one of them has to
-    converge at every step."""
+    is on the admissible seeds: parameters finite and below 1e3 (they start at 1..5; a seed at 1e17 has left the problem
+    for good), beta > 0, both quadratic weights > 0.05.  Every one of them has to converge at every step."""
     from lfsd_amd import CPDP
     B = 1024
     th0 = _arm_seeds(B)
@@ -355,7 +355,7 @@ def test_robotarm_12_vanilla_steps_every_gradient_applied():
                                method="Vanilla", learning_rate=d["lr"], skip_unconverged=False)
     for k in range(13):
         th = L.theta.double().cpu().numpy()
-        adm = np.isfinite(th).all(1) & (th[:, 0] > 0) & (th[:, 1] > 0.05) & (th[:, 3] > 0.05)
+        adm = np.isfinite(th).all(1) & (np.abs(th) < 1e3).all(1) & (th[:, 0] > 0) & (th[:, 1] > 0.05) & (th[:, 3] > 0.05)
         L.step()
         st = L._sol["status"].cpu().numpy()
         assert np.isin(st[adm], (1, 2)).mean() == 1.0, (k, np.bincount(st[adm], minlength=5))

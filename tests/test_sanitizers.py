@@ -14,7 +14,8 @@ EMU = os.path.join(ROOT, "tests", "emu")
 
 
 # pendulum: 8-lane groups; robot arm: 16-lane groups, 8-lane forward sweep; quadrotor: 32-lane groups, packed fp32
-# roll-out on 16-lane groups with the relayed backward sweep, 16-lane forward sweep.  Batch 5 leaves a partial workgroup.
+# roll-out on 16-lane groups with the MFMA backward sweep (emulated), 16-lane forward sweep.  Batch 5 leaves a partial
+# workgroup.  Every model runs the lock-step AND the wide (one trajectory per wavefront) OC kernels.
 @pytest.mark.parametrize("kind", ["pendulum", "robotarm", "quadrotor"])
 def test_asan_ubsan_clean(tmp_path, kind):
     oc, _, _ = models.ZOO[kind]()
@@ -30,4 +31,4 @@ def test_asan_ubsan_clean(tmp_path, kind):
     r = subprocess.run([exe], capture_output=True, text=True, env=env, timeout=600)
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
     assert "ERROR: AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stderr[-4000:]
-    assert r.stdout.count("rc 0") == 6, r.stdout
+    assert r.stdout.count("rc 0") == 12, r.stdout
