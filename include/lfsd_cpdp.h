@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define LFSD_ABI_VERSION 2
+#define LFSD_ABI_VERSION 3
 #define LFSD_F32 0
 #define LFSD_F64 1
 #define LFSD_EINVAL (-1)   /* bad argument (null pointer, non-positive size, unknown enum) */
@@ -72,10 +72,16 @@ size_t lfsd_coc_workspace_bytes(int dtype, int batch, int n_grid);
  * solver: Gauss-Newton steps first, then Newton steps; `exact_after` = iteration from which the exact
  *   Lagrangian Hessian of the RK4 stages (what IPOPT gets from CasADi) is forced: 16 is the default policy,
  *   0 = exact from the first iteration, <0 = never (Gauss-Newton / Hamiltonian model only).
- *   steps_per_grid <= 8.                                                                        */
+ *   steps_per_grid <= 8.
+ *   control_lb / control_ub [n_control] (shared by the batch) or NULL: finite control bounds, the reference's
+ *   setControlVariable(control, control_lb, control_ub) -> lbw / ubw of the NLP (CPDP.py:33-46, 150-153).  Both or
+ *   neither; entries beyond +-1e19 mean "unbounded in that direction".  Solved by a control-limited backward sweep
+ *   (box QP per stage, zero feedback gain on clamped components, clamped roll-out); the initial guess is the midpoint of
+ *   finite bounds as in the reference.  State bounds are not supported.                                          */
 int lfsd_coc_solve(int dtype, int batch, int n_grid, int steps_per_grid,
                    const void* ini_state, const void* horizon, const void* auxvar,
                    const void* consts, int const_per_traj, const void* u_init,
+                   const void* control_lb, const void* control_ub,
                    void* state_grid, void* control_grid, void* costate_grid,
                    void* cost, int* iters, int* status,
                    int max_iter, double tol, int exact_after,

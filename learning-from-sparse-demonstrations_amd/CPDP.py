@@ -53,23 +53,34 @@ class COCSys:
         self.n_auxvar = len(self.auxvar)
         self._lib = None
 
-    def _bounds(self, lb, ub, what):
-        lb, ub = list(lb), list(ub)
-        if any(np.isfinite(v) and abs(v) < 1e19 for v in lb + ub):
-            raise NotImplementedError("finite %s bounds are not supported by the HIP solver (the reference's "
-                                      "examples never set them)" % what)
-
     def setStateVariable(self, state, state_lb=[], state_ub=[]):
+        """CPDP.py:20-31.  Finite state bounds are NLP variable bounds on the shooting nodes in the reference (IPOPT's
+        interior point handles them); the DDP solver here has no counterpart and refuses them."""
         self.state = symbolic._flat([state])
         self.n_state = len(self.state)
-        self._bounds(state_lb, state_ub, "state")
+        if len(state_lb) == self.n_state and len(state_ub) == self.n_state and \
+                any(np.isfinite(v) and abs(v) < 1e19 for v in list(state_lb) + list(state_ub)):
+            raise NotImplementedError("finite state bounds are not supported by the HIP solver (the reference's "
+                                      "examples never set them)")
         self._lib = None
 
     def setControlVariable(self, control, control_lb=[], control_ub=[]):
+        """CPDP.py:33-46: bounds are used only when their length equals n_control (otherwise +-1e20, as the reference).
+        Finite control bounds are honoured by the control-limited backward sweep of the HIP solver."""
         self.control = symbolic._flat([control])
         self.n_control = len(self.control)
-        self._bounds(control_lb, control_ub, "control")
+        self.control_lb = [float(v) for v in control_lb] if len(control_lb) == self.n_control else self.n_control * [-1e20]
+        self.control_ub = [float(v) for v in control_ub] if len(control_ub) == self.n_control else self.n_control * [1e20]
+        if any(l > u for l, u in zip(self.control_lb, self.control_ub)):
+            raise ValueError("control_lb > control_ub")
         self._lib = None
+
+    def _control_bounds(self):
+        """(lb, ub) device tensors, or (None, None) when no bound is finite."""
+        lb, ub = getattr(self, "control_lb", None), getattr(self, "control_ub", None)
+        if lb is None or not any(abs(v) < 1e19 for v in lb + ub):
+            return None, None
+        return self._t(lb), self._t(ub)
 
     def setTimeVariable(self, t=None):
         self.time = t if t is not None else sp.Symbol('time', real=True)
@@ -226,9 +237,10 @@ class COCSys:
             hz = hz.expand(B).contiguous()
         if consts is None:
             consts = self.consts_tensor()
+        clb, cub = self._control_bounds()
         sol = lib.coc_solve(x0, hz, th, consts, self.n_grid, self.steps_per_grid, u_init=u_init,
                             max_iter=self.max_iter, tol=self.tol, workspace=workspace, out=out,
-                            exact_after=self.exact_after)
+                            exact_after=self.exact_after, control_lb=clb, control_ub=cub)
         sol.update(horizon=hz, auxvar=th, consts=consts, ini_state=x0, n_grid=self.n_grid)
         return sol
 

@@ -302,6 +302,63 @@ template <int n, typename T> LFSD_DEV void chol_solve(const T* Lm, T* b) {
     b[i] = s / Lm[i * n + i];
   }
 }
+// Box-constrained stage problem of the control-limited backward sweep (finite control_lb / control_ub of
+// COCSys.setControlVariable, CPDP.py:33-46, which the reference hands to IPOPT as lbw / ubw):
+//     min_x  1/2 x^T Q x + q^T x   s.t.  lo <= x <= hi            (Q = Q_uu + mu I positive definite, n <= 4 controls)
+// by a primal active-set iteration on the masked system (clamped rows / columns replaced by identity): solve, clamp the
+// components that left the box, re-solve; when nothing moves, release the clamped component whose multiplier has the
+// wrong sign most.  Returns the Cholesky factor of the final masked matrix in Lf (the feedback gains of the free
+// components are solved with it; clamped components get zero gain) and the clamp mask.
+template <int n, typename T> LFSD_DEV bool box_qp(const T* Q, const T* q, const T* lo, const T* hi, T* x, unsigned& mask, T* Lf, T& dmin) {
+  mask = 0u;
+  T xc[n];
+#pragma unroll
+  for (int i = 0; i < n; ++i) xc[i] = T(0);
+  bool ok = true;
+  for (int round = 0; round < 3 * n + 2; ++round) {
+    T b[n];
+#pragma unroll
+    for (int i = 0; i < n; ++i) {
+      const bool ci = (mask >> i) & 1u;
+      T s = ci ? xc[i] : -q[i];
+#pragma unroll
+      for (int j = 0; j < n; ++j) {
+        const bool cj = (mask >> j) & 1u;
+        Lf[i * n + j] = (ci || cj) ? ((i == j) ? T(1) : T(0)) : Q[i * n + j];
+        if (!ci && cj) s -= Q[i * n + j] * xc[j];
+      }
+      b[i] = s;
+    }
+    T dd = T(0);
+    if (!chol_factor<n>(Lf, dd)) { ok = false; if (dd < dmin) dmin = dd; break; }
+    chol_solve<n>(Lf, b);
+    unsigned newmask = mask;
+#pragma unroll
+    for (int i = 0; i < n; ++i) {
+      if ((mask >> i) & 1u) continue;
+      if (b[i] < lo[i]) { newmask |= 1u << i; xc[i] = lo[i]; }
+      else if (b[i] > hi[i]) { newmask |= 1u << i; xc[i] = hi[i]; }
+    }
+#pragma unroll
+    for (int i = 0; i < n; ++i) x[i] = ((newmask >> i) & 1u) ? xc[i] : b[i];
+    if (newmask != mask) { mask = newmask; continue; }
+    // stationary for this active set: multipliers g_i = (Q x + q)_i of the clamped components must push outward
+    int worst = -1;
+    T wv = T(0);
+#pragma unroll
+    for (int i = 0; i < n; ++i) {
+      if (!((mask >> i) & 1u)) continue;
+      T g = q[i];
+#pragma unroll
+      for (int j = 0; j < n; ++j) g += Q[i * n + j] * x[j];
+      const T viol = (xc[i] <= lo[i]) ? -g : g;         // at the lower bound the gradient must be >= 0, at the upper <= 0
+      if (viol > wv) { wv = viol; worst = i; }
+    }
+    if (worst < 0) break;
+    mask &= ~(1u << worst);
+  }
+  return ok;
+}
 // LU without pivoting, in place (unit lower + upper).  For I + small and SPD-like matrices.
 template <int n, typename T> LFSD_DEV void lu_factor(T* A) {
 #pragma unroll
@@ -441,6 +498,8 @@ template <typename T> struct OcArgs {
   int it_start;         // iteration counter to start from (phase 2 of a two-launch solve)
   int max_iter_total;   // overall iteration limit of the solve (phase 1 only hands over if a phase 2 follows)
   int resume;           // 1: continue only trajectories whose status is ST_MAXITER, warm-started from control_grid
+  const T* u_lb;        // [NU] finite control bounds (CPDP.py:33-46) or nullptr; handled by the wide kernel
+  const T* u_ub;
 };
 
 template <class M> struct OcLayout {
@@ -487,8 +546,9 @@ template <class M> struct OcLayout {
   template <int G> static constexpr int lds_elems() { return ((lds_ex<G>() + 8 * NX * G + 3) / 4) * 4; }
 };
 
-template <class M, typename T, int G, bool EXACT> struct OcSolver {
+template <class M, typename T, int G, bool EXACT, bool BND = false> struct OcSolver {
   static constexpr int NX = M::NX, NU = M::NU, NP = M::NP, NC = M::NC, NXU = NX + NU;
+  T ulb[BND ? NU : 1], uub[BND ? NU : 1];      // BND: box on the controls (clamped roll-out, box-QP backward sweep)
   static constexpr int NALPHA = (G < 10) ? G : 10;
   using Lay = OcLayout<M>;
 
@@ -549,6 +609,10 @@ template <class M, typename T, int G, bool EXACT> struct OcSolver {
 #pragma unroll
         for (int a = 0; a < NU; ++a) u[a] += Kk[i * NU + a] * dx;
       }
+    }
+    if (BND) {
+#pragma unroll
+      for (int a = 0; a < NU; ++a) u[a] = t_min(t_max(u[a], ulb[a]), uub[a]);
     }
   }
 
@@ -849,7 +913,15 @@ template <class M, typename T, int G, bool EXACT> struct OcSolver {
 #pragma unroll
         for (int a = 0; a < NU; ++a) ldsQuu[b * NU + a] = Quxj[a];
         ldsQu[b] = Qg;
-        gl_max = t_max(gl_max, t_abs(gl));
+        T glp = gl;
+        if (BND) {
+          // projected gradient: a control sitting on a bound with the descent direction pointing out of the box is stationary
+          T ukb = T(0), lbb = T(0), ubb = T(0);
+#pragma unroll
+          for (int a = 0; a < NU; ++a) { if (a == b) { ukb = uk[a]; lbb = ulb[a]; ubb = uub[a]; } }
+          if ((ukb <= lbb && gl > T(0)) || (ukb >= ubb && gl < T(0))) glp = T(0);
+        }
+        gl_max = t_max(gl_max, t_abs(glp));
       }
       __syncthreads();
       T Quu0[NU * NU], Lc[NU * NU], Qu[NU], kff[NU], Kj[NU], t1[NU];
@@ -863,15 +935,28 @@ template <class M, typename T, int G, bool EXACT> struct OcSolver {
       for (int i = 0; i < NU * NU; ++i) Lc[i] = Quu0[i];
 #pragma unroll
       for (int a = 0; a < NU; ++a) Lc[a * NU + a] += mu;
-      if (ok) ok = chol_factor<NU>(Lc, dmin); else { T dd = T(0); chol_factor<NU>(Lc, dd); }   // first failing pivot sizes the shift
       if (LFSD_REG_CONSISTENT) {
 #pragma unroll
         for (int a = 0; a < NU; ++a) Quu0[a * NU + a] += mu;
       }
+      if (BND) {
+        // control-limited step: box QP for the feed-forward part, zero feedback gain on the clamped components
+        T lo[NU], hi[NU], Lf[NU * NU], dd = T(0);
 #pragma unroll
-      for (int a = 0; a < NU; ++a) { kff[a] = -Qu[a]; Kj[a] = -Quxj[a]; }
-      chol_solve<NU>(Lc, kff);
-      chol_solve<NU>(Lc, Kj);
+        for (int a = 0; a < NU; ++a) { lo[a] = ulb[a] - uk[a]; hi[a] = uub[a] - uk[a]; }
+        unsigned cmask = 0u;
+        const bool okq = box_qp<NU>(Lc, Qu, lo, hi, kff, cmask, Lf, dd);
+        if (ok && !okq) { ok = false; if (dd < dmin) dmin = dd; }
+#pragma unroll
+        for (int a = 0; a < NU; ++a) Kj[a] = ((cmask >> a) & 1u) ? T(0) : -Quxj[a];
+        chol_solve<NU>(Lf, Kj);
+      } else {
+        if (ok) ok = chol_factor<NU>(Lc, dmin); else { T dd = T(0); chol_factor<NU>(Lc, dd); }   // first failing pivot sizes the shift
+#pragma unroll
+        for (int a = 0; a < NU; ++a) { kff[a] = -Qu[a]; Kj[a] = -Quxj[a]; }
+        chol_solve<NU>(Lc, kff);
+        chol_solve<NU>(Lc, Kj);
+      }
       T qk[NU];
       matvec<NU>(Quu0, kff, qk);
 #pragma unroll
@@ -1203,8 +1288,8 @@ template <class M, typename T, int G, bool EXACT> struct OcSolver {
 //   costate_sweep       lambda_k = q_x + A_k^T lambda_k+1 (sequential, NX FMAs per interval)
 //   hessians_parallel   exact stage Hessian columns for every (k, column): second-order adjoint sweeps, N*NXU/64 rounds
 // which leaves only the cheap Riccati-type recursion of OcSolver::backward sequential in k.
-template <class M, typename T, bool EXACT> struct OcWide : OcSolver<M, T, 64, EXACT> {
-  using Base = OcSolver<M, T, 64, EXACT>;
+template <class M, typename T, bool EXACT, bool BND = false> struct OcWide : OcSolver<M, T, 64, EXACT, BND> {
+  using Base = OcSolver<M, T, 64, EXACT, BND>;
   using Lay = OcLayout<M>;
   static constexpr int NX = M::NX, NU = M::NU, NP = M::NP, NXU = NX + NU;
   static constexpr int NAL = 16;                       // step lengths 2^0 .. 2^-15
@@ -1642,9 +1727,9 @@ __global__ void __launch_bounds__(64, LFSD_WAVES_OC) oc_solve_kernel(OcArgs<T> a
 // once, so "optimistic full step, then line search" is a single phase: the largest step length that passes the Armijo
 // test is taken).  Control flow is uniform per workgroup -- no votes, no lock-step partners.  lfsd_coc_solve picks this
 // kernel when the lock-step mapping would leave most SIMDs without a wavefront (LFSD_OC_WIDE overrides).
-template <class M, typename T, bool EXACT>
+template <class M, typename T, bool EXACT, bool BND = false>
 __global__ void __launch_bounds__(64, 1) oc_solve_wide_kernel(OcArgs<T> a) {
-  using Sol = OcWide<M, T, EXACT>;
+  using Sol = OcWide<M, T, EXACT, BND>;
   using Lay = OcLayout<M>;
   constexpr int NX = M::NX, NU = M::NU, NP = M::NP, NC = M::NC, NAL = Sol::NAL;
   constexpr int RS = EXACT ? Lay::template lds_elems<64>() : ((Lay::template lds_ex<64>() + 3) / 4) * 4;
@@ -1667,8 +1752,21 @@ __global__ void __launch_bounds__(64, 1) oc_solve_wide_kernel(OcArgs<T> a) {
     for (int i = s.lane; i < NX; i += 64) lx[i] = a.ini_state[traj * NX + i];
   }
   T* ldsRed = s.lds + Lay::LDS_RED;
-  // initial guess into buffer 1, rolled out without gains into buffer 0, linearised
-  for (int i = s.lane; i < N * NU; i += 64) s.ub[1][i] = a.u_init ? a.u_init[traj * N * NU + i] : T(0);
+  if constexpr (BND) {
+#pragma unroll
+    for (int b = 0; b < NU; ++b) { s.ulb[b] = a.u_lb[b]; s.uub[b] = a.u_ub[b]; }
+  }
+  // initial guess into buffer 1 (the reference's w0: zero, or the midpoint of finite control bounds, CPDP.py:153), rolled out
+  // without gains into buffer 0, linearised
+  for (int i = s.lane; i < N * NU; i += 64) {
+    T u0 = a.u_init ? a.u_init[traj * N * NU + i] : T(0);
+    if constexpr (BND) {
+      const T lb = a.u_lb[i % NU], ub_ = a.u_ub[i % NU];
+      if (!a.u_init && t_abs(lb) < T(1e19) && t_abs(ub_) < T(1e19)) u0 = T(0.5) * (lb + ub_);
+      u0 = t_min(t_max(u0, lb), ub_);
+    }
+    s.ub[1][i] = u0;
+  }
   __syncthreads();
   int cur = 0;
   T alpha_l = T(0);
@@ -1730,7 +1828,9 @@ __global__ void __launch_bounds__(64, 1) oc_solve_wide_kernel(OcArgs<T> a) {
         accept = true; ia = 0; Jn = ldsRed[0]; g_flat = gnorm;      // Newton-like step below rounding noise, gradient still contracting
       } else if (mode == 1 && !LFSD_HAM_SHIFT) {
         mode = 0; ham_ok = false;
-      } else if (mu > T(1e10) || ((J - Jmin) <= T(8) * Eps<T>::v() * t_abs(J) && (mode == 0 || flat_full || mu > T(1e6)))) {
+      } else if (mu > T(1e10) || ((J - Jmin) <= T(8) * Eps<T>::v() * t_abs(J) && ((mode == 0 && !BND) || flat_full || mu > T(1e6)))) {
+        // (with a box on the controls the clamped closed loop can fail every step length although the Gauss-Newton
+        //  direction is a descent direction of the unclamped model: that is a reason to shorten the step, not to stop)
         status = ST_STALLED;
       } else {
         mu_bad = mu; mu_hold = 0;

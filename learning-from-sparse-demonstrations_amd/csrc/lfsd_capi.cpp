@@ -60,12 +60,14 @@ LFSD_API size_t lfsd_coc_workspace_bytes(int dtype, int batch, int n_grid) {
   const size_t es = dtype == LFSD_F32 ? 4 : 8;
   const size_t lock = (size_t)padded_batch(batch) * (size_t)lfsd::OcLayout<Model>::template ws_elems<G>(n_grid) * es;
   const size_t wide = (size_t)batch * (size_t)lfsd::OcLayout<Model>::ws_elems_wide(n_grid) * es;
-  return (wide_possible(batch) && wide > lock) ? wide : lock;
+  (void)wide_possible;
+  return wide > lock ? wide : lock;      // (a bounded problem runs the wide kernel at any batch size)
 }
 
 template <typename T>
 static int coc_solve_t(int batch, int n_grid, int steps_per_grid, const void* ini_state, const void* horizon,
                        const void* auxvar, const void* consts, int const_per_traj, const void* u_init,
+                       const void* control_lb, const void* control_ub,
                        void* state_grid, void* control_grid, void* costate_grid, void* cost, int* iters, int* status,
                        int max_iter, double tol, int exact_after, void* workspace, size_t workspace_bytes,
                        void* stream) {
@@ -75,16 +77,18 @@ static int coc_solve_t(int batch, int n_grid, int steps_per_grid, const void* in
   a.consts = consts ? (const T*)consts : (const T*)horizon;      // NC_REAL == 0: any readable word, never used
   a.const_stride = (consts && const_per_traj) ? Model::NC : 0;
   a.u_init = (const T*)u_init;
+  a.u_lb = (const T*)control_lb; a.u_ub = (const T*)control_ub;
   a.state_grid = (T*)state_grid; a.control_grid = (T*)control_grid; a.costate_grid = (T*)costate_grid;
   a.cost = (T*)cost; a.iters = iters; a.status = status;
   a.ws = (T*)workspace; a.ws_stride = lfsd::OcLayout<Model>::template ws_elems<G>(n_grid);
   a.tol = (T)tol;
   a.exact_after = exact_after;
-  if (use_wide<T>(batch, exact_after)) {
+  if (control_lb || use_wide<T>(batch, exact_after)) {       // bounded problems: the wide kernel at every batch size
     a.ws_stride = lfsd::OcLayout<Model>::ws_elems_wide(n_grid);
     if (workspace_bytes < (size_t)batch * (size_t)a.ws_stride * sizeof(T)) return LFSD_ENOSPC;
     a.it_start = 0; a.resume = 0; a.max_iter_total = max_iter;
-    if (exact_after < 0) { LFSD_LAUNCH((lfsd::oc_solve_wide_kernel<Model, T, false>), (unsigned)batch, 64, stream, a); }
+    if (control_lb) { LFSD_LAUNCH((lfsd::oc_solve_wide_kernel<Model, T, true, true>), (unsigned)batch, 64, stream, a); }
+    else if (exact_after < 0) { LFSD_LAUNCH((lfsd::oc_solve_wide_kernel<Model, T, false>), (unsigned)batch, 64, stream, a); }
     else { LFSD_LAUNCH((lfsd::oc_solve_wide_kernel<Model, T, true>), (unsigned)batch, 64, stream, a); }
     return launch_status();
   }
@@ -116,7 +120,8 @@ static int coc_solve_t(int batch, int n_grid, int steps_per_grid, const void* in
 
 LFSD_API int lfsd_coc_solve(int dtype, int batch, int n_grid, int steps_per_grid, const void* ini_state,
                               const void* horizon, const void* auxvar, const void* consts, int const_per_traj,
-                              const void* u_init, void* state_grid, void* control_grid, void* costate_grid, void* cost,
+                              const void* u_init, const void* control_lb, const void* control_ub, void* state_grid,
+                              void* control_grid, void* costate_grid, void* cost,
                               int* iters, int* status, int max_iter, double tol, int exact_after,
                               void* workspace, size_t workspace_bytes, void* stream) {
   if (batch <= 0 || n_grid <= 0 || steps_per_grid <= 0 || max_iter < 0 || !(tol >= 0)) return LFSD_EINVAL;
@@ -125,13 +130,14 @@ LFSD_API int lfsd_coc_solve(int dtype, int batch, int n_grid, int steps_per_grid
       !status || !workspace)
     return LFSD_EINVAL;
   if (Model::NC_REAL > 0 && !consts) return LFSD_EINVAL;
+  if ((control_lb == nullptr) != (control_ub == nullptr)) return LFSD_EINVAL;
   if (dtype == LFSD_F32)
     return coc_solve_t<float>(batch, n_grid, steps_per_grid, ini_state, horizon, auxvar, consts, const_per_traj, u_init,
-                              state_grid, control_grid, costate_grid, cost, iters, status, max_iter, tol, exact_after,
+                              control_lb, control_ub, state_grid, control_grid, costate_grid, cost, iters, status, max_iter, tol, exact_after,
                               workspace, workspace_bytes, stream);
   if (dtype == LFSD_F64)
     return coc_solve_t<double>(batch, n_grid, steps_per_grid, ini_state, horizon, auxvar, consts, const_per_traj,
-                               u_init, state_grid, control_grid, costate_grid, cost, iters, status, max_iter, tol,
+                               u_init, control_lb, control_ub, state_grid, control_grid, costate_grid, cost, iters, status, max_iter, tol,
                                exact_after, workspace, workspace_bytes, stream);
   return LFSD_EINVAL;
 }

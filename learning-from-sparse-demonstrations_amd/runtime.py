@@ -160,7 +160,7 @@ class ModelLibrary:
         L.lfsd_const_default.restype = cd
         L.lfsd_coc_workspace_bytes.argtypes = [ci, ci, ci]
         L.lfsd_coc_workspace_bytes.restype = ctypes.c_size_t
-        L.lfsd_coc_solve.argtypes = [ci, ci, ci, ci, vp, vp, vp, vp, ci, vp, vp, vp, vp, vp, vp, vp, ci, cd, ci, vp,
+        L.lfsd_coc_solve.argtypes = [ci, ci, ci, ci, vp, vp, vp, vp, ci, vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, cd, ci, vp,
                                      ctypes.c_size_t, vp]
         L.lfsd_aux_solve.argtypes = [ci, ci, ci, vp, vp, vp, ci, vp, vp, vp, vp, ci, ci, vp, vp, vp, vp, vp, vp, vp,
                                      ci, vp]
@@ -171,7 +171,7 @@ class ModelLibrary:
         L.lfsd_lookahead.argtypes = [ci, ctypes.c_longlong, cd, vp, vp, vp, vp]
         info = _ModelInfo()
         rc = L.lfsd_get_model_info(ctypes.byref(info))
-        if rc != 0 or info.abi_version != 2:
+        if rc != 0 or info.abi_version != 3:
             raise LfsdError("ABI mismatch in %s" % path)
         self.n_state, self.n_control, self.n_auxvar, self.n_const = (info.n_state, info.n_control, info.n_auxvar,
                                                                       info.n_const)
@@ -227,7 +227,7 @@ class ModelLibrary:
         return int(self.lib.lfsd_coc_workspace_bytes(_DT[dtype], batch, n_grid))
 
     def coc_solve(self, ini_state, horizon, auxvar, consts, n_grid, steps_per_grid=4, u_init=None, max_iter=100,
-                  tol=None, workspace=None, out=None, exact_after=16):
+                  tol=None, workspace=None, out=None, exact_after=16, control_lb=None, control_ub=None):
         dt = ini_state.dtype
         B = ini_state.shape[0]
         n, m, p, nc = self.n_state, self.n_control, self.n_auxvar, self.n_const
@@ -246,6 +246,10 @@ class ModelLibrary:
         else:
             consts = None
         self._check(u_init, (B, n_grid, m), dt, "u_init", optional=True)
+        self._check(control_lb, (m,), dt, "control_lb", optional=True)
+        self._check(control_ub, (m,), dt, "control_ub", optional=True)
+        if (control_lb is None) != (control_ub is None):
+            raise LfsdError("control_lb and control_ub go together")
         dev = ini_state.device
         if out is None:
             out = dict(state_grid=torch.empty((B, n_grid + 1, n), dtype=dt, device=dev),
@@ -260,7 +264,8 @@ class ModelLibrary:
         if tol is None:
             tol = 1e-6 if dt == torch.float32 else 1e-9
         args = (_DT[dt], B, n_grid, steps_per_grid, self._p(ini_state), self._p(horizon), self._p(auxvar),
-                self._p(consts), per_traj, self._p(u_init), self._p(out["state_grid"]), self._p(out["control_grid"]),
+                self._p(consts), per_traj, self._p(u_init), self._p(control_lb), self._p(control_ub),
+                self._p(out["state_grid"]), self._p(out["control_grid"]),
                 self._p(out["costate_grid"]), self._p(out["cost"]), self._p(out["iters"]), self._p(out["status"]),
                 int(max_iter), float(tol), int(exact_after), self._p(workspace),
                 workspace.numel() * workspace.element_size(), self._stream(ini_state))

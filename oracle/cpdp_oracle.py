@@ -349,6 +349,44 @@ class COCSys:
             return time_grid, opt_sol, state_grid, control_grid, costate_grid
         return time_grid, opt_sol
 
+    def cocSolverBounded(self, ini_state, horizon, auxvar_value, control_lb, control_ub, U_init=None, tol=1e-12):
+        """The NLP of CPDP.py:110-175 with finite control bounds lbw / ubw (CPDP.py:150-153), solved in single-shooting form
+        by scipy's L-BFGS-B with complex-step gradients of the plain RK4 roll-out -- no code shared with the HIP solver's
+        control-limited sweep or with this oracle's own DDP.  Initial guess: the midpoint of the bounds, as the reference's
+        w0.  Returns (time_grid, state_grid, control_grid [N+1, last row repeated], costate_grid, J)."""
+        from scipy.optimize import minimize
+        self.diffPMP()
+        n, m, N = self.n_state, self.n_control, self.n_grid
+        e = np.asarray(auxvar_value, dtype=float).ravel()
+        x0 = np.asarray(ini_state, dtype=float).ravel()
+        lb, ub = np.asarray(control_lb, dtype=float), np.asarray(control_ub, dtype=float)
+        DT = horizon / N / self.steps_per_grid
+        tg = np.linspace(0, horizon, N + 1)
+
+        def fun(u):
+            return float(self.rollout_cost(x0, horizon, e, u.reshape(N, m))[0])
+
+        def grad(u):
+            g = np.zeros(N * m)
+            for i in range(N * m):
+                uc = u.astype(complex)
+                uc[i] += 1e-30j
+                g[i] = self.rollout_cost(x0, horizon, e, uc.reshape(N, m))[0].imag / 1e-30
+            return g
+        u0 = np.tile(np.where((np.abs(lb) < 1e19) & (np.abs(ub) < 1e19), 0.5 * (lb + ub), np.clip(0.0, lb, ub)), N) \
+            if U_init is None else np.clip(np.asarray(U_init, dtype=float), lb, ub).ravel()
+        r = minimize(fun, u0, jac=grad, method="L-BFGS-B", bounds=list(zip(np.tile(lb, N), np.tile(ub, N))),
+                     options=dict(maxiter=5000, ftol=1e-16, gtol=tol, maxcor=30))
+        U = r.x.reshape(N, m)
+        J, X = self.rollout_cost(x0, horizon, e, U)
+        lam = np.zeros((N + 1, n))
+        lam[N] = self._call('dhx', tg[-1], X[N], e).ravel()
+        for k in range(N - 1, -1, -1):
+            _, _, M = self.grid_map(tg[k], X[k], U[k], e, DT, derivs=True)
+            lam[k] = M[n, :n] + M[:n, :n].T @ lam[k + 1]
+        self.last_cost = float(J)
+        return tg, np.asarray(X), np.vstack([U, U[-1:]]), lam, float(J)
+
     def kkt_certificate(self, ini_state, horizon, e, state_grid, control_grid, costate_grid, h=1e-30):
         """Solver-independent check that (X,U,lambda) is the KKT point of the NLP at CPDP.py:126-179.
 

@@ -126,3 +126,58 @@ def rocket_mixed_precision(prepare, n_grid=15):
     assert abs(aux["loss"][1].item() - r["loss"]) < 1e-6 * max(1.0, r["loss"])
     assert rel(aux["grad"][1].cpu().numpy(), r["grad"]) < 1e-3
     return sol, aux
+
+
+def control_bounds(prepare, dtype=torch.float64):
+    """Finite control bounds (COCSys.setControlVariable(control, control_lb, control_ub), CPDP.py:33-46 -> lbw / ubw of the
+    NLP): the control-limited sweep of the HIP solver against an independent bounded solve of the same NLP (the oracle's
+    L-BFGS-B on the plain RK4 roll-out with complex-step gradients).  Pendulum with a symmetric and a one-sided box,
+    robot arm with a box on both torques; bounds chosen so that several intervals sit on them."""
+    from lfsd_amd import CPDP, JinEnv
+    from lfsd_amd.symbolic import SX, vertcat
+    from conftest import make_oracle
+    tol = dict(x=1e-6, u=1e-5, j=1e-9) if dtype == torch.float64 else dict(x=5e-3, u=2e-2, j=1e-5)
+
+    def bounded(kind, n_grid, lb, ub):
+        if kind == "pendulum":
+            env = JinEnv.SinglePendulum(); env.initDyn(l=1, m=1, damping_ratio=0.1); env.initCost(wu=.01)
+        else:
+            env = JinEnv.RobotArm(); env.initDyn(l1=1, m1=1, l2=1, m2=1, g=0); env.initCost_Polynomial(wu=.5)
+        oc = CPDP.COCSys()
+        beta = SX.sym('beta')
+        oc.setAuxvarVariable(vertcat(beta, env.cost_auxvar)); oc.setStateVariable(env.X)
+        oc.setControlVariable(env.U, lb, ub)
+        oc.setDyn(beta * env.f); oc.setPathCost(beta * env.path_cost); oc.setFinalCost(env.final_cost)
+        oc.setIntegrator(n_grid)
+        return oc
+    cases = [("pendulum", 10, [-4.0], [4.0], [0.0, 0.0], [2.0, 1.0, 1.0]),
+             ("pendulum", 10, [-1e20], [6.0], [0.0, 0.0], [2.0, 1.0, 1.0]),          # one-sided: unbounded below
+             ("robotarm", 12, [-2.0, -1.0], [2.0, 1.0], [-np.pi / 2, 0, 0, 0], [3., 0.5, 2, 1.5, 0.2])]
+    for kind, N, lb, ub, x0, th in cases:
+        oc = bounded(kind, N, lb, ub)
+        prepare(oc, dtype)
+        sol = oc.cocSolverBatch([x0] * 3, 1.0, [th] * 3)                # ragged batch of 3
+        assert set(sol["status"].tolist()) <= {1, 2}, (kind, sol["status"])
+        U = sol["control_grid"][1].double().cpu().numpy()
+        assert (U >= np.array(lb) - 1e-12).all() and (U <= np.array(ub) + 1e-12).all()
+        at_bound = (np.abs(U - np.array(ub)) < 1e-9) | (np.abs(U - np.array(lb)) < 1e-9)
+        assert at_bound.sum() >= 3, (kind, at_bound.sum())              # the box is really active
+        o = make_oracle(kind, N)
+        rel = lambda a, b: np.abs(a - b).max() / np.abs(b).max()
+        # (1) the kernel's answer is a KKT point of the bounded NLP: the independent solver, started there, stays there.
+        #     (The non-convex arm problem has several bounded minima -- cold starts of the two solvers reach different
+        #     ones -- so the comparison is basin-independent, as for the rocket.)
+        tg, Xo, Uo, Lo, Jo = o.cocSolverBounded(x0, 1.0, th, lb, ub, U_init=U[:N])
+        assert abs(float(sol["cost"][1]) - Jo) < tol["j"] * abs(Jo), (kind, float(sol["cost"][1]), Jo)
+        assert rel(U, Uo) < tol["u"], (kind, rel(U, Uo))
+        assert rel(sol["state_grid"][1].double().cpu().numpy(), Xo) < tol["x"], kind
+        assert rel(sol["costate_grid"][1].double().cpu().numpy(), Lo) < 10 * tol["u"], kind
+        # (2) the independent solver's own cold-start answer is a fixed point of the kernel
+        tg, Xc, Uc, Lc, Jc = o.cocSolverBounded(x0, 1.0, th, lb, ub)
+        dev = sol["state_grid"].device
+        s2 = oc.cocSolverBatch([x0], 1.0, [th], u_init=torch.as_tensor(Uc[None, :N].copy(), dtype=dtype, device=dev))
+        assert set(s2["status"].tolist()) <= {1, 2}
+        assert abs(float(s2["cost"][0]) - Jc) < tol["j"] * abs(Jc) and rel(s2["control_grid"][0].double().cpu().numpy(), Uc) < 10 * tol["u"], kind
+    # bounds of the wrong length are ignored, as in the reference (CPDP.py:37-46)
+    oc = bounded("pendulum", 10, [-1.0, -1.0], [1.0, 1.0])
+    assert oc.control_lb == [-1e20] and oc.control_ub == [1e20]

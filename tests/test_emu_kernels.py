@@ -224,7 +224,11 @@ def test_error_behaviour_matches_reference(emu):
     with pytest.raises(AssertionError, match="Define the state variable first!"):
         oc.model_spec()
     with pytest.raises(NotImplementedError):
-        oc.setControlVariable(u, control_lb=[-1.0], control_ub=[1.0])
+        oc.setStateVariable(x, state_lb=[-1.0], state_ub=[1.0])                                  # state bounds: not supported
+    oc.setControlVariable(u, control_lb=[-1.0], control_ub=[1.0])                                 # control bounds: supported
+    assert oc.control_lb == [-1.0] and oc.control_ub == [1.0]
+    with pytest.raises(ValueError):
+        oc.setControlVariable(u, control_lb=[1.0], control_ub=[-1.0])
     oc.setStateVariable(x); oc.setControlVariable(u, control_lb=[-1e20], control_ub=[1e20])   # the reference's "no bound"
     with pytest.raises(AssertionError, match="Define the system dynamics first!"):
         oc.model_spec()
@@ -471,3 +475,23 @@ def test_waypoints_outside_the_horizon_raise_like_interp1d(emu):
     with pytest.raises(ValueError):
         CPDP.SparseDemoLearner(oc, [d["ini_state"]], d["horizon"], [0.3, 1.5], [[0.5], [1.0]], d["interface"], [1.0, 0.5, 1.5])
     oc.auxSysSolverBatch(sol, [0.0, 1.0], [[0.5], [1.0]], d["interface"])           # both ends are inside
+
+
+def test_control_bounds_vs_independent_bounded_solve(emu):
+    """Finite control_lb / control_ub (CPDP.py:33-46, 150-153): control-limited sweep vs the oracle's L-BFGS-B solve of the
+    same bounded NLP (tests/parity_cases.control_bounds)."""
+    import parity_cases as pc
+
+    def prepare(oc, dtype):
+        emu(oc)
+        oc.setDevice(dtype=dtype)
+        return oc
+    pc.control_bounds(prepare, torch.float64)
+
+
+def test_state_bounds_are_refused():
+    oc, env, d = models.pendulum(n_grid=10)
+    with pytest.raises(NotImplementedError):
+        oc.setStateVariable(env.X, [-1.0, -5.0], [1.0, 5.0])
+    oc.setStateVariable(env.X, [-1e20, -1e20], [1e20, 1e20])          # the reference's defaults are fine
+    oc.setStateVariable(env.X, [-1.0], [1.0])                          # wrong length: ignored, as in the reference (CPDP.py:23-31)

@@ -444,3 +444,10 @@ def test_full_size_properties_rocket_n100_mixed_precision():
         (r["defect"], r["gmax"], r["lmax"], J)
     assert abs(aux["loss"][b].item() - r["loss"]) < 1e-5 * max(1.0, r["loss"])
     assert rel(aux["grad"][b], r["grad"]) < 5e-3
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+def test_control_bounds_vs_independent_bounded_solve(dtype):
+    """Finite control bounds of setControlVariable (CPDP.py:33-46) on the GPU: control-limited backward sweep + clamped
+    roll-out vs the oracle's L-BFGS-B solve of the same bounded NLP (basin-independent, both directions)."""
+    pc.control_bounds(gpu_prepare, dtype)
