@@ -211,12 +211,12 @@ def main(argv=None):
     import torch
     import torch.distributed as dist
     use_dist = in_launcher and world > 1
+    assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no CPU fallback)"
+    dev = torch.device("cuda", local_rank % torch.cuda.device_count())
+    torch.cuda.set_device(dev)                         # one process per GPU; the device is bound before the communicator exists
     if in_launcher:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(args.backend, rank=rank, world_size=world)       # "nccl" == RCCL on ROCm
-    assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no CPU fallback)"
-    dev = torch.device("cuda", local_rank % torch.cuda.device_count())
-    torch.cuda.set_device(dev)
 
     import lfsd_amd  # noqa: F401
     from lfsd_amd import models, perf_model

@@ -12,6 +12,10 @@ EMU_DIR = os.path.join(ROOT, "tests", "emu")
 EMU_BUILD = os.path.join(EMU_DIR, "_build")
 
 
+def pytest_addoption(parser):
+    parser.addoption("--sanitize-all", action="store_true", help="run the AddressSanitizer build for every model (slow)")
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run by the driver with -m gpu)")
 
