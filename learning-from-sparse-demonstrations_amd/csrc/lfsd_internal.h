@@ -17,8 +17,26 @@ static constexpr int GPB = 64 / G;
 #define LFSD_LAUNCH(kern, grid, block, stream, args) emu::launch(dim3(grid), dim3(block), [&] { kern(args); })
 static int launch_status() { return 0; }
 #else
-#define LFSD_LAUNCH(kern, grid, block, stream, args) \
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(block), 0, (hipStream_t)(stream), args)
+#include <cstdio>
+#include <cstdlib>
+// A launch error shows up in hipGetLastError() at once; a fault INSIDE the kernel (e.g. a memory aperture violation) only at
+// the caller's next synchronisation, without a name attached.  LFSD_SYNC_CHECK=1 in the environment makes every launch of
+// this library synchronise its stream and report the kernel by name (debugging aid: it serialises the stream).
+static bool lfsd_sync_check() {
+  static const int on = [] { const char* e = getenv("LFSD_SYNC_CHECK"); return (e && atoi(e) != 0) ? 1 : 0; }();
+  return on != 0;
+}
+#define LFSD_LAUNCH(kern, grid, block, stream, args)                                                          \
+  do {                                                                                                        \
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(block), 0, (hipStream_t)(stream), args);                        \
+    if (lfsd_sync_check()) {                                                                                  \
+      const hipError_t e1_ = hipPeekAtLastError();                                                            \
+      const hipError_t e2_ = hipStreamSynchronize((hipStream_t)(stream));                                     \
+      if (e1_ != hipSuccess || e2_ != hipSuccess)                                                             \
+        fprintf(stderr, "lfsd: kernel %s (grid %u) failed: launch %s, execution %s\n", #kern, (unsigned)(grid), \
+                hipGetErrorString(e1_), hipGetErrorString(e2_));                                              \
+    }                                                                                                         \
+  } while (0)
 static int launch_status() { return (int)hipGetLastError(); }
 #endif
 
