@@ -39,7 +39,9 @@ class COCSys:
         self.dtype = torch.float32
         self._lib = None
         self._lib_override = None
-        self.aux_substeps = 0           # 0 = library default
+        self.aux_substeps = 0           # minimum split units per grid interval; 0 = library default (1 with aux_rtol > 0)
+        self.aux_rtol = 1e-3            # error-controlled sub-stepping of the auxiliary sweeps at the reference's own
+                                        # solve_ivp tolerance (CPDP.py:335, 368: scipy's default rtol); 0: fixed aux_substeps
         self.max_iter = 300              # (IPOPT's default is 3000; an iteration here is one DDP sweep)
         self.tol = None
         self.exact_after = 16            # iteration from which the exact stage Hessian is forced
@@ -118,7 +120,7 @@ class COCSys:
         if aux_dtype is not None:
             self.aux_dtype = aux_dtype
 
-    def setSolverOptions(self, max_iter=None, tol=None, aux_substeps=None, exact_after=None):
+    def setSolverOptions(self, max_iter=None, tol=None, aux_substeps=None, exact_after=None, aux_rtol=None):
         if max_iter is not None:
             self.max_iter = int(max_iter)
         if tol is not None:
@@ -127,6 +129,8 @@ class COCSys:
             self.aux_substeps = int(aux_substeps)
         if exact_after is not None:
             self.exact_after = int(exact_after)
+        if aux_rtol is not None:
+            self.aux_rtol = float(aux_rtol)
 
     def use_library(self, path_or_lib):
         """Bind an already built model library (tests use this to inject the SIMT-emulator build)."""
@@ -281,7 +285,7 @@ class COCSys:
             cv = lambda t: None if t is None else t.to(ad).contiguous()
             hz, th, cs, X, U, Lm, tt, wp = (cv(t) for t in (hz, th, cs, X, U, Lm, tt, wp))
         return lib.aux_solve(hz, th, cs, X, U, Lm, tt, wp, ii, substeps=self.aux_substeps, want_grids=want_grids,
-                             Z_grid=Z_grid, out=out, phase_hook=phase_hook)
+                             Z_grid=Z_grid, out=out, phase_hook=phase_hook, rtol=self.aux_rtol)
 
     # ---- the reference's one-trajectory calls --------------------------------------------------------
     def cocSolver(self, ini_state, horizon, auxvar_value=1, interplation_level=1, print_level=0):

@@ -1878,6 +1878,8 @@ template <typename T> struct AuxArgs {
   int batch, n_grid, substeps;    // substeps = minimum coarse split-steps per grid interval (fine = 2x, Richardson)
   T rate_max;                     // refine an interval until  dt * |Huu^-1 fu^T P fu|_inf <= rate_max
   int max_refine;                 // cap on that refinement (factor over `substeps`)
+  T rtol;                         // > 0: error-controlled sub-stepping -- an interval is redone with twice the units while the
+                                  // Richardson estimate |fine - coarse| / 3 of a column exceeds rtol * (its magnitude + floor)
   const T* horizon;               // [B]
   const T* auxvar;                // [B][NP]
   const T* consts; int const_stride;
@@ -1905,7 +1907,9 @@ template <class M> struct AuxLayout {
   // each kernel uses only its own
   static constexpr int LDS_KN = LDS_T;                        // 3 stiff nodes x (NX x NU) feedback rows K^T
   static constexpr int LDS_PSI = LDS_KN + 3 * NX * NU;        // 3 stiff nodes x {phi1(h/4 K fu), phi1(h/2 K fu)}
-  static constexpr int LDS_E = LDS_T + (NX * NZ > 3 * NX * NU + 6 * NU * NU ? NX * NZ : 3 * NX * NU + 6 * NU * NU);
+  static constexpr int LDS_TSZ0 = (NX * NZ > 3 * NX * NU + 6 * NU * NU ? NX * NZ : 3 * NX * NU + 6 * NU * NU);
+  static constexpr int LDS_TSZ = LDS_TSZ0 > 128 ? LDS_TSZ0 : 128;      // (>= 2 x 64: the error reduction of the step control)
+  static constexpr int LDS_E = LDS_T + LDS_TSZ;
                                                               // cold per-trajectory state: auxvar, consts,
   static constexpr int LDS_C = LDS_E + NP;                    // and the (x,u,lambda) grid values at both interval ends
   static constexpr int LDS_GA = LDS_C + M::NC;                // [x_k u_k l_k]
@@ -2352,28 +2356,72 @@ __global__ void __launch_bounds__(64, (sizeof(T) == 4 ? LFSD_WAVES_RIC : 1)) aux
     }
   }
   T* ldsT = s.lds + Lay::LDS_T;
+  int units_hint = Sa;
   for (int k = N - 1; k >= 0; --k) {
     s.load_interval(a, traj, k, N);
     // stiffness-aware sub-stepping: P is largest at the later end of the interval (terminal transient)
     s.stage_nodes(T(1), T(0));
-    const int units = s.units_for(s.stiff_rate(z, s.node(0)), Sa, a.rate_max, a.max_refine);
-    const T hc = s.dgrid / T(units);
-    const T ds = T(1) / T(4 * units);
-    for (int unit = 0; unit < units; ++unit) {
-      const T s_hi = T(1) - T(unit) / T(units);
-      s.stage_nodes(s_hi, -ds);                  // node i sits at fraction s_hi - i/(4 Sa)
-      s.ric_cols();
-      // coarse chain in place, then the fine chain in place from the parked start value (the barriers inside the chains
-      // keep the compiler from carrying the parked column in registers)
-      T* zpark = s.lds + Lay::template ric_park<G>();
+    int units = s.units_for(s.stiff_rate(z, s.node(0)), Sa, a.rate_max, a.max_refine);
+    // error-driven refinement stops at max_refine x the minimum units -- and as soon as a doubling fails to halve the
+    // estimate: next to a conjugate point (finite escape of the Riccati solution) no step size meets a relative tolerance,
+    // and one such trajectory must not stall the batch
+    const long long units_cap = (long long)Sa * a.max_refine;
+    if (units < units_hint) units = (int)t_min((long long)units_hint, units_cap);
+    T ratio_prev = T(-1);
+    // Error-controlled sub-stepping (a.rtol > 0): the Richardson pair gives |fine - coarse| / 3 as an estimate of the
+    // second-order error that the extrapolation removes; while it exceeds rtol relative to the column's size the interval
+    // is redone from its stored start value Z(t_k+1) with twice the units.  (solve_ivp's rtol of the reference, CPDP.py:335,
+    // is 1e-3 on the un-extrapolated estimate of its pair; the default here is 1e-4.)
+    for (;;) {
+      const T hc = s.dgrid / T(units);
+      const T ds = T(1) / T(4 * units);
+      T err_l = T(0), scl_l = T(0);
+      for (int unit = 0; unit < units; ++unit) {
+        const T s_hi = T(1) - T(unit) / T(units);
+        s.stage_nodes(s_hi, -ds);                  // node i sits at fraction s_hi - i/(4 Sa)
+        s.ric_cols();
+        // coarse chain in place, then the fine chain in place from the parked start value (the barriers inside the chains
+        // keep the compiler from carrying the parked column in registers)
+        T* zpark = s.lds + Lay::template ric_park<G>();
 #pragma unroll
-      for (int i = 0; i < NX; ++i) zpark[i * G + lane] = z[i];
-      s.ric_strang(z, 0, 2, 4, hc);
+        for (int i = 0; i < NX; ++i) zpark[i * G + lane] = z[i];
+        s.ric_strang(z, 0, 2, 4, hc);
 #pragma unroll
-      for (int i = 0; i < NX; ++i) { const T z0 = zpark[i * G + lane]; zpark[i * G + lane] = z[i]; z[i] = z0; }
-      s.ric_strang2(z, hc);
+        for (int i = 0; i < NX; ++i) { const T z0 = zpark[i * G + lane]; zpark[i * G + lane] = z[i]; z[i] = z0; }
+        s.ric_strang2(z, hc);
 #pragma unroll
-      for (int i = 0; i < NX; ++i) z[i] = (T(4) * z[i] - zpark[i * G + lane]) / T(3);     // Richardson (Strang is O(h^2), symmetric)
+        for (int i = 0; i < NX; ++i) {
+          const T zc = zpark[i * G + lane];
+          err_l = t_max(err_l, t_abs(z[i] - zc));
+          z[i] = (T(4) * z[i] - zc) / T(3);     // Richardson (Strang is O(h^2), symmetric)
+          scl_l = t_max(scl_l, t_abs(z[i]));
+        }
+      }
+      if (!(a.rtol > T(0))) break;
+      // per block of columns (P: lanes < NX, W: the rest) the worst estimate against that block's magnitude
+      ldsT[lane] = err_l; ldsT[G + lane] = scl_l;
+      __syncthreads();
+      T eP = T(0), sP = T(0), eW = T(0), sW = T(0);
+      for (int l = 0; l < NZ; ++l) {
+        if (l < NX) { eP = t_max(eP, ldsT[l]); sP = t_max(sP, ldsT[G + l]); }
+        else { eW = t_max(eW, ldsT[l]); sW = t_max(sW, ldsT[G + l]); }
+      }
+      __syncthreads();
+      const T tolP = T(3) * a.rtol * sP, tolW = T(3) * a.rtol * (sW + T(1e-3) * sP);
+      const bool fine_enough = (eP <= tolP && eW <= tolW) || !(t_finite(eP) && t_finite(eW));
+      const T ratio = t_max(eP / t_max(tolP, T(1e-30)), eW / t_max(tolW, T(1e-30)));
+      const bool no_gain = ratio_prev >= T(0) && ratio > T(0.5) * ratio_prev;
+      ratio_prev = ratio;
+      if (fine_enough || no_gain || !valid || (long long)units * 2 > units_cap) {
+        // next interval: start from this interval's units, or half of them when the estimate had a 32-fold margin
+        units_hint = (eP * T(32) <= tolP && eW * T(32) <= tolW && units > Sa) ? units / 2 : units;
+        break;
+      }
+      units *= 2;
+      if (lane < NZ) {
+#pragma unroll
+        for (int i = 0; i < NX; ++i) z[i] = Zt[((long long)(k + 1) * NZ + lane) * NX + i];
+      }
     }
     // keep P symmetric (the closed-form stiff update relies on it) and store the grid value
     if (lane < NX) {
@@ -2422,6 +2470,7 @@ __global__ void __launch_bounds__(64, (sizeof(T) == 4 ? LFSD_WAVES_FWD : 1)) aux
   const T* pA = (lane < NX) ? ldsPA + lane * NX : ldsP0;
   const T* pB = (lane < NX) ? ldsPB + lane * NX : ldsP0;
   T loss = T(0), gacc = T(0);
+  int units_hint = Sa;
   T* Xo = a.auxX_grid ? a.auxX_grid + traj * (long long)(N + 1) * NP * NX : nullptr;
   T* Uo = a.auxU_grid ? a.auxU_grid + traj * (long long)(N + 1) * NP * NU : nullptr;
   if (valid && Xo && xlane) {
@@ -2445,49 +2494,77 @@ __global__ void __launch_bounds__(64, (sizeof(T) == 4 ? LFSD_WAVES_FWD : 1)) aux
     }
     s.stage_nodes(T(0), T(0.25));
     const T rate = t_max(s.stiff_rate(pA, s.node(0)), s.stiff_rate(pB, s.node(4)));
-    const int units = s.units_for(rate, Sa, a.rate_max, a.max_refine);
-    const T hc = s.dgrid / T(units);
-    const T ds = T(1) / T(4 * units);
-    for (int unit = 0; unit < units; ++unit) {
-      const T s_lo = T(unit) / T(units);
-      s.stage_nodes(s_lo, ds);
-      if (Uo && unit == 0) {
-        T uo[NU];
-        s.aux_control(xa, pA, wA, s.node(0), uo);
-        if (valid && xlane) {
+    int units = s.units_for(rate, Sa, a.rate_max, a.max_refine);
+    const long long units_cap = (long long)Sa * a.max_refine;
+    if (units < units_hint) units = (int)t_min((long long)units_hint, units_cap);
+    T ratio_prev = T(-1);
+    for (;;) {                         // error-controlled sub-stepping, as in the Riccati sweep; the start value X(t_k) is `xprev`
+      const T hc = s.dgrid / T(units);
+      const T ds = T(1) / T(4 * units);
+      T err_l = T(0), scl_l = T(0);
+      for (int unit = 0; unit < units; ++unit) {
+        const T s_lo = T(unit) / T(units);
+        s.stage_nodes(s_lo, ds);
+        if (Uo && unit == 0) {
+          T uo[NU];
+          s.aux_control(xa, pA, wA, s.node(0), uo);
+          if (valid && xlane) {
 #pragma unroll
-          for (int b = 0; b < NU; ++b) Uo[((long long)k * NP + s.xcol) * NU + b] = uo[b];
+            for (int b = 0; b < NU; ++b) Uo[((long long)k * NP + s.xcol) * NU + b] = uo[b];
+          }
+        }
+        T xc[NX], xf[NX];
+#pragma unroll
+        for (int i = 0; i < NX; ++i) { xc[i] = xa[i]; xf[i] = xa[i]; }
+        const T hq = hc * T(0.25);
+        s.fwd_prep(pA, pB, s_lo, ds, hq);
+        s.fwd_cols(wA, wB, s_lo, ds);
+        // coarse Strang step (stiff h/2, RK4 h, stiff h/2) and two fine ones; the two adjacent fine stiff
+        // quarter-steps at the middle node compose exactly into one half-step.  (Unlike the Riccati sweep, which runs its
+        // two chains in place with the other value parked in LDS, this one-wave-per-SIMD kernel is 20 % faster with both
+        // chains as independent instruction streams the compiler can interleave.)
+        s.fwd_stiff(xc, 0, true, hq);
+        s.fwd_rk4(xc, 0, 2, 4, hc);
+        s.fwd_stiff(xc, 2, true, hq);
+        s.fwd_stiff(xf, 0, false, hq);
+        s.fwd_rk4(xf, 0, 1, 2, hc * T(0.5));
+        s.fwd_stiff(xf, 1, true, hq);
+        s.fwd_rk4(xf, 2, 3, 4, hc * T(0.5));
+        s.fwd_stiff(xf, 2, false, hq);
+        __syncthreads();      // all reads of this unit's staged coefficients are done before the next staging
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+          if (xlane) err_l = t_max(err_l, t_abs(xf[i] - xc[i]));
+          xa[i] = xlane ? (T(4) * xf[i] - xc[i]) / T(3) : T(0);
+          scl_l = t_max(scl_l, t_abs(xa[i]));
+        }
+        if (Uo && k == N - 1 && unit == units - 1) {
+          T uo[NU];
+          s.aux_control(xa, pB, wB, s.node(4), uo);
+          if (valid && xlane) {
+#pragma unroll
+            for (int b = 0; b < NU; ++b) Uo[((long long)N * NP + s.xcol) * NU + b] = uo[b];
+          }
         }
       }
-      T xc[NX], xf[NX];
-#pragma unroll
-      for (int i = 0; i < NX; ++i) { xc[i] = xa[i]; xf[i] = xa[i]; }
-      const T hq = hc * T(0.25);
-      s.fwd_prep(pA, pB, s_lo, ds, hq);
-      s.fwd_cols(wA, wB, s_lo, ds);
-      // coarse Strang step (stiff h/2, RK4 h, stiff h/2) and two fine ones; the two adjacent fine stiff
-      // quarter-steps at the middle node compose exactly into one half-step.  (Unlike the Riccati sweep, which runs its
-      // two chains in place with the other value parked in LDS, this one-wave-per-SIMD kernel is 20 % faster with both
-      // chains as independent instruction streams the compiler can interleave.)
-      s.fwd_stiff(xc, 0, true, hq);
-      s.fwd_rk4(xc, 0, 2, 4, hc);
-      s.fwd_stiff(xc, 2, true, hq);
-      s.fwd_stiff(xf, 0, false, hq);
-      s.fwd_rk4(xf, 0, 1, 2, hc * T(0.5));
-      s.fwd_stiff(xf, 1, true, hq);
-      s.fwd_rk4(xf, 2, 3, 4, hc * T(0.5));
-      s.fwd_stiff(xf, 2, false, hq);
-      __syncthreads();      // all reads of this unit's staged coefficients are done before the next staging
-#pragma unroll
-      for (int i = 0; i < NX; ++i) xa[i] = xlane ? (T(4) * xf[i] - xc[i]) / T(3) : T(0);
-      if (Uo && k == N - 1 && unit == units - 1) {
-        T uo[NU];
-        s.aux_control(xa, pB, wB, s.node(4), uo);
-        if (valid && xlane) {
-#pragma unroll
-          for (int b = 0; b < NU; ++b) Uo[((long long)N * NP + s.xcol) * NU + b] = uo[b];
-        }
+      if (!(a.rtol > T(0))) break;
+      T* ldsR = s.lds + Lay::LDS_T;           // (the feedback / phi1 images of the last unit are dead by now)
+      ldsR[lane] = err_l; ldsR[G + lane] = scl_l;
+      __syncthreads();
+      T eX = T(0), sX = T(0);
+      for (int l = 0; l < NP; ++l) { eX = t_max(eX, ldsR[l]); sX = t_max(sX, ldsR[G + l]); }
+      __syncthreads();
+      const T tolX = T(3) * a.rtol * (sX + T(1e-2));       // dx/dtheta starts from zero: absolute floor 1e-2 * rtol
+      const T ratio = eX / tolX;
+      const bool no_gain = ratio_prev >= T(0) && ratio > T(0.5) * ratio_prev;
+      ratio_prev = ratio;
+      if (eX <= tolX || no_gain || !t_finite(eX) || (long long)units * 2 > units_cap) {
+        units_hint = (eX * T(32) <= tolX && units > Sa) ? units / 2 : units;
+        break;
       }
+      units *= 2;
+#pragma unroll
+      for (int i = 0; i < NX; ++i) xa[i] = xlane ? xprev[i * NP + s.xcol] : T(0);
     }
     if (valid && Xo && xlane) {
 #pragma unroll

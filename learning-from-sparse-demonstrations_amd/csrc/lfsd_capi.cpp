@@ -147,9 +147,12 @@ static int aux_phase_t(int phases, int batch, int n_grid, const void* horizon, c
                        int const_per_traj, const void* state_grid, const void* control_grid, const void* costate_grid,
                        void* Z_grid, int n_waypoints, int n_iface, const int* iface_idx, const void* taus,
                        const void* waypoints, void* loss, void* grad, void* auxX_grid, void* auxU_grid, int substeps,
-                       void* stream) {
+                       double rtol, void* stream) {
   lfsd::AuxArgs<T> a;
-  a.batch = batch; a.n_grid = n_grid; a.substeps = substeps > 0 ? substeps : 4;
+  // rtol > 0: error-controlled sub-stepping from `substeps` (default 1) units per interval upwards;
+  // rtol = 0: a fixed minimum of `substeps` (default 4) units, refined for stiffness only (the round-1 behaviour)
+  a.batch = batch; a.n_grid = n_grid; a.substeps = substeps > 0 ? substeps : (rtol > 0 ? 1 : 4);
+  a.rtol = (T)rtol;
   a.rate_max = (T)(8.0 / a.substeps); a.max_refine = 256;   // substeps = 4 -> dt*rate <= 2
   a.horizon = (const T*)horizon; a.auxvar = (const T*)auxvar;
   a.consts = consts ? (const T*)consts : (const T*)horizon;
@@ -181,8 +184,8 @@ static int aux_dispatch(int phases, int dtype, int batch, int n_grid, const void
                         const void* consts, int const_per_traj, const void* state_grid, const void* control_grid,
                         const void* costate_grid, void* Z_grid, int n_waypoints, int n_iface, const int* iface_idx,
                         const void* taus, const void* waypoints, void* loss, void* grad, void* auxX_grid,
-                        void* auxU_grid, int substeps, void* stream) {
-  if (batch <= 0 || n_grid <= 0 || n_waypoints < 0 || n_iface < 0 || substeps < 0) return LFSD_EINVAL;
+                        void* auxU_grid, int substeps, double rtol, void* stream) {
+  if (batch <= 0 || n_grid <= 0 || n_waypoints < 0 || n_iface < 0 || substeps < 0 || !(rtol >= 0)) return LFSD_EINVAL;
   if (!horizon || !auxvar || !state_grid || !control_grid || !costate_grid || !Z_grid) return LFSD_EINVAL;
   if ((phases & 2) && (!loss || !grad)) return LFSD_EINVAL;
   if ((phases & 2) && n_waypoints > 0 && (n_iface <= 0 || !iface_idx || !taus || !waypoints)) return LFSD_EINVAL;
@@ -190,11 +193,11 @@ static int aux_dispatch(int phases, int dtype, int batch, int n_grid, const void
   if (dtype == LFSD_F32)
     return aux_phase_t<float>(phases, batch, n_grid, horizon, auxvar, consts, const_per_traj, state_grid, control_grid,
                               costate_grid, Z_grid, n_waypoints, n_iface, iface_idx, taus, waypoints, loss, grad,
-                              auxX_grid, auxU_grid, substeps, stream);
+                              auxX_grid, auxU_grid, substeps, rtol, stream);
   if (dtype == LFSD_F64)
     return aux_phase_t<double>(phases, batch, n_grid, horizon, auxvar, consts, const_per_traj, state_grid,
                                control_grid, costate_grid, Z_grid, n_waypoints, n_iface, iface_idx, taus, waypoints,
-                               loss, grad, auxX_grid, auxU_grid, substeps, stream);
+                               loss, grad, auxX_grid, auxU_grid, substeps, rtol, stream);
   return LFSD_EINVAL;
 }
 
@@ -202,29 +205,29 @@ LFSD_API int lfsd_aux_solve(int dtype, int batch, int n_grid, const void* horizo
                             const void* consts, int const_per_traj, const void* state_grid, const void* control_grid,
                             const void* costate_grid, void* Z_grid, int n_waypoints, int n_iface,
                             const int* iface_idx, const void* taus, const void* waypoints, void* loss, void* grad,
-                            void* auxX_grid, void* auxU_grid, int substeps, void* stream) {
+                            void* auxX_grid, void* auxU_grid, int substeps, double rtol, void* stream) {
   return aux_dispatch(3, dtype, batch, n_grid, horizon, auxvar, consts, const_per_traj, state_grid, control_grid,
                       costate_grid, Z_grid, n_waypoints, n_iface, iface_idx, taus, waypoints, loss, grad, auxX_grid,
-                      auxU_grid, substeps, stream);
+                      auxU_grid, substeps, rtol, stream);
 }
 
 LFSD_API int lfsd_aux_riccati(int dtype, int batch, int n_grid, const void* horizon, const void* auxvar,
                               const void* consts, int const_per_traj, const void* state_grid,
                               const void* control_grid, const void* costate_grid, void* Z_grid, int substeps,
-                              void* stream) {
+                              double rtol, void* stream) {
   return aux_dispatch(1, dtype, batch, n_grid, horizon, auxvar, consts, const_per_traj, state_grid, control_grid,
                       costate_grid, Z_grid, 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
-                      substeps, stream);
+                      substeps, rtol, stream);
 }
 
 LFSD_API int lfsd_aux_forward(int dtype, int batch, int n_grid, const void* horizon, const void* auxvar,
                               const void* consts, int const_per_traj, const void* state_grid,
                               const void* control_grid, const void* costate_grid, const void* Z_grid, int n_waypoints,
                               int n_iface, const int* iface_idx, const void* taus, const void* waypoints, void* loss,
-                              void* grad, void* auxX_grid, void* auxU_grid, int substeps, void* stream) {
+                              void* grad, void* auxX_grid, void* auxU_grid, int substeps, double rtol, void* stream) {
   return aux_dispatch(2, dtype, batch, n_grid, horizon, auxvar, consts, const_per_traj, state_grid, control_grid,
                       costate_grid, const_cast<void*>(Z_grid), n_waypoints, n_iface, iface_idx, taus, waypoints, loss,
-                      grad, auxX_grid, auxU_grid, substeps, stream);
+                      grad, auxX_grid, auxU_grid, substeps, rtol, stream);
 }
 
 template <typename T>

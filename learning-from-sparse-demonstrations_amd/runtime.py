@@ -163,15 +163,15 @@ class ModelLibrary:
         L.lfsd_coc_solve.argtypes = [ci, ci, ci, ci, vp, vp, vp, vp, ci, vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, cd, ci, vp,
                                      ctypes.c_size_t, vp]
         L.lfsd_aux_solve.argtypes = [ci, ci, ci, vp, vp, vp, ci, vp, vp, vp, vp, ci, ci, vp, vp, vp, vp, vp, vp, vp,
-                                     ci, vp]
-        L.lfsd_aux_riccati.argtypes = [ci, ci, ci, vp, vp, vp, ci, vp, vp, vp, vp, ci, vp]
+                                     ci, cd, vp]
+        L.lfsd_aux_riccati.argtypes = [ci, ci, ci, vp, vp, vp, ci, vp, vp, vp, vp, ci, cd, vp]
         L.lfsd_aux_forward.argtypes = [ci, ci, ci, vp, vp, vp, ci, vp, vp, vp, vp, ci, ci, vp, vp, vp, vp, vp, vp, vp,
-                                       ci, vp]
+                                       ci, cd, vp]
         L.lfsd_optimizer_step.argtypes = [ci, ci, ci, ci, ci, cd, cd, cd, cd, cd, vp, vp, vp, vp, vp, vp, vp, vp]
         L.lfsd_lookahead.argtypes = [ci, ctypes.c_longlong, cd, vp, vp, vp, vp]
         info = _ModelInfo()
         rc = L.lfsd_get_model_info(ctypes.byref(info))
-        if rc != 0 or info.abi_version != 3:
+        if rc != 0 or info.abi_version != 4:
             raise LfsdError("ABI mismatch in %s" % path)
         self.n_state, self.n_control, self.n_auxvar, self.n_const = (info.n_state, info.n_control, info.n_auxvar,
                                                                       info.n_const)
@@ -275,7 +275,7 @@ class ModelLibrary:
         return out
 
     def aux_solve(self, horizon, auxvar, consts, state_grid, control_grid, costate_grid, taus, waypoints, iface_idx,
-                  substeps=0, want_grids=False, Z_grid=None, out=None, phase_hook=None):
+                  substeps=0, want_grids=False, Z_grid=None, out=None, phase_hook=None, rtol=1e-3):
         """``phase_hook(name)``, if given, is called before/after each of the two launches
         ("riccati", "forward") so a caller can bracket them with HIP events (bench.py)."""
         dt = state_grid.dtype
@@ -316,13 +316,13 @@ class ModelLibrary:
         common = (_DT[dt], B, N, self._p(horizon), self._p(auxvar), self._p(consts), per_traj,
                   self._p(state_grid), self._p(control_grid), self._p(costate_grid), self._p(Z_grid))
         tail = (nw, ni, self._p(iface_idx), self._p(taus), self._p(waypoints), self._p(out["loss"]),
-                self._p(out["grad"]), self._p(auxX), self._p(auxU), int(substeps), self._stream(state_grid))
+                self._p(out["grad"]), self._p(auxX), self._p(auxU), int(substeps), float(rtol), self._stream(state_grid))
         with self._on(state_grid):
             if phase_hook is None:
                 self._rc(self.lib.lfsd_aux_solve(*common, *tail), "lfsd_aux_solve")
             else:
                 phase_hook("riccati")
-                self._rc(self.lib.lfsd_aux_riccati(*common, int(substeps), self._stream(state_grid)),
+                self._rc(self.lib.lfsd_aux_riccati(*common, int(substeps), float(rtol), self._stream(state_grid)),
                          "lfsd_aux_riccati")
                 phase_hook("forward")
                 self._rc(self.lib.lfsd_aux_forward(*common, *tail), "lfsd_aux_forward")

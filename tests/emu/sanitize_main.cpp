@@ -26,7 +26,7 @@ int main() {
                             cost.data(), it.data(), st.data(), 40, dtype ? 1e-9 : 1e-6, 3, ws.data(), wsb, nullptr);
     printf("dtype %d coc rc %d status %d iters %d\n", dtype, rc, st[0], it[0]);
     rc = lfsd_aux_solve(dtype, B, N, hz.data(), th.data(), nc ? cs.data() : nullptr, 0, X.data(), U.data(), L.data(), Z.data(), nw, ni, iface.data(),
-                        taus.data(), wps.data(), loss.data(), grad.data(), aX.data(), aU.data(), 4, nullptr);
+                        taus.data(), wps.data(), loss.data(), grad.data(), aX.data(), aU.data(), (pass & 2) ? 1 : 4, (pass & 2) ? 1e-3 : 0.0, nullptr);
     printf("dtype %d aux rc %d\n", dtype, rc);
     for (int meth = 0; meth < 5; ++meth)
       rc |= lfsd_optimizer_step(dtype, meth, B, p, 0, 0.01, 0.9, 0.9, 0.999, 1e-8, th.data(), grad.data(), mm.data(), mv.data(), mvh.data(), nullptr, nullptr, nullptr);

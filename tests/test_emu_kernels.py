@@ -29,11 +29,11 @@ def rel(a, b):
     return np.abs(a - b).max() / max(np.abs(b).max(), 1e-300)
 
 
-def run_case(emu, kind, dtype, thetas, taus, wps, n_grid, batch_pad=0, substeps=8):
+def run_case(emu, kind, dtype, thetas, taus, wps, n_grid, batch_pad=0, substeps=8, rtol=None):
     oc, env, d = models.ZOO[kind](n_grid=n_grid)
     emu(oc)
     oc.setDevice(dtype=dtype)
-    oc.setSolverOptions(aux_substeps=substeps)
+    oc.setSolverOptions(aux_substeps=substeps, aux_rtol=rtol)
     thetas = np.atleast_2d(np.asarray(thetas, dtype=np.float64))
     B = thetas.shape[0]
     sol = oc.cocSolverBatch(np.tile(d["ini_state"], (B, 1)), d["horizon"], thetas)
@@ -70,10 +70,30 @@ def test_aux_sweeps_converge_at_fourth_order(emu):
     r = None
     errs = []
     for sub in (4, 8, 16):
-        oc, d, sol, aux = run_case(emu, "pendulum", torch.float64, thetas, taus, wps, 10, substeps=sub)
+        oc, d, sol, aux = run_case(emu, "pendulum", torch.float64, thetas, taus, wps, 10, substeps=sub, rtol=0.0)   # fixed units
         r = r or oracle_loss_grad(o, d["ini_state"], d["horizon"], thetas[0], taus, wps, d["interface"])
         errs.append(rel(aux["grad"][0], r["grad"]))
     assert errs[0] / errs[1] > 8 and errs[1] / errs[2] > 8 and errs[2] < 2e-5, errs
+
+
+def test_error_controlled_substepping_beats_fixed_units(emu):
+    """aux_rtol > 0 (the default is 1e-3, scipy's default rtol with which the reference calls solve_ivp): an interval is redone with twice the split units while the Richardson estimate
+    |fine - coarse| / 3 exceeds rtol.  On the coarse pendulum grid (10 intervals of 0.1-0.2 s) one unit per interval is far
+    too few and four -- the fixed round-1 default -- leave 1e-3; the controlled sweep must deliver its tolerance class from
+    the library defaults (no aux_substeps), and a tighter rtol must not be less accurate."""
+    thetas, taus, wps = [[2.0, 1.0, 1.0]], [0.1, 0.3, 0.6, 0.7, 0.9], [[0.4], [1.2], [2.1], [2.4], [2.9]]
+    o = make_oracle("pendulum", 10)
+    err = {}
+    r = None
+    for key, sub, rtol in (("fixed4", 4, 0.0), ("default", 0, None), ("rtol1e-4", 0, 1e-4), ("rtol1e-6", 0, 1e-6)):
+        oc, d, sol, aux = run_case(emu, "pendulum", torch.float64, thetas, taus, wps, 10, substeps=sub, rtol=rtol)
+        r = r or oracle_loss_grad(o, d["ini_state"], d["horizon"], thetas[0], taus, wps, d["interface"])
+        n, p = 2, 3
+        err[key] = (rel(aux["grad"][0], r["grad"]), rel(aux["auxX_grid"][0].numpy().transpose(0, 2, 1).reshape(-1, n * p), r["vX"]))
+    assert err["fixed4"][0] > 5e-4                                    # what the fixed default leaves on this grid
+    assert err["default"][0] < 1e-4 and err["default"][1] < 5e-4, err               # library default: rtol 1e-3
+    assert err["rtol1e-4"][0] < 1e-5 and err["rtol1e-4"][1] < 5e-5, err
+    assert err["rtol1e-6"][0] <= err["rtol1e-4"][0] * 1.5 and err["rtol1e-6"][1] < 1e-5, err
 
 
 def test_robotarm_and_cartpole_fp32(emu):
