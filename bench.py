@@ -231,7 +231,11 @@ def main(argv=None):
         oc.use_library(args.library)
     oc.setDevice(dev, dtype)
     oc.setSolverOptions(aux_substeps=args.substeps, aux_rtol=args.aux_rtol)
+    if use_dist and rank != 0:
+        dist.barrier()                                 # rank 0 makes sure the model library exists (it is normally prebuilt)
     lib = oc.compile()
+    if use_dist and rank == 0:
+        dist.barrier()
     assert not lib.is_emulator
     B = args.batch
     L, theta0, x0 = build_learner(args, oc, d, lib, rank, world, mode)

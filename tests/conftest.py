@@ -94,7 +94,21 @@ def make_oracle(kind, n_grid, **kw):
 TIGHT = dict(riccati_method='Radau', ivp_kwargs=dict(rtol=1e-10, atol=1e-12))
 
 
+_REF_CACHE = {}
+
+
 def oracle_loss_grad(oc, ini_state, horizon, theta, taus, wps, iface, tight=True, **solver_kw):
+    """(cached per session: several tests and parametrisations compare against the same oracle solution)"""
+    import numpy as np
+    key = (id(type(oc)), tuple(map(str, oc.state)), str(oc.dyn), str(oc.path_cost), str(oc.final_cost), oc.n_grid,
+           tuple(np.ravel(ini_state).tolist()), float(horizon), tuple(np.ravel(theta).tolist()),
+           tuple(np.ravel(taus).tolist()), tuple(np.ravel(wps).tolist()), tuple(iface), tight, tuple(sorted(solver_kw.items())))
+    if key not in _REF_CACHE:
+        _REF_CACHE[key] = _oracle_loss_grad(oc, ini_state, horizon, theta, taus, wps, iface, tight=tight, **solver_kw)
+    return _REF_CACHE[key]
+
+
+def _oracle_loss_grad(oc, ini_state, horizon, theta, taus, wps, iface, tight=True, **solver_kw):
     from oracle.cpdp_oracle import getloss_corrections
     tg, sol, X, U, L = oc.cocSolver(ini_state, horizon, theta, return_grids=True, **solver_kw)
     aux, PW, vX, vU = oc.auxSysSolver(tg, sol, theta, return_grids=True, **(TIGHT if tight else {}))
