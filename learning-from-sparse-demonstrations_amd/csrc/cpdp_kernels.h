@@ -557,6 +557,11 @@ template <class M, typename T, int G, bool EXACT, bool BND = false> struct OcSol
   T horizon, dgrid, DT;
   T *xb[2], *ub[2], *Mws[2], *Kws, *kws, *lds, *exws, *Hws;
   T *xa = nullptr, *ua = nullptr, *exwu = nullptr;      // wide mapping only: per-step-length roll-outs, per-lane sub-step states
+  // the double-buffered arrays are picked by a select, not by indexing the pointer arrays with a run-time value: that would
+  // put the arrays in scratch (it was the lean kernel's last 168 B/lane of scratch)
+  LFSD_DEV T* xbp(int i) const { return i ? xb[1] : xb[0]; }
+  LFSD_DEV T* ubp(int i) const { return i ? ub[1] : ub[0]; }
+  LFSD_DEV T* Mwp(int i) const { return i ? Mws[1] : Mws[0]; }
   bool reuse_hess = false;   // exact stage Hessians in Hws belong to the nominal being swept (a retry with another shift)
   T* lam_out;   // costate grid of this trajectory (or scratch when invalid)
 
@@ -594,11 +599,11 @@ template <class M, typename T, int G, bool EXACT, bool BND = false> struct OcSol
 
   // closed-loop control  u = ubar + alpha*kff + K (x - xbar)   (all operands group-uniform loads)
   LFSD_DEV void control(int cur, int k, const T* x, T alpha, bool gains, T* u) const {
-    const T* ubk = ub[cur] + k * NU;
+    const T* ubk = ubp(cur) + k * NU;
 #pragma unroll
     for (int a = 0; a < NU; ++a) u[a] = ubk[a];
     if (gains) {
-      const T* xbk = xb[cur] + k * NX;
+      const T* xbk = xbp(cur) + k * NX;
       const T* Kk = Kws + k * NX * NU;
       const T* kk = kws + k * NU;
 #pragma unroll
@@ -626,9 +631,9 @@ template <class M, typename T, int G, bool EXACT, bool BND = false> struct OcSol
       control(cur, k, x, alpha, gains, u);
       if (lane == 0) {
 #pragma unroll
-        for (int i = 0; i < NX; ++i) xb[nxt][k * NX + i] = x[i];
+        for (int i = 0; i < NX; ++i) xbp(nxt)[k * NX + i] = x[i];
 #pragma unroll
-        for (int a = 0; a < NU; ++a) ub[nxt][k * NU + a] = u[a];
+        for (int a = 0; a < NU; ++a) ubp(nxt)[k * NU + a] = u[a];
       }
       T m[NX], du[NU], mq = T(0), q = T(0);
 #pragma unroll
@@ -639,7 +644,7 @@ template <class M, typename T, int G, bool EXACT, bool BND = false> struct OcSol
       for (int s = 0; s < S; ++s) rk4_step<true>(t, x, q, u, m, mq, du);
       J += q;
       if (lane < NXU) {
-        T* Mk = Mws[nxt] + (long long)k * Lay::M_ELEMS + lane;
+        T* Mk = Mwp(nxt) + (long long)k * Lay::M_ELEMS + lane;
 #pragma unroll
         for (int i = 0; i < NX; ++i) Mk[i * Lay::NXUP] = m[i];
         Mk[NX * Lay::NXUP] = mq;
@@ -647,7 +652,7 @@ template <class M, typename T, int G, bool EXACT, bool BND = false> struct OcSol
     }
     if (lane == 0) {
 #pragma unroll
-      for (int i = 0; i < NX; ++i) xb[nxt][N * NX + i] = x[i];
+      for (int i = 0; i < NX; ++i) xbp(nxt)[N * NX + i] = x[i];
     }
     J += M::final_cost(tk(N), x, e, c);
     return J;
@@ -665,9 +670,9 @@ template <class M, typename T, int G, bool EXACT, bool BND = false> struct OcSol
       control(cur, k, x, alpha, gains, u);
       if (lane == 0) {
 #pragma unroll
-        for (int i = 0; i < NX; ++i) xb[nxt][k * NX + i] = x[i];
+        for (int i = 0; i < NX; ++i) xbp(nxt)[k * NX + i] = x[i];
 #pragma unroll
-        for (int a = 0; a < NU; ++a) ub[nxt][k * NU + a] = u[a];
+        for (int a = 0; a < NU; ++a) ubp(nxt)[k * NU + a] = u[a];
       }
       V m[NX], du[NU], mq = V(T(0));
       T q = T(0);
@@ -679,7 +684,7 @@ template <class M, typename T, int G, bool EXACT, bool BND = false> struct OcSol
       for (int s = 0; s < S; ++s) rk4_step<true, V>(t, x, q, u, m, mq, du);
       J += q;
       if (c0 < NXU) {          // columns c0, c0+1 of every row as one 8-byte store (c1 < NXUP: the pad column of an odd NXU)
-        V* Mk = reinterpret_cast<V*>(Mws[nxt] + (long long)k * Lay::M_ELEMS + c0);
+        V* Mk = reinterpret_cast<V*>(Mwp(nxt) + (long long)k * Lay::M_ELEMS + c0);
 #pragma unroll
         for (int i = 0; i < NX; ++i) Mk[i * (Lay::NXUP / 2)] = m[i];
         Mk[NX * (Lay::NXUP / 2)] = mq;
@@ -687,7 +692,7 @@ template <class M, typename T, int G, bool EXACT, bool BND = false> struct OcSol
     }
     if (lane == 0) {
 #pragma unroll
-      for (int i = 0; i < NX; ++i) xb[nxt][N * NX + i] = x[i];
+      for (int i = 0; i < NX; ++i) xbp(nxt)[N * NX + i] = x[i];
     }
     J += M::final_cost(tk(N), x, e, c);
     return J;
@@ -789,7 +794,7 @@ template <class M, typename T, int G, bool EXACT, bool BND = false> struct OcSol
     T gl_max = T(0);
     dV1 = T(0); dV2 = T(0); dmin = T(0);
     {
-      const T* xN = xb[cur] + N * NX;
+      const T* xN = xbp(cur) + N * NX;
 #pragma unroll
       for (int i = 0; i < NX; ++i) xk[i] = xN[i];
       M::final_grad(tk(N), xk, e, c, Vx);
@@ -808,7 +813,7 @@ template <class M, typename T, int G, bool EXACT, bool BND = false> struct OcSol
     // while interval k is being processed (one wave per SIMD: nothing else would hide their latency)
     auto load_stage = [&](int k_, T* m_, T& mq_, T* xk_, T* uk_) LFSD_LAMBDA_INLINE {
       if (lane < NXU) {
-        const T* Mk = Mws[cur] + (long long)k_ * Lay::M_ELEMS + lane;
+        const T* Mk = Mwp(cur) + (long long)k_ * Lay::M_ELEMS + lane;
 #pragma unroll
         for (int i = 0; i < NX; ++i) m_[i] = Mk[i * Lay::NXUP];
         mq_ = Mk[NX * Lay::NXUP];
@@ -817,7 +822,7 @@ template <class M, typename T, int G, bool EXACT, bool BND = false> struct OcSol
         for (int i = 0; i < NX; ++i) m_[i] = T(0);
         mq_ = T(0);
       }
-      const T* xp = xb[cur] + k_ * NX;  const T* up = ub[cur] + k_ * NU;
+      const T* xp = xbp(cur) + k_ * NX;  const T* up = ubp(cur) + k_ * NU;
 #pragma unroll
       for (int i = 0; i < NX; ++i) xk_[i] = xp[i];
 #pragma unroll
@@ -1051,7 +1056,7 @@ template <class M, typename T, int G, bool EXACT, bool BND = false> struct OcSol
     T gl_max = T(0);
     dV1 = T(0); dV2 = T(0); dmin = T(0);
     {
-      const T* xN = xb[cur] + N * NX;
+      const T* xN = xbp(cur) + N * NX;
 #pragma unroll
       for (int i = 0; i < NX; ++i) xk[i] = xN[i];
       M::final_grad(tk(N), xk, e, c, Vx);
@@ -1068,7 +1073,7 @@ template <class M, typename T, int G, bool EXACT, bool BND = false> struct OcSol
     }
     for (int k = N - 1; k >= 0; --k) {
       T m[NX], mq = T(0);
-      const T* Mk = Mws[cur] + (long long)k * Lay::M_ELEMS;
+      const T* Mk = Mwp(cur) + (long long)k * Lay::M_ELEMS;
       if (lane < NCL) {
 #pragma unroll
         for (int i = 0; i < NX; ++i) m[i] = Mk[i * Lay::NXUP + lane];
@@ -1081,7 +1086,7 @@ template <class M, typename T, int G, bool EXACT, bool BND = false> struct OcSol
         if (lane <= NX) ldsME[lane] = Mk[lane * Lay::NXUP + NCL];
       }
       {
-        const T* xp = xb[cur] + k * NX;  const T* up = ub[cur] + k * NU;
+        const T* xp = xbp(cur) + k * NX;  const T* up = ubp(cur) + k * NU;
 #pragma unroll
         for (int i = 0; i < NX; ++i) xk[i] = xp[i];
 #pragma unroll
@@ -1293,7 +1298,7 @@ template <class M, typename T, bool EXACT, bool BND = false> struct OcWide : OcS
   using Lay = OcLayout<M>;
   static constexpr int NX = M::NX, NU = M::NU, NP = M::NP, NXU = NX + NU;
   static constexpr int NAL = 16;                       // step lengths 2^0 .. 2^-15
-  using Base::lane; using Base::N; using Base::S; using Base::e; using Base::c; using Base::x0; using Base::xb; using Base::ub;
+  using Base::lane; using Base::N; using Base::S; using Base::e; using Base::c; using Base::x0; using Base::xb; using Base::ub; using Base::xbp; using Base::ubp; using Base::Mwp;
   using Base::Mws; using Base::Hws; using Base::lds; using Base::xa; using Base::ua; using Base::lam_out; using Base::DT;
 
   // lane l < NAL rolls the closed loop out with step length 2^-l and parks states / controls at [k][component][l]
@@ -1326,8 +1331,8 @@ template <class M, typename T, bool EXACT, bool BND = false> struct OcWide : OcS
   // the roll-out of step length index ia becomes nominal `nxt`
   LFSD_DEV void adopt_alpha(int ia, int nxt) {
     __syncthreads();
-    for (int i = lane; i < (N + 1) * NX; i += 64) xb[nxt][i] = xa[i * NAL + ia];
-    for (int i = lane; i < N * NU; i += 64) ub[nxt][i] = ua[i * NAL + ia];
+    for (int i = lane; i < (N + 1) * NX; i += 64) xbp(nxt)[i] = xa[i * NAL + ia];
+    for (int i = lane; i < N * NU; i += 64) ubp(nxt)[i] = ua[i * NAL + ia];
     __syncthreads();
   }
   // linearise the shooting map along nominal `nxt`, all intervals at once
@@ -1340,12 +1345,12 @@ template <class M, typename T, bool EXACT, bool BND = false> struct OcWide : OcS
         T x[NX], u[NU], q = T(0);
         V m[NX], du[NU], mq = V(T(0));
 #pragma unroll
-        for (int i = 0; i < NX; ++i) { x[i] = xb[nxt][k * NX + i]; m[i] = mk2<T>((c0 == i) ? T(1) : T(0), (c1 == i) ? T(1) : T(0)); }
+        for (int i = 0; i < NX; ++i) { x[i] = xbp(nxt)[k * NX + i]; m[i] = mk2<T>((c0 == i) ? T(1) : T(0), (c1 == i) ? T(1) : T(0)); }
 #pragma unroll
-        for (int a = 0; a < NU; ++a) { u[a] = ub[nxt][k * NU + a]; du[a] = mk2<T>((c0 == NX + a) ? T(1) : T(0), (c1 == NX + a) ? T(1) : T(0)); }
+        for (int a = 0; a < NU; ++a) { u[a] = ubp(nxt)[k * NU + a]; du[a] = mk2<T>((c0 == NX + a) ? T(1) : T(0), (c1 == NX + a) ? T(1) : T(0)); }
         const T tt = this->tk(k);
         for (int s = 0; s < S; ++s) this->template rk4_step<true, V>(tt, x, q, u, m, mq, du);
-        V* Mk = reinterpret_cast<V*>(Mws[nxt] + (long long)k * Lay::M_ELEMS + c0);
+        V* Mk = reinterpret_cast<V*>(Mwp(nxt) + (long long)k * Lay::M_ELEMS + c0);
 #pragma unroll
         for (int i = 0; i < NX; ++i) Mk[i * (Lay::NXUP / 2)] = m[i];
         Mk[NX * (Lay::NXUP / 2)] = mq;
@@ -1355,12 +1360,12 @@ template <class M, typename T, bool EXACT, bool BND = false> struct OcWide : OcS
         const int k = t / NXU, col = t % NXU;
         T x[NX], u[NU], m[NX], du[NU], q = T(0), mq = T(0);
 #pragma unroll
-        for (int i = 0; i < NX; ++i) { x[i] = xb[nxt][k * NX + i]; m[i] = (col == i) ? T(1) : T(0); }
+        for (int i = 0; i < NX; ++i) { x[i] = xbp(nxt)[k * NX + i]; m[i] = (col == i) ? T(1) : T(0); }
 #pragma unroll
-        for (int a = 0; a < NU; ++a) { u[a] = ub[nxt][k * NU + a]; du[a] = (col == NX + a) ? T(1) : T(0); }
+        for (int a = 0; a < NU; ++a) { u[a] = ubp(nxt)[k * NU + a]; du[a] = (col == NX + a) ? T(1) : T(0); }
         const T tt = this->tk(k);
         for (int s = 0; s < S; ++s) this->template rk4_step<true>(tt, x, q, u, m, mq, du);
-        T* Mk = Mws[nxt] + (long long)k * Lay::M_ELEMS + col;
+        T* Mk = Mwp(nxt) + (long long)k * Lay::M_ELEMS + col;
 #pragma unroll
         for (int i = 0; i < NX; ++i) Mk[i * Lay::NXUP] = m[i];
         Mk[NX * Lay::NXUP] = mq;
@@ -1373,7 +1378,7 @@ template <class M, typename T, bool EXACT, bool BND = false> struct OcWide : OcS
     T* ldsLam = lds + Lay::LDS_LAM;  T* ldsRed = lds + Lay::LDS_RED;
     T lam[NX], xN[NX];
 #pragma unroll
-    for (int i = 0; i < NX; ++i) xN[i] = xb[cur][N * NX + i];
+    for (int i = 0; i < NX; ++i) xN[i] = xbp(cur)[N * NX + i];
     M::final_grad(this->tk(N), xN, e, c, lam);
     if (lane == 0) {
 #pragma unroll
@@ -1383,7 +1388,7 @@ template <class M, typename T, bool EXACT, bool BND = false> struct OcWide : OcS
     for (int k = N - 1; k >= 0; --k) {
       T gl = T(0);
       if (lane < NXU) {
-        const T* Mk = Mws[cur] + (long long)k * Lay::M_ELEMS + lane;
+        const T* Mk = Mwp(cur) + (long long)k * Lay::M_ELEMS + lane;
         gl = Mk[NX * Lay::NXUP];
 #pragma unroll
         for (int i = 0; i < NX; ++i) gl += Mk[i * Lay::NXUP] * lam[i];
@@ -1409,9 +1414,9 @@ template <class M, typename T, bool EXACT, bool BND = false> struct OcWide : OcS
       const int k = t / NXU, col = t % NXU;
       T xk[NX], uk[NU], ln[NX], hx[NX], hu[NU];
 #pragma unroll
-      for (int i = 0; i < NX; ++i) { xk[i] = xb[cur][k * NX + i]; ln[i] = lam_out[(k + 1) * NX + i]; }
+      for (int i = 0; i < NX; ++i) { xk[i] = xbp(cur)[k * NX + i]; ln[i] = lam_out[(k + 1) * NX + i]; }
 #pragma unroll
-      for (int a = 0; a < NU; ++a) uk[a] = ub[cur][k * NU + a];
+      for (int a = 0; a < NU; ++a) uk[a] = ubp(cur)[k * NU + a];
       this->template stage_hessian_col<true>(k, xk, uk, ln, hx, hu, col);
       T* hcol = Hws + (long long)k * Lay::H_ELEMS + col;
 #pragma unroll
@@ -1716,8 +1721,8 @@ __global__ void __launch_bounds__(64, LFSD_WAVES_OC) oc_solve_kernel(OcArgs<T> a
   if (valid) {
     T* xo = a.state_grid + traj * (N + 1) * NX;
     T* uo = a.control_grid + traj * (N + 1) * NU;
-    for (int i = s.lane; i < (N + 1) * NX; i += GR) xo[i] = s.xb[cur][i];
-    for (int i = s.lane; i < (N + 1) * NU; i += GR) uo[i] = s.ub[cur][(i < N * NU) ? i : i - NU];
+    for (int i = s.lane; i < (N + 1) * NX; i += GR) xo[i] = s.xbp(cur)[i];
+    for (int i = s.lane; i < (N + 1) * NU; i += GR) uo[i] = s.ubp(cur)[(i < N * NU) ? i : i - NU];
     if (s.lane == 0) { a.cost[traj] = J; a.iters[traj] = my_iters; a.status[traj] = status; }
   }
 }
@@ -1865,8 +1870,8 @@ __global__ void __launch_bounds__(64, 1) oc_solve_wide_kernel(OcArgs<T> a) {
   {
     T* xo = a.state_grid + traj * (N + 1) * NX;
     T* uo = a.control_grid + traj * (N + 1) * NU;
-    for (int i = s.lane; i < (N + 1) * NX; i += 64) xo[i] = s.xb[cur][i];
-    for (int i = s.lane; i < (N + 1) * NU; i += 64) uo[i] = s.ub[cur][(i < N * NU) ? i : i - NU];
+    for (int i = s.lane; i < (N + 1) * NX; i += 64) xo[i] = s.xbp(cur)[i];
+    for (int i = s.lane; i < (N + 1) * NU; i += 64) uo[i] = s.ubp(cur)[(i < N * NU) ? i : i - NU];
     if (s.lane == 0) { a.cost[traj] = J; a.iters[traj] = (status == ST_CONVERGED) ? it + 1 : it; a.status[traj] = status; }
   }
 }
