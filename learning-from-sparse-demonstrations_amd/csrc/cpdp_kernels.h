@@ -2364,8 +2364,11 @@ __global__ void __launch_bounds__(64, (sizeof(T) == 4 ? LFSD_WAVES_RIC : 1)) aux
   int units_hint = Sa;
   for (int k = N - 1; k >= 0; --k) {
     s.load_interval(a, traj, k, N);
-    // stiffness-aware sub-stepping: P is largest at the later end of the interval (terminal transient)
-    s.stage_nodes(T(1), T(0));
+    // stiffness-aware sub-stepping: P is largest at the later end of the interval (terminal transient).  The coefficients
+    // are staged for the first unit of the expected unit count at once: node 0 sits at the interval end either way, and
+    // when the stiffness estimate confirms the count the first unit need not stage again
+    const int units_guess = units_hint;
+    s.stage_nodes(T(1), T(-1) / T(4 * units_guess));
     int units = s.units_for(s.stiff_rate(z, s.node(0)), Sa, a.rate_max, a.max_refine);
     // error-driven refinement stops at max_refine x the minimum units -- and as soon as a doubling fails to halve the
     // estimate: next to a conjugate point (finite escape of the Riccati solution) no step size meets a relative tolerance,
@@ -2373,6 +2376,7 @@ __global__ void __launch_bounds__(64, (sizeof(T) == 4 ? LFSD_WAVES_RIC : 1)) aux
     const long long units_cap = (long long)Sa * a.max_refine;
     if (units < units_hint) units = (int)t_min((long long)units_hint, units_cap);
     T ratio_prev = T(-1);
+    bool staged = (units == units_guess);
     // Error-controlled sub-stepping (a.rtol > 0): the Richardson pair gives |fine - coarse| / 3 as an estimate of the
     // second-order error that the extrapolation removes; while it exceeds rtol relative to the column's size the interval
     // is redone from its stored start value Z(t_k+1) with twice the units.  (solve_ivp's rtol of the reference, CPDP.py:335,
@@ -2383,7 +2387,8 @@ __global__ void __launch_bounds__(64, (sizeof(T) == 4 ? LFSD_WAVES_RIC : 1)) aux
       T err_l = T(0), scl_l = T(0);
       for (int unit = 0; unit < units; ++unit) {
         const T s_hi = T(1) - T(unit) / T(units);
-        s.stage_nodes(s_hi, -ds);                  // node i sits at fraction s_hi - i/(4 Sa)
+        if (!(staged && unit == 0)) s.stage_nodes(s_hi, -ds);      // node i sits at fraction s_hi - i/(4 units)
+        staged = false;
         s.ric_cols();
         // coarse chain in place, then the fine chain in place from the parked start value (the barriers inside the chains
         // keep the compiler from carrying the parked column in registers)
@@ -2497,19 +2502,21 @@ __global__ void __launch_bounds__(64, (sizeof(T) == 4 ? LFSD_WAVES_FWD : 1)) aux
 #pragma unroll
       for (int i = 0; i < NX; ++i) xprev[i * NP + s.xcol] = xa[i];
     }
-    s.stage_nodes(T(0), T(0.25));
-    const T rate = t_max(s.stiff_rate(pA, s.node(0)), s.stiff_rate(pB, s.node(4)));
+    s.stage_nodes(T(0), T(0.25));          // nodes at 0, 1/4 .. 1 of the interval: the stiffness at both ends -- and exactly
+    const T rate = t_max(s.stiff_rate(pA, s.node(0)), s.stiff_rate(pB, s.node(4)));      // the staging of a single unit
     int units = s.units_for(rate, Sa, a.rate_max, a.max_refine);
     const long long units_cap = (long long)Sa * a.max_refine;
     if (units < units_hint) units = (int)t_min((long long)units_hint, units_cap);
     T ratio_prev = T(-1);
+    bool staged = (units == 1);
     for (;;) {                         // error-controlled sub-stepping, as in the Riccati sweep; the start value X(t_k) is `xprev`
       const T hc = s.dgrid / T(units);
       const T ds = T(1) / T(4 * units);
       T err_l = T(0), scl_l = T(0);
       for (int unit = 0; unit < units; ++unit) {
         const T s_lo = T(unit) / T(units);
-        s.stage_nodes(s_lo, ds);
+        if (!(staged && unit == 0)) s.stage_nodes(s_lo, ds);
+        staged = false;
         if (Uo && unit == 0) {
           T uo[NU];
           s.aux_control(xa, pA, wA, s.node(0), uo);
