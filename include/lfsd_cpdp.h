@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define LFSD_ABI_VERSION 4
+#define LFSD_ABI_VERSION 5
 #define LFSD_F32 0
 #define LFSD_F64 1
 #define LFSD_EINVAL (-1)   /* bad argument (null pointer, non-positive size, unknown enum) */
@@ -36,6 +36,11 @@ extern "C" {
 #define LFSD_ST_STALLED   2   /* no step improves J beyond rounding: converged to precision */
 #define LFSD_ST_MAXITER   3
 #define LFSD_ST_FAILED    4   /* non-finite cost / regularisation exhausted            */
+
+/* mapping of the optimal-control solve onto the machine (lfsd_coc_solve) */
+#define LFSD_MAP_AUTO     0   /* by batch size / model / exact_after */
+#define LFSD_MAP_LOCKSTEP 1   /* several trajectories per wavefront, shooting intervals in sequence */
+#define LFSD_MAP_WIDE     2   /* one trajectory per wavefront, intervals / step lengths in parallel */
 
 /* optimizer methods (lib/QuadAlgorithm.py:164-188) */
 #define LFSD_OPT_VANILLA  0
@@ -77,14 +82,15 @@ size_t lfsd_coc_workspace_bytes(int dtype, int batch, int n_grid);
  *   setControlVariable(control, control_lb, control_ub) -> lbw / ubw of the NLP (CPDP.py:33-46, 150-153).  Both or
  *   neither; entries beyond +-1e19 mean "unbounded in that direction".  Solved by a control-limited backward sweep
  *   (box QP per stage, zero feedback gain on clamped components, clamped roll-out); the initial guess is the midpoint of
- *   finite bounds as in the reference.  State bounds are not supported.                                          */
+ *   finite bounds as in the reference.  State bounds are not supported.
+ *   mapping: LFSD_MAP_AUTO, or force one of the two mappings of the same algorithm (same KKT points either way).   */
 int lfsd_coc_solve(int dtype, int batch, int n_grid, int steps_per_grid,
                    const void* ini_state, const void* horizon, const void* auxvar,
                    const void* consts, int const_per_traj, const void* u_init,
                    const void* control_lb, const void* control_ub,
                    void* state_grid, void* control_grid, void* costate_grid,
                    void* cost, int* iters, int* status,
-                   int max_iter, double tol, int exact_after,
+                   int max_iter, double tol, int exact_after, int mapping,
                    void* workspace, size_t workspace_bytes, void* stream);
 
 /* Differentiate the maximum principle along the solved trajectories and evaluate the

@@ -46,6 +46,7 @@ class COCSys:
         self.tol = None
         self.exact_after = 16            # iteration from which the exact stage Hessian is forced
         self.aux_dtype = None            # None: same as dtype; torch.float64: fp64 auxiliary (Riccati/sensitivity) pass
+        self.mapping = "auto"            # "auto" | "lockstep" | "wide": mapping of the OC solve onto the machine
 
     # ---- model definition (CPDP.py:15-87) ------------------------------------------------------
     def setAuxvarVariable(self, auxvar=None):
@@ -120,7 +121,7 @@ class COCSys:
         if aux_dtype is not None:
             self.aux_dtype = aux_dtype
 
-    def setSolverOptions(self, max_iter=None, tol=None, aux_substeps=None, exact_after=None, aux_rtol=None):
+    def setSolverOptions(self, max_iter=None, tol=None, aux_substeps=None, exact_after=None, aux_rtol=None, mapping=None):
         if max_iter is not None:
             self.max_iter = int(max_iter)
         if tol is not None:
@@ -131,6 +132,10 @@ class COCSys:
             self.exact_after = int(exact_after)
         if aux_rtol is not None:
             self.aux_rtol = float(aux_rtol)
+        if mapping is not None:
+            if mapping not in runtime.MAPPINGS:
+                raise LfsdError("mapping must be one of %s" % sorted(runtime.MAPPINGS))
+            self.mapping = mapping
 
     def use_library(self, path_or_lib):
         """Bind an already built model library (tests use this to inject the SIMT-emulator build)."""
@@ -244,7 +249,7 @@ class COCSys:
         clb, cub = self._control_bounds()
         sol = lib.coc_solve(x0, hz, th, consts, self.n_grid, self.steps_per_grid, u_init=u_init,
                             max_iter=self.max_iter, tol=self.tol, workspace=workspace, out=out,
-                            exact_after=self.exact_after, control_lb=clb, control_ub=cub)
+                            exact_after=self.exact_after, control_lb=clb, control_ub=cub, mapping=self.mapping)
         sol.update(horizon=hz, auxvar=th, consts=consts, ini_state=x0, n_grid=self.n_grid)
         return sol
 

@@ -41,12 +41,18 @@ static long long padded_batch(int batch) { return ((long long)(batch + OC_GPB - 
 // machine from ~4096 trajectories up; below ~1500 most of the 1024 SIMDs would have no wavefront, and where an iteration is
 // expensive -- exact stage Hessians: robot arm, rocket -- the WIDE kernel (one trajectory per wavefront, intervals in
 // parallel: oc_solve_wide_kernel) is 3.5-6x faster (robot arm 1024 seeds 108 -> 18.6 ms, rocket n_grid 100 763 -> 215 ms).
-// The fp32 models with the packed / MFMA lean kernel that converge in a handful of cheap iterations (quadrotor: 5) stay
-// on the lock-step mapping, which is faster for them at every batch size (profiles/r02_d_wide_vs_lockstep.txt).
-// LFSD_OC_WIDE=0/1 in the environment overrides.
-template <typename T> static bool use_wide(int batch, int exact_after) {
+// Models that converge in a handful of cheap iterations (quadrotor: 5, pendulum, cart-pole) are faster on the lock-step
+// mapping from a few thousand trajectories up, the fp32 packed / MFMA lean kernel at every batch size; models that spend
+// most iterations on exact stage Hessians are faster on the wide mapping at every batch size measured (robot arm 4096:
+// 113 -> 41 ms, 8192: 202 -> 75 ms; rocket 4096: 1315 -> 525 ms; profiles/r02_d_wide_vs_lockstep.txt).  The caller can say
+// so (`mapping`: LFSD_MAP_AUTO / _LOCKSTEP / _WIDE; lfsd_amd.models does for the robot arm); LFSD_OC_WIDE=0/1 in the
+// environment overrides everything.
+template <typename T> static bool use_wide(int batch, int exact_after, int mapping) {
   if (const char* ev = getenv("LFSD_OC_WIDE")) return atoi(ev) != 0;
-  const bool lean_mfma = OC_PK && sizeof(T) == 4 && exact_after != 0;
+  if (mapping == LFSD_MAP_LOCKSTEP) return false;
+  if (mapping == LFSD_MAP_WIDE) return true;
+  if (exact_after == 0) return true;      // Newton from the first iteration (rocket): wide wins at every batch size measured
+  const bool lean_mfma = OC_PK && sizeof(T) == 4;
   return batch <= LFSD_WIDE_MAX_BATCH && !lean_mfma;
 }
 // (the workspace query does not know exact_after: it returns the larger of the two layouts where wide is possible)
@@ -69,7 +75,7 @@ static int coc_solve_t(int batch, int n_grid, int steps_per_grid, const void* in
                        const void* auxvar, const void* consts, int const_per_traj, const void* u_init,
                        const void* control_lb, const void* control_ub,
                        void* state_grid, void* control_grid, void* costate_grid, void* cost, int* iters, int* status,
-                       int max_iter, double tol, int exact_after, void* workspace, size_t workspace_bytes,
+                       int max_iter, double tol, int exact_after, int mapping, void* workspace, size_t workspace_bytes,
                        void* stream) {
   lfsd::OcArgs<T> a;
   a.batch = batch; a.n_grid = n_grid; a.steps_per_grid = steps_per_grid; a.max_iter = max_iter;
@@ -83,7 +89,7 @@ static int coc_solve_t(int batch, int n_grid, int steps_per_grid, const void* in
   a.ws = (T*)workspace; a.ws_stride = lfsd::OcLayout<Model>::template ws_elems<G>(n_grid);
   a.tol = (T)tol;
   a.exact_after = exact_after;
-  if (control_lb || use_wide<T>(batch, exact_after)) {       // bounded problems: the wide kernel at every batch size
+  if (control_lb || use_wide<T>(batch, exact_after, mapping)) {       // bounded problems: the wide kernel at every batch size
     a.ws_stride = lfsd::OcLayout<Model>::ws_elems_wide(n_grid);
     if (workspace_bytes < (size_t)batch * (size_t)a.ws_stride * sizeof(T)) return LFSD_ENOSPC;
     a.it_start = 0; a.resume = 0; a.max_iter_total = max_iter;
@@ -122,9 +128,10 @@ LFSD_API int lfsd_coc_solve(int dtype, int batch, int n_grid, int steps_per_grid
                               const void* horizon, const void* auxvar, const void* consts, int const_per_traj,
                               const void* u_init, const void* control_lb, const void* control_ub, void* state_grid,
                               void* control_grid, void* costate_grid, void* cost,
-                              int* iters, int* status, int max_iter, double tol, int exact_after,
+                              int* iters, int* status, int max_iter, double tol, int exact_after, int mapping,
                               void* workspace, size_t workspace_bytes, void* stream) {
   if (batch <= 0 || n_grid <= 0 || steps_per_grid <= 0 || max_iter < 0 || !(tol >= 0)) return LFSD_EINVAL;
+  if (mapping < LFSD_MAP_AUTO || mapping > LFSD_MAP_WIDE) return LFSD_EINVAL;
   if (steps_per_grid > lfsd::OcLayout<Model>::SMAX) return LFSD_EINVAL;
   if (!ini_state || !horizon || !auxvar || !state_grid || !control_grid || !costate_grid || !cost || !iters ||
       !status || !workspace)
@@ -134,11 +141,11 @@ LFSD_API int lfsd_coc_solve(int dtype, int batch, int n_grid, int steps_per_grid
   if (dtype == LFSD_F32)
     return coc_solve_t<float>(batch, n_grid, steps_per_grid, ini_state, horizon, auxvar, consts, const_per_traj, u_init,
                               control_lb, control_ub, state_grid, control_grid, costate_grid, cost, iters, status, max_iter, tol, exact_after,
-                              workspace, workspace_bytes, stream);
+                              mapping, workspace, workspace_bytes, stream);
   if (dtype == LFSD_F64)
     return coc_solve_t<double>(batch, n_grid, steps_per_grid, ini_state, horizon, auxvar, consts, const_per_traj,
                                u_init, control_lb, control_ub, state_grid, control_grid, costate_grid, cost, iters, status, max_iter, tol,
-                               exact_after, workspace, workspace_bytes, stream);
+                               exact_after, mapping, workspace, workspace_bytes, stream);
   return LFSD_EINVAL;
 }
 

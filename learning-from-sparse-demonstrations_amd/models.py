@@ -66,6 +66,9 @@ def robotarm(n_grid=30):
     env.initDyn(l1=1, m1=1, l2=1, m2=1, g=0)
     env.initCost_Polynomial(wu=.5)
     oc = _warp(env, CPDP.COCSys(), "robotarm_poly_tw", n_grid)
+    # most of this problem's iterations run on exact stage Hessians: the wide mapping (one trajectory per wavefront) is
+    # 2.7-6x faster than the lock-step kernels at every batch size measured (profiles/r02_d_wide_vs_lockstep.txt)
+    oc.setSolverOptions(mapping="wide")
     return oc, env, dict(ini_state=[-math.pi / 2, 0, 0, 0], horizon=1.0, theta0=[5., 1, 1, 1, 1], lr=1e-1,
                          interface=[0, 1], taus=[0.3], waypoints=[[-math.pi / 4, 2 * math.pi / 3]])
 

@@ -20,6 +20,7 @@ INCLUDE_DIR = os.path.join(os.path.dirname(PKG_DIR), "include")
 LFSD_F32, LFSD_F64 = 0, 1
 STATUS = {1: "converged", 2: "stalled", 3: "maxiter", 4: "failed"}
 OPT_METHODS = {"Vanilla": 0, "Nesterov": 1, "Adam": 2, "Nadam": 3, "AMSGrad": 4}
+MAPPINGS = {"auto": 0, "lockstep": 1, "wide": 2}
 
 
 class LfsdError(RuntimeError):
@@ -160,7 +161,7 @@ class ModelLibrary:
         L.lfsd_const_default.restype = cd
         L.lfsd_coc_workspace_bytes.argtypes = [ci, ci, ci]
         L.lfsd_coc_workspace_bytes.restype = ctypes.c_size_t
-        L.lfsd_coc_solve.argtypes = [ci, ci, ci, ci, vp, vp, vp, vp, ci, vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, cd, ci, vp,
+        L.lfsd_coc_solve.argtypes = [ci, ci, ci, ci, vp, vp, vp, vp, ci, vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, cd, ci, ci, vp,
                                      ctypes.c_size_t, vp]
         L.lfsd_aux_solve.argtypes = [ci, ci, ci, vp, vp, vp, ci, vp, vp, vp, vp, ci, ci, vp, vp, vp, vp, vp, vp, vp,
                                      ci, cd, vp]
@@ -171,7 +172,7 @@ class ModelLibrary:
         L.lfsd_lookahead.argtypes = [ci, ctypes.c_longlong, cd, vp, vp, vp, vp]
         info = _ModelInfo()
         rc = L.lfsd_get_model_info(ctypes.byref(info))
-        if rc != 0 or info.abi_version != 4:
+        if rc != 0 or info.abi_version != 5:
             raise LfsdError("ABI mismatch in %s" % path)
         self.n_state, self.n_control, self.n_auxvar, self.n_const = (info.n_state, info.n_control, info.n_auxvar,
                                                                       info.n_const)
@@ -227,7 +228,7 @@ class ModelLibrary:
         return int(self.lib.lfsd_coc_workspace_bytes(_DT[dtype], batch, n_grid))
 
     def coc_solve(self, ini_state, horizon, auxvar, consts, n_grid, steps_per_grid=4, u_init=None, max_iter=100,
-                  tol=None, workspace=None, out=None, exact_after=16, control_lb=None, control_ub=None):
+                  tol=None, workspace=None, out=None, exact_after=16, control_lb=None, control_ub=None, mapping="auto"):
         dt = ini_state.dtype
         B = ini_state.shape[0]
         n, m, p, nc = self.n_state, self.n_control, self.n_auxvar, self.n_const
@@ -267,7 +268,7 @@ class ModelLibrary:
                 self._p(consts), per_traj, self._p(u_init), self._p(control_lb), self._p(control_ub),
                 self._p(out["state_grid"]), self._p(out["control_grid"]),
                 self._p(out["costate_grid"]), self._p(out["cost"]), self._p(out["iters"]), self._p(out["status"]),
-                int(max_iter), float(tol), int(exact_after), self._p(workspace),
+                int(max_iter), float(tol), int(exact_after), MAPPINGS[mapping], self._p(workspace),
                 workspace.numel() * workspace.element_size(), self._stream(ini_state))
         with self._on(ini_state):
             self._rc(self.lib.lfsd_coc_solve(*args), "lfsd_coc_solve")

@@ -23,7 +23,7 @@ int main() {
     size_t wsb = lfsd_coc_workspace_bytes(dtype, B, N);
     std::vector<char> ws(wsb);
     int rc = lfsd_coc_solve(dtype, B, N, 4, x0.data(), hz.data(), th.data(), nc ? cs.data() : nullptr, 0, nullptr, nullptr, nullptr, X.data(), U.data(), L.data(),
-                            cost.data(), it.data(), st.data(), 40, dtype ? 1e-9 : 1e-6, 3, ws.data(), wsb, nullptr);
+                            cost.data(), it.data(), st.data(), 40, dtype ? 1e-9 : 1e-6, 3, LFSD_MAP_AUTO, ws.data(), wsb, nullptr);
     printf("dtype %d coc rc %d status %d iters %d\n", dtype, rc, st[0], it[0]);
     rc = lfsd_aux_solve(dtype, B, N, hz.data(), th.data(), nc ? cs.data() : nullptr, 0, X.data(), U.data(), L.data(), Z.data(), nw, ni, iface.data(),
                         taus.data(), wps.data(), loss.data(), grad.data(), aX.data(), aU.data(), (pass & 2) ? 1 : 4, (pass & 2) ? 1e-3 : 0.0, nullptr);
