@@ -1,0 +1,748 @@
+// Auxiliary control system: Riccati and forward-sensitivity sweeps + waypoint loss (COCSys.auxSysSolver, CPDP.py:316-381).
+// Part of the kernel sources collected by cpdp_kernels.h (include that header, not this one).
+#pragma once
+#include "cpdp_common.h"
+
+namespace lfsd {
+
+// =====================================================================================
+//  Auxiliary control system (differentiated maximum principle)
+// =====================================================================================
+template <typename T> struct AuxArgs {
+  int batch, n_grid, substeps;    // substeps = minimum coarse split-steps per grid interval (fine = 2x, Richardson)
+  T rate_max;                     // refine an interval until  dt * |Huu^-1 fu^T P fu|_inf <= rate_max
+  int max_refine;                 // cap on that refinement (factor over `substeps`)
+  T rtol;                         // > 0: error-controlled sub-stepping -- an interval is redone with twice the units while the
+                                  // Richardson estimate |fine - coarse| / 3 of a column exceeds rtol * (its magnitude + floor)
+  const T* horizon;               // [B]
+  const T* auxvar;                // [B][NP]
+  const T* consts; int const_stride;
+  const T* state_grid;            // [B][N+1][NX]
+  const T* control_grid;          // [B][N+1][NU]
+  const T* costate_grid;          // [B][N+1][NX]
+  T* Z_grid;                      // [B][N+1][NX+NP][NX]   column-major Z = [P W]
+  // forward sweep / loss
+  int n_waypoints, n_iface;
+  const int* iface_idx;           // [n_iface] state components the interface exposes
+  const T* taus;                  // [B][n_waypoints]
+  const T* waypoints;             // [B][n_waypoints][n_iface]
+  T* loss;                        // [B]
+  T* grad;                        // [B][NP]
+  T* auxX_grid;                   // [B][N+1][NP][NX] or nullptr  (dx/dtheta, column-major)
+  T* auxU_grid;                   // [B][N+1][NP][NU] or nullptr
+};
+
+template <class M> struct AuxLayout {
+  static constexpr int NX = M::NX, NU = M::NU, NP = M::NP, NZ = NX + NP, NNODE = 5;
+  static constexpr int LDS_L = 0;
+  static constexpr int LDS_S = LDS_L + NNODE * M::NCOEF;
+  static constexpr int LDS_T = LDS_S + NX * NU;
+  // LDS_T (transposed exchange of the Riccati right-hand side) and LDS_KN/LDS_PSI (forward sweep) share one region:
+  // each kernel uses only its own
+  static constexpr int LDS_KN = LDS_T;                        // 3 stiff nodes x (NX x NU) feedback rows K^T
+  static constexpr int LDS_PSI = LDS_KN + 3 * NX * NU;        // 3 stiff nodes x {phi1(h/4 K fu), phi1(h/2 K fu)}
+  static constexpr int LDS_TSZ0 = (NX * NZ > 3 * NX * NU + 6 * NU * NU ? NX * NZ : 3 * NX * NU + 6 * NU * NU);
+  static constexpr int LDS_TSZ = LDS_TSZ0 > 128 ? LDS_TSZ0 : 128;      // (>= 2 x 64: the error reduction of the step control)
+  static constexpr int LDS_E = LDS_T + LDS_TSZ;
+                                                              // cold per-trajectory state: auxvar, consts,
+  static constexpr int LDS_C = LDS_E + NP;                    // and the (x,u,lambda) grid values at both interval ends
+  static constexpr int LDS_GA = LDS_C + M::NC;                // [x_k u_k l_k]
+  static constexpr int LDS_GB = LDS_GA + 2 * NX + NU;         // [x_k+1 u_k+1 l_k+1]
+  static constexpr int LDS_END = LDS_GB + 2 * NX + NU;
+  static constexpr int lds_elems() { return ((LDS_END + 3) / 4) * 4; }
+  // forward kernel only: parking slot for X(t_k) (row i of column j at [i*NP + j])
+  // ... plus, per node and column, the X-independent part of the right-hand side (fe - fu Huu^-1 (fu^T W + Hue)) e_j
+  // ... plus the P columns at both ends of the interval ([end][column][row], and one zero row that lanes without a P
+  // column point at): they are needed three times per unit only, too cold for 2*NX registers per lane
+  static constexpr int FWD_P = NX * NP + NNODE * NX * NP;                 // offset of that block behind LDS_END
+  template <int G> static constexpr int lds_elems_fwd() { return ((LDS_END + FWD_P + 2 * NX * NX + NX + 3) / 4) * 4; }
+  // Riccati kernel only: per node and lane, this lane's column of [Hxx Hxe] and of Huu^-1 [Hux Hue]
+  static constexpr int RIC_ROWS = LFSD_RIC_CACHE == 1 ? NX + NU : (LFSD_RIC_CACHE == 2 ? NU : 0);
+  // ... plus one parking slot per lane for a column of Z (row i of lane l at [i*G + l]): of the unit's start value and
+  // the coarse Richardson result only one has to be in registers at a time
+  template <int G> static constexpr int ric_park() { return LDS_END + NNODE * RIC_ROWS * G; }
+  template <int G> static constexpr int lds_elems_ric() { return ((ric_park<G>() + NX * G + 3) / 4) * 4; }
+};
+
+// Lanes per trajectory of the forward sweep.  Only the NP columns of X = dx/dtheta advance there; the NX columns of P are
+// merely interpolated.  One lane carries P column `lane` (lane < NX) AND X / W column `lane` (lane < NP), so
+// max(NX, NP) lanes are enough (quadrotor: 16 instead of the 32 the Riccati sweep needs for its NX+NP columns).
+template <class M> constexpr int fwd_lanes() {
+  int need = M::NX > M::NP ? M::NX : M::NP;
+  if (need < AuxLayout<M>::NNODE) need = AuxLayout<M>::NNODE;
+  int g = 8;
+  while (g < need) g *= 2;
+  return g;
+}
+
+// LAY: packing order of the staged coefficients (0: Riccati sweep, transposed operators contiguous; 1: forward sweep)
+template <class M, typename T, int G, int LAY> struct AuxCtx {
+  static constexpr int NX = M::NX, NU = M::NU, NP = M::NP, NC = M::NC, NZ = NX + NP;
+  using Lay = AuxLayout<M>;
+  int lane;
+  int xcol;                  // forward sweep: column of X = dx/dtheta (and of W) this lane carries (lanes < NP), else 0
+  bool xlane;
+  const T *e, *c;            // [NP], [NC] in LDS
+  const T *xa_, *ua_, *la_, *xb_, *ub_, *lb_;   // grid values at both ends of the interval, in LDS
+  T t_a, dgrid;
+  T* lds;
+  T ox[NX], oe[NP];    // one-hot selectors of this lane's column
+
+  LFSD_DEV void load_interval(const AuxArgs<T>& a, long long traj, int k, int N) {
+    const T* xs = a.state_grid + (traj * (N + 1) + k) * NX;
+    const T* us = a.control_grid + (traj * (N + 1) + k) * NU;
+    const T* ls = a.costate_grid + (traj * (N + 1) + k) * NX;
+    T* ga = lds + Lay::LDS_GA;
+    T* gb = lds + Lay::LDS_GB;
+    __syncthreads();                         // previous interval's readers are done
+    for (int i = lane; i < NX; i += G) { ga[i] = xs[i]; gb[i] = xs[NX + i]; ga[NX + NU + i] = ls[i]; gb[NX + NU + i] = ls[NX + i]; }
+    for (int i = lane; i < NU; i += G) { ga[NX + i] = us[i]; gb[NX + i] = us[NU + i]; }
+    xa_ = ga; ua_ = ga + NX; la_ = ga + NX + NU; xb_ = gb; ub_ = gb + NX; lb_ = gb + NX + NU;
+    t_a = M::TIME_VARYING ? dgrid * T(k) : T(0);
+    __syncthreads();
+  }
+  // Lane `node` (< 5) evaluates the packed PMP coefficients at its own time node s (fraction of the
+  // interval) on the reference's linear interpolant of (x,u,lambda) (CPDP.py:320-323) and stages them in LDS.
+  LFSD_DEV void stage_nodes(T s_first, T s_step) {
+    if (lane < Lay::NNODE) {
+      const T s = s_first + s_step * T(lane);
+      T x[NX], u[NU], l[NX];
+#pragma unroll
+      for (int i = 0; i < NX; ++i) { x[i] = xa_[i] + s * (xb_[i] - xa_[i]); l[i] = la_[i] + s * (lb_[i] - la_[i]); }
+#pragma unroll
+      for (int i = 0; i < NU; ++i) u[i] = ua_[i] + s * (ub_[i] - ua_[i]);
+      T* L = lds + Lay::LDS_L + lane * M::NCOEF;
+      M::template pmp_coeffs<LAY>(t_a + s * dgrid, x, u, l, e, c, L);
+      T Huu[NU * NU], iH[NU * NU];
+#pragma unroll
+      for (int i = 0; i < NU * NU; ++i) Huu[i] = L[M::OFF_HUU + i];
+      mat_inverse<NU>(Huu, iH);       // casadi.pinv(ddHuu) of a nonsingular Huu (CPDP.py:262)
+#pragma unroll
+      for (int i = 0; i < NU * NU; ++i) L[M::OFF_IHUU + i] = iH[i];
+    }
+    __syncthreads();
+  }
+  LFSD_DEV const T* node(int i) const { return lds + Lay::LDS_L + i * M::NCOEF; }
+
+  // |Huu^-1 fu^T P fu|_inf : rate of the stiff closed-loop modes at one node (P = first NX lanes' columns)
+  LFSD_DEV T stiff_rate(const T* zt, const T* L) {
+    T* ldsS = lds + Lay::LDS_S;
+    const T* iH = L + M::OFF_IHUU;
+    T s[NU], kj[NU];
+    M::template fu_mulT<false, LAY>(L, zt, s);
+    matvec<NU>(iH, s, kj);
+    if (lane < NX) {
+#pragma unroll
+      for (int a = 0; a < NU; ++a) ldsS[lane * NU + a] = kj[a];
+    }
+    __syncthreads();
+    T Mx[NU * NU];
+    M::template fu_gram<false, LAY>(L, ldsS, Mx);
+    T nrm = T(0);
+#pragma unroll
+    for (int a = 0; a < NU; ++a) {
+      T r = T(0);
+#pragma unroll
+      for (int b = 0; b < NU; ++b) r += t_abs(Mx[a * NU + b]);
+      nrm = t_max(nrm, r);
+    }
+    __syncthreads();
+    return nrm;
+  }
+  LFSD_DEV int units_for(T rate, int Sa, T rate_max, int max_refine) const {
+    T want = rate * dgrid / rate_max;
+    if (!t_finite(want)) want = T(Sa);
+    int u = Sa;
+    const long long cap = (long long)Sa * max_refine;
+    while ((T)u < want && (long long)u * 2 <= cap) u *= 2;
+    return u;
+  }
+  // ---- Riccati (backward in time; tau = -t) -------------------------------------------------
+  // stiff sub-flow  dZ/dtau = -P R Z,  R = fu Huu^-1 fu^T :   Z <- Z - P fu (Huu/dt + fu^T P fu)^-1 fu^T Z
+  LFSD_DEV void ric_stiff(T* z, const T* L, T dt) {
+    T* ldsS = lds + Lay::LDS_S;
+    T s[NU];
+    M::template fu_mulT<false, LAY>(L, z, s);
+    if (lane < NX) {
+#pragma unroll
+      for (int a = 0; a < NU; ++a) ldsS[lane * NU + a] = s[a];
+    }
+    __syncthreads();
+    T Gm[NU * NU];
+    const T idt = T(1) / dt;
+#pragma unroll
+    for (int i = 0; i < NU * NU; ++i) Gm[i] = L[M::OFF_HUU + i] * idt;
+    M::template fu_gram<true, LAY>(L, ldsS, Gm);
+    lu_factor<NU>(Gm);
+    lu_solve<NU>(Gm, s);
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+      T d = T(0);
+#pragma unroll
+      for (int a = 0; a < NU; ++a) d += ldsS[i * NU + a] * s[a];
+      z[i] -= d;
+    }
+    __syncthreads();
+  }
+  // The columns of [Hxx Hxe] and Huu^-1 [Hux Hue] this lane needs do not depend on Z: once per staged node
+  // instead of once per right-hand-side evaluation (12 per unit).  Parked per lane at [(node*(NX+NU)+r)*G + lane].
+  LFSD_DEV void ric_cols() {
+    if (Lay::RIC_ROWS == 0) return;
+    constexpr int R = Lay::RIC_ROWS, HX = LFSD_RIC_CACHE == 1 ? NX : 0;
+    T* hc = lds + Lay::LDS_END;
+    LFSD_RIC_NODE_LOOP
+    for (int nd = 0; nd < Lay::NNODE; ++nd) {
+      const T* L = node(nd);
+      T hu[NU], wq[NU];
+      if (LFSD_RIC_CACHE == 1) {
+        T hx[NX];
+        M::template Hxx_mul<false, LAY>(L, ox, hx);
+        M::template Hxe_mul<true, LAY>(L, oe, hx);
+#pragma unroll
+        for (int i = 0; i < NX; ++i) hc[(nd * R + i) * G + lane] = hx[i];
+      }
+      M::template Hxu_mulT<false, LAY>(L, ox, hu);
+      M::template Hue_mul<true, LAY>(L, oe, hu);
+      matvec<NU>(L + M::OFF_IHUU, hu, wq);
+#pragma unroll
+      for (int a = 0; a < NU; ++a) hc[(nd * R + HX + a) * G + lane] = wq[a];
+    }
+  }
+  // non-stiff part  dZ/dtau = [Qt qt] + A^T Z + P [A rt]   (A, Qt, rt, qt of CPDP.py:265-269)
+  LFSD_DEV void ric_rhs(const T* z, int nd, T* y) {
+    constexpr int R = Lay::RIC_ROWS, HX = LFSD_RIC_CACHE == 1 ? NX : 0;
+    T* ldsT = lds + Lay::LDS_T;
+    const T* L = node(nd);
+    const T* hc = lds + Lay::LDS_END + nd * R * G;
+    const T* iH = L + M::OFF_IHUU;
+    T s[NU], v[NU], w[NU], nv[NU], r[NP], wq[NU];
+    if (R == 0) {
+      T hu[NU];
+      M::template Hxu_mulT<false, LAY>(L, ox, hu);
+      M::template Hue_mul<true, LAY>(L, oe, hu);
+      matvec<NU>(iH, hu, wq);
+    } else {
+#pragma unroll
+      for (int a = 0; a < NU; ++a) wq[a] = hc[(HX + a) * G + lane];
+    }
+    M::template fu_mulT<false, LAY>(L, z, s);
+    matvec<NU>(iH, s, v);
+#pragma unroll
+    for (int a = 0; a < NU; ++a) { nv[a] = -v[a]; w[a] = -(wq[a] + v[a]); }
+    M::template fx_mulT<false, LAY>(L, z, y);
+    if (lane < NX) {
+      T tv[NX];
+#pragma unroll
+      for (int i = 0; i < NX; ++i) tv[i] = y[i];
+      M::template Hxu_mul<true, LAY>(L, nv, tv);
+      M::template fe_mulT<false, LAY>(L, z, r);
+      M::template Hue_mulT<true, LAY>(L, nv, r);
+#pragma unroll
+      for (int i = 0; i < NX; ++i) ldsT[lane * NZ + i] = tv[i];
+#pragma unroll
+      for (int i = 0; i < NP; ++i) ldsT[lane * NZ + NX + i] = r[i];
+    }
+    if (LFSD_RIC_CACHE == 1) {
+#pragma unroll
+      for (int i = 0; i < NX; ++i) y[i] += hc[i * G + lane];
+    } else {
+      M::template Hxx_mul<true, LAY>(L, ox, y);
+      M::template Hxe_mul<true, LAY>(L, oe, y);
+    }
+    M::template Hxu_mul<true, LAY>(L, w, y);
+    __syncthreads();
+    if (lane < NZ) {
+#pragma unroll
+      for (int i = 0; i < NX; ++i) y[i] += ldsT[i * NZ + lane];
+    }
+    __syncthreads();
+  }
+  // non-stiff RK4 step of length h over nodes (n0, n1, n2)
+  LFSD_DEV void ric_rk4(T* z, int n0, int n1, int n2, T h) {
+    T k[NX], acc[NX], zs[NX];
+    ric_rhs(z, n0, k);
+#pragma unroll
+    for (int i = 0; i < NX; ++i) { acc[i] = k[i]; zs[i] = z[i] + T(0.5) * h * k[i]; }
+    ric_rhs(zs, n1, k);
+#pragma unroll
+    for (int i = 0; i < NX; ++i) { acc[i] += T(2) * k[i]; zs[i] = z[i] + T(0.5) * h * k[i]; }
+    ric_rhs(zs, n1, k);
+#pragma unroll
+    for (int i = 0; i < NX; ++i) { acc[i] += T(2) * k[i]; zs[i] = z[i] + h * k[i]; }
+    ric_rhs(zs, n2, k);
+#pragma unroll
+    for (int i = 0; i < NX; ++i) z[i] += h / T(6) * (acc[i] + k[i]);
+  }
+  // Strang step: stiff h/2, non-stiff h, stiff h/2
+  LFSD_DEV void ric_strang(T* z, int n0, int n1, int n2, T h) {
+    ric_stiff(z, node(n0), h * T(0.5));
+    ric_rk4(z, n0, n1, n2, h);
+    ric_stiff(z, node(n2), h * T(0.5));
+  }
+  // two Strang steps of length h/2 over nodes (0,1,2) and (2,3,4): the two adjacent stiff quarter-steps at the middle
+  // node are the exact flow of the same frozen system, so they compose exactly into one half-step
+  LFSD_DEV void ric_strang2(T* z, T h) {
+    ric_stiff(z, node(0), h * T(0.25));
+    ric_rk4(z, 0, 1, 2, h * T(0.5));
+    ric_stiff(z, node(2), h * T(0.5));
+    ric_rk4(z, 2, 3, 4, h * T(0.5));
+    ric_stiff(z, node(4), h * T(0.25));
+  }
+
+  // ---- forward auxiliary state -----------------------------------------------------------------
+  // lanes < NX carry P columns (interpolated); lanes < NP also carry one X = dx/dtheta column and its W column.
+  // stiff sub-flow  X' = -fu K X,  K = Huu^-1 fu^T P (frozen over the sub-step), solved exactly:
+  //   X(dt) = X - dt fu phi1(dt K fu) K X,   phi1(M) = M^-1 (I - e^-M)   (m x m matrix function).
+  // (An A-stable rational step is not enough here: with a cheap control cost dt*|K fu| reaches O(10^2).)
+  // fwd_prep: for the three stiff nodes (0, 2, 4) of a unit the P lanes gather K(t_node); then lanes 0..2
+  // each evaluate phi1 for ONE node (quarter and half step), so the matrix function costs one evaluation per unit.
+  LFSD_DEV void fwd_prep(const T* zA, const T* zB, T s0, T ds, T hq) {
+    T* ldsK = lds + Lay::LDS_KN;
+    T* ldsP = lds + Lay::LDS_PSI;
+    LFSD_FWD_NODE_LOOP
+    for (int r = 0; r < 3; ++r) {
+      const T* L = node(2 * r);
+      const T sr = s0 + T(2 * r) * ds;
+      T zt[NX], sv[NU], kj[NU];
+#pragma unroll
+      for (int i = 0; i < NX; ++i) zt[i] = zA[i] + sr * (zB[i] - zA[i]);
+      M::template fu_mulT<false, LAY>(L, zt, sv);
+      matvec<NU>(L + M::OFF_IHUU, sv, kj);
+      if (lane < NX) {
+#pragma unroll
+        for (int a = 0; a < NU; ++a) ldsK[(r * NX + lane) * NU + a] = kj[a];
+      }
+    }
+    __syncthreads();
+    if (lane < 3) {
+      T Mx[NU * NU], Pq[NU * NU], Ph[NU * NU];
+      M::template fu_gram<false, LAY>(node(2 * lane), ldsK + lane * NX * NU, Mx);       // K fu
+#pragma unroll
+      for (int i = 0; i < NU * NU; ++i) Mx[i] *= hq;
+      phi1_neg<NU>(Mx, Pq, Ph);
+#pragma unroll
+      for (int i = 0; i < NU * NU; ++i) { ldsP[lane * 2 * NU * NU + i] = Pq[i]; ldsP[(lane * 2 + 1) * NU * NU + i] = Ph[i]; }
+    }
+    __syncthreads();
+  }
+  // apply the prepared exact stiff step of node r (0..2); half = false: dt = hq, true: dt = 2 hq
+  LFSD_DEV void fwd_stiff(T* xa, int r, bool half, T hq) {
+    const T* Kn = lds + Lay::LDS_KN + r * NX * NU;
+    const T* Psi = lds + Lay::LDS_PSI + (r * 2 + (half ? 1 : 0)) * NU * NU;
+    T kx[NU], y[NU];
+#pragma unroll
+    for (int a = 0; a < NU; ++a) kx[a] = T(0);
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+#pragma unroll
+      for (int a = 0; a < NU; ++a) kx[a] += Kn[i * NU + a] * xa[i];
+    }
+    matvec<NU>(Psi, kx, y);
+    const T dt = half ? T(2) * hq : hq;
+#pragma unroll
+    for (int a = 0; a < NU; ++a) y[a] *= -dt;
+    M::template fu_mul<true, LAY>(node(2 * r), y, xa);
+  }
+  // non-stiff part  X' = fx X + fe - fu Huu^-1 (Hux X + Hue + fu^T W).  Its X-independent part
+  //   b_j(t) = (fe - fu Huu^-1 (fu^T W(t) + Hue)) e_j
+  // is evaluated once per staged node (fwd_cols) and parked per lane; the 12 right-hand sides of a unit then cost
+  //   y = fx x - fu Huu^-1 Hux x + b_j.
+  LFSD_DEV void fwd_cols(const T* zA, const T* zB, T s0, T ds) {
+    T* bc = lds + Lay::LDS_END + NX * NP;
+    LFSD_FWD_NODE_LOOP
+    for (int nd = 0; nd < Lay::NNODE; ++nd) {
+      const T* L = node(nd);
+      const T sr = s0 + T(nd) * ds;
+      T wt[NX], sv[NU], v[NU], b[NX];
+#pragma unroll
+      for (int i = 0; i < NX; ++i) wt[i] = zA[i] + sr * (zB[i] - zA[i]);
+      M::template fu_mulT<false, LAY>(L, wt, sv);
+      M::template Hue_mul<true, LAY>(L, oe, sv);
+      matvec<NU>(L + M::OFF_IHUU, sv, v);
+#pragma unroll
+      for (int a = 0; a < NU; ++a) v[a] = -v[a];
+      M::template fe_mul<false, LAY>(L, oe, b);
+      M::template fu_mul<true, LAY>(L, v, b);
+      if (xlane) {
+#pragma unroll
+        for (int i = 0; i < NX; ++i) bc[(nd * NX + i) * NP + xcol] = b[i];
+      }
+    }
+  }
+  LFSD_DEV void fwd_rhs(const T* xa, int nd, T* y) {
+    const T* L = node(nd);
+    const T* bc = lds + Lay::LDS_END + NX * NP + nd * NX * NP;     // lanes without an X column read column 0; their result is dropped
+    T s[NU], v[NU];
+    M::template Hxu_mulT<false, LAY>(L, xa, s);
+    matvec<NU>(L + M::OFF_IHUU, s, v);
+#pragma unroll
+    for (int a = 0; a < NU; ++a) v[a] = -v[a];
+    M::template fx_mul<false, LAY>(L, xa, y);
+    M::template fu_mul<true, LAY>(L, v, y);
+#pragma unroll
+    for (int i = 0; i < NX; ++i) y[i] += bc[i * NP + xcol];
+  }
+  // non-stiff RK4 step of length h over nodes (n0, n1, n2)
+  LFSD_DEV void fwd_rk4(T* xa, int n0, int n1, int n2, T h) {
+    T k[NX], acc[NX], xs[NX];
+    fwd_rhs(xa, n0, k);
+#pragma unroll
+    for (int i = 0; i < NX; ++i) { acc[i] = k[i]; xs[i] = xa[i] + T(0.5) * h * k[i]; }
+    fwd_rhs(xs, n1, k);
+#pragma unroll
+    for (int i = 0; i < NX; ++i) { acc[i] += T(2) * k[i]; xs[i] = xa[i] + T(0.5) * h * k[i]; }
+    fwd_rhs(xs, n1, k);
+#pragma unroll
+    for (int i = 0; i < NX; ++i) { acc[i] += T(2) * k[i]; xs[i] = xa[i] + h * k[i]; }
+    fwd_rhs(xs, n2, k);
+#pragma unroll
+    for (int i = 0; i < NX; ++i) xa[i] += h / T(6) * (acc[i] + k[i]);
+  }
+  // auxiliary control at a grid point (CPDP.py:295):  U = -Huu^-1((Hux + fu^T P) X + fu^T W + Hue)
+  LFSD_DEV void aux_control(const T* xa, const T* pt, const T* wt, const T* L, T* uo) {
+    T* ldsS = lds + Lay::LDS_S;
+    const T* iH = L + M::OFF_IHUU;
+    T s[NU];
+    M::template fu_mulT<false, LAY>(L, pt, s);          // P role: row `lane` of (fu^T P)^T
+    if (lane < NX) {
+#pragma unroll
+      for (int a = 0; a < NU; ++a) ldsS[lane * NU + a] = s[a];
+    }
+    __syncthreads();
+    M::template fu_mulT<false, LAY>(L, wt, s);          // X role: s = fu^T w_j + Hue e_j + Hux x_j + fu^T P x_j
+    M::template Hue_mul<true, LAY>(L, oe, s);
+    M::template Hxu_mulT<true, LAY>(L, xa, s);
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+#pragma unroll
+      for (int a = 0; a < NU; ++a) s[a] += ldsS[i * NU + a] * xa[i];
+    }
+    matvec<NU>(iH, s, uo);
+#pragma unroll
+    for (int a = 0; a < NU; ++a) uo[a] = -uo[a];
+    __syncthreads();
+  }
+};
+
+template <class M, typename T, int G, int LAY> LFSD_DEV void aux_setup(AuxCtx<M, T, G, LAY>& s, const AuxArgs<T>& a, long long traj,
+                                                            T* lds_all, int lds_stride = AuxLayout<M>::lds_elems()) {
+  constexpr int NX = M::NX, NP = M::NP, NC = M::NC;
+  using Lay = AuxLayout<M>;
+  const int gib = threadIdx.x / G;
+  s.lane = threadIdx.x % G;
+  s.xlane = (LAY == 1) && (s.lane < NP);
+  s.xcol = s.xlane ? s.lane : 0;
+  s.lds = lds_all + gib * lds_stride;
+  {
+    T* le = s.lds + Lay::LDS_E;
+    T* lc = s.lds + Lay::LDS_C;
+    for (int i = s.lane; i < NP; i += G) le[i] = a.auxvar[traj * NP + i];
+    for (int i = s.lane; i < NC; i += G) lc[i] = a.consts[traj * a.const_stride + i];
+    s.e = le; s.c = lc;
+  }
+  __syncthreads();
+  s.dgrid = a.horizon[traj] / T(a.n_grid);
+#pragma unroll
+  for (int i = 0; i < NX; ++i) s.ox[i] = (s.lane == i) ? T(1) : T(0);
+#pragma unroll
+  for (int i = 0; i < NP; ++i) s.oe[i] = (LAY == 1 ? (s.xlane && s.lane == i) : (s.lane == NX + i)) ? T(1) : T(0);
+}
+
+// Barriers in the two auxiliary sweeps: the number of split units per interval (`units`) follows each trajectory's own
+// stiffness, so lane groups of one workgroup pass different numbers of __syncthreads().  That is well defined here --
+// and only here -- because a workgroup is exactly ONE wavefront (launched with 64 threads, checked below): s_barrier is
+// a scalar instruction the wavefront executes as a whole whatever its EXEC mask, it has nobody to wait for, and what
+// remains of __syncthreads() is the LDS fence (s_waitcnt lgkmcnt(0)) every group needs for its own private LDS slice.
+// A port to multi-wave workgroups would have to make `units` block-uniform first (as oc_solve_kernel does with its votes).
+template <class M, typename T, int G>
+__global__ void __launch_bounds__(64, (sizeof(T) == 4 ? LFSD_WAVES_RIC : 1)) aux_riccati_kernel(AuxArgs<T> a) {
+  if (blockDim.x != 64) return;                   // one wavefront per workgroup: see the note on barriers above
+  using Ctx = AuxCtx<M, T, G, 0>;
+  using Lay = AuxLayout<M>;
+  constexpr int NX = M::NX, NP = M::NP, NZ = NX + NP;
+  constexpr int GPB = 64 / G;
+  static_assert(64 % G == 0 && G >= NZ && G >= Lay::NNODE, "lane group must hold one column of [P W] per lane");
+  __shared__ T lds_all[GPB * Lay::template lds_elems_ric<G>() + LFSD_AUX_LDS_PAD];
+  poison_lds(lds_all, GPB * Lay::template lds_elems_ric<G>());
+  const long long slot = (long long)blockIdx.x * GPB + threadIdx.x / G;
+  const bool valid = slot < a.batch;
+  const long long traj = valid ? slot : (long long)a.batch - 1;
+  Ctx s;
+  aux_setup<M, T, G, 0>(s, a, traj, lds_all, Lay::template lds_elems_ric<G>());
+  const int N = a.n_grid, Sa = a.substeps;
+  const int lane = s.lane;
+  T* Zt = a.Z_grid + traj * (long long)(N + 1) * NZ * NX;
+  T z[NX];
+  {
+    T xN[NX];
+    const T* xs = a.state_grid + (traj * (N + 1) + N) * NX;
+#pragma unroll
+    for (int i = 0; i < NX; ++i) xN[i] = xs[i];
+    const T tN = M::TIME_VARYING ? s.dgrid * T(N) : T(0);
+    M::final_hess_mul(tN, xN, s.e, s.c, s.ox, s.oe, z);      // [ddhxx ddhxe], CPDP.py:330-331
+    if (lane >= NZ) {
+#pragma unroll
+      for (int i = 0; i < NX; ++i) z[i] = T(0);
+    }
+    if (valid && lane < NZ) {
+#pragma unroll
+      for (int i = 0; i < NX; ++i) Zt[((long long)N * NZ + lane) * NX + i] = z[i];
+    }
+  }
+  T* ldsT = s.lds + Lay::LDS_T;
+  int units_hint = Sa;
+  for (int k = N - 1; k >= 0; --k) {
+    s.load_interval(a, traj, k, N);
+    // stiffness-aware sub-stepping: P is largest at the later end of the interval (terminal transient).  The coefficients
+    // are staged for the first unit of the expected unit count at once: node 0 sits at the interval end either way, and
+    // when the stiffness estimate confirms the count the first unit need not stage again
+    const int units_guess = units_hint;
+    s.stage_nodes(T(1), T(-1) / T(4 * units_guess));
+    int units = s.units_for(s.stiff_rate(z, s.node(0)), Sa, a.rate_max, a.max_refine);
+    // error-driven refinement stops at max_refine x the minimum units -- and as soon as a doubling fails to halve the
+    // estimate: next to a conjugate point (finite escape of the Riccati solution) no step size meets a relative tolerance,
+    // and one such trajectory must not stall the batch
+    const long long units_cap = (long long)Sa * a.max_refine;
+    if (units < units_hint) units = (int)t_min((long long)units_hint, units_cap);
+    T ratio_prev = T(-1);
+    bool staged = (units == units_guess);
+    // Error-controlled sub-stepping (a.rtol > 0): the Richardson pair gives |fine - coarse| / 3 as an estimate of the
+    // second-order error that the extrapolation removes; while it exceeds rtol relative to the column's size the interval
+    // is redone from its stored start value Z(t_k+1) with twice the units.  (solve_ivp's rtol of the reference, CPDP.py:335,
+    // is 1e-3 on the un-extrapolated estimate of its pair; the default here is 1e-4.)
+    for (;;) {
+      const T hc = s.dgrid / T(units);
+      const T ds = T(1) / T(4 * units);
+      T err_l = T(0), scl_l = T(0);
+      for (int unit = 0; unit < units; ++unit) {
+        const T s_hi = T(1) - T(unit) / T(units);
+        if (!(staged && unit == 0)) s.stage_nodes(s_hi, -ds);      // node i sits at fraction s_hi - i/(4 units)
+        staged = false;
+        s.ric_cols();
+        // coarse chain in place, then the fine chain in place from the parked start value (the barriers inside the chains
+        // keep the compiler from carrying the parked column in registers)
+        T* zpark = s.lds + Lay::template ric_park<G>();
+#pragma unroll
+        for (int i = 0; i < NX; ++i) zpark[i * G + lane] = z[i];
+        s.ric_strang(z, 0, 2, 4, hc);
+#pragma unroll
+        for (int i = 0; i < NX; ++i) { const T z0 = zpark[i * G + lane]; zpark[i * G + lane] = z[i]; z[i] = z0; }
+        s.ric_strang2(z, hc);
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+          const T zc = zpark[i * G + lane];
+          err_l = t_max(err_l, t_abs(z[i] - zc));
+          z[i] = (T(4) * z[i] - zc) / T(3);     // Richardson (Strang is O(h^2), symmetric)
+          scl_l = t_max(scl_l, t_abs(z[i]));
+        }
+      }
+      if (!(a.rtol > T(0))) break;
+      // per block of columns (P: lanes < NX, W: the rest) the worst estimate against that block's magnitude
+      ldsT[lane] = err_l; ldsT[G + lane] = scl_l;
+      __syncthreads();
+      T eP = T(0), sP = T(0), eW = T(0), sW = T(0);
+      for (int l = 0; l < NZ; ++l) {
+        if (l < NX) { eP = t_max(eP, ldsT[l]); sP = t_max(sP, ldsT[G + l]); }
+        else { eW = t_max(eW, ldsT[l]); sW = t_max(sW, ldsT[G + l]); }
+      }
+      __syncthreads();
+      const T tolP = T(3) * a.rtol * sP, tolW = T(3) * a.rtol * (sW + T(1e-3) * sP);
+      const bool fine_enough = (eP <= tolP && eW <= tolW) || !(t_finite(eP) && t_finite(eW));
+      const T ratio = t_max(eP / t_max(tolP, T(1e-30)), eW / t_max(tolW, T(1e-30)));
+      const bool no_gain = ratio_prev >= T(0) && ratio > T(0.5) * ratio_prev;
+      ratio_prev = ratio;
+      if (fine_enough || no_gain || !valid || (long long)units * 2 > units_cap) {
+        // next interval: start from this interval's units, or half of them when the estimate had a 32-fold margin
+        units_hint = (eP * T(32) <= tolP && eW * T(32) <= tolW && units > Sa) ? units / 2 : units;
+        break;
+      }
+      units *= 2;
+      if (lane < NZ) {
+#pragma unroll
+        for (int i = 0; i < NX; ++i) z[i] = Zt[((long long)(k + 1) * NZ + lane) * NX + i];
+      }
+    }
+    // keep P symmetric (the closed-form stiff update relies on it) and store the grid value
+    if (lane < NX) {
+#pragma unroll
+      for (int i = 0; i < NX; ++i) ldsT[lane * NZ + i] = z[i];
+    }
+    __syncthreads();
+    if (lane < NX) {
+#pragma unroll
+      for (int i = 0; i < NX; ++i) z[i] = T(0.5) * (z[i] + ldsT[i * NZ + lane]);
+    }
+    __syncthreads();
+    if (valid && lane < NZ) {
+#pragma unroll
+      for (int i = 0; i < NX; ++i) Zt[((long long)k * NZ + lane) * NX + i] = z[i];
+    }
+  }
+}
+
+template <class M, typename T, int G>
+__global__ void __launch_bounds__(64, (sizeof(T) == 4 ? LFSD_WAVES_FWD : 1)) aux_forward_kernel(AuxArgs<T> a) {
+  if (blockDim.x != 64) return;                   // one wavefront per workgroup: see the note above aux_riccati_kernel
+  using Ctx = AuxCtx<M, T, G, 1>;
+  using Lay = AuxLayout<M>;
+  constexpr int NX = M::NX, NU = M::NU, NP = M::NP, NZ = NX + NP;
+  constexpr int GPB = 64 / G;
+  static_assert(64 % G == 0 && G >= NX && G >= NP && G >= Lay::NNODE, "forward lane group: one P column and one X column per lane");
+  __shared__ T lds_all[GPB * Lay::template lds_elems_fwd<G>() + LFSD_AUX_LDS_PAD];
+  poison_lds(lds_all, GPB * Lay::template lds_elems_fwd<G>());
+  const long long slot = (long long)blockIdx.x * GPB + threadIdx.x / G;
+  const bool valid = slot < a.batch;
+  const long long traj = valid ? slot : (long long)a.batch - 1;
+  Ctx s;
+  aux_setup<M, T, G, 1>(s, a, traj, lds_all, Lay::template lds_elems_fwd<G>());
+  const int N = a.n_grid, Sa = a.substeps;
+  const int lane = s.lane;
+  const bool xlane = s.xlane;
+  const T* Zt = a.Z_grid + traj * (long long)(N + 1) * NZ * NX;
+  T xa[NX], wA[NX], wB[NX];     // X column; W column at both ends of the interval (the P columns live in LDS)
+#pragma unroll
+  for (int i = 0; i < NX; ++i) { xa[i] = T(0); wA[i] = T(0); wB[i] = T(0); }     // X(0) = 0, CPDP.py:355
+  T* ldsPA = s.lds + Lay::LDS_END + Lay::FWD_P;
+  T* ldsPB = ldsPA + NX * NX;
+  T* ldsP0 = ldsPB + NX * NX;                                  // zero row
+  for (int i = lane; i < NX; i += G) ldsP0[i] = T(0);
+  const T* pA = (lane < NX) ? ldsPA + lane * NX : ldsP0;
+  const T* pB = (lane < NX) ? ldsPB + lane * NX : ldsP0;
+  T loss = T(0), gacc = T(0);
+  int units_hint = Sa;
+  T* Xo = a.auxX_grid ? a.auxX_grid + traj * (long long)(N + 1) * NP * NX : nullptr;
+  T* Uo = a.auxU_grid ? a.auxU_grid + traj * (long long)(N + 1) * NP * NU : nullptr;
+  if (valid && Xo && xlane) {
+#pragma unroll
+    for (int i = 0; i < NX; ++i) Xo[(long long)s.xcol * NX + i] = T(0);
+  }
+  for (int k = 0; k < N; ++k) {
+    s.load_interval(a, traj, k, N);
+    if (lane < NX) {           // (load_interval's barriers fence the previous interval's readers; stage_nodes' the writers)
+#pragma unroll
+      for (int i = 0; i < NX; ++i) { ldsPA[lane * NX + i] = Zt[((long long)k * NZ + lane) * NX + i]; ldsPB[lane * NX + i] = Zt[((long long)(k + 1) * NZ + lane) * NX + i]; }
+    }
+    if (xlane) {
+#pragma unroll
+      for (int i = 0; i < NX; ++i) { wA[i] = Zt[((long long)k * NZ + NX + lane) * NX + i]; wB[i] = Zt[((long long)(k + 1) * NZ + NX + lane) * NX + i]; }
+    }
+    T* xprev = s.lds + Lay::LDS_END;                 // this lane's X(t_k), parked in LDS until the loss needs it
+    if (xlane) {
+#pragma unroll
+      for (int i = 0; i < NX; ++i) xprev[i * NP + s.xcol] = xa[i];
+    }
+    s.stage_nodes(T(0), T(0.25));          // nodes at 0, 1/4 .. 1 of the interval: the stiffness at both ends -- and exactly
+    const T rate = t_max(s.stiff_rate(pA, s.node(0)), s.stiff_rate(pB, s.node(4)));      // the staging of a single unit
+    int units = s.units_for(rate, Sa, a.rate_max, a.max_refine);
+    const long long units_cap = (long long)Sa * a.max_refine;
+    if (units < units_hint) units = (int)t_min((long long)units_hint, units_cap);
+    T ratio_prev = T(-1);
+    bool staged = (units == 1);
+    for (;;) {                         // error-controlled sub-stepping, as in the Riccati sweep; the start value X(t_k) is `xprev`
+      const T hc = s.dgrid / T(units);
+      const T ds = T(1) / T(4 * units);
+      T err_l = T(0), scl_l = T(0);
+      for (int unit = 0; unit < units; ++unit) {
+        const T s_lo = T(unit) / T(units);
+        if (!(staged && unit == 0)) s.stage_nodes(s_lo, ds);
+        staged = false;
+        if (Uo && unit == 0) {
+          T uo[NU];
+          s.aux_control(xa, pA, wA, s.node(0), uo);
+          if (valid && xlane) {
+#pragma unroll
+            for (int b = 0; b < NU; ++b) Uo[((long long)k * NP + s.xcol) * NU + b] = uo[b];
+          }
+        }
+        T xc[NX], xf[NX];
+#pragma unroll
+        for (int i = 0; i < NX; ++i) { xc[i] = xa[i]; xf[i] = xa[i]; }
+        const T hq = hc * T(0.25);
+        s.fwd_prep(pA, pB, s_lo, ds, hq);
+        s.fwd_cols(wA, wB, s_lo, ds);
+        // coarse Strang step (stiff h/2, RK4 h, stiff h/2) and two fine ones; the two adjacent fine stiff
+        // quarter-steps at the middle node compose exactly into one half-step.  (Unlike the Riccati sweep, which runs its
+        // two chains in place with the other value parked in LDS, this one-wave-per-SIMD kernel is 20 % faster with both
+        // chains as independent instruction streams the compiler can interleave.)
+        s.fwd_stiff(xc, 0, true, hq);
+        s.fwd_rk4(xc, 0, 2, 4, hc);
+        s.fwd_stiff(xc, 2, true, hq);
+        s.fwd_stiff(xf, 0, false, hq);
+        s.fwd_rk4(xf, 0, 1, 2, hc * T(0.5));
+        s.fwd_stiff(xf, 1, true, hq);
+        s.fwd_rk4(xf, 2, 3, 4, hc * T(0.5));
+        s.fwd_stiff(xf, 2, false, hq);
+        __syncthreads();      // all reads of this unit's staged coefficients are done before the next staging
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+          if (xlane) err_l = t_max(err_l, t_abs(xf[i] - xc[i]));
+          xa[i] = xlane ? (T(4) * xf[i] - xc[i]) / T(3) : T(0);
+          scl_l = t_max(scl_l, t_abs(xa[i]));
+        }
+        if (Uo && k == N - 1 && unit == units - 1) {
+          T uo[NU];
+          s.aux_control(xa, pB, wB, s.node(4), uo);
+          if (valid && xlane) {
+#pragma unroll
+            for (int b = 0; b < NU; ++b) Uo[((long long)N * NP + s.xcol) * NU + b] = uo[b];
+          }
+        }
+      }
+      if (!(a.rtol > T(0))) break;
+      T* ldsR = s.lds + Lay::LDS_T;           // (the feedback / phi1 images of the last unit are dead by now)
+      ldsR[lane] = err_l; ldsR[G + lane] = scl_l;
+      __syncthreads();
+      T eX = T(0), sX = T(0);
+      for (int l = 0; l < NP; ++l) { eX = t_max(eX, ldsR[l]); sX = t_max(sX, ldsR[G + l]); }
+      __syncthreads();
+      const T tolX = T(3) * a.rtol * (sX + T(1e-2));       // dx/dtheta starts from zero: absolute floor 1e-2 * rtol
+      const T ratio = eX / tolX;
+      const bool no_gain = ratio_prev >= T(0) && ratio > T(0.5) * ratio_prev;
+      ratio_prev = ratio;
+      if (eX <= tolX || no_gain || !t_finite(eX) || (long long)units * 2 > units_cap) {
+        units_hint = (eX * T(32) <= tolX && units > Sa) ? units / 2 : units;
+        break;
+      }
+      units *= 2;
+#pragma unroll
+      for (int i = 0; i < NX; ++i) xa[i] = xlane ? xprev[i * NP + s.xcol] : T(0);
+    }
+    if (valid && Xo && xlane) {
+#pragma unroll
+      for (int i = 0; i < NX; ++i) Xo[((long long)(k + 1) * NP + s.xcol) * NX + i] = xa[i];
+    }
+    // loss and gradient contributions of the waypoints that fall into this interval
+    // (linear interpolation of the grid values, exactly what opt_sol(t)/auxsys_sol(t) do: CPDP.py:386)
+    for (int w = 0; w < a.n_waypoints; ++w) {
+      const T tau = a.taus[traj * a.n_waypoints + w];
+      int kw = (int)t_floor(tau / s.dgrid);
+      kw = kw < 0 ? 0 : (kw > N - 1 ? N - 1 : kw);
+      if (kw != k) continue;
+      const T sw = (tau - T(k) * s.dgrid) / s.dgrid;
+      T rvec[NX];
+#pragma unroll
+      for (int i = 0; i < NX; ++i) rvec[i] = T(0);
+      for (int q = 0; q < a.n_iface; ++q) {
+        const int idx = a.iface_idx[q];
+        const T target = a.waypoints[(traj * a.n_waypoints + w) * a.n_iface + q];
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+          if (i == idx) {
+            const T cur = s.xa_[i] + sw * (s.xb_[i] - s.xa_[i]);
+            const T r = cur - target;
+            rvec[i] += r;
+            loss += r * r;
+          }
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < NX; ++i) { const T xp = xprev[i * NP + s.xcol]; gacc += rvec[i] * (xp + sw * (xa[i] - xp)); }
+    }
+  }
+  if (valid) {
+    if (lane == 0) a.loss[traj] = loss;
+    if (xlane) a.grad[traj * NP + s.xcol] = gacc;
+  }
+}
+
+}  // namespace lfsd

@@ -1,0 +1,458 @@
+// Build switches, packed/MFMA primitives and the small dense helpers shared by every kernel.
+// Part of the kernel sources collected by cpdp_kernels.h (include that header, not this one).
+#pragma once
+
+
+#if defined(LFSD_EMU)
+#include "simt_emu.h"
+#define LFSD_LAMBDA_INLINE
+#define LFSD_LAMBDA_BW
+#define LFSD_LAMBDA_RO
+#define LFSD_HD
+#else
+#include <hip/hip_runtime.h>
+#define LFSD_DEV __device__ __forceinline__
+#define LFSD_HD __host__ __device__
+// lambdas inside kernels must be inlined as well: a real call passes their by-reference captures through scratch
+// (experiment knob LFSD_PHASE_CALLS: bit 0 keeps the backward sweep of oc_solve_kernel a real call, bit 1 the roll-out, so
+// that each phase gets its own register allocation; profiles/r02_e_phase_calls.txt)
+#define LFSD_LAMBDA_INLINE __attribute__((always_inline))
+#if defined(LFSD_PHASE_CALLS) && (LFSD_PHASE_CALLS & 1)
+#define LFSD_LAMBDA_BW __attribute__((noinline))
+#else
+#define LFSD_LAMBDA_BW __attribute__((always_inline))
+#endif
+#if defined(LFSD_PHASE_CALLS) && (LFSD_PHASE_CALLS & 2)
+#define LFSD_LAMBDA_RO __attribute__((noinline))
+#else
+#define LFSD_LAMBDA_RO __attribute__((always_inline))
+#endif
+#endif
+
+// register budget: measured on MI355X (tools/tune.py) 1 wave/SIMD with all 512 VGPR+AGPR beats 2-3 waves with scratch spills
+#ifndef LFSD_WAVES_PER_SIMD
+#define LFSD_WAVES_PER_SIMD 1
+#endif
+#ifndef LFSD_WAVES_OC
+#define LFSD_WAVES_OC LFSD_WAVES_PER_SIMD
+#endif
+// aux kernels and occupancy, measured on MI355X.  Compiled with clang's SLP vectoriser (profiles/r01_tune_aux_occupancy.txt)
+// a second wave per SIMD never paid: held to 256 VGPRs the kernels spilled 0.5-1.3 KB/lane (Riccati 8.8 -> 9.0 ms, forward
+// 5.8 -> 11.1 ms).  Without SLP (profiles/r01_tune_compiler_flags.txt) the fp32 Riccati sweep needs 256 + 84 registers: with
+// the small column cache (LFSD_RIC_CACHE 2) it runs two waves per SIMD -- the 2048 waves of the benchmark batch in one
+// round instead of two, 8.2 -> 7.1 ms with 0.4 KB/lane of spills, and 5.7 ms with none (246 VGPRs) once the coarse and the
+// fine Richardson chain run in place with the other column parked in LDS.  The forward sweep stays at one wave per SIMD
+// (256 + 256 registers) and keeps its two chains as independent instruction streams: in place it is 20 % slower.
+// tuning only: extra LDS elements per workgroup of the aux kernels, to lower their occupancy (tools/tune.py)
+#ifndef LFSD_AUX_LDS_PAD
+#define LFSD_AUX_LDS_PAD 0
+#endif
+// Riccati kernel: which Z-independent columns are parked per lane in LDS (0 none, 1 [Hxx Hxe] and Huu^-1 [Hux Hue],
+// 2 only Huu^-1 [Hux Hue]).  Mode 2 leaves 16 KB of LDS per workgroup, which admits the second wave per SIMD below.
+#ifndef LFSD_RIC_CACHE
+#define LFSD_RIC_CACHE 2
+#endif
+// outer per-node loops of the once-per-unit preparation (ric_cols; fwd_prep, fwd_cols): rolled.  Measured: 6 % faster in
+// the Riccati sweep; the forward sweep preferred them unrolled (7 %) until it was compiled with the max-ILP scheduler,
+// since then rolled is 5 % faster there too (profiles/r01_tune_aux_occupancy.txt, r01_tune_compiler_flags.txt)
+#ifndef LFSD_RIC_NODE_LOOP
+#define LFSD_RIC_NODE_LOOP _Pragma("unroll 1")
+#endif
+#ifndef LFSD_FWD_NODE_LOOP
+#define LFSD_FWD_NODE_LOOP _Pragma("unroll 1")
+#endif
+#ifndef LFSD_WAVES_RIC
+#define LFSD_WAVES_RIC 2
+#endif
+#ifndef LFSD_WAVES_FWD
+#define LFSD_WAVES_FWD 1
+#endif
+
+// Levenberg shift ladder of the OC solve: factor up after a failed backward sweep / line search, factor down after an
+// accepted full step, and how many accepted full steps to hold before the shift returns to a level that has just failed.
+// Measured on BASELINE configs[1] (robot arm, 1024 seeds, tools/tune_arm.py, profiles/r01_tune_step_control.txt): with
+// x10 / x0.1 the accepted steps land on shifts up to 10x larger than necessary (over-damped) and every other backward
+// sweep fails; sqrt(10) rungs + a one-step hold cut the slowest seed from 87 to 65 iterations and the seeds that run
+// out of iterations at the step-1 parameters from 98 to 65 of 1024.  Handing over to the exact model as soon as
+// Gauss-Newton crawls (the oracle's rule, LFSD_GN_CRAWL) costs iterations here (27 -> 40 on average) and stays off.
+#ifndef LFSD_MU_UP
+#define LFSD_MU_UP 3.1623
+#endif
+#ifndef LFSD_MU_DOWN
+#define LFSD_MU_DOWN 0.31623
+#endif
+#ifndef LFSD_MU_HOLD
+#define LFSD_MU_HOLD 1
+#endif
+#ifndef LFSD_MU_HOLD_BACKOFF
+#define LFSD_MU_HOLD_BACKOFF 0
+#endif
+#ifndef LFSD_GN_CRAWL
+#define LFSD_GN_CRAWL 1
+#endif
+// Levenberg shift of the Newton modes, measured on BASELINE configs[1] (robot arm, 1024 seeds, emulator + MI355X,
+// profiles/r02_arm_step_control.txt).  LFSD_REG_CONSISTENT: the value recursion continues with the SHIFTED Q_uu, i.e. the
+// sweep is the block LDL^T factorisation of (Lagrangian Hessian + mu I_u) -- the model the step actually minimises, and
+// what IPOPT's inertia correction delta_w does to the KKT matrix (CPDP.py:177-184).  With the unshifted Q_uu in the
+// recursion (Tassa's form) an indefinite Q_uu feeds -mu K^T K into V_xx, the sweep needs shifts 30x larger, and 64 of
+// 1024 seeds ran out of 100 iterations.  LFSD_HAM_SHIFT: shift the cheap Hamiltonian model as well instead of falling
+// back to Gauss-Newton (measured: no gain).
+// backward sweep: issue the loads of interval k-1 while interval k is processed (costs NX+1 + NX+NU registers)
+#ifndef LFSD_BW_PREFETCH
+#define LFSD_BW_PREFETCH 1
+#endif
+// lean fp32 kernel of the 32-lane models: backward sweep on the matrix cores (1) or relayed on the vector pipe (0)
+#ifndef LFSD_MFMA_BACKWARD
+#define LFSD_MFMA_BACKWARD 1
+#endif
+#ifndef LFSD_REG_CONSISTENT
+#define LFSD_REG_CONSISTENT 1
+#endif
+#ifndef LFSD_HAM_SHIFT
+#define LFSD_HAM_SHIFT 0
+#endif
+
+// LFSD_SCHED_FENCE: stop the instruction scheduler from hoisting loads across this point (bounds live ranges in
+// the fully unrolled contractions); no-op in the emulator build
+#if defined(LFSD_EMU) || !defined(LFSD_USE_SCHED_FENCE)
+#define LFSD_SCHED_FENCE()
+#else
+#define LFSD_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+#endif
+
+namespace lfsd {
+
+// debug aid for the emulator build: start every kernel with NaN-filled LDS so that a read of
+// never-written shared memory cannot go unnoticed (tests build with -DLFSD_POISON_LDS)
+template <typename T> LFSD_DEV void poison_lds(T* p, int n) {
+#if defined(LFSD_POISON_LDS)
+  for (int i = threadIdx.x; i < n; i += 64) p[i] = T(0) / T(0);
+  __syncthreads();
+#else
+  (void)p; (void)n;
+#endif
+}
+
+enum Status { ST_RUNNING = 0, ST_CONVERGED = 1, ST_STALLED = 2, ST_MAXITER = 3, ST_FAILED = 4 };
+enum OptMethod { OPT_VANILLA = 0, OPT_NESTEROV = 1, OPT_ADAM = 2, OPT_NADAM = 3, OPT_AMSGRAD = 4 };
+
+// Two values per lane, for the kernels that carry two tangent columns on one lane: native 2-vectors on the GPU (the
+// tangent code is linear, so it compiles to v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 at the scalar issue rate), a plain
+// struct in the CPU emulator build.
+#if defined(LFSD_EMU)
+template <typename T> struct pk2 {
+  T x, y;
+  pk2() = default;
+  pk2(T s) : x(s), y(s) {}
+  pk2(T a, T b) : x(a), y(b) {}
+};
+template <typename T> inline pk2<T> operator+(pk2<T> a, pk2<T> b) { return pk2<T>(a.x + b.x, a.y + b.y); }
+template <typename T> inline pk2<T> operator-(pk2<T> a, pk2<T> b) { return pk2<T>(a.x - b.x, a.y - b.y); }
+template <typename T> inline pk2<T> operator-(pk2<T> a) { return pk2<T>(-a.x, -a.y); }
+template <typename T> inline pk2<T> operator*(pk2<T> a, pk2<T> b) { return pk2<T>(a.x * b.x, a.y * b.y); }
+template <typename T> inline pk2<T> operator*(T a, pk2<T> b) { return pk2<T>(a * b.x, a * b.y); }
+template <typename T> inline pk2<T> operator*(pk2<T> a, T b) { return pk2<T>(a.x * b, a.y * b); }
+template <typename T> inline pk2<T> operator+(T a, pk2<T> b) { return pk2<T>(a + b.x, a + b.y); }
+template <typename T> inline pk2<T> operator+(pk2<T> a, T b) { return pk2<T>(a.x + b, a.y + b); }
+template <typename T> inline pk2<T> operator/(pk2<T> a, T b) { return pk2<T>(a.x / b, a.y / b); }
+template <typename T> inline pk2<T> operator/(pk2<T> a, pk2<T> b) { return pk2<T>(a.x / b.x, a.y / b.y); }
+template <typename T> inline pk2<T> operator-(pk2<T> a, T b) { return pk2<T>(a.x - b, a.y - b); }
+template <typename T> inline pk2<T> operator-(T a, pk2<T> b) { return pk2<T>(a - b.x, a - b.y); }
+template <typename T> inline pk2<T>& operator+=(pk2<T>& a, pk2<T> b) { a.x += b.x; a.y += b.y; return a; }
+template <typename T> inline pk2<T>& operator-=(pk2<T>& a, pk2<T> b) { a.x -= b.x; a.y -= b.y; return a; }
+#else
+template <typename T> using pk2 = T __attribute__((ext_vector_type(2)));
+#endif
+template <typename T> LFSD_DEV pk2<T> mk2(T a, T b) { pk2<T> v; v.x = a; v.y = b; return v; }
+
+// ---- wave-level matrix helpers of the MFMA backward sweep (fp32, four 16-lane trajectories per wavefront) --------------
+// mfma4b: v_mfma_f32_16x16x1_4b_f32 -- four independent 16x16 rank-1 updates, block b fed by the lanes of 16-lane group b:
+//   D_b[i][j] += a(lane 16b+i) * b(lane 16b+j);  D_b[i][j] lives in register 4b + i%4 of lane 16(i/4) + j.
+// tile_transpose: afterwards lane 16b+j holds D_b[i][j] in register i (column j of ITS block: the column-per-lane layout
+//   of the rest of the kernel), by 8 v_permlane32_swap + 8 v_permlane16_swap.
+// Both must be reached by all 64 lanes.  The emulator build restates them with an exchange buffer.
+#if defined(LFSD_EMU)
+struct f32x16 {
+  float v[16];
+  float& operator[](int i) { return v[i]; }
+  const float& operator[](int i) const { return v[i]; }
+};
+inline void mfma4b(float a, float b, f32x16& acc) {
+  static float sa[64], sb[64];
+  const int l = threadIdx.x;
+  sa[l] = a; sb[l] = b;
+  __syncthreads();
+  for (int r = 0; r < 16; ++r) {
+    const int blk = r / 4, i = 4 * (l >> 4) + r % 4, j = l & 15;
+    acc[r] = std::fmaf(sa[16 * blk + i], sb[16 * blk + j], acc[r]);      // the hardware's k-ordered fmaf chain
+  }
+  __syncthreads();
+}
+inline void tile_transpose(f32x16& acc) {
+  static float sx[64][16];
+  const int l = threadIdx.x, b = l >> 4, j = l & 15;
+  for (int r = 0; r < 16; ++r) sx[l][r] = acc[r];
+  __syncthreads();
+  for (int q = 0; q < 4; ++q)
+    for (int r = 0; r < 4; ++r) acc[4 * q + r] = sx[16 * q + j][4 * b + r];
+  __syncthreads();
+}
+#else
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+LFSD_DEV void mfma4b(float a, float b, f32x16& acc) { acc = __builtin_amdgcn_mfma_f32_16x16x1f32(a, b, acc, 0, 0, 0); }
+LFSD_DEV void tile_transpose(f32x16& acc) {
+  // exchange the block index (register group 4R..4R+3) with the lane-group index, one bit per stage
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+#pragma unroll
+    for (int R0 = 0; R0 < 2; ++R0) {        // bit 1: register groups R0 / R0+2  <->  lane halves
+      const float lo = acc[4 * R0 + r], hi = acc[4 * (R0 + 2) + r];      // (scalars first: __builtin_bit_cast applied to a
+      const auto v = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, lo),      //  vector ELEMENT reads element 0)
+                                                      __builtin_bit_cast(unsigned, hi), false, false);
+      const unsigned v0 = v[0], v1 = v[1];
+      acc[4 * R0 + r] = __builtin_bit_cast(float, v0);
+      acc[4 * (R0 + 2) + r] = __builtin_bit_cast(float, v1);
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+#pragma unroll
+    for (int R1 = 0; R1 < 2; ++R1) {        // bit 0: register groups 2R1 / 2R1+1  <->  odd / even 16-lane rows
+      const float lo = acc[8 * R1 + r], hi = acc[8 * R1 + 4 + r];
+      const auto v = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, lo),
+                                                      __builtin_bit_cast(unsigned, hi), false, false);
+      const unsigned v0 = v[0], v1 = v[1];
+      acc[8 * R1 + r] = __builtin_bit_cast(float, v0);
+      acc[8 * R1 + 4 + r] = __builtin_bit_cast(float, v1);
+    }
+  }
+}
+#endif
+
+template <typename T> struct Eps;
+template <> struct Eps<float> { static LFSD_DEV float v() { return 1.1920929e-07f; } };
+template <> struct Eps<double> { static LFSD_DEV double v() { return 2.220446049250313e-16; } };
+
+template <typename T> LFSD_DEV T t_abs(T a) { return a < T(0) ? -a : a; }
+template <typename T> LFSD_DEV T t_max(T a, T b) { return a > b ? a : b; }
+template <typename T> LFSD_DEV T t_min(T a, T b) { return a < b ? a : b; }
+template <typename T> LFSD_DEV bool t_finite(T a) { return (a - a) == T(0); }
+LFSD_DEV float t_sqrt(float a) { return sqrtf(a); }
+LFSD_DEV double t_sqrt(double a) { return sqrt(a); }
+LFSD_DEV float t_floor(float a) { return floorf(a); }
+LFSD_DEV double t_floor(double a) { return floor(a); }
+LFSD_DEV float t_pow(float a, float b) { return powf(a, b); }
+LFSD_DEV double t_pow(double a, double b) { return pow(a, b); }
+
+// ---- tiny dense helpers on group-uniform n x n matrices (row-major, in registers) -----------
+// Cholesky A = L L^T in place (lower); false if not positive definite.
+template <int n, typename T> LFSD_DEV bool chol_factor(T* A, T& dmin) {
+  bool ok = true;
+#pragma unroll
+  for (int j = 0; j < n; ++j) {
+    T d = A[j * n + j];
+#pragma unroll
+    for (int k = 0; k < j; ++k) d -= A[j * n + k] * A[j * n + k];
+    if (!(d > T(0))) { if (ok && d < dmin) dmin = d; ok = false; d = T(1); }    // only the first failing pivot is meaningful
+    d = t_sqrt(d);
+    A[j * n + j] = d;
+    const T inv = T(1) / d;
+#pragma unroll
+    for (int i = j + 1; i < n; ++i) {
+      T s = A[i * n + j];
+#pragma unroll
+      for (int k = 0; k < j; ++k) s -= A[i * n + k] * A[j * n + k];
+      A[i * n + j] = s * inv;
+    }
+  }
+  return ok;
+}
+template <int n, typename T> LFSD_DEV void chol_solve(const T* Lm, T* b) {
+#pragma unroll
+  for (int i = 0; i < n; ++i) {
+    T s = b[i];
+#pragma unroll
+    for (int k = 0; k < i; ++k) s -= Lm[i * n + k] * b[k];
+    b[i] = s / Lm[i * n + i];
+  }
+#pragma unroll
+  for (int i = n - 1; i >= 0; --i) {
+    T s = b[i];
+#pragma unroll
+    for (int k = i + 1; k < n; ++k) s -= Lm[k * n + i] * b[k];
+    b[i] = s / Lm[i * n + i];
+  }
+}
+// Box-constrained stage problem of the control-limited backward sweep (finite control_lb / control_ub of
+// COCSys.setControlVariable, CPDP.py:33-46, which the reference hands to IPOPT as lbw / ubw):
+//     min_x  1/2 x^T Q x + q^T x   s.t.  lo <= x <= hi            (Q = Q_uu + mu I positive definite, n <= 4 controls)
+// by a primal active-set iteration on the masked system (clamped rows / columns replaced by identity): solve, clamp the
+// components that left the box, re-solve; when nothing moves, release the clamped component whose multiplier has the
+// wrong sign most.  Returns the Cholesky factor of the final masked matrix in Lf (the feedback gains of the free
+// components are solved with it; clamped components get zero gain) and the clamp mask.
+template <int n, typename T> LFSD_DEV bool box_qp(const T* Q, const T* q, const T* lo, const T* hi, T* x, unsigned& mask, T* Lf, T& dmin) {
+  mask = 0u;
+  T xc[n];
+#pragma unroll
+  for (int i = 0; i < n; ++i) xc[i] = T(0);
+  bool ok = true;
+  for (int round = 0; round < 3 * n + 2; ++round) {
+    T b[n];
+#pragma unroll
+    for (int i = 0; i < n; ++i) {
+      const bool ci = (mask >> i) & 1u;
+      T s = ci ? xc[i] : -q[i];
+#pragma unroll
+      for (int j = 0; j < n; ++j) {
+        const bool cj = (mask >> j) & 1u;
+        Lf[i * n + j] = (ci || cj) ? ((i == j) ? T(1) : T(0)) : Q[i * n + j];
+        if (!ci && cj) s -= Q[i * n + j] * xc[j];
+      }
+      b[i] = s;
+    }
+    T dd = T(0);
+    if (!chol_factor<n>(Lf, dd)) { ok = false; if (dd < dmin) dmin = dd; break; }
+    chol_solve<n>(Lf, b);
+    unsigned newmask = mask;
+#pragma unroll
+    for (int i = 0; i < n; ++i) {
+      if ((mask >> i) & 1u) continue;
+      if (b[i] < lo[i]) { newmask |= 1u << i; xc[i] = lo[i]; }
+      else if (b[i] > hi[i]) { newmask |= 1u << i; xc[i] = hi[i]; }
+    }
+#pragma unroll
+    for (int i = 0; i < n; ++i) x[i] = ((newmask >> i) & 1u) ? xc[i] : b[i];
+    if (newmask != mask) { mask = newmask; continue; }
+    // stationary for this active set: multipliers g_i = (Q x + q)_i of the clamped components must push outward
+    int worst = -1;
+    T wv = T(0);
+#pragma unroll
+    for (int i = 0; i < n; ++i) {
+      if (!((mask >> i) & 1u)) continue;
+      T g = q[i];
+#pragma unroll
+      for (int j = 0; j < n; ++j) g += Q[i * n + j] * x[j];
+      const T viol = (xc[i] <= lo[i]) ? -g : g;         // at the lower bound the gradient must be >= 0, at the upper <= 0
+      if (viol > wv) { wv = viol; worst = i; }
+    }
+    if (worst < 0) break;
+    mask &= ~(1u << worst);
+  }
+  return ok;
+}
+// LU without pivoting, in place (unit lower + upper).  For I + small and SPD-like matrices.
+template <int n, typename T> LFSD_DEV void lu_factor(T* A) {
+#pragma unroll
+  for (int j = 0; j < n; ++j) {
+    const T inv = T(1) / A[j * n + j];
+#pragma unroll
+    for (int i = j + 1; i < n; ++i) {
+      const T f = A[i * n + j] * inv;
+      A[i * n + j] = f;
+#pragma unroll
+      for (int k = j + 1; k < n; ++k) A[i * n + k] -= f * A[j * n + k];
+    }
+  }
+}
+template <int n, typename T> LFSD_DEV void lu_solve(const T* A, T* b) {
+#pragma unroll
+  for (int i = 0; i < n; ++i) {
+#pragma unroll
+    for (int k = 0; k < i; ++k) b[i] -= A[i * n + k] * b[k];
+  }
+#pragma unroll
+  for (int i = n - 1; i >= 0; --i) {
+#pragma unroll
+    for (int k = i + 1; k < n; ++k) b[i] -= A[i * n + k] * b[k];
+    b[i] /= A[i * n + i];
+  }
+}
+template <int n, typename T> LFSD_DEV void mat_inverse(const T* A, T* Ainv) {
+  T F[n * n];
+#pragma unroll
+  for (int i = 0; i < n * n; ++i) F[i] = A[i];
+  lu_factor<n>(F);
+#pragma unroll
+  for (int c = 0; c < n; ++c) {
+    T b[n];
+#pragma unroll
+    for (int i = 0; i < n; ++i) b[i] = (i == c) ? T(1) : T(0);
+    lu_solve<n>(F, b);
+#pragma unroll
+    for (int i = 0; i < n; ++i) Ainv[i * n + c] = b[i];
+  }
+}
+template <int n, typename T> LFSD_DEV void matmul(const T* A, const T* B, T* C) {
+#pragma unroll
+  for (int i = 0; i < n; ++i) {
+#pragma unroll
+    for (int j = 0; j < n; ++j) {
+      T s = T(0);
+#pragma unroll
+      for (int k = 0; k < n; ++k) s += A[i * n + k] * B[k * n + j];
+      C[i * n + j] = s;
+    }
+  }
+}
+// P = phi1(M) = M^-1 (I - exp(-M)) for a small matrix with non-negative spectrum
+// (scaling and squaring: Taylor of degree 8 on M/2^s, then phi1(2A) = (I + e^-A) phi1(A) / 2).
+template <typename T> struct PhiDeg;
+template <> struct PhiDeg<float> { static constexpr int v = 6; };
+template <> struct PhiDeg<double> { static constexpr int v = 9; };
+// P = phi1(M), P2 = phi1(2M)
+template <int n, typename T> LFSD_DEV void phi1_neg(const T* M, T* P, T* P2) {
+  T nrm = T(0);
+#pragma unroll
+  for (int i = 0; i < n; ++i) {
+    T r = T(0);
+#pragma unroll
+    for (int j = 0; j < n; ++j) r += t_abs(M[i * n + j]);
+    nrm = t_max(nrm, r);
+  }
+  int sq = 0;
+  T sc = T(1);
+  while (nrm * sc > T(0.25) && sq < 60) { sc *= T(0.5); ++sq; }
+  T A[n * n], E[n * n], W[n * n];
+#pragma unroll
+  for (int i = 0; i < n * n; ++i) { A[i] = M[i] * sc; P[i] = T(0); }
+  const T ck[10] = {T(1), T(1) / T(2), T(1) / T(6), T(1) / T(24), T(1) / T(120), T(1) / T(720), T(1) / T(5040),
+                    T(1) / T(40320), T(1) / T(362880), T(1) / T(3628800)};
+  constexpr int DEG = PhiDeg<T>::v;       // |A| <= 1/4: truncation 4^-(DEG+1)/(DEG+2)! below round-off
+#pragma unroll
+  for (int i = 0; i < n; ++i) P[i * n + i] = ck[DEG];
+#pragma unroll
+  for (int k = DEG - 1; k >= 0; --k) {
+    matmul<n>(A, P, W);
+#pragma unroll
+    for (int i = 0; i < n * n; ++i) P[i] = -W[i];
+#pragma unroll
+    for (int i = 0; i < n; ++i) P[i * n + i] += ck[k];
+  }
+  matmul<n>(A, P, W);
+#pragma unroll
+  for (int i = 0; i < n * n; ++i) E[i] = -W[i];
+#pragma unroll
+  for (int i = 0; i < n; ++i) E[i * n + i] += T(1);
+  for (int it = 0; it < sq; ++it) {
+    matmul<n>(E, P, W);
+#pragma unroll
+    for (int i = 0; i < n * n; ++i) P[i] = T(0.5) * (P[i] + W[i]);
+    matmul<n>(E, E, W);
+#pragma unroll
+    for (int i = 0; i < n * n; ++i) E[i] = W[i];
+  }
+  matmul<n>(E, P, W);
+#pragma unroll
+  for (int i = 0; i < n * n; ++i) P2[i] = T(0.5) * (P[i] + W[i]);
+}
+template <int n, typename T> LFSD_DEV void matvec(const T* A, const T* v, T* y) {
+#pragma unroll
+  for (int i = 0; i < n; ++i) {
+    T s = T(0);
+#pragma unroll
+    for (int k = 0; k < n; ++k) s += A[i * n + k] * v[k];
+    y[i] = s;
+  }
+}
+
+}  // namespace lfsd

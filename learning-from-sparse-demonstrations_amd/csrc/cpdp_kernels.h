@@ -20,2655 +20,11 @@
 //
 // The same source builds for the GPU with hipcc and, with -DLFSD_EMU, for the CPU
 // SIMT emulator in tests/emu (test infrastructure; never used by the product path).
+//
+// Sources: cpdp_common.h (switches, primitives, dense helpers), cpdp_oc.h (OC solve), cpdp_aux.h (auxiliary
+// system sweeps + loss), cpdp_opt.h (update rules).
 #pragma once
-
-#if defined(LFSD_EMU)
-#include "simt_emu.h"
-#define LFSD_LAMBDA_INLINE
-#define LFSD_LAMBDA_BW
-#define LFSD_LAMBDA_RO
-#define LFSD_HD
-#else
-#include <hip/hip_runtime.h>
-#define LFSD_DEV __device__ __forceinline__
-#define LFSD_HD __host__ __device__
-// lambdas inside kernels must be inlined as well: a real call passes their by-reference captures through scratch
-// (experiment knob LFSD_PHASE_CALLS: bit 0 keeps the backward sweep of oc_solve_kernel a real call, bit 1 the roll-out, so
-// that each phase gets its own register allocation; profiles/r02_e_phase_calls.txt)
-#define LFSD_LAMBDA_INLINE __attribute__((always_inline))
-#if defined(LFSD_PHASE_CALLS) && (LFSD_PHASE_CALLS & 1)
-#define LFSD_LAMBDA_BW __attribute__((noinline))
-#else
-#define LFSD_LAMBDA_BW __attribute__((always_inline))
-#endif
-#if defined(LFSD_PHASE_CALLS) && (LFSD_PHASE_CALLS & 2)
-#define LFSD_LAMBDA_RO __attribute__((noinline))
-#else
-#define LFSD_LAMBDA_RO __attribute__((always_inline))
-#endif
-#endif
-
-// register budget: measured on MI355X (tools/tune.py) 1 wave/SIMD with all 512 VGPR+AGPR beats 2-3 waves with scratch spills
-#ifndef LFSD_WAVES_PER_SIMD
-#define LFSD_WAVES_PER_SIMD 1
-#endif
-#ifndef LFSD_WAVES_OC
-#define LFSD_WAVES_OC LFSD_WAVES_PER_SIMD
-#endif
-// aux kernels and occupancy, measured on MI355X.  Compiled with clang's SLP vectoriser (profiles/r01_tune_aux_occupancy.txt)
-// a second wave per SIMD never paid: held to 256 VGPRs the kernels spilled 0.5-1.3 KB/lane (Riccati 8.8 -> 9.0 ms, forward
-// 5.8 -> 11.1 ms).  Without SLP (profiles/r01_tune_compiler_flags.txt) the fp32 Riccati sweep needs 256 + 84 registers: with
-// the small column cache (LFSD_RIC_CACHE 2) it runs two waves per SIMD -- the 2048 waves of the benchmark batch in one
-// round instead of two, 8.2 -> 7.1 ms with 0.4 KB/lane of spills, and 5.7 ms with none (246 VGPRs) once the coarse and the
-// fine Richardson chain run in place with the other column parked in LDS.  The forward sweep stays at one wave per SIMD
-// (256 + 256 registers) and keeps its two chains as independent instruction streams: in place it is 20 % slower.
-// tuning only: extra LDS elements per workgroup of the aux kernels, to lower their occupancy (tools/tune.py)
-#ifndef LFSD_AUX_LDS_PAD
-#define LFSD_AUX_LDS_PAD 0
-#endif
-// Riccati kernel: which Z-independent columns are parked per lane in LDS (0 none, 1 [Hxx Hxe] and Huu^-1 [Hux Hue],
-// 2 only Huu^-1 [Hux Hue]).  Mode 2 leaves 16 KB of LDS per workgroup, which admits the second wave per SIMD below.
-#ifndef LFSD_RIC_CACHE
-#define LFSD_RIC_CACHE 2
-#endif
-// outer per-node loops of the once-per-unit preparation (ric_cols; fwd_prep, fwd_cols): rolled.  Measured: 6 % faster in
-// the Riccati sweep; the forward sweep preferred them unrolled (7 %) until it was compiled with the max-ILP scheduler,
-// since then rolled is 5 % faster there too (profiles/r01_tune_aux_occupancy.txt, r01_tune_compiler_flags.txt)
-#ifndef LFSD_RIC_NODE_LOOP
-#define LFSD_RIC_NODE_LOOP _Pragma("unroll 1")
-#endif
-#ifndef LFSD_FWD_NODE_LOOP
-#define LFSD_FWD_NODE_LOOP _Pragma("unroll 1")
-#endif
-#ifndef LFSD_WAVES_RIC
-#define LFSD_WAVES_RIC 2
-#endif
-#ifndef LFSD_WAVES_FWD
-#define LFSD_WAVES_FWD 1
-#endif
-
-// Levenberg shift ladder of the OC solve: factor up after a failed backward sweep / line search, factor down after an
-// accepted full step, and how many accepted full steps to hold before the shift returns to a level that has just failed.
-// Measured on BASELINE configs[1] (robot arm, 1024 seeds, tools/tune_arm.py, profiles/r01_tune_step_control.txt): with
-// x10 / x0.1 the accepted steps land on shifts up to 10x larger than necessary (over-damped) and every other backward
-// sweep fails; sqrt(10) rungs + a one-step hold cut the slowest seed from 87 to 65 iterations and the seeds that run
-// out of iterations at the step-1 parameters from 98 to 65 of 1024.  Handing over to the exact model as soon as
-// Gauss-Newton crawls (the oracle's rule, LFSD_GN_CRAWL) costs iterations here (27 -> 40 on average) and stays off.
-#ifndef LFSD_MU_UP
-#define LFSD_MU_UP 3.1623
-#endif
-#ifndef LFSD_MU_DOWN
-#define LFSD_MU_DOWN 0.31623
-#endif
-#ifndef LFSD_MU_HOLD
-#define LFSD_MU_HOLD 1
-#endif
-#ifndef LFSD_MU_HOLD_BACKOFF
-#define LFSD_MU_HOLD_BACKOFF 0
-#endif
-#ifndef LFSD_GN_CRAWL
-#define LFSD_GN_CRAWL 1
-#endif
-// Levenberg shift of the Newton modes, measured on BASELINE configs[1] (robot arm, 1024 seeds, emulator + MI355X,
-// profiles/r02_arm_step_control.txt).  LFSD_REG_CONSISTENT: the value recursion continues with the SHIFTED Q_uu, i.e. the
-// sweep is the block LDL^T factorisation of (Lagrangian Hessian + mu I_u) -- the model the step actually minimises, and
-// what IPOPT's inertia correction delta_w does to the KKT matrix (CPDP.py:177-184).  With the unshifted Q_uu in the
-// recursion (Tassa's form) an indefinite Q_uu feeds -mu K^T K into V_xx, the sweep needs shifts 30x larger, and 64 of
-// 1024 seeds ran out of 100 iterations.  LFSD_HAM_SHIFT: shift the cheap Hamiltonian model as well instead of falling
-// back to Gauss-Newton (measured: no gain).
-// backward sweep: issue the loads of interval k-1 while interval k is processed (costs NX+1 + NX+NU registers)
-#ifndef LFSD_BW_PREFETCH
-#define LFSD_BW_PREFETCH 1
-#endif
-// lean fp32 kernel of the 32-lane models: backward sweep on the matrix cores (1) or relayed on the vector pipe (0)
-#ifndef LFSD_MFMA_BACKWARD
-#define LFSD_MFMA_BACKWARD 1
-#endif
-#ifndef LFSD_REG_CONSISTENT
-#define LFSD_REG_CONSISTENT 1
-#endif
-#ifndef LFSD_HAM_SHIFT
-#define LFSD_HAM_SHIFT 0
-#endif
-
-// LFSD_SCHED_FENCE: stop the instruction scheduler from hoisting loads across this point (bounds live ranges in
-// the fully unrolled contractions); no-op in the emulator build
-#if defined(LFSD_EMU) || !defined(LFSD_USE_SCHED_FENCE)
-#define LFSD_SCHED_FENCE()
-#else
-#define LFSD_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
-#endif
-
-namespace lfsd {
-
-// debug aid for the emulator build: start every kernel with NaN-filled LDS so that a read of
-// never-written shared memory cannot go unnoticed (tests build with -DLFSD_POISON_LDS)
-template <typename T> LFSD_DEV void poison_lds(T* p, int n) {
-#if defined(LFSD_POISON_LDS)
-  for (int i = threadIdx.x; i < n; i += 64) p[i] = T(0) / T(0);
-  __syncthreads();
-#else
-  (void)p; (void)n;
-#endif
-}
-
-enum Status { ST_RUNNING = 0, ST_CONVERGED = 1, ST_STALLED = 2, ST_MAXITER = 3, ST_FAILED = 4 };
-enum OptMethod { OPT_VANILLA = 0, OPT_NESTEROV = 1, OPT_ADAM = 2, OPT_NADAM = 3, OPT_AMSGRAD = 4 };
-
-// Two values per lane, for the kernels that carry two tangent columns on one lane: native 2-vectors on the GPU (the
-// tangent code is linear, so it compiles to v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 at the scalar issue rate), a plain
-// struct in the CPU emulator build.
-#if defined(LFSD_EMU)
-template <typename T> struct pk2 {
-  T x, y;
-  pk2() = default;
-  pk2(T s) : x(s), y(s) {}
-  pk2(T a, T b) : x(a), y(b) {}
-};
-template <typename T> inline pk2<T> operator+(pk2<T> a, pk2<T> b) { return pk2<T>(a.x + b.x, a.y + b.y); }
-template <typename T> inline pk2<T> operator-(pk2<T> a, pk2<T> b) { return pk2<T>(a.x - b.x, a.y - b.y); }
-template <typename T> inline pk2<T> operator-(pk2<T> a) { return pk2<T>(-a.x, -a.y); }
-template <typename T> inline pk2<T> operator*(pk2<T> a, pk2<T> b) { return pk2<T>(a.x * b.x, a.y * b.y); }
-template <typename T> inline pk2<T> operator*(T a, pk2<T> b) { return pk2<T>(a * b.x, a * b.y); }
-template <typename T> inline pk2<T> operator*(pk2<T> a, T b) { return pk2<T>(a.x * b, a.y * b); }
-template <typename T> inline pk2<T> operator+(T a, pk2<T> b) { return pk2<T>(a + b.x, a + b.y); }
-template <typename T> inline pk2<T> operator+(pk2<T> a, T b) { return pk2<T>(a.x + b, a.y + b); }
-template <typename T> inline pk2<T> operator/(pk2<T> a, T b) { return pk2<T>(a.x / b, a.y / b); }
-template <typename T> inline pk2<T> operator/(pk2<T> a, pk2<T> b) { return pk2<T>(a.x / b.x, a.y / b.y); }
-template <typename T> inline pk2<T> operator-(pk2<T> a, T b) { return pk2<T>(a.x - b, a.y - b); }
-template <typename T> inline pk2<T> operator-(T a, pk2<T> b) { return pk2<T>(a - b.x, a - b.y); }
-template <typename T> inline pk2<T>& operator+=(pk2<T>& a, pk2<T> b) { a.x += b.x; a.y += b.y; return a; }
-template <typename T> inline pk2<T>& operator-=(pk2<T>& a, pk2<T> b) { a.x -= b.x; a.y -= b.y; return a; }
-#else
-template <typename T> using pk2 = T __attribute__((ext_vector_type(2)));
-#endif
-template <typename T> LFSD_DEV pk2<T> mk2(T a, T b) { pk2<T> v; v.x = a; v.y = b; return v; }
-
-// ---- wave-level matrix helpers of the MFMA backward sweep (fp32, four 16-lane trajectories per wavefront) --------------
-// mfma4b: v_mfma_f32_16x16x1_4b_f32 -- four independent 16x16 rank-1 updates, block b fed by the lanes of 16-lane group b:
-//   D_b[i][j] += a(lane 16b+i) * b(lane 16b+j);  D_b[i][j] lives in register 4b + i%4 of lane 16(i/4) + j.
-// tile_transpose: afterwards lane 16b+j holds D_b[i][j] in register i (column j of ITS block: the column-per-lane layout
-//   of the rest of the kernel), by 8 v_permlane32_swap + 8 v_permlane16_swap.
-// Both must be reached by all 64 lanes.  The emulator build restates them with an exchange buffer.
-#if defined(LFSD_EMU)
-struct f32x16 {
-  float v[16];
-  float& operator[](int i) { return v[i]; }
-  const float& operator[](int i) const { return v[i]; }
-};
-inline void mfma4b(float a, float b, f32x16& acc) {
-  static float sa[64], sb[64];
-  const int l = threadIdx.x;
-  sa[l] = a; sb[l] = b;
-  __syncthreads();
-  for (int r = 0; r < 16; ++r) {
-    const int blk = r / 4, i = 4 * (l >> 4) + r % 4, j = l & 15;
-    acc[r] = std::fmaf(sa[16 * blk + i], sb[16 * blk + j], acc[r]);      // the hardware's k-ordered fmaf chain
-  }
-  __syncthreads();
-}
-inline void tile_transpose(f32x16& acc) {
-  static float sx[64][16];
-  const int l = threadIdx.x, b = l >> 4, j = l & 15;
-  for (int r = 0; r < 16; ++r) sx[l][r] = acc[r];
-  __syncthreads();
-  for (int q = 0; q < 4; ++q)
-    for (int r = 0; r < 4; ++r) acc[4 * q + r] = sx[16 * q + j][4 * b + r];
-  __syncthreads();
-}
-#else
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-LFSD_DEV void mfma4b(float a, float b, f32x16& acc) { acc = __builtin_amdgcn_mfma_f32_16x16x1f32(a, b, acc, 0, 0, 0); }
-LFSD_DEV void tile_transpose(f32x16& acc) {
-  // exchange the block index (register group 4R..4R+3) with the lane-group index, one bit per stage
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-#pragma unroll
-    for (int R0 = 0; R0 < 2; ++R0) {        // bit 1: register groups R0 / R0+2  <->  lane halves
-      const float lo = acc[4 * R0 + r], hi = acc[4 * (R0 + 2) + r];      // (scalars first: __builtin_bit_cast applied to a
-      const auto v = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, lo),      //  vector ELEMENT reads element 0)
-                                                      __builtin_bit_cast(unsigned, hi), false, false);
-      const unsigned v0 = v[0], v1 = v[1];
-      acc[4 * R0 + r] = __builtin_bit_cast(float, v0);
-      acc[4 * (R0 + 2) + r] = __builtin_bit_cast(float, v1);
-    }
-  }
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-#pragma unroll
-    for (int R1 = 0; R1 < 2; ++R1) {        // bit 0: register groups 2R1 / 2R1+1  <->  odd / even 16-lane rows
-      const float lo = acc[8 * R1 + r], hi = acc[8 * R1 + 4 + r];
-      const auto v = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, lo),
-                                                      __builtin_bit_cast(unsigned, hi), false, false);
-      const unsigned v0 = v[0], v1 = v[1];
-      acc[8 * R1 + r] = __builtin_bit_cast(float, v0);
-      acc[8 * R1 + 4 + r] = __builtin_bit_cast(float, v1);
-    }
-  }
-}
-#endif
-
-template <typename T> struct Eps;
-template <> struct Eps<float> { static LFSD_DEV float v() { return 1.1920929e-07f; } };
-template <> struct Eps<double> { static LFSD_DEV double v() { return 2.220446049250313e-16; } };
-
-template <typename T> LFSD_DEV T t_abs(T a) { return a < T(0) ? -a : a; }
-template <typename T> LFSD_DEV T t_max(T a, T b) { return a > b ? a : b; }
-template <typename T> LFSD_DEV T t_min(T a, T b) { return a < b ? a : b; }
-template <typename T> LFSD_DEV bool t_finite(T a) { return (a - a) == T(0); }
-LFSD_DEV float t_sqrt(float a) { return sqrtf(a); }
-LFSD_DEV double t_sqrt(double a) { return sqrt(a); }
-LFSD_DEV float t_floor(float a) { return floorf(a); }
-LFSD_DEV double t_floor(double a) { return floor(a); }
-LFSD_DEV float t_pow(float a, float b) { return powf(a, b); }
-LFSD_DEV double t_pow(double a, double b) { return pow(a, b); }
-
-// ---- tiny dense helpers on group-uniform n x n matrices (row-major, in registers) -----------
-// Cholesky A = L L^T in place (lower); false if not positive definite.
-template <int n, typename T> LFSD_DEV bool chol_factor(T* A, T& dmin) {
-  bool ok = true;
-#pragma unroll
-  for (int j = 0; j < n; ++j) {
-    T d = A[j * n + j];
-#pragma unroll
-    for (int k = 0; k < j; ++k) d -= A[j * n + k] * A[j * n + k];
-    if (!(d > T(0))) { if (ok && d < dmin) dmin = d; ok = false; d = T(1); }    // only the first failing pivot is meaningful
-    d = t_sqrt(d);
-    A[j * n + j] = d;
-    const T inv = T(1) / d;
-#pragma unroll
-    for (int i = j + 1; i < n; ++i) {
-      T s = A[i * n + j];
-#pragma unroll
-      for (int k = 0; k < j; ++k) s -= A[i * n + k] * A[j * n + k];
-      A[i * n + j] = s * inv;
-    }
-  }
-  return ok;
-}
-template <int n, typename T> LFSD_DEV void chol_solve(const T* Lm, T* b) {
-#pragma unroll
-  for (int i = 0; i < n; ++i) {
-    T s = b[i];
-#pragma unroll
-    for (int k = 0; k < i; ++k) s -= Lm[i * n + k] * b[k];
-    b[i] = s / Lm[i * n + i];
-  }
-#pragma unroll
-  for (int i = n - 1; i >= 0; --i) {
-    T s = b[i];
-#pragma unroll
-    for (int k = i + 1; k < n; ++k) s -= Lm[k * n + i] * b[k];
-    b[i] = s / Lm[i * n + i];
-  }
-}
-// Box-constrained stage problem of the control-limited backward sweep (finite control_lb / control_ub of
-// COCSys.setControlVariable, CPDP.py:33-46, which the reference hands to IPOPT as lbw / ubw):
-//     min_x  1/2 x^T Q x + q^T x   s.t.  lo <= x <= hi            (Q = Q_uu + mu I positive definite, n <= 4 controls)
-// by a primal active-set iteration on the masked system (clamped rows / columns replaced by identity): solve, clamp the
-// components that left the box, re-solve; when nothing moves, release the clamped component whose multiplier has the
-// wrong sign most.  Returns the Cholesky factor of the final masked matrix in Lf (the feedback gains of the free
-// components are solved with it; clamped components get zero gain) and the clamp mask.
-template <int n, typename T> LFSD_DEV bool box_qp(const T* Q, const T* q, const T* lo, const T* hi, T* x, unsigned& mask, T* Lf, T& dmin) {
-  mask = 0u;
-  T xc[n];
-#pragma unroll
-  for (int i = 0; i < n; ++i) xc[i] = T(0);
-  bool ok = true;
-  for (int round = 0; round < 3 * n + 2; ++round) {
-    T b[n];
-#pragma unroll
-    for (int i = 0; i < n; ++i) {
-      const bool ci = (mask >> i) & 1u;
-      T s = ci ? xc[i] : -q[i];
-#pragma unroll
-      for (int j = 0; j < n; ++j) {
-        const bool cj = (mask >> j) & 1u;
-        Lf[i * n + j] = (ci || cj) ? ((i == j) ? T(1) : T(0)) : Q[i * n + j];
-        if (!ci && cj) s -= Q[i * n + j] * xc[j];
-      }
-      b[i] = s;
-    }
-    T dd = T(0);
-    if (!chol_factor<n>(Lf, dd)) { ok = false; if (dd < dmin) dmin = dd; break; }
-    chol_solve<n>(Lf, b);
-    unsigned newmask = mask;
-#pragma unroll
-    for (int i = 0; i < n; ++i) {
-      if ((mask >> i) & 1u) continue;
-      if (b[i] < lo[i]) { newmask |= 1u << i; xc[i] = lo[i]; }
-      else if (b[i] > hi[i]) { newmask |= 1u << i; xc[i] = hi[i]; }
-    }
-#pragma unroll
-    for (int i = 0; i < n; ++i) x[i] = ((newmask >> i) & 1u) ? xc[i] : b[i];
-    if (newmask != mask) { mask = newmask; continue; }
-    // stationary for this active set: multipliers g_i = (Q x + q)_i of the clamped components must push outward
-    int worst = -1;
-    T wv = T(0);
-#pragma unroll
-    for (int i = 0; i < n; ++i) {
-      if (!((mask >> i) & 1u)) continue;
-      T g = q[i];
-#pragma unroll
-      for (int j = 0; j < n; ++j) g += Q[i * n + j] * x[j];
-      const T viol = (xc[i] <= lo[i]) ? -g : g;         // at the lower bound the gradient must be >= 0, at the upper <= 0
-      if (viol > wv) { wv = viol; worst = i; }
-    }
-    if (worst < 0) break;
-    mask &= ~(1u << worst);
-  }
-  return ok;
-}
-// LU without pivoting, in place (unit lower + upper).  For I + small and SPD-like matrices.
-template <int n, typename T> LFSD_DEV void lu_factor(T* A) {
-#pragma unroll
-  for (int j = 0; j < n; ++j) {
-    const T inv = T(1) / A[j * n + j];
-#pragma unroll
-    for (int i = j + 1; i < n; ++i) {
-      const T f = A[i * n + j] * inv;
-      A[i * n + j] = f;
-#pragma unroll
-      for (int k = j + 1; k < n; ++k) A[i * n + k] -= f * A[j * n + k];
-    }
-  }
-}
-template <int n, typename T> LFSD_DEV void lu_solve(const T* A, T* b) {
-#pragma unroll
-  for (int i = 0; i < n; ++i) {
-#pragma unroll
-    for (int k = 0; k < i; ++k) b[i] -= A[i * n + k] * b[k];
-  }
-#pragma unroll
-  for (int i = n - 1; i >= 0; --i) {
-#pragma unroll
-    for (int k = i + 1; k < n; ++k) b[i] -= A[i * n + k] * b[k];
-    b[i] /= A[i * n + i];
-  }
-}
-template <int n, typename T> LFSD_DEV void mat_inverse(const T* A, T* Ainv) {
-  T F[n * n];
-#pragma unroll
-  for (int i = 0; i < n * n; ++i) F[i] = A[i];
-  lu_factor<n>(F);
-#pragma unroll
-  for (int c = 0; c < n; ++c) {
-    T b[n];
-#pragma unroll
-    for (int i = 0; i < n; ++i) b[i] = (i == c) ? T(1) : T(0);
-    lu_solve<n>(F, b);
-#pragma unroll
-    for (int i = 0; i < n; ++i) Ainv[i * n + c] = b[i];
-  }
-}
-template <int n, typename T> LFSD_DEV void matmul(const T* A, const T* B, T* C) {
-#pragma unroll
-  for (int i = 0; i < n; ++i) {
-#pragma unroll
-    for (int j = 0; j < n; ++j) {
-      T s = T(0);
-#pragma unroll
-      for (int k = 0; k < n; ++k) s += A[i * n + k] * B[k * n + j];
-      C[i * n + j] = s;
-    }
-  }
-}
-// P = phi1(M) = M^-1 (I - exp(-M)) for a small matrix with non-negative spectrum
-// (scaling and squaring: Taylor of degree 8 on M/2^s, then phi1(2A) = (I + e^-A) phi1(A) / 2).
-template <typename T> struct PhiDeg;
-template <> struct PhiDeg<float> { static constexpr int v = 6; };
-template <> struct PhiDeg<double> { static constexpr int v = 9; };
-// P = phi1(M), P2 = phi1(2M)
-template <int n, typename T> LFSD_DEV void phi1_neg(const T* M, T* P, T* P2) {
-  T nrm = T(0);
-#pragma unroll
-  for (int i = 0; i < n; ++i) {
-    T r = T(0);
-#pragma unroll
-    for (int j = 0; j < n; ++j) r += t_abs(M[i * n + j]);
-    nrm = t_max(nrm, r);
-  }
-  int sq = 0;
-  T sc = T(1);
-  while (nrm * sc > T(0.25) && sq < 60) { sc *= T(0.5); ++sq; }
-  T A[n * n], E[n * n], W[n * n];
-#pragma unroll
-  for (int i = 0; i < n * n; ++i) { A[i] = M[i] * sc; P[i] = T(0); }
-  const T ck[10] = {T(1), T(1) / T(2), T(1) / T(6), T(1) / T(24), T(1) / T(120), T(1) / T(720), T(1) / T(5040),
-                    T(1) / T(40320), T(1) / T(362880), T(1) / T(3628800)};
-  constexpr int DEG = PhiDeg<T>::v;       // |A| <= 1/4: truncation 4^-(DEG+1)/(DEG+2)! below round-off
-#pragma unroll
-  for (int i = 0; i < n; ++i) P[i * n + i] = ck[DEG];
-#pragma unroll
-  for (int k = DEG - 1; k >= 0; --k) {
-    matmul<n>(A, P, W);
-#pragma unroll
-    for (int i = 0; i < n * n; ++i) P[i] = -W[i];
-#pragma unroll
-    for (int i = 0; i < n; ++i) P[i * n + i] += ck[k];
-  }
-  matmul<n>(A, P, W);
-#pragma unroll
-  for (int i = 0; i < n * n; ++i) E[i] = -W[i];
-#pragma unroll
-  for (int i = 0; i < n; ++i) E[i * n + i] += T(1);
-  for (int it = 0; it < sq; ++it) {
-    matmul<n>(E, P, W);
-#pragma unroll
-    for (int i = 0; i < n * n; ++i) P[i] = T(0.5) * (P[i] + W[i]);
-    matmul<n>(E, E, W);
-#pragma unroll
-    for (int i = 0; i < n * n; ++i) E[i] = W[i];
-  }
-  matmul<n>(E, P, W);
-#pragma unroll
-  for (int i = 0; i < n * n; ++i) P2[i] = T(0.5) * (P[i] + W[i]);
-}
-template <int n, typename T> LFSD_DEV void matvec(const T* A, const T* v, T* y) {
-#pragma unroll
-  for (int i = 0; i < n; ++i) {
-    T s = T(0);
-#pragma unroll
-    for (int k = 0; k < n; ++k) s += A[i * n + k] * v[k];
-    y[i] = s;
-  }
-}
-
-// =====================================================================================
-//  Optimal-control solve
-// =====================================================================================
-template <typename T> struct OcArgs {
-  int batch, n_grid, steps_per_grid, max_iter;
-  const T* ini_state;   // [B][NX]
-  const T* horizon;     // [B]
-  const T* auxvar;      // [B][NP]
-  const T* consts;      // [B or 1][NC]
-  int const_stride;     // NC or 0
-  const T* u_init;      // [B][N][NU] or nullptr (zeros, the reference's w0 for unbounded controls)
-  T* state_grid;        // [B][N+1][NX]
-  T* control_grid;      // [B][N+1][NU]  (last row repeats row N-1, CPDP.py:191)
-  T* costate_grid;      // [B][N+1][NX]
-  T* cost;              // [B]
-  int* iters;           // [B]
-  int* status;          // [B]
-  T* ws;                // per-trajectory scratch, ws_stride elements each
-  long long ws_stride;
-  T tol;                // stop when max|dJ/du| < tol*(1+|J|)
-  int exact_after;      // iteration from which the exact stage Hessian is forced (0: from the start, <0: never)
-  int it_start;         // iteration counter to start from (phase 2 of a two-launch solve)
-  int max_iter_total;   // overall iteration limit of the solve (phase 1 only hands over if a phase 2 follows)
-  int resume;           // 1: continue only trajectories whose status is ST_MAXITER, warm-started from control_grid
-  const T* u_lb;        // [NU] finite control bounds (CPDP.py:33-46) or nullptr; handled by the wide kernel
-  const T* u_ub;
-};
-
-template <class M> struct OcLayout {
-  static constexpr int NX = M::NX, NU = M::NU, NXU = NX + NU;
-  // scratch per trajectory (elements)
-  static constexpr int SMAX = 8;       // RK4 sub-steps per grid interval supported by the exact-Hessian sweep
-  // The linearisation [A B; q] of interval k and its exact stage Hessian are stored ROW-major with the column index
-  // fastest ([k][row][column], rows padded to an even length): lane j owns column j, so one store / load instruction of
-  // the tangent sweep (writer) and of the backward sweep (reader) touches NXU consecutive words -- one or two cache lines
-  // -- where the column-major layout of round 1 touched NXU lines at a 56-byte stride (83x the algorithmic traffic in
-  // the round-1 profile).  An even row length keeps the two-column stores of the packed roll-out 8-byte aligned.
-  static constexpr int NXUP = (NXU + 1) / 2 * 2;
-  static constexpr int M_ELEMS = (NX + 1) * NXUP;                // [A B] rows + the cost-gradient row q, per interval
-  static constexpr int H_ELEMS = NXU * NXUP;
-  template <int G> LFSD_HD static long long ws_elems(int N) {
-    const long long n = 2LL * (N + 1) * NX + 2LL * N * NU + 2LL * N * M_ELEMS + 1LL * N * NX * NU + 1LL * N * NU +
-           1LL * (N + 1) * NX + 1LL * SMAX * NX * (1 + G) +     // + sub-step start states (uniform | per lane)
-           1LL * N * H_ELEMS;                                    // + exact stage Hessians of the current nominal
-    return (n + 1) / 2 * 2;
-  }
-  // wide mapping (one trajectory per wavefront): the above for 64 lanes + the parked roll-outs of the 16 step lengths
-  // + per-lane sub-step start states of the exact-Hessian sweeps
-  static constexpr int WIDE_NAL = 16;
-  LFSD_HD static long long ws_elems_wide(int N) {
-    const long long n = ws_elems<64>(N) + 1LL * WIDE_NAL * ((N + 1) * NX + N * NU) + 1LL * SMAX * NX * 64;
-    return (n + 1) / 2 * 2;
-  }
-  // LDS per group (elements)
-  static constexpr int LDS_V = 0;
-  static constexpr int LDS_M = LDS_V + NX * NX;
-  static constexpr int LDS_K = LDS_M + NXU * NX;
-  static constexpr int LDS_QUX = LDS_K + NX * NU;
-  static constexpr int LDS_QUU = LDS_QUX + NX * NU;
-  static constexpr int LDS_QU = LDS_QUU + NU * NU;
-  static constexpr int LDS_VX = LDS_QU + NU;
-  static constexpr int LDS_LAM = LDS_VX + NX;
-  static constexpr int LDS_RED = LDS_LAM + NX;       // G entries
-  // cold per-trajectory state kept in LDS rather than in (spilling) registers
-  template <int G> static constexpr int lds_e() { return LDS_RED + G; }
-  template <int G> static constexpr int lds_c() { return lds_e<G>() + M::NP; }
-  template <int G> static constexpr int lds_x0() { return lds_c<G>() + M::NC; }
-  // exact-Hessian sweep: per-lane slots for the 4 RK4 stage points (uniform copy + this lane's tangent)
-  template <int G> static constexpr int lds_ex() { return lds_x0<G>() + NX; }
-  template <int G> static constexpr int lds_elems() { return ((lds_ex<G>() + 8 * NX * G + 3) / 4) * 4; }
-};
-
-template <class M, typename T, int G, bool EXACT, bool BND = false> struct OcSolver {
-  static constexpr int NX = M::NX, NU = M::NU, NP = M::NP, NC = M::NC, NXU = NX + NU;
-  T ulb[BND ? NU : 1], uub[BND ? NU : 1];      // BND: box on the controls (clamped roll-out, box-QP backward sweep)
-  static constexpr int NALPHA = (G < 10) ? G : 10;
-  using Lay = OcLayout<M>;
-
-  int lane, N, S;
-  const T *e, *c, *x0;      // [NP], [NC], [NX] in LDS
-  T horizon, dgrid, DT;
-  T *xb[2], *ub[2], *Mws[2], *Kws, *kws, *lds, *exws, *Hws;
-  T *xa = nullptr, *ua = nullptr, *exwu = nullptr;      // wide mapping only: per-step-length roll-outs, per-lane sub-step states
-  // the double-buffered arrays are picked by a select, not by indexing the pointer arrays with a run-time value: that would
-  // put the arrays in scratch (it was the lean kernel's last 168 B/lane of scratch)
-  LFSD_DEV T* xbp(int i) const { return i ? xb[1] : xb[0]; }
-  LFSD_DEV T* ubp(int i) const { return i ? ub[1] : ub[0]; }
-  LFSD_DEV T* Mwp(int i) const { return i ? Mws[1] : Mws[0]; }
-  bool reuse_hess = false;   // exact stage Hessians in Hws belong to the nominal being swept (a retry with another shift)
-  T* lam_out;   // costate grid of this trajectory (or scratch when invalid)
-
-  LFSD_DEV T tk(int k) const { return M::TIME_VARYING ? dgrid * T(k) : T(0); }
-
-  // One RK4 step of (x, q) with frozen control; optionally with the per-lane tangent (m, mq).
-  // V: tangent type -- T (one column per lane) or pk2<T> (two columns per lane, packed math)
-  template <bool SENS, class V = T>
-  LFSD_DEV void rk4_step(T t, T* x, T& q, const T* u, V* m, V& mq, const V* du) const {
-    T xs[NX], ax[NX], f[NX], cq, aq;
-    V ms[NX], am[NX], d[NX], dq, adq;
-    const T hh = DT * T(0.5);
-    if (SENS) M::dyn_cost_jvp(t, x, u, e, c, m, du, f, cq, d, dq); else M::dyn_cost(t, x, u, e, c, f, cq);
-    aq = cq; if (SENS) adq = dq;
-#pragma unroll
-    for (int i = 0; i < NX; ++i) { ax[i] = f[i]; xs[i] = x[i] + hh * f[i]; if (SENS) { am[i] = d[i]; ms[i] = m[i] + hh * d[i]; } }
-    LFSD_SCHED_FENCE();
-    if (SENS) M::dyn_cost_jvp(t, xs, u, e, c, ms, du, f, cq, d, dq); else M::dyn_cost(t, xs, u, e, c, f, cq);
-    aq += T(2) * cq; if (SENS) adq += T(2) * dq;
-#pragma unroll
-    for (int i = 0; i < NX; ++i) { ax[i] += T(2) * f[i]; xs[i] = x[i] + hh * f[i]; if (SENS) { am[i] += T(2) * d[i]; ms[i] = m[i] + hh * d[i]; } }
-    LFSD_SCHED_FENCE();
-    if (SENS) M::dyn_cost_jvp(t, xs, u, e, c, ms, du, f, cq, d, dq); else M::dyn_cost(t, xs, u, e, c, f, cq);
-    aq += T(2) * cq; if (SENS) adq += T(2) * dq;
-#pragma unroll
-    for (int i = 0; i < NX; ++i) { ax[i] += T(2) * f[i]; xs[i] = x[i] + DT * f[i]; if (SENS) { am[i] += T(2) * d[i]; ms[i] = m[i] + DT * d[i]; } }
-    LFSD_SCHED_FENCE();
-    if (SENS) M::dyn_cost_jvp(t, xs, u, e, c, ms, du, f, cq, d, dq); else M::dyn_cost(t, xs, u, e, c, f, cq);
-    aq += cq; if (SENS) adq += dq;
-    const T h6 = DT / T(6);
-#pragma unroll
-    for (int i = 0; i < NX; ++i) { x[i] += h6 * (ax[i] + f[i]); if (SENS) m[i] += h6 * (am[i] + d[i]); }
-    q += h6 * aq; if (SENS) mq += h6 * adq;
-  }
-
-  // closed-loop control  u = ubar + alpha*kff + K (x - xbar)   (all operands group-uniform loads)
-  LFSD_DEV void control(int cur, int k, const T* x, T alpha, bool gains, T* u) const {
-    const T* ubk = ubp(cur) + k * NU;
-#pragma unroll
-    for (int a = 0; a < NU; ++a) u[a] = ubk[a];
-    if (gains) {
-      const T* xbk = xbp(cur) + k * NX;
-      const T* Kk = Kws + k * NX * NU;
-      const T* kk = kws + k * NU;
-#pragma unroll
-      for (int a = 0; a < NU; ++a) u[a] += alpha * kk[a];
-#pragma unroll
-      for (int i = 0; i < NX; ++i) {
-        const T dx = x[i] - xbk[i];
-#pragma unroll
-        for (int a = 0; a < NU; ++a) u[a] += Kk[i * NU + a] * dx;
-      }
-    }
-    if (BND) {
-#pragma unroll
-      for (int a = 0; a < NU; ++a) u[a] = t_min(t_max(u[a], ulb[a]), uub[a]);
-    }
-  }
-
-  // Roll the (closed-loop) nominal out into buffer `nxt` and linearise the shooting map along it:
-  // lane j < NX+NU propagates column j of d(x_{k+1}, Q_k)/d(x_k, u_k) through the RK4 stages.
-  LFSD_DEV T rollout_sens(int cur, int nxt, T alpha, bool gains) {
-    T x[NX], u[NU], J = T(0);
-#pragma unroll
-    for (int i = 0; i < NX; ++i) x[i] = x0[i];
-    for (int k = 0; k < N; ++k) {
-      control(cur, k, x, alpha, gains, u);
-      if (lane == 0) {
-#pragma unroll
-        for (int i = 0; i < NX; ++i) xbp(nxt)[k * NX + i] = x[i];
-#pragma unroll
-        for (int a = 0; a < NU; ++a) ubp(nxt)[k * NU + a] = u[a];
-      }
-      T m[NX], du[NU], mq = T(0), q = T(0);
-#pragma unroll
-      for (int i = 0; i < NX; ++i) m[i] = (lane == i) ? T(1) : T(0);
-#pragma unroll
-      for (int a = 0; a < NU; ++a) du[a] = (lane == NX + a) ? T(1) : T(0);
-      const T t = tk(k);
-      for (int s = 0; s < S; ++s) rk4_step<true>(t, x, q, u, m, mq, du);
-      J += q;
-      if (lane < NXU) {
-        T* Mk = Mwp(nxt) + (long long)k * Lay::M_ELEMS + lane;
-#pragma unroll
-        for (int i = 0; i < NX; ++i) Mk[i * Lay::NXUP] = m[i];
-        Mk[NX * Lay::NXUP] = mq;
-      }
-    }
-    if (lane == 0) {
-#pragma unroll
-      for (int i = 0; i < NX; ++i) xbp(nxt)[N * NX + i] = x[i];
-    }
-    J += M::final_cost(tk(N), x, e, c);
-    return J;
-  }
-
-  // The same sweep with two columns per lane: lane l < (NX+NU+1)/2 propagates columns 2l and 2l+1 as one packed
-  // tangent, so a trajectory needs half the lanes (quadrotor: 9 of a 16-lane group, four trajectories per wavefront).
-  LFSD_DEV T rollout_sens_pk(int cur, int nxt, T alpha, bool gains) {
-    using V = pk2<T>;
-    T x[NX], u[NU], J = T(0);
-#pragma unroll
-    for (int i = 0; i < NX; ++i) x[i] = x0[i];
-    const int c0 = 2 * lane, c1 = 2 * lane + 1;
-    for (int k = 0; k < N; ++k) {
-      control(cur, k, x, alpha, gains, u);
-      if (lane == 0) {
-#pragma unroll
-        for (int i = 0; i < NX; ++i) xbp(nxt)[k * NX + i] = x[i];
-#pragma unroll
-        for (int a = 0; a < NU; ++a) ubp(nxt)[k * NU + a] = u[a];
-      }
-      V m[NX], du[NU], mq = V(T(0));
-      T q = T(0);
-#pragma unroll
-      for (int i = 0; i < NX; ++i) m[i] = mk2<T>((c0 == i) ? T(1) : T(0), (c1 == i) ? T(1) : T(0));
-#pragma unroll
-      for (int a = 0; a < NU; ++a) du[a] = mk2<T>((c0 == NX + a) ? T(1) : T(0), (c1 == NX + a) ? T(1) : T(0));
-      const T t = tk(k);
-      for (int s = 0; s < S; ++s) rk4_step<true, V>(t, x, q, u, m, mq, du);
-      J += q;
-      if (c0 < NXU) {          // columns c0, c0+1 of every row as one 8-byte store (c1 < NXUP: the pad column of an odd NXU)
-        V* Mk = reinterpret_cast<V*>(Mwp(nxt) + (long long)k * Lay::M_ELEMS + c0);
-#pragma unroll
-        for (int i = 0; i < NX; ++i) Mk[i * (Lay::NXUP / 2)] = m[i];
-        Mk[NX * (Lay::NXUP / 2)] = mq;
-      }
-    }
-    if (lane == 0) {
-#pragma unroll
-      for (int i = 0; i < NX; ++i) xbp(nxt)[N * NX + i] = x[i];
-    }
-    J += M::final_cost(tk(N), x, e, c);
-    return J;
-  }
-
-  // Column `lane` of the exact Hessian of the stage Lagrangian  Q_k(x,u) + lam'^T F_k(x,u)  w.r.t. (x_k,u_k):
-  // second-order adjoint sweep through the S x 4 RK4 stages (tangent forward, adjoint + its tangent backward).
-  // No cross-lane traffic: every lane recomputes the group-uniform stage states and parks them, with its own
-  // tangents, in its private LDS slots (index (slot)*G + lane), so the routine may run under a divergent branch.
-  // WIDE (one trajectory per wavefront, lanes work on different intervals): `col` is the column, `lane` only names the
-  // private slots, and the sub-step start states are per lane too (exwu).
-  template <bool WIDE = false>
-  LFSD_DEV void stage_hessian_col(int k, const T* xk, const T* uk, const T* lam_next, T* hx, T* hu, int col = -1) {
-    constexpr int SMAX = Lay::SMAX;
-    if (!WIDE) col = lane;
-    T* ex = lds + Lay::template lds_ex<G>();
-    T* exu = WIDE ? exwu + lane : exws;      // [S][NX] uniform (all lanes store the same value) | [S][NX][G] per lane
-    constexpr int XS = WIDE ? G : 1;
-    T* exl = exws + SMAX * NX;               // [S][NX][G] per lane
-    const T t = tk(k);
-    const T h = DT;
-    T x[NX], m[NX], du[NU], q = T(0), mq = T(0);
-#pragma unroll
-    for (int i = 0; i < NX; ++i) { x[i] = xk[i]; m[i] = (col == i) ? T(1) : T(0); }
-#pragma unroll
-    for (int a = 0; a < NU; ++a) du[a] = (col == NX + a) ? T(1) : T(0);
-    for (int s = 0; s < S; ++s) {
-#pragma unroll
-      for (int i = 0; i < NX; ++i) { exu[(s * NX + i) * XS] = x[i]; exl[(s * NX + i) * G + lane] = m[i]; }
-      rk4_step<true>(t, x, q, uk, m, mq, du);
-    }
-    T lam[NX], dlam[NX];
-#pragma unroll
-    for (int i = 0; i < NX; ++i) { lam[i] = lam_next[i]; dlam[i] = T(0); }
-#pragma unroll
-    for (int a = 0; a < NU; ++a) hu[a] = T(0);
-    const T wgt[4] = {h / T(6), h / T(3), h / T(3), h / T(6)};
-    const T car[4] = {h * T(0.5), h * T(0.5), h, T(0)};      // kappa_i = w_i*lam + car_i * ybar_{i+1}
-    const T adv[3] = {h * T(0.5), h * T(0.5), h};
-    for (int s = S - 1; s >= 0; --s) {
-      // recompute the four stage points of this sub-step and park them
-      T x0s[NX], m0s[NX];
-#pragma unroll
-      for (int i = 0; i < NX; ++i) { x0s[i] = exu[(s * NX + i) * XS]; m0s[i] = exl[(s * NX + i) * G + lane]; }
-#pragma unroll
-      for (int i = 0; i < NX; ++i) { x[i] = x0s[i]; m[i] = m0s[i]; }
-      for (int st = 0; st < 4; ++st) {
-#pragma unroll
-        for (int i = 0; i < NX; ++i) { ex[(st * NX + i) * G + lane] = x[i]; ex[((4 + st) * NX + i) * G + lane] = m[i]; }
-        if (st < 3) {
-          T f[NX], d[NX], cq, dq;
-          M::dyn_cost_jvp(t, x, uk, e, c, m, du, f, cq, d, dq);
-#pragma unroll
-          for (int i = 0; i < NX; ++i) { x[i] = x0s[i] + adv[st] * f[i]; m[i] = m0s[i] + adv[st] * d[i]; }
-        }
-      }
-      T yb[NX], dyb[NX], lam_new[NX], dlam_new[NX];
-#pragma unroll
-      for (int i = 0; i < NX; ++i) { yb[i] = T(0); dyb[i] = T(0); lam_new[i] = lam[i]; dlam_new[i] = dlam[i]; }
-      for (int st = 3; st >= 0; --st) {
-        T kap[NX], dkap[NX], ls[NX], xs[NX], ms[NX], y1[NX], t2x[NX], t2u[NU], gx[NX], gu[NU];
-        const T w = wgt[st], cc = car[st], iw = T(1) / w;
-#pragma unroll
-        for (int i = 0; i < NX; ++i) {
-          kap[i] = w * lam[i] + cc * yb[i];
-          dkap[i] = w * dlam[i] + cc * dyb[i];
-          ls[i] = kap[i] * iw;
-          xs[i] = ex[(st * NX + i) * G + lane];
-          ms[i] = ex[((4 + st) * NX + i) * G + lane];
-        }
-        M::dyn_vjp2(t, xs, uk, e, c, kap, w, dkap, y1, t2x, t2u);
-        M::ham_hess_mul(t, xs, uk, ls, e, c, ms, du, gx, gu);
-#pragma unroll
-        for (int i = 0; i < NX; ++i) {
-          yb[i] = y1[i];
-          dyb[i] = t2x[i] + w * gx[i];
-          lam_new[i] += yb[i];
-          dlam_new[i] += dyb[i];
-        }
-#pragma unroll
-        for (int a = 0; a < NU; ++a) hu[a] += t2u[a] + w * gu[a];
-      }
-#pragma unroll
-      for (int i = 0; i < NX; ++i) { lam[i] = lam_new[i]; dlam[i] = dlam_new[i]; }
-    }
-#pragma unroll
-    for (int i = 0; i < NX; ++i) hx[i] = dlam[i];
-  }
-
-  // Backward sweep on buffer `cur`: DDP gains + exact discrete costate (== IPOPT's lam_g).
-  // Stage Hessian model: mode 0 Gauss-Newton (cost curvature), 1 interval * Hamiltonian Hessian (cheap Newton-like),
-  // 2 exact Lagrangian Hessian of the RK4 stage (stage_hessian_col).
-  LFSD_DEV bool backward(int cur, int mode, T mu, T& gnorm, T& dV1, T& dV2, T& dmin) {
-    T* ldsV = lds + Lay::LDS_V;  T* ldsM = lds + Lay::LDS_M;  T* ldsK = lds + Lay::LDS_K;
-    T* ldsQux = lds + Lay::LDS_QUX;  T* ldsQuu = lds + Lay::LDS_QUU;  T* ldsQu = lds + Lay::LDS_QU;
-    T* ldsVx = lds + Lay::LDS_VX;  T* ldsLam = lds + Lay::LDS_LAM;  T* ldsRed = lds + Lay::LDS_RED;
-    T Vx[NX], lam[NX], vcol[NX], xk[NX], uk[NU];
-    bool ok = true;
-    T gl_max = T(0);
-    dV1 = T(0); dV2 = T(0); dmin = T(0);
-    {
-      const T* xN = xbp(cur) + N * NX;
-#pragma unroll
-      for (int i = 0; i < NX; ++i) xk[i] = xN[i];
-      M::final_grad(tk(N), xk, e, c, Vx);
-      T ox[NX], oe[NP];
-#pragma unroll
-      for (int i = 0; i < NX; ++i) { ox[i] = (lane == i) ? T(1) : T(0); lam[i] = Vx[i]; }
-#pragma unroll
-      for (int i = 0; i < NP; ++i) oe[i] = T(0);
-      M::final_hess_mul(tk(N), xk, e, c, ox, oe, vcol);
-      if (lane == 0) {
-#pragma unroll
-        for (int i = 0; i < NX; ++i) lam_out[N * NX + i] = lam[i];
-      }
-    }
-    // this lane's column of [A B; q] and the nominal (x_k, u_k) of one interval.  The loads of interval k-1 are issued
-    // while interval k is being processed (one wave per SIMD: nothing else would hide their latency)
-    auto load_stage = [&](int k_, T* m_, T& mq_, T* xk_, T* uk_) LFSD_LAMBDA_INLINE {
-      if (lane < NXU) {
-        const T* Mk = Mwp(cur) + (long long)k_ * Lay::M_ELEMS + lane;
-#pragma unroll
-        for (int i = 0; i < NX; ++i) m_[i] = Mk[i * Lay::NXUP];
-        mq_ = Mk[NX * Lay::NXUP];
-      } else {
-#pragma unroll
-        for (int i = 0; i < NX; ++i) m_[i] = T(0);
-        mq_ = T(0);
-      }
-      const T* xp = xbp(cur) + k_ * NX;  const T* up = ubp(cur) + k_ * NU;
-#pragma unroll
-      for (int i = 0; i < NX; ++i) xk_[i] = xp[i];
-#pragma unroll
-      for (int a = 0; a < NU; ++a) uk_[a] = up[a];
-    };
-    T m[NX], mq = T(0), mN[NX], mqN = T(0), xkN[NX], ukN[NU];
-    load_stage(N - 1, m, mq, xk, uk);
-    for (int k = N - 1; k >= 0; --k) {
-      if (lane < NX) {
-#pragma unroll
-        for (int i = 0; i < NX; ++i) ldsV[lane * NX + i] = vcol[i];
-      }
-      if (lane < NXU) {
-#pragma unroll
-        for (int i = 0; i < NX; ++i) ldsM[lane * NX + i] = m[i];
-      }
-      __syncthreads();
-      if (LFSD_BW_PREFETCH && k > 0) load_stage(k - 1, mN, mqN, xkN, ukN);
-      // Y = Vxx' m_j ;  Qcol = [A B]^T Y
-      T Y[NX], Qcol[NXU];
-#pragma unroll
-      for (int i = 0; i < NX; ++i) {
-        T s = T(0);
-#pragma unroll
-        for (int kk = 0; kk < NX; ++kk) s += ldsV[i * NX + kk] * m[kk];
-        Y[i] = s;
-        LFSD_SCHED_FENCE();
-      }
-#pragma unroll
-      for (int r = 0; r < NXU; ++r) {
-        T s = T(0);
-#pragma unroll
-        for (int i = 0; i < NX; ++i) s += ldsM[r * NX + i] * Y[i];
-        Qcol[r] = s;
-        LFSD_SCHED_FENCE();
-      }
-      if (EXACT && mode == 2) {
-        // column `lane` of the exact stage Hessian depends on the nominal and its costates only, not on the shift: a
-        // retry of the sweep with a larger shift reads it back instead of repeating the second-order adjoint
-        T hx[NX], hu[NU];
-        T* hcol = Hws + (long long)k * Lay::H_ELEMS + (lane < NXU ? lane : 0);      // [row][column], column = lane
-        if (reuse_hess) {
-#pragma unroll
-          for (int i = 0; i < NX; ++i) hx[i] = hcol[i * Lay::NXUP];
-#pragma unroll
-          for (int a = 0; a < NU; ++a) hu[a] = hcol[(NX + a) * Lay::NXUP];
-        } else {
-          stage_hessian_col(k, xk, uk, lam, hx, hu);
-          if (lane < NXU) {
-#pragma unroll
-            for (int i = 0; i < NX; ++i) hcol[i * Lay::NXUP] = hx[i];
-#pragma unroll
-            for (int a = 0; a < NU; ++a) hcol[(NX + a) * Lay::NXUP] = hu[a];
-          }
-        }
-#if defined(LFSD_TRACE)
-        if (lane < NXU && blockIdx.x == 0 && threadIdx.x < G) {
-          printf("HCOL k %d lane %d x", k, lane); for (int i = 0; i < NX; ++i) printf(" %.17g", (double)xk[i]);
-          printf(" u"); for (int a = 0; a < NU; ++a) printf(" %.17g", (double)uk[a]);
-          printf(" l"); for (int i = 0; i < NX; ++i) printf(" %.17g", (double)lam[i]);
-          printf(" h"); for (int i = 0; i < NX; ++i) printf(" %.17g", (double)hx[i]); for (int a = 0; a < NU; ++a) printf(" %.17g", (double)hu[a]);
-          printf("\n");
-        }
-#endif
-#pragma unroll
-        for (int i = 0; i < NX; ++i) Qcol[i] += hx[i];
-#pragma unroll
-        for (int a = 0; a < NU; ++a) Qcol[NX + a] += hu[a];
-      } else {
-        T ox[NX], ou[NU], ls[NX], hx[NX], hu[NU];
-        const T HL = (mode == 1) ? T(1) : T(0);
-#pragma unroll
-        for (int i = 0; i < NX; ++i) { ox[i] = (lane == i) ? T(1) : T(0); ls[i] = HL * lam[i]; }
-#pragma unroll
-        for (int a = 0; a < NU; ++a) ou[a] = (lane == NX + a) ? T(1) : T(0);
-        M::ham_hess_mul(tk(k), xk, uk, ls, e, c, ox, ou, hx, hu);
-#pragma unroll
-        for (int i = 0; i < NX; ++i) Qcol[i] += dgrid * hx[i];
-#pragma unroll
-        for (int a = 0; a < NU; ++a) Qcol[NX + a] += dgrid * hu[a];
-      }
-      T Qg = mq, gl = mq;
-#pragma unroll
-      for (int i = 0; i < NX; ++i) { Qg += m[i] * Vx[i]; gl += m[i] * lam[i]; }
-      T Quxj[NU];
-#pragma unroll
-      for (int a = 0; a < NU; ++a) Quxj[a] = Qcol[NX + a];
-      if (lane < NX) {
-#pragma unroll
-        for (int a = 0; a < NU; ++a) ldsQux[lane * NU + a] = Quxj[a];
-      } else if (lane < NXU) {
-        const int b = lane - NX;
-#pragma unroll
-        for (int a = 0; a < NU; ++a) ldsQuu[b * NU + a] = Quxj[a];
-        ldsQu[b] = Qg;
-        T glp = gl;
-        if (BND) {
-          // projected gradient: a control sitting on a bound with the descent direction pointing out of the box is stationary
-          T ukb = T(0), lbb = T(0), ubb = T(0);
-#pragma unroll
-          for (int a = 0; a < NU; ++a) { if (a == b) { ukb = uk[a]; lbb = ulb[a]; ubb = uub[a]; } }
-          if ((ukb <= lbb && gl > T(0)) || (ukb >= ubb && gl < T(0))) glp = T(0);
-        }
-        gl_max = t_max(gl_max, t_abs(glp));
-      }
-      __syncthreads();
-      T Quu0[NU * NU], Lc[NU * NU], Qu[NU], kff[NU], Kj[NU], t1[NU];
-#pragma unroll
-      for (int a = 0; a < NU; ++a) {
-        Qu[a] = ldsQu[a];
-#pragma unroll
-        for (int b = 0; b < NU; ++b) Quu0[a * NU + b] = T(0.5) * (ldsQuu[b * NU + a] + ldsQuu[a * NU + b]);
-      }
-#pragma unroll
-      for (int i = 0; i < NU * NU; ++i) Lc[i] = Quu0[i];
-#pragma unroll
-      for (int a = 0; a < NU; ++a) Lc[a * NU + a] += mu;
-      if (LFSD_REG_CONSISTENT) {
-#pragma unroll
-        for (int a = 0; a < NU; ++a) Quu0[a * NU + a] += mu;
-      }
-      if (BND) {
-        // control-limited step: box QP for the feed-forward part, zero feedback gain on the clamped components
-        T lo[NU], hi[NU], Lf[NU * NU], dd = T(0);
-#pragma unroll
-        for (int a = 0; a < NU; ++a) { lo[a] = ulb[a] - uk[a]; hi[a] = uub[a] - uk[a]; }
-        unsigned cmask = 0u;
-        const bool okq = box_qp<NU>(Lc, Qu, lo, hi, kff, cmask, Lf, dd);
-        if (ok && !okq) { ok = false; if (dd < dmin) dmin = dd; }
-#pragma unroll
-        for (int a = 0; a < NU; ++a) Kj[a] = ((cmask >> a) & 1u) ? T(0) : -Quxj[a];
-        chol_solve<NU>(Lf, Kj);
-      } else {
-        if (ok) ok = chol_factor<NU>(Lc, dmin); else { T dd = T(0); chol_factor<NU>(Lc, dd); }   // first failing pivot sizes the shift
-#pragma unroll
-        for (int a = 0; a < NU; ++a) { kff[a] = -Qu[a]; Kj[a] = -Quxj[a]; }
-        chol_solve<NU>(Lc, kff);
-        chol_solve<NU>(Lc, Kj);
-      }
-      T qk[NU];
-      matvec<NU>(Quu0, kff, qk);
-#pragma unroll
-      for (int a = 0; a < NU; ++a) { dV1 += kff[a] * Qu[a]; dV2 += T(0.5) * kff[a] * qk[a]; }
-      T Vxj = Qg;
-#pragma unroll
-      for (int a = 0; a < NU; ++a) Vxj += Kj[a] * (qk[a] + Qu[a]) + Quxj[a] * kff[a];
-      if (lane < NX) {
-#pragma unroll
-        for (int a = 0; a < NU; ++a) ldsK[lane * NU + a] = Kj[a];
-        ldsVx[lane] = Vxj;
-        ldsLam[lane] = gl;
-        T* Kout = Kws + ((long long)k * NX + lane) * NU;
-#pragma unroll
-        for (int a = 0; a < NU; ++a) Kout[a] = Kj[a];
-      }
-      if (lane == 0) {
-#pragma unroll
-        for (int a = 0; a < NU; ++a) kws[k * NU + a] = kff[a];
-      }
-      __syncthreads();
-      matvec<NU>(Quu0, Kj, t1);
-#pragma unroll
-      for (int a = 0; a < NU; ++a) t1[a] += Quxj[a];
-#pragma unroll
-      for (int i = 0; i < NX; ++i) {
-        T s = Qcol[i];
-#pragma unroll
-        for (int a = 0; a < NU; ++a) s += ldsK[i * NU + a] * t1[a] + ldsQux[i * NU + a] * Kj[a];
-        vcol[i] = s;
-        Vx[i] = ldsVx[i];
-        lam[i] = ldsLam[i];
-      }
-      if (lane == 0) {
-#pragma unroll
-        for (int i = 0; i < NX; ++i) lam_out[k * NX + i] = lam[i];
-      }
-      // symmetrise V_xx through LDS (ldsV of this stage has been fully consumed above)
-      if (lane < NX) {
-#pragma unroll
-        for (int i = 0; i < NX; ++i) ldsV[lane * NX + i] = vcol[i];
-      }
-      __syncthreads();
-      if (lane < NX) {
-#pragma unroll
-        for (int i = 0; i < NX; ++i) vcol[i] = T(0.5) * (vcol[i] + ldsV[i * NX + lane]);
-      }
-      __syncthreads();
-      if (k > 0) {
-        if (LFSD_BW_PREFETCH) {
-#pragma unroll
-          for (int i = 0; i < NX; ++i) { m[i] = mN[i]; xk[i] = xkN[i]; }
-#pragma unroll
-          for (int a = 0; a < NU; ++a) uk[a] = ukN[a];
-          mq = mqN;
-        } else {
-          load_stage(k - 1, m, mq, xk, uk);
-        }
-      }
-    }
-    ldsRed[lane] = gl_max;
-    __syncthreads();
-    gnorm = T(0);
-#pragma unroll
-    for (int a = 0; a < NU; ++a) gnorm = t_max(gnorm, ldsRed[NX + a]);
-    __syncthreads();
-    if (!t_finite(gnorm) || !t_finite(dV1) || !t_finite(dV2)) ok = false;
-    return ok;
-  }
-
-  // ---- the backward sweep on the matrix cores (fp32, 16-lane groups: four trajectories per wavefront, ONE pass) -------
-  // The two dense products of a stage,  Y = V_xx [A B]  and  Q = [A B]^T Y,  run as rank-1 updates of the 4-block MFMA
-  // v_mfma_f32_16x16x1_4b_f32 (mfma4b): block b = trajectory b of the wavefront, operands straight from the registers
-  // of the column-per-lane layout (lane i of a group owns column i of V_xx -- symmetric, so also row i -- and column i
-  // of [A B]); the result comes back column-per-lane after one register/lane-group transposition (tile_transpose).
-  // 2 x NX MFMAs per stage for FOUR trajectories replace 2 x (NX*NX + NXU*NX) LDS-fed FMAs per lane for two of them.
-  // The 16 lanes carry columns 0..15; a 17th column (quadrotor: NX + NU = 17) is carried as a row-per-lane vector in LDS
-  // and enters through NX-term dot products; its rows of Q and of the stage Hessian follow from symmetry, its diagonal
-  // element from M::ham_huu.  Stage-Hessian models 0 / 1 only (lean kernel); the exact model keeps the 32-lane sweep.
-  static constexpr int NCL = (NXU < 16) ? NXU : 16;      // columns carried by lanes
-  static constexpr int NUL = NCL - NX;                   // ... of them control columns
-  static constexpr int NEXT = NXU - NCL;                 // columns carried in LDS (0 or 1)
-  LFSD_DEV bool backward_mf(int cur, int mode, T mu, bool live, T& gnorm, T& dV1, T& dV2, T& dmin) {
-    static_assert(G == 16 && NX <= 16 && NEXT <= 1, "MFMA backward sweep: 16-lane groups, at most one column beyond 16");
-    T* ldsV = lds + Lay::LDS_V;  T* ldsK = lds + Lay::LDS_K;
-    T* ldsQux = lds + Lay::LDS_QUX;  T* ldsQuu = lds + Lay::LDS_QUU;  T* ldsQu = lds + Lay::LDS_QU;
-    T* ldsVx = lds + Lay::LDS_VX;  T* ldsLam = lds + Lay::LDS_LAM;  T* ldsRed = lds + Lay::LDS_RED;
-    T* ldsME = lds + Lay::LDS_M;              // [NX] extra column of [A B], [NX] its q entry   (LDS_M region: NXU*NX words)
-    T* ldsYE = ldsME + NX + 1;                // [NX] V_xx times that column
-    T Vx[NX], lam[NX], vcol[NX], xk[NX], uk[NU];
-    bool ok = true;
-    T gl_max = T(0);
-    dV1 = T(0); dV2 = T(0); dmin = T(0);
-    {
-      const T* xN = xbp(cur) + N * NX;
-#pragma unroll
-      for (int i = 0; i < NX; ++i) xk[i] = xN[i];
-      M::final_grad(tk(N), xk, e, c, Vx);
-      T ox[NX], oe[NP];
-#pragma unroll
-      for (int i = 0; i < NX; ++i) { ox[i] = (lane == i) ? T(1) : T(0); lam[i] = Vx[i]; }
-#pragma unroll
-      for (int i = 0; i < NP; ++i) oe[i] = T(0);
-      M::final_hess_mul(tk(N), xk, e, c, ox, oe, vcol);      // lanes >= NX: ox = 0  ->  vcol = 0
-      if (lane == 0 && live) {
-#pragma unroll
-        for (int i = 0; i < NX; ++i) lam_out[N * NX + i] = lam[i];
-      }
-    }
-    for (int k = N - 1; k >= 0; --k) {
-      T m[NX], mq = T(0);
-      const T* Mk = Mwp(cur) + (long long)k * Lay::M_ELEMS;
-      if (lane < NCL) {
-#pragma unroll
-        for (int i = 0; i < NX; ++i) m[i] = Mk[i * Lay::NXUP + lane];
-        mq = Mk[NX * Lay::NXUP + lane];
-      } else {
-#pragma unroll
-        for (int i = 0; i < NX; ++i) m[i] = T(0);
-      }
-      if (NEXT) {                                  // column NCL of [A B; q]: row `lane` of it, parked in LDS
-        if (lane <= NX) ldsME[lane] = Mk[lane * Lay::NXUP + NCL];
-      }
-      {
-        const T* xp = xbp(cur) + k * NX;  const T* up = ubp(cur) + k * NU;
-#pragma unroll
-        for (int i = 0; i < NX; ++i) xk[i] = xp[i];
-#pragma unroll
-        for (int a = 0; a < NU; ++a) uk[a] = up[a];
-      }
-      // Y = V_xx [A B](:, 0..15)
-      f32x16 acc;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-#pragma unroll
-      for (int kk = 0; kk < NX; ++kk) mfma4b(vcol[kk], m[kk], acc);
-      // stage-Hessian column of this lane (vector pipe; independent of the products in flight on the matrix pipe)
-      T hx[NX], hu[NU], huu[NU * NU];
-      {
-        T ox[NX], ou[NU], ls[NX];
-        const T HL = (mode == 1) ? T(1) : T(0);
-#pragma unroll
-        for (int i = 0; i < NX; ++i) { ox[i] = (lane == i) ? T(1) : T(0); ls[i] = HL * lam[i]; }
-#pragma unroll
-        for (int a = 0; a < NU; ++a) ou[a] = (lane == NX + a) ? T(1) : T(0);
-        M::ham_hess_mul(tk(k), xk, uk, ls, e, c, ox, ou, hx, hu);
-        if (NEXT) M::ham_huu(tk(k), xk, uk, ls, e, c, huu);
-      }
-      tile_transpose(acc);
-      T ycol[16];
-#pragma unroll
-      for (int r = 0; r < 16; ++r) ycol[r] = acc[r];
-      __syncthreads();                             // ldsME visible
-      T q_e = T(0), q_ee = T(0), Qg_e = T(0), gl_e = T(0);      // row NCL of Q at this lane's column; its diagonal; gradient terms
-      if (NEXT) {
-        T ye = T(0);
-#pragma unroll
-        for (int kk = 0; kk < NX; ++kk) { ye += vcol[kk] * ldsME[kk]; q_e += ldsME[kk] * ycol[kk]; }
-        if (lane < NX) ldsYE[lane] = ye;           // (V_xx m_e)_lane : V_xx row `lane` == this lane's column
-      }
-      // Q(0..15, 0..15) = [A B]^T Y
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-#pragma unroll
-      for (int kk = 0; kk < NX; ++kk) mfma4b(m[kk], ycol[kk], acc);
-      T Qg = mq, gl = mq;
-#pragma unroll
-      for (int i = 0; i < NX; ++i) { Qg += m[i] * Vx[i]; gl += m[i] * lam[i]; }
-      tile_transpose(acc);
-      T Qcol[NXU];
-#pragma unroll
-      for (int r = 0; r < NCL; ++r) Qcol[r] = acc[r];
-      __syncthreads();                             // ldsYE visible
-      if (NEXT) {
-        Qg_e = ldsME[NX]; gl_e = ldsME[NX];
-#pragma unroll
-        for (int kk = 0; kk < NX; ++kk) { q_ee += ldsME[kk] * ldsYE[kk]; Qg_e += ldsME[kk] * Vx[kk]; gl_e += ldsME[kk] * lam[kk]; }
-        // symmetry of the stage Hessian: row NCL of column j is the last control entry of column j's own product
-        q_e += dgrid * hu[NU - 1];
-        q_ee += dgrid * huu[NU * NU - 1];
-        Qcol[NCL] = q_e;
-      }
-#pragma unroll
-      for (int i = 0; i < NX; ++i) Qcol[i] += dgrid * hx[i];
-#pragma unroll
-      for (int a = 0; a < NUL; ++a) Qcol[NX + a] += dgrid * hu[a];
-      T Quxj[NU];
-#pragma unroll
-      for (int a = 0; a < NU; ++a) Quxj[a] = Qcol[NX + a];
-      if (lane < NX) {
-#pragma unroll
-        for (int a = 0; a < NU; ++a) ldsQux[lane * NU + a] = Quxj[a];
-      } else if (lane < NCL) {
-        const int b = lane - NX;
-#pragma unroll
-        for (int a = 0; a < NU; ++a) ldsQuu[b * NU + a] = Quxj[a];
-        ldsQu[b] = Qg;
-        gl_max = t_max(gl_max, t_abs(gl));
-        if (NEXT) ldsQuu[(NU - 1) * NU + b] = q_e;           // column NCL of Q_uu from its row (symmetric)
-      }
-      if (NEXT) {
-        if (lane == 0) { ldsQuu[NU * NU - 1] = q_ee; ldsQu[NU - 1] = Qg_e; }
-        gl_max = t_max(gl_max, (lane == NX) ? t_abs(gl_e) : T(0));
-      }
-      __syncthreads();
-      T Quu0[NU * NU], Lc[NU * NU], Qu[NU], kff[NU], Kj[NU], t1[NU];
-#pragma unroll
-      for (int a = 0; a < NU; ++a) {
-        Qu[a] = ldsQu[a];
-#pragma unroll
-        for (int b = 0; b < NU; ++b) Quu0[a * NU + b] = T(0.5) * (ldsQuu[b * NU + a] + ldsQuu[a * NU + b]);
-      }
-#pragma unroll
-      for (int i = 0; i < NU * NU; ++i) Lc[i] = Quu0[i];
-#pragma unroll
-      for (int a = 0; a < NU; ++a) Lc[a * NU + a] += mu;
-      if (ok) ok = chol_factor<NU>(Lc, dmin); else { T dd = T(0); chol_factor<NU>(Lc, dd); }
-      if (LFSD_REG_CONSISTENT) {
-#pragma unroll
-        for (int a = 0; a < NU; ++a) Quu0[a * NU + a] += mu;
-      }
-#pragma unroll
-      for (int a = 0; a < NU; ++a) { kff[a] = -Qu[a]; Kj[a] = -Quxj[a]; }
-      chol_solve<NU>(Lc, kff);
-      chol_solve<NU>(Lc, Kj);
-      T qk[NU];
-      matvec<NU>(Quu0, kff, qk);
-#pragma unroll
-      for (int a = 0; a < NU; ++a) { dV1 += kff[a] * Qu[a]; dV2 += T(0.5) * kff[a] * qk[a]; }
-      T Vxj = Qg;
-#pragma unroll
-      for (int a = 0; a < NU; ++a) Vxj += Kj[a] * (qk[a] + Qu[a]) + Quxj[a] * kff[a];
-      if (lane < NX) {
-#pragma unroll
-        for (int a = 0; a < NU; ++a) ldsK[lane * NU + a] = Kj[a];
-        ldsVx[lane] = Vxj;
-        ldsLam[lane] = gl;
-        if (live) {
-          T* Kout = Kws + ((long long)k * NX + lane) * NU;
-#pragma unroll
-          for (int a = 0; a < NU; ++a) Kout[a] = Kj[a];
-        }
-      }
-      if (lane == 0 && live) {
-#pragma unroll
-        for (int a = 0; a < NU; ++a) kws[k * NU + a] = kff[a];
-      }
-      __syncthreads();
-      matvec<NU>(Quu0, Kj, t1);
-#pragma unroll
-      for (int a = 0; a < NU; ++a) t1[a] += Quxj[a];
-#pragma unroll
-      for (int i = 0; i < NX; ++i) {
-        T sacc = Qcol[i];
-#pragma unroll
-        for (int a = 0; a < NU; ++a) sacc += ldsK[i * NU + a] * t1[a] + ldsQux[i * NU + a] * Kj[a];
-        vcol[i] = sacc;
-        Vx[i] = ldsVx[i];
-        lam[i] = ldsLam[i];
-      }
-      if (lane == 0 && live) {
-#pragma unroll
-        for (int i = 0; i < NX; ++i) lam_out[k * NX + i] = lam[i];
-      }
-      // symmetrise V_xx through LDS (the rank-1 feeds above rely on row i == column i); lanes >= NX carry no column
-      if (lane < NX) {
-#pragma unroll
-        for (int i = 0; i < NX; ++i) ldsV[lane * NX + i] = vcol[i];
-      }
-      __syncthreads();
-#pragma unroll
-      for (int i = 0; i < NX; ++i) vcol[i] = (lane < NX) ? T(0.5) * (vcol[i] + ldsV[i * NX + lane]) : T(0);
-      __syncthreads();
-    }
-    ldsRed[lane] = gl_max;
-    __syncthreads();
-    gnorm = T(0);
-#pragma unroll
-    for (int a = 0; a < NUL; ++a) gnorm = t_max(gnorm, ldsRed[NX + a]);      // (lane NX also carries the LDS column's entry)
-    __syncthreads();
-    if (!t_finite(gnorm) || !t_finite(dV1) || !t_finite(dV2)) ok = false;
-    return ok;
-  }
-
-  // Lane l tries step length 2^-l (all candidate roll-outs run concurrently in the group).
-  // Returns the index of the largest accepted step (or -1) and the best cost seen.
-  LFSD_DEV int linesearch(int cur, T J, T dV1, T dV2, T& alpha_out, T& Jmin, bool& flat_full) {
-    T* ldsRed = lds + Lay::LDS_RED;
-    T alpha = T(0);
-    if (lane < NALPHA) { alpha = T(1); for (int i = 0; i < lane; ++i) alpha *= T(0.5); }
-    T x[NX], u[NU], Ja = T(0), dummy = T(0);
-#pragma unroll
-    for (int i = 0; i < NX; ++i) x[i] = x0[i];
-    for (int k = 0; k < N; ++k) {
-      control(cur, k, x, alpha, true, u);
-      T q = T(0);
-      const T t = tk(k);
-      for (int s = 0; s < S; ++s) rk4_step<false>(t, x, q, u, x, dummy, u);
-      Ja += q;
-    }
-    Ja += M::final_cost(tk(N), x, e, c);
-    ldsRed[lane] = Ja;
-    __syncthreads();
-    int ia = -1;
-    Jmin = J;
-    T a = T(1);
-    alpha_out = T(0);
-    const T flat = T(8) * Eps<T>::v() * t_abs(J);
-    flat_full = t_finite(ldsRed[0]) && t_abs(ldsRed[0] - J) <= T(64) * Eps<T>::v() * t_abs(J);
-    for (int l = 0; l < NALPHA; ++l) {
-      const T Jl = ldsRed[l];
-      const T expected = -(a * dV1 + a * a * dV2);
-      const bool okl = t_finite(Jl) && ((J - Jl) >= T(1e-4) * expected - flat) && (Jl < J);
-      if (okl && ia < 0) { ia = l; alpha_out = a; }
-      if (t_finite(Jl)) Jmin = t_min(Jmin, Jl);
-      a *= T(0.5);
-    }
-    __syncthreads();
-    return ia;
-  }
-};
-
-// The same steps for the WIDE mapping -- one trajectory per wavefront (OcSolver<M, T, 64, EXACT>), for batches that leave most
-// of the machine idle under the lock-step mapping (robot arm / rocket at 1024 trajectories per GPU: 256-512 wavefronts
-// for 1024 SIMDs, and an iteration as long as N sequential intervals).  What depends only on the nominal of ONE interval
-// is done for all intervals at once, spread over the 64 lanes:
-//   rollout_alphas      the closed-loop roll-outs of 16 step lengths, one per lane (the line search IS the roll-out)
-//   linearise_parallel  [A_k B_k; q_k] for every interval k: lane <- (k, column pair), N*ceil(NXU/2)/64 rounds
-//   costate_sweep       lambda_k = q_x + A_k^T lambda_k+1 (sequential, NX FMAs per interval)
-//   hessians_parallel   exact stage Hessian columns for every (k, column): second-order adjoint sweeps, N*NXU/64 rounds
-// which leaves only the cheap Riccati-type recursion of OcSolver::backward sequential in k.
-template <class M, typename T, bool EXACT, bool BND = false> struct OcWide : OcSolver<M, T, 64, EXACT, BND> {
-  using Base = OcSolver<M, T, 64, EXACT, BND>;
-  using Lay = OcLayout<M>;
-  static constexpr int NX = M::NX, NU = M::NU, NP = M::NP, NXU = NX + NU;
-  static constexpr int NAL = 16;                       // step lengths 2^0 .. 2^-15
-  using Base::lane; using Base::N; using Base::S; using Base::e; using Base::c; using Base::x0; using Base::xb; using Base::ub; using Base::xbp; using Base::ubp; using Base::Mwp;
-  using Base::Mws; using Base::Hws; using Base::lds; using Base::xa; using Base::ua; using Base::lam_out; using Base::DT;
-
-  // lane l < NAL rolls the closed loop out with step length 2^-l and parks states / controls at [k][component][l]
-  LFSD_DEV T rollout_alphas(int cur, bool gains, T& alpha) {
-    alpha = T(0);
-    if (lane < NAL) { alpha = T(1); for (int i = 0; i < lane; ++i) alpha *= T(0.5); }
-    T x[NX], u[NU], Ja = T(0), dummy = T(0);
-#pragma unroll
-    for (int i = 0; i < NX; ++i) x[i] = x0[i];
-    for (int k = 0; k < N; ++k) {
-      this->control(cur, k, x, alpha, gains, u);
-      if (lane < NAL) {
-#pragma unroll
-        for (int i = 0; i < NX; ++i) xa[(k * NX + i) * NAL + lane] = x[i];
-#pragma unroll
-        for (int a = 0; a < NU; ++a) ua[(k * NU + a) * NAL + lane] = u[a];
-      }
-      T q = T(0);
-      const T t = this->tk(k);
-      for (int s = 0; s < S; ++s) this->template rk4_step<false>(t, x, q, u, x, dummy, u);
-      Ja += q;
-    }
-    if (lane < NAL) {
-#pragma unroll
-      for (int i = 0; i < NX; ++i) xa[(N * NX + i) * NAL + lane] = x[i];
-    }
-    Ja += M::final_cost(this->tk(N), x, e, c);
-    return Ja;
-  }
-  // the roll-out of step length index ia becomes nominal `nxt`
-  LFSD_DEV void adopt_alpha(int ia, int nxt) {
-    __syncthreads();
-    for (int i = lane; i < (N + 1) * NX; i += 64) xbp(nxt)[i] = xa[i * NAL + ia];
-    for (int i = lane; i < N * NU; i += 64) ubp(nxt)[i] = ua[i * NAL + ia];
-    __syncthreads();
-  }
-  // linearise the shooting map along nominal `nxt`, all intervals at once
-  LFSD_DEV void linearise_parallel(int nxt) {
-    if constexpr (sizeof(T) == 4) {
-      using V = pk2<T>;
-      constexpr int NCT = (NXU + 1) / 2;
-      for (int t = lane; t < N * NCT; t += 64) {
-        const int k = t / NCT, c0 = 2 * (t % NCT), c1 = c0 + 1;
-        T x[NX], u[NU], q = T(0);
-        V m[NX], du[NU], mq = V(T(0));
-#pragma unroll
-        for (int i = 0; i < NX; ++i) { x[i] = xbp(nxt)[k * NX + i]; m[i] = mk2<T>((c0 == i) ? T(1) : T(0), (c1 == i) ? T(1) : T(0)); }
-#pragma unroll
-        for (int a = 0; a < NU; ++a) { u[a] = ubp(nxt)[k * NU + a]; du[a] = mk2<T>((c0 == NX + a) ? T(1) : T(0), (c1 == NX + a) ? T(1) : T(0)); }
-        const T tt = this->tk(k);
-        for (int s = 0; s < S; ++s) this->template rk4_step<true, V>(tt, x, q, u, m, mq, du);
-        V* Mk = reinterpret_cast<V*>(Mwp(nxt) + (long long)k * Lay::M_ELEMS + c0);
-#pragma unroll
-        for (int i = 0; i < NX; ++i) Mk[i * (Lay::NXUP / 2)] = m[i];
-        Mk[NX * (Lay::NXUP / 2)] = mq;
-      }
-    } else {
-      for (int t = lane; t < N * NXU; t += 64) {
-        const int k = t / NXU, col = t % NXU;
-        T x[NX], u[NU], m[NX], du[NU], q = T(0), mq = T(0);
-#pragma unroll
-        for (int i = 0; i < NX; ++i) { x[i] = xbp(nxt)[k * NX + i]; m[i] = (col == i) ? T(1) : T(0); }
-#pragma unroll
-        for (int a = 0; a < NU; ++a) { u[a] = ubp(nxt)[k * NU + a]; du[a] = (col == NX + a) ? T(1) : T(0); }
-        const T tt = this->tk(k);
-        for (int s = 0; s < S; ++s) this->template rk4_step<true>(tt, x, q, u, m, mq, du);
-        T* Mk = Mwp(nxt) + (long long)k * Lay::M_ELEMS + col;
-#pragma unroll
-        for (int i = 0; i < NX; ++i) Mk[i * Lay::NXUP] = m[i];
-        Mk[NX * Lay::NXUP] = mq;
-      }
-    }
-    __syncthreads();
-  }
-  // exact discrete costates (== IPOPT's lam_g) of nominal `cur` into lam_out; returns max |dJ/du|
-  LFSD_DEV T costate_sweep(int cur) {
-    T* ldsLam = lds + Lay::LDS_LAM;  T* ldsRed = lds + Lay::LDS_RED;
-    T lam[NX], xN[NX];
-#pragma unroll
-    for (int i = 0; i < NX; ++i) xN[i] = xbp(cur)[N * NX + i];
-    M::final_grad(this->tk(N), xN, e, c, lam);
-    if (lane == 0) {
-#pragma unroll
-      for (int i = 0; i < NX; ++i) lam_out[N * NX + i] = lam[i];
-    }
-    T gl_max = T(0);
-    for (int k = N - 1; k >= 0; --k) {
-      T gl = T(0);
-      if (lane < NXU) {
-        const T* Mk = Mwp(cur) + (long long)k * Lay::M_ELEMS + lane;
-        gl = Mk[NX * Lay::NXUP];
-#pragma unroll
-        for (int i = 0; i < NX; ++i) gl += Mk[i * Lay::NXUP] * lam[i];
-        if (lane < NX) { ldsLam[lane] = gl; lam_out[k * NX + lane] = gl; }
-        else gl_max = t_max(gl_max, t_abs(gl));
-      }
-      __syncthreads();
-#pragma unroll
-      for (int i = 0; i < NX; ++i) lam[i] = ldsLam[i];
-      __syncthreads();
-    }
-    ldsRed[lane] = gl_max;
-    __syncthreads();
-    T g = T(0);
-#pragma unroll
-    for (int a = 0; a < NU; ++a) g = t_max(g, ldsRed[NX + a]);
-    __syncthreads();
-    return g;
-  }
-  // exact stage Hessians of nominal `cur` (costates must be on lam_out), every (interval, column) at once
-  LFSD_DEV void hessians_parallel(int cur) {
-    for (int t = lane; t < N * NXU; t += 64) {
-      const int k = t / NXU, col = t % NXU;
-      T xk[NX], uk[NU], ln[NX], hx[NX], hu[NU];
-#pragma unroll
-      for (int i = 0; i < NX; ++i) { xk[i] = xbp(cur)[k * NX + i]; ln[i] = lam_out[(k + 1) * NX + i]; }
-#pragma unroll
-      for (int a = 0; a < NU; ++a) uk[a] = ubp(cur)[k * NU + a];
-      this->template stage_hessian_col<true>(k, xk, uk, ln, hx, hu, col);
-      T* hcol = Hws + (long long)k * Lay::H_ELEMS + col;
-#pragma unroll
-      for (int i = 0; i < NX; ++i) hcol[i * Lay::NXUP] = hx[i];
-#pragma unroll
-      for (int a = 0; a < NU; ++a) hcol[(NX + a) * Lay::NXUP] = hu[a];
-    }
-    __syncthreads();
-  }
-};
-
-// Point a solver view at one trajectory: its LDS region, its scratch slot and its costate rows.  GL is the lane-group
-// size the LDS / workspace layouts were sized for (the Riccati-style "one column per lane" mapping).
-template <class M, typename T, int GL, class Sol>
-LFSD_DEV void oc_bind(Sol& s, const OcArgs<T>& a, T* region, long long slot, bool valid, long long traj) {
-  using Lay = OcLayout<M>;
-  constexpr int NX = M::NX, NU = M::NU;
-  s.N = a.n_grid; s.S = a.steps_per_grid;
-  s.lds = region;
-  s.e = region + Lay::template lds_e<GL>();
-  s.c = region + Lay::template lds_c<GL>();
-  s.x0 = region + Lay::template lds_x0<GL>();
-  s.horizon = a.horizon[traj];
-  s.dgrid = s.horizon / T(s.N);
-  s.DT = s.dgrid / T(s.S);
-  const int N = s.N;
-  T* w = a.ws + slot * a.ws_stride;
-  s.xb[0] = w; w += (N + 1) * NX;
-  s.xb[1] = w; w += (N + 1) * NX;
-  s.ub[0] = w; w += N * NU;
-  s.ub[1] = w; w += N * NU;
-  s.Mws[0] = w; w += (long long)N * Lay::M_ELEMS;
-  s.Mws[1] = w; w += (long long)N * Lay::M_ELEMS;
-  s.Kws = w; w += (long long)N * NX * NU;
-  s.kws = w; w += N * NU;
-  s.exws = w; w += (long long)Lay::SMAX * NX * (1 + GL);
-  s.Hws = w; w += (long long)N * Lay::H_ELEMS;
-  // padding groups (slot >= batch) clone the last trajectory and keep their costates in scratch
-  s.lam_out = valid ? a.costate_grid + traj * (N + 1) * NX : w;
-}
-
-// EXACT = false: lean instantiation without the exact-Hessian code (Gauss-Newton / Hamiltonian models only);
-// EXACT = true: may switch to the exact stage Hessians.  lfsd_coc_solve runs the lean kernel for the first
-// `exact_after` iterations and resumes the unfinished trajectories in the exact-capable one.
-// PK = true (lean kernel of the 32-lane models only): the roll-out + linearisation and the line search run on
-// 16-lane groups -- two tangent columns per lane on packed math (rollout_sens_pk) -- so a wavefront carries four
-// trajectories instead of two; the backward sweep keeps its one-column-per-lane mapping on 32-lane groups and is run
-// in two passes.  The phases already meet in the per-trajectory scratch ([A B q], gains, nominal), so only the
-// few scalars of the step control cross between the mappings, through an LDS mailbox.
-template <class M, typename T, int G, bool EXACT, bool PK = false>
-__global__ void __launch_bounds__(64, LFSD_WAVES_OC) oc_solve_kernel(OcArgs<T> a) {
-  constexpr int GR = PK ? 16 : G;                 // lanes per trajectory of the roll-out / line-search mapping
-  using Sol = OcSolver<M, T, GR, EXACT>;
-  using SolB = OcSolver<M, T, G, EXACT>;          // backward-sweep mapping
-  using Lay = OcLayout<M>;
-  constexpr int NX = M::NX, NU = M::NU, NP = M::NP, NC = M::NC;
-  constexpr int GPB = 64 / GR;
-  // backward sweep of the packed kernel on the matrix cores (OcSolver::backward_mf) where the model fits 16-lane groups
-  constexpr bool MF = PK && (LFSD_MFMA_BACKWARD != 0) && sizeof(T) == 4 && NX <= 16 && NX + NU <= 17;
-  constexpr int RS = EXACT ? Lay::template lds_elems<G>() : ((Lay::template lds_ex<G>() + 3) / 4) * 4;
-  constexpr int MB = 12;                          // mailbox floats per trajectory
-  static_assert(64 % G == 0 && G >= NX + NU, "lane group must hold one column of [A B] per lane");
-  static_assert(!PK || (!EXACT && G == 32 && 2 * GR >= NX + NU), "packed roll-out: lean kernel of a 32-lane model");
-  __shared__ T lds_all[GPB * RS];
-  __shared__ T mbox[PK ? GPB * MB : 1];
-  __shared__ int vote[3];
-  poison_lds(lds_all, GPB * RS);
-  Sol s;
-  const int gib = threadIdx.x / GR;
-  s.lane = threadIdx.x % GR;
-  const long long slot = (long long)blockIdx.x * GPB + gib;      // scratch slot (padded batch)
-  const bool in_batch = slot < a.batch;
-  const long long traj = in_batch ? slot : (long long)a.batch - 1;
-  // phase 2 of a two-launch solve: only trajectories the first launch left at MAXITER are continued; the others
-  // ride along as clones whose outputs are not written
-  const bool valid = in_batch && (!a.resume || a.status[traj] == ST_MAXITER);
-  if (a.resume) {
-    if (threadIdx.x == 0) vote[0] = 0;
-    __syncthreads();
-    if (valid) vote[0] = 1;
-    __syncthreads();
-    if (!vote[0]) return;              // nothing to do in this workgroup
-    __syncthreads();
-  }
-  oc_bind<M, T, G>(s, a, lds_all + gib * RS, slot, valid, traj);
-  {
-    T* le = s.lds + Lay::template lds_e<G>();
-    T* lc = s.lds + Lay::template lds_c<G>();
-    T* lx = s.lds + Lay::template lds_x0<G>();
-    for (int i = s.lane; i < NP; i += GR) le[i] = a.auxvar[traj * NP + i];
-    for (int i = s.lane; i < NC; i += GR) lc[i] = a.consts[traj * a.const_stride + i];
-    for (int i = s.lane; i < NX; i += GR) lx[i] = a.ini_state[traj * NX + i];
-  }
-  __syncthreads();
-  const int N = s.N;
-
-  // backward sweep of this lane's trajectory; `force`: also when the trajectory is no longer running (final refresh
-  // of the costates).  Returns whether the sweep ran (PK skips a pass none of whose trajectories wants it).
-  auto do_backward = [&](int cur_, int mode_, T mu_, bool want_, T& gnorm_, T& dV1_, T& dV2_, T& dmin_, bool& ok_) LFSD_LAMBDA_BW -> bool {
-    if constexpr (MF) {
-      // all four trajectories of the wavefront sweep together on the matrix cores; a group that does not want the sweep
-      // rides along without writing anything (the MFMAs need every lane)
-      if (threadIdx.x == 0) vote[2] = 0;
-      __syncthreads();
-      if (want_) vote[2] = 1;
-      __syncthreads();
-      const bool any = vote[2] != 0;
-      __syncthreads();
-      if (!any) return false;
-      T g_, d1_, d2_, dm_;
-      const bool okb = s.backward_mf(cur_, mode_, mu_, want_, g_, d1_, d2_, dm_);
-      if (want_) { ok_ = okb; gnorm_ = g_; dV1_ = d1_; dV2_ = d2_; dmin_ = dm_; }
-      return want_;
-    } else if constexpr (!PK) {
-      ok_ = s.backward(cur_, mode_, mu_, gnorm_, dV1_, dV2_, dmin_);
-      return true;
-    } else {
-      T* mb = mbox + gib * MB;
-      if (s.lane == 0) { mb[0] = T(cur_); mb[1] = T(mode_); mb[2] = mu_; mb[3] = want_ ? T(1) : T(0); }
-      __syncthreads();
-      SolB sb;
-      sb.lane = threadIdx.x % G;
-      for (int pass = 0; pass < GPB * G / 64; ++pass) {
-        const int t0 = pass * (64 / G);
-        bool want_pass = false;
-        for (int j = 0; j < 64 / G; ++j) want_pass = want_pass || (mbox[(t0 + j) * MB + 3] != T(0));
-        const int tb = t0 + threadIdx.x / G;
-        T* mo = mbox + tb * MB;
-        if (want_pass) {
-          const long long slot_b = (long long)blockIdx.x * GPB + tb;
-          const bool valid_b = slot_b < a.batch;
-          oc_bind<M, T, G>(sb, a, lds_all + tb * RS, slot_b, valid_b, valid_b ? slot_b : (long long)a.batch - 1);
-          T g_, d1_, d2_, dm_;
-          const bool okb = sb.backward((int)mo[0], (int)mo[1], mo[2], g_, d1_, d2_, dm_);
-          if (sb.lane == 0) { mo[4] = okb ? T(1) : T(0); mo[5] = g_; mo[6] = d1_; mo[7] = d2_; mo[8] = dm_; mo[9] = T(1); }
-        } else if (sb.lane == 0) {
-          mo[9] = T(0);
-        }
-        __syncthreads();
-      }
-      const bool ran = mb[9] != T(0);
-      if (ran) { ok_ = mb[4] != T(0); gnorm_ = mb[5]; dV1_ = mb[6]; dV2_ = mb[7]; dmin_ = mb[8]; }
-      __syncthreads();
-      return ran;
-    }
-  };
-  auto do_rollout = [&](int cur_, int nxt_, T alpha_, bool gains_) LFSD_LAMBDA_RO -> T {
-    if constexpr (PK) return s.rollout_sens_pk(cur_, nxt_, alpha_, gains_);
-    else return s.rollout_sens(cur_, nxt_, alpha_, gains_);
-  };
-
-  // initial guess into buffer 1, then "roll out" 1 -> 0 without gains
-  for (int i = s.lane; i < N * NU; i += GR)
-    s.ub[1][i] = a.resume ? a.control_grid[traj * (N + 1) * NU + i] : (a.u_init ? a.u_init[traj * N * NU + i] : T(0));
-  __syncthreads();
-  int cur = 0;
-  T J = do_rollout(1, 0, T(0), false);
-  __syncthreads();
-  T mu = T(0);
-  int mode = 0;             // stage Hessian model: 0 Gauss-Newton, 1 Hamiltonian (cheap Newton-like), 2 exact
-  bool ham_ok = true;       // the cheap Newton-like model has not failed on this trajectory yet
-  bool optimistic = true;   // try the full step directly (skips the parallel line search while alpha = 1 keeps working)
-  const int it_off = (a.resume && in_batch) ? (a.iters[traj] - a.it_start) : 0;   // iterations already spent in phase 1
-  int status = ST_RUNNING, it = a.it_start, my_iters = a.it_start;
-  bool need_bw = true;      // costates on `lam_out` are stale
-  T gnorm = T(0), dV1 = T(0), dV2 = T(0);
-  T g_flat = T(-1);         // gradient norm at the last accepted noise-level ("flat") step; <0: none yet
-  T J_ref = J;              // cost 4 accepted steps ago (stagnation window)
-  int n_acc = 0;
-  bool hess_ok = false;     // Hws holds the exact stage Hessians of nominal `cur`
-  bool gn_crawl = false;    // Gauss-Newton is all that is left (Hamiltonian model failed) and its full steps gain < 1 %
-  T mu_bad = T(-1);         // largest Levenberg shift that failed recently (<0: none)
-  int mu_hold = 0, mu_hold_need = LFSD_MU_HOLD;   // accepted full steps to wait before the shift returns to a level <= mu_bad
-  if (!t_finite(J)) status = ST_FAILED;
-  for (; it < a.max_iter; ++it) {
-    if (threadIdx.x == 0) vote[0] = 0;
-    __syncthreads();
-    if (status == ST_RUNNING) vote[0] = 1;
-    __syncthreads();
-    if (!vote[0]) break;
-    __syncthreads();
-    // hand over to the exact stage Hessians at the iteration limit of the cheap models.  (Measured: handing over
-    // earlier, e.g. after three full Gauss-Newton steps, costs more regularised Newton steps than it saves.)
-    // ... or as soon as Gauss-Newton is reduced to crawling (the oracle's "close: switch to Newton" rule)
-    const bool want_exact = a.exact_after >= 0 && mode < 2 && (it >= a.exact_after || gn_crawl);
-    if (EXACT) { if (want_exact) mode = 2; }
-    else if (want_exact && status == ST_RUNNING && it < a.max_iter_total - 1) { status = ST_MAXITER; my_iters = it + it_off; }
-    T dmin = T(0);
-    bool bw_ok = false;
-    s.reuse_hess = EXACT && mode == 2 && hess_ok;
-    if (do_backward(cur, mode, mu, status == ST_RUNNING, gnorm, dV1, dV2, dmin, bw_ok)) { need_bw = false; hess_ok = EXACT && mode == 2; }
-    bool try_step = false;
-    if (status == ST_RUNNING) {
-      my_iters = it + 1 + it_off;
-      if (!bw_ok) {
-        // indefinite Q_uu: the cheap Newton-like model hands over to the exact one; otherwise Levenberg shift
-        if (mode == 1 && !LFSD_HAM_SHIFT) { mode = 0; ham_ok = false; }     // back to Gauss-Newton until the exact model takes over
-        else {
-          mu_bad = mu; mu_hold = 0;
-          if (mu == T(0) && mode >= 1 && t_finite(dmin))
-            mu = t_min(t_max(T(-2) * dmin, T(1e-4)), T(1e6));     // first shift: the size of the negative pivot
-          else
-            mu = t_max(mu * T(LFSD_MU_UP), mode == 2 ? T(1e-4) : T(1e-6));
-          if (mu > T(1e12)) status = ST_FAILED;
-        }
-      } else if (gnorm < a.tol * (T(1) + t_abs(J))) {
-        status = ST_CONVERGED;
-      } else {
-        try_step = true;
-      }
-    }
-    // Step selection.  Optimistic groups roll the full step (alpha = 1) out together with its linearisation and
-    // keep it if it passes the Armijo test; only after a failure do they pay for the parallel line search.
-    const bool opt_try = try_step && optimistic;
-    const bool ls_try = try_step && !optimistic;
-    T alpha = T(0), Jmin = J;
-    bool flat_full = false;
-    int ia = -1;
-    if (threadIdx.x == 0) vote[1] = 0;
-    __syncthreads();
-    if (ls_try) vote[1] = 1;
-    __syncthreads();
-    const bool any_ls = vote[1] != 0;
-    __syncthreads();
-    if (any_ls) ia = s.linesearch(cur, J, dV1, dV2, alpha, Jmin, flat_full);
-    bool accept = false;
-    if (ls_try) {
-      if (ia >= 0) {
-        accept = true;
-      } else if (mode >= 1 && flat_full && (g_flat < T(0) || gnorm < T(0.7) * g_flat)) {
-        // Newton-like step whose cost change is below rounding noise: take it as long as the
-        // gradient norm keeps contracting (this is what lets fp32 reach its gradient floor)
-        accept = true; ia = 0; alpha = T(1); g_flat = gnorm;
-      } else if (mode == 1 && !LFSD_HAM_SHIFT) {
-        mode = 0; ham_ok = false;
-      } else if (mu > T(1e10) ||
-                 ((J - Jmin) <= T(8) * Eps<T>::v() * t_abs(J) && (mode == 0 || flat_full || mu > T(1e6)))) {
-        status = ST_STALLED;      // no step length gains more than rounding noise
-      } else {                    // (exact model far from the optimum: indefinite direction -> larger shift)
-        mu_bad = mu; mu_hold = 0;
-        mu = t_max(mu * T(LFSD_MU_UP), mode == 2 ? T(1e-4) : T(1e-6));
-      }
-    }
-#if defined(LFSD_TRACE)
-    if (s.lane == 0 && slot == 0) printf("it %d st %d mode %d bw_ok %d g %.6e J %.12e opt %d ia %d alpha %g accept %d mu %g dV1 %.4e dV2 %.4e Jmin %.12e flat %d\n", it, status, mode, (int)bw_ok, (double)gnorm, (double)J, (int)opt_try, ia, (double)alpha, (int)accept, (double)mu, (double)dV1, (double)dV2, (double)Jmin, (int)flat_full);
-#endif
-    const bool roll = accept || opt_try;
-    if (threadIdx.x == 0) vote[1] = 0;
-    __syncthreads();
-    if (roll) vote[1] = 1;
-    __syncthreads();
-    if (vote[1]) {
-      const T Jn = do_rollout(cur, cur ^ 1, opt_try ? T(1) : (accept ? alpha : T(0)), roll);
-      if (opt_try) {
-        const T flat = T(8) * Eps<T>::v() * t_abs(J);
-        const bool fin = t_finite(Jn);
-        if (fin && (J - Jn) >= T(1e-4) * (-(dV1 + dV2)) - flat && Jn < J) {
-          accept = true; ia = 0;
-        } else if (fin && mode >= 1 && t_abs(Jn - J) <= T(64) * Eps<T>::v() * t_abs(J) &&
-                   (g_flat < T(0) || gnorm < T(0.7) * g_flat)) {
-          accept = true; ia = 0; g_flat = gnorm;
-        } else {
-          optimistic = false;     // same gains, parallel line search next round
-        }
-      }
-      if (accept) {
-        cur ^= 1;
-        need_bw = true;
-        hess_ok = false;
-        optimistic = (ia == 0);
-        if (ia == 0) {
-          // relax the shift after a full step -- but not straight back to a level that has just failed: hold for
-          // mu_hold_need accepted steps first, and twice as long after every failed return (a shift that bounces
-          // between a failing and a working level wastes every other backward sweep)
-          const T mu_next = (mu > T(1e-8)) ? mu * T(LFSD_MU_DOWN) : T(0);
-          if (mu > T(0) && mu_bad >= T(0) && mu_next <= mu_bad && mu_hold < mu_hold_need) {
-            ++mu_hold;
-          } else {
-            if (LFSD_MU_HOLD_BACKOFF && mu > T(0) && mu_bad >= T(0) && mu_next <= mu_bad) mu_hold_need = mu_hold_need < 16 ? 2 * mu_hold_need : 16;
-            mu = mu_next; mu_hold = 0;
-          }
-          if (mode == 0 && ham_ok && (J - Jn) < T(0.3) * t_abs(Jn)) mode = 1;      // past the first big drops: Newton-like
-          else if (LFSD_GN_CRAWL && mode == 0 && !ham_ok && (J - Jn) < T(1e-2) * t_abs(Jn)) gn_crawl = true;
-        }
-        J = Jn;
-        if (++n_acc >= 4) {
-          // four accepted steps that together gain less than rounding noise: converged to working precision
-          if (status == ST_RUNNING && J_ref - J <= T(16) * Eps<T>::v() * t_abs(J)) status = ST_STALLED;
-          J_ref = J; n_acc = 0;
-        }
-      }
-    }
-    __syncthreads();
-  }
-  if (status == ST_RUNNING) { status = ST_MAXITER; }
-  if (threadIdx.x == 0) vote[0] = 0;
-  __syncthreads();
-  if (need_bw) vote[0] = 1;
-  __syncthreads();
-  { T dmin = T(0); bool okf = false; if (vote[0]) do_backward(cur, 0, T(0), need_bw, gnorm, dV1, dV2, dmin, okf); }   // refresh costates on the final nominal
-  __syncthreads();
-  if (valid) {
-    T* xo = a.state_grid + traj * (N + 1) * NX;
-    T* uo = a.control_grid + traj * (N + 1) * NU;
-    for (int i = s.lane; i < (N + 1) * NX; i += GR) xo[i] = s.xbp(cur)[i];
-    for (int i = s.lane; i < (N + 1) * NU; i += GR) uo[i] = s.ubp(cur)[(i < N * NU) ? i : i - NU];
-    if (s.lane == 0) { a.cost[traj] = J; a.iters[traj] = my_iters; a.status[traj] = status; }
-  }
-}
-
-// The WIDE solver: one trajectory per wavefront (grid = batch), same discretisation, same stage-Hessian models and the same
-// step control as oc_solve_kernel (one backward sweep = one iteration; the step lengths 2^0..2^-15 are all rolled out at
-// once, so "optimistic full step, then line search" is a single phase: the largest step length that passes the Armijo
-// test is taken).  Control flow is uniform per workgroup -- no votes, no lock-step partners.  lfsd_coc_solve picks this
-// kernel when the lock-step mapping would leave most SIMDs without a wavefront (LFSD_OC_WIDE overrides).
-template <class M, typename T, bool EXACT, bool BND = false>
-__global__ void __launch_bounds__(64, 1) oc_solve_wide_kernel(OcArgs<T> a) {
-  using Sol = OcWide<M, T, EXACT, BND>;
-  using Lay = OcLayout<M>;
-  constexpr int NX = M::NX, NU = M::NU, NP = M::NP, NC = M::NC, NAL = Sol::NAL;
-  constexpr int RS = EXACT ? Lay::template lds_elems<64>() : ((Lay::template lds_ex<64>() + 3) / 4) * 4;
-  __shared__ T lds_all[RS];
-  if (blockDim.x != 64) return;
-  poison_lds(lds_all, RS);
-  Sol s;
-  s.lane = threadIdx.x;
-  const long long traj = blockIdx.x;
-  oc_bind<M, T, 64>(s, a, lds_all, traj, true, traj);
-  const int N = s.N;
-  {
-    T* w2 = a.ws + traj * a.ws_stride + Lay::template ws_elems<64>(N);
-    s.xa = w2; s.ua = s.xa + (long long)NAL * (N + 1) * NX; s.exwu = s.ua + (long long)NAL * N * NU;
-    T* le = s.lds + Lay::template lds_e<64>();
-    T* lc = s.lds + Lay::template lds_c<64>();
-    T* lx = s.lds + Lay::template lds_x0<64>();
-    for (int i = s.lane; i < NP; i += 64) le[i] = a.auxvar[traj * NP + i];
-    for (int i = s.lane; i < NC; i += 64) lc[i] = a.consts[traj * a.const_stride + i];
-    for (int i = s.lane; i < NX; i += 64) lx[i] = a.ini_state[traj * NX + i];
-  }
-  T* ldsRed = s.lds + Lay::LDS_RED;
-  if constexpr (BND) {
-#pragma unroll
-    for (int b = 0; b < NU; ++b) { s.ulb[b] = a.u_lb[b]; s.uub[b] = a.u_ub[b]; }
-  }
-  // initial guess into buffer 1 (the reference's w0: zero, or the midpoint of finite control bounds, CPDP.py:153), rolled out
-  // without gains into buffer 0, linearised
-  for (int i = s.lane; i < N * NU; i += 64) {
-    T u0 = a.u_init ? a.u_init[traj * N * NU + i] : T(0);
-    if constexpr (BND) {
-      const T lb = a.u_lb[i % NU], ub_ = a.u_ub[i % NU];
-      if (!a.u_init && t_abs(lb) < T(1e19) && t_abs(ub_) < T(1e19)) u0 = T(0.5) * (lb + ub_);
-      u0 = t_min(t_max(u0, lb), ub_);
-    }
-    s.ub[1][i] = u0;
-  }
-  __syncthreads();
-  int cur = 0;
-  T alpha_l = T(0);
-  T J = s.rollout_alphas(1, false, alpha_l);             // (every lane rolls the same controls out; lane 0's copy is adopted)
-  ldsRed[s.lane] = J;
-  __syncthreads();
-  J = ldsRed[0];
-  s.adopt_alpha(0, 0);
-  s.linearise_parallel(0);
-  T mu = T(0);
-  int mode = (EXACT && a.exact_after == 0) ? 2 : 0;
-  bool ham_ok = true, hess_ok = false, gn_crawl = false, costates_ok = false;
-  int status = t_finite(J) ? ST_RUNNING : ST_FAILED, it = 0;
-  T gnorm = T(0), dV1 = T(0), dV2 = T(0), g_flat = T(-1), J_ref = J, mu_bad = T(-1);
-  int n_acc = 0, mu_hold = 0;
-  const int mu_hold_need = LFSD_MU_HOLD;
-  for (; it < a.max_iter && status == ST_RUNNING; ++it) {
-    if (EXACT && a.exact_after >= 0 && mode < 2 && (it >= a.exact_after || gn_crawl)) mode = 2;
-    if (EXACT && mode == 2 && !hess_ok) {
-      s.costate_sweep(cur);
-      s.hessians_parallel(cur);
-      hess_ok = true;
-    }
-    s.reuse_hess = EXACT && mode == 2;
-    T dmin = T(0);
-    const bool bw_ok = s.backward(cur, mode, mu, gnorm, dV1, dV2, dmin);
-    costates_ok = true;
-    if (!bw_ok) {
-      if (mode == 1 && !LFSD_HAM_SHIFT) { mode = 0; ham_ok = false; }
-      else {
-        mu_bad = mu; mu_hold = 0;
-        if (mu == T(0) && mode >= 1 && t_finite(dmin)) mu = t_min(t_max(T(-2) * dmin, T(1e-4)), T(1e6));
-        else mu = t_max(mu * T(LFSD_MU_UP), mode == 2 ? T(1e-4) : T(1e-6));
-        if (mu > T(1e12)) status = ST_FAILED;
-      }
-      continue;
-    }
-    if (gnorm < a.tol * (T(1) + t_abs(J))) { status = ST_CONVERGED; break; }
-    // all step lengths at once; the largest one that passes the Armijo test is taken
-    const T Ja = s.rollout_alphas(cur, true, alpha_l);
-    ldsRed[s.lane] = Ja;
-    __syncthreads();
-    int ia = -1;
-    T Jmin = J, Jn = J, aa = T(1);
-    const T flat = T(8) * Eps<T>::v() * t_abs(J);
-    const bool flat_full = t_finite(ldsRed[0]) && t_abs(ldsRed[0] - J) <= T(64) * Eps<T>::v() * t_abs(J);
-    for (int l = 0; l < NAL; ++l) {
-      const T Jl = ldsRed[l];
-      const T expected = -(aa * dV1 + aa * aa * dV2);
-      const bool okl = t_finite(Jl) && ((J - Jl) >= T(1e-4) * expected - flat) && (Jl < J);
-      if (okl && ia < 0) { ia = l; Jn = Jl; }
-      if (t_finite(Jl)) Jmin = t_min(Jmin, Jl);
-      aa *= T(0.5);
-    }
-    __syncthreads();
-    bool accept = ia >= 0;
-    if (!accept) {
-      if (mode >= 1 && flat_full && (g_flat < T(0) || gnorm < T(0.7) * g_flat)) {
-        accept = true; ia = 0; Jn = ldsRed[0]; g_flat = gnorm;      // Newton-like step below rounding noise, gradient still contracting
-      } else if (mode == 1 && !LFSD_HAM_SHIFT) {
-        mode = 0; ham_ok = false;
-      } else if (mu > T(1e10) || ((J - Jmin) <= T(8) * Eps<T>::v() * t_abs(J) && ((mode == 0 && !BND) || flat_full || mu > T(1e6)))) {
-        // (with a box on the controls the clamped closed loop can fail every step length although the Gauss-Newton
-        //  direction is a descent direction of the unclamped model: that is a reason to shorten the step, not to stop)
-        status = ST_STALLED;
-      } else {
-        mu_bad = mu; mu_hold = 0;
-        mu = t_max(mu * T(LFSD_MU_UP), mode == 2 ? T(1e-4) : T(1e-6));
-      }
-    }
-#if defined(LFSD_TRACE)
-    if (s.lane == 0 && traj == 0) printf("wide it %d st %d mode %d g %.6e J %.12e ia %d accept %d mu %g dV1 %.4e dV2 %.4e Jmin %.12e\n", it, status, mode, (double)gnorm, (double)J, ia, (int)accept, (double)mu, (double)dV1, (double)dV2, (double)Jmin);
-#endif
-    if (accept) {
-      s.adopt_alpha(ia, cur ^ 1);
-      s.linearise_parallel(cur ^ 1);
-      cur ^= 1;
-      hess_ok = false; costates_ok = false;
-      if (ia == 0) {
-        const T mu_next = (mu > T(1e-8)) ? mu * T(LFSD_MU_DOWN) : T(0);
-        if (mu > T(0) && mu_bad >= T(0) && mu_next <= mu_bad && mu_hold < mu_hold_need) ++mu_hold;
-        else { mu = mu_next; mu_hold = 0; }
-        if (mode == 0 && ham_ok && (J - Jn) < T(0.3) * t_abs(Jn)) mode = 1;
-        else if (LFSD_GN_CRAWL && mode == 0 && !ham_ok && (J - Jn) < T(1e-2) * t_abs(Jn)) gn_crawl = true;
-      }
-      J = Jn;
-      if (++n_acc >= 4) {
-        if (J_ref - J <= T(16) * Eps<T>::v() * t_abs(J)) status = ST_STALLED;
-        J_ref = J; n_acc = 0;
-      }
-    }
-  }
-  if (status == ST_RUNNING) status = ST_MAXITER;
-  if (!costates_ok) s.costate_sweep(cur);                 // costates of the final nominal
-  __syncthreads();
-  {
-    T* xo = a.state_grid + traj * (N + 1) * NX;
-    T* uo = a.control_grid + traj * (N + 1) * NU;
-    for (int i = s.lane; i < (N + 1) * NX; i += 64) xo[i] = s.xbp(cur)[i];
-    for (int i = s.lane; i < (N + 1) * NU; i += 64) uo[i] = s.ubp(cur)[(i < N * NU) ? i : i - NU];
-    if (s.lane == 0) { a.cost[traj] = J; a.iters[traj] = (status == ST_CONVERGED) ? it + 1 : it; a.status[traj] = status; }
-  }
-}
-
-// =====================================================================================
-//  Auxiliary control system (differentiated maximum principle)
-// =====================================================================================
-template <typename T> struct AuxArgs {
-  int batch, n_grid, substeps;    // substeps = minimum coarse split-steps per grid interval (fine = 2x, Richardson)
-  T rate_max;                     // refine an interval until  dt * |Huu^-1 fu^T P fu|_inf <= rate_max
-  int max_refine;                 // cap on that refinement (factor over `substeps`)
-  T rtol;                         // > 0: error-controlled sub-stepping -- an interval is redone with twice the units while the
-                                  // Richardson estimate |fine - coarse| / 3 of a column exceeds rtol * (its magnitude + floor)
-  const T* horizon;               // [B]
-  const T* auxvar;                // [B][NP]
-  const T* consts; int const_stride;
-  const T* state_grid;            // [B][N+1][NX]
-  const T* control_grid;          // [B][N+1][NU]
-  const T* costate_grid;          // [B][N+1][NX]
-  T* Z_grid;                      // [B][N+1][NX+NP][NX]   column-major Z = [P W]
-  // forward sweep / loss
-  int n_waypoints, n_iface;
-  const int* iface_idx;           // [n_iface] state components the interface exposes
-  const T* taus;                  // [B][n_waypoints]
-  const T* waypoints;             // [B][n_waypoints][n_iface]
-  T* loss;                        // [B]
-  T* grad;                        // [B][NP]
-  T* auxX_grid;                   // [B][N+1][NP][NX] or nullptr  (dx/dtheta, column-major)
-  T* auxU_grid;                   // [B][N+1][NP][NU] or nullptr
-};
-
-template <class M> struct AuxLayout {
-  static constexpr int NX = M::NX, NU = M::NU, NP = M::NP, NZ = NX + NP, NNODE = 5;
-  static constexpr int LDS_L = 0;
-  static constexpr int LDS_S = LDS_L + NNODE * M::NCOEF;
-  static constexpr int LDS_T = LDS_S + NX * NU;
-  // LDS_T (transposed exchange of the Riccati right-hand side) and LDS_KN/LDS_PSI (forward sweep) share one region:
-  // each kernel uses only its own
-  static constexpr int LDS_KN = LDS_T;                        // 3 stiff nodes x (NX x NU) feedback rows K^T
-  static constexpr int LDS_PSI = LDS_KN + 3 * NX * NU;        // 3 stiff nodes x {phi1(h/4 K fu), phi1(h/2 K fu)}
-  static constexpr int LDS_TSZ0 = (NX * NZ > 3 * NX * NU + 6 * NU * NU ? NX * NZ : 3 * NX * NU + 6 * NU * NU);
-  static constexpr int LDS_TSZ = LDS_TSZ0 > 128 ? LDS_TSZ0 : 128;      // (>= 2 x 64: the error reduction of the step control)
-  static constexpr int LDS_E = LDS_T + LDS_TSZ;
-                                                              // cold per-trajectory state: auxvar, consts,
-  static constexpr int LDS_C = LDS_E + NP;                    // and the (x,u,lambda) grid values at both interval ends
-  static constexpr int LDS_GA = LDS_C + M::NC;                // [x_k u_k l_k]
-  static constexpr int LDS_GB = LDS_GA + 2 * NX + NU;         // [x_k+1 u_k+1 l_k+1]
-  static constexpr int LDS_END = LDS_GB + 2 * NX + NU;
-  static constexpr int lds_elems() { return ((LDS_END + 3) / 4) * 4; }
-  // forward kernel only: parking slot for X(t_k) (row i of column j at [i*NP + j])
-  // ... plus, per node and column, the X-independent part of the right-hand side (fe - fu Huu^-1 (fu^T W + Hue)) e_j
-  // ... plus the P columns at both ends of the interval ([end][column][row], and one zero row that lanes without a P
-  // column point at): they are needed three times per unit only, too cold for 2*NX registers per lane
-  static constexpr int FWD_P = NX * NP + NNODE * NX * NP;                 // offset of that block behind LDS_END
-  template <int G> static constexpr int lds_elems_fwd() { return ((LDS_END + FWD_P + 2 * NX * NX + NX + 3) / 4) * 4; }
-  // Riccati kernel only: per node and lane, this lane's column of [Hxx Hxe] and of Huu^-1 [Hux Hue]
-  static constexpr int RIC_ROWS = LFSD_RIC_CACHE == 1 ? NX + NU : (LFSD_RIC_CACHE == 2 ? NU : 0);
-  // ... plus one parking slot per lane for a column of Z (row i of lane l at [i*G + l]): of the unit's start value and
-  // the coarse Richardson result only one has to be in registers at a time
-  template <int G> static constexpr int ric_park() { return LDS_END + NNODE * RIC_ROWS * G; }
-  template <int G> static constexpr int lds_elems_ric() { return ((ric_park<G>() + NX * G + 3) / 4) * 4; }
-};
-
-// Lanes per trajectory of the forward sweep.  Only the NP columns of X = dx/dtheta advance there; the NX columns of P are
-// merely interpolated.  One lane carries P column `lane` (lane < NX) AND X / W column `lane` (lane < NP), so
-// max(NX, NP) lanes are enough (quadrotor: 16 instead of the 32 the Riccati sweep needs for its NX+NP columns).
-template <class M> constexpr int fwd_lanes() {
-  int need = M::NX > M::NP ? M::NX : M::NP;
-  if (need < AuxLayout<M>::NNODE) need = AuxLayout<M>::NNODE;
-  int g = 8;
-  while (g < need) g *= 2;
-  return g;
-}
-
-// LAY: packing order of the staged coefficients (0: Riccati sweep, transposed operators contiguous; 1: forward sweep)
-template <class M, typename T, int G, int LAY> struct AuxCtx {
-  static constexpr int NX = M::NX, NU = M::NU, NP = M::NP, NC = M::NC, NZ = NX + NP;
-  using Lay = AuxLayout<M>;
-  int lane;
-  int xcol;                  // forward sweep: column of X = dx/dtheta (and of W) this lane carries (lanes < NP), else 0
-  bool xlane;
-  const T *e, *c;            // [NP], [NC] in LDS
-  const T *xa_, *ua_, *la_, *xb_, *ub_, *lb_;   // grid values at both ends of the interval, in LDS
-  T t_a, dgrid;
-  T* lds;
-  T ox[NX], oe[NP];    // one-hot selectors of this lane's column
-
-  LFSD_DEV void load_interval(const AuxArgs<T>& a, long long traj, int k, int N) {
-    const T* xs = a.state_grid + (traj * (N + 1) + k) * NX;
-    const T* us = a.control_grid + (traj * (N + 1) + k) * NU;
-    const T* ls = a.costate_grid + (traj * (N + 1) + k) * NX;
-    T* ga = lds + Lay::LDS_GA;
-    T* gb = lds + Lay::LDS_GB;
-    __syncthreads();                         // previous interval's readers are done
-    for (int i = lane; i < NX; i += G) { ga[i] = xs[i]; gb[i] = xs[NX + i]; ga[NX + NU + i] = ls[i]; gb[NX + NU + i] = ls[NX + i]; }
-    for (int i = lane; i < NU; i += G) { ga[NX + i] = us[i]; gb[NX + i] = us[NU + i]; }
-    xa_ = ga; ua_ = ga + NX; la_ = ga + NX + NU; xb_ = gb; ub_ = gb + NX; lb_ = gb + NX + NU;
-    t_a = M::TIME_VARYING ? dgrid * T(k) : T(0);
-    __syncthreads();
-  }
-  // Lane `node` (< 5) evaluates the packed PMP coefficients at its own time node s (fraction of the
-  // interval) on the reference's linear interpolant of (x,u,lambda) (CPDP.py:320-323) and stages them in LDS.
-  LFSD_DEV void stage_nodes(T s_first, T s_step) {
-    if (lane < Lay::NNODE) {
-      const T s = s_first + s_step * T(lane);
-      T x[NX], u[NU], l[NX];
-#pragma unroll
-      for (int i = 0; i < NX; ++i) { x[i] = xa_[i] + s * (xb_[i] - xa_[i]); l[i] = la_[i] + s * (lb_[i] - la_[i]); }
-#pragma unroll
-      for (int i = 0; i < NU; ++i) u[i] = ua_[i] + s * (ub_[i] - ua_[i]);
-      T* L = lds + Lay::LDS_L + lane * M::NCOEF;
-      M::template pmp_coeffs<LAY>(t_a + s * dgrid, x, u, l, e, c, L);
-      T Huu[NU * NU], iH[NU * NU];
-#pragma unroll
-      for (int i = 0; i < NU * NU; ++i) Huu[i] = L[M::OFF_HUU + i];
-      mat_inverse<NU>(Huu, iH);       // casadi.pinv(ddHuu) of a nonsingular Huu (CPDP.py:262)
-#pragma unroll
-      for (int i = 0; i < NU * NU; ++i) L[M::OFF_IHUU + i] = iH[i];
-    }
-    __syncthreads();
-  }
-  LFSD_DEV const T* node(int i) const { return lds + Lay::LDS_L + i * M::NCOEF; }
-
-  // |Huu^-1 fu^T P fu|_inf : rate of the stiff closed-loop modes at one node (P = first NX lanes' columns)
-  LFSD_DEV T stiff_rate(const T* zt, const T* L) {
-    T* ldsS = lds + Lay::LDS_S;
-    const T* iH = L + M::OFF_IHUU;
-    T s[NU], kj[NU];
-    M::template fu_mulT<false, LAY>(L, zt, s);
-    matvec<NU>(iH, s, kj);
-    if (lane < NX) {
-#pragma unroll
-      for (int a = 0; a < NU; ++a) ldsS[lane * NU + a] = kj[a];
-    }
-    __syncthreads();
-    T Mx[NU * NU];
-    M::template fu_gram<false, LAY>(L, ldsS, Mx);
-    T nrm = T(0);
-#pragma unroll
-    for (int a = 0; a < NU; ++a) {
-      T r = T(0);
-#pragma unroll
-      for (int b = 0; b < NU; ++b) r += t_abs(Mx[a * NU + b]);
-      nrm = t_max(nrm, r);
-    }
-    __syncthreads();
-    return nrm;
-  }
-  LFSD_DEV int units_for(T rate, int Sa, T rate_max, int max_refine) const {
-    T want = rate * dgrid / rate_max;
-    if (!t_finite(want)) want = T(Sa);
-    int u = Sa;
-    const long long cap = (long long)Sa * max_refine;
-    while ((T)u < want && (long long)u * 2 <= cap) u *= 2;
-    return u;
-  }
-  // ---- Riccati (backward in time; tau = -t) -------------------------------------------------
-  // stiff sub-flow  dZ/dtau = -P R Z,  R = fu Huu^-1 fu^T :   Z <- Z - P fu (Huu/dt + fu^T P fu)^-1 fu^T Z
-  LFSD_DEV void ric_stiff(T* z, const T* L, T dt) {
-    T* ldsS = lds + Lay::LDS_S;
-    T s[NU];
-    M::template fu_mulT<false, LAY>(L, z, s);
-    if (lane < NX) {
-#pragma unroll
-      for (int a = 0; a < NU; ++a) ldsS[lane * NU + a] = s[a];
-    }
-    __syncthreads();
-    T Gm[NU * NU];
-    const T idt = T(1) / dt;
-#pragma unroll
-    for (int i = 0; i < NU * NU; ++i) Gm[i] = L[M::OFF_HUU + i] * idt;
-    M::template fu_gram<true, LAY>(L, ldsS, Gm);
-    lu_factor<NU>(Gm);
-    lu_solve<NU>(Gm, s);
-#pragma unroll
-    for (int i = 0; i < NX; ++i) {
-      T d = T(0);
-#pragma unroll
-      for (int a = 0; a < NU; ++a) d += ldsS[i * NU + a] * s[a];
-      z[i] -= d;
-    }
-    __syncthreads();
-  }
-  // The columns of [Hxx Hxe] and Huu^-1 [Hux Hue] this lane needs do not depend on Z: once per staged node
-  // instead of once per right-hand-side evaluation (12 per unit).  Parked per lane at [(node*(NX+NU)+r)*G + lane].
-  LFSD_DEV void ric_cols() {
-    if (Lay::RIC_ROWS == 0) return;
-    constexpr int R = Lay::RIC_ROWS, HX = LFSD_RIC_CACHE == 1 ? NX : 0;
-    T* hc = lds + Lay::LDS_END;
-    LFSD_RIC_NODE_LOOP
-    for (int nd = 0; nd < Lay::NNODE; ++nd) {
-      const T* L = node(nd);
-      T hu[NU], wq[NU];
-      if (LFSD_RIC_CACHE == 1) {
-        T hx[NX];
-        M::template Hxx_mul<false, LAY>(L, ox, hx);
-        M::template Hxe_mul<true, LAY>(L, oe, hx);
-#pragma unroll
-        for (int i = 0; i < NX; ++i) hc[(nd * R + i) * G + lane] = hx[i];
-      }
-      M::template Hxu_mulT<false, LAY>(L, ox, hu);
-      M::template Hue_mul<true, LAY>(L, oe, hu);
-      matvec<NU>(L + M::OFF_IHUU, hu, wq);
-#pragma unroll
-      for (int a = 0; a < NU; ++a) hc[(nd * R + HX + a) * G + lane] = wq[a];
-    }
-  }
-  // non-stiff part  dZ/dtau = [Qt qt] + A^T Z + P [A rt]   (A, Qt, rt, qt of CPDP.py:265-269)
-  LFSD_DEV void ric_rhs(const T* z, int nd, T* y) {
-    constexpr int R = Lay::RIC_ROWS, HX = LFSD_RIC_CACHE == 1 ? NX : 0;
-    T* ldsT = lds + Lay::LDS_T;
-    const T* L = node(nd);
-    const T* hc = lds + Lay::LDS_END + nd * R * G;
-    const T* iH = L + M::OFF_IHUU;
-    T s[NU], v[NU], w[NU], nv[NU], r[NP], wq[NU];
-    if (R == 0) {
-      T hu[NU];
-      M::template Hxu_mulT<false, LAY>(L, ox, hu);
-      M::template Hue_mul<true, LAY>(L, oe, hu);
-      matvec<NU>(iH, hu, wq);
-    } else {
-#pragma unroll
-      for (int a = 0; a < NU; ++a) wq[a] = hc[(HX + a) * G + lane];
-    }
-    M::template fu_mulT<false, LAY>(L, z, s);
-    matvec<NU>(iH, s, v);
-#pragma unroll
-    for (int a = 0; a < NU; ++a) { nv[a] = -v[a]; w[a] = -(wq[a] + v[a]); }
-    M::template fx_mulT<false, LAY>(L, z, y);
-    if (lane < NX) {
-      T tv[NX];
-#pragma unroll
-      for (int i = 0; i < NX; ++i) tv[i] = y[i];
-      M::template Hxu_mul<true, LAY>(L, nv, tv);
-      M::template fe_mulT<false, LAY>(L, z, r);
-      M::template Hue_mulT<true, LAY>(L, nv, r);
-#pragma unroll
-      for (int i = 0; i < NX; ++i) ldsT[lane * NZ + i] = tv[i];
-#pragma unroll
-      for (int i = 0; i < NP; ++i) ldsT[lane * NZ + NX + i] = r[i];
-    }
-    if (LFSD_RIC_CACHE == 1) {
-#pragma unroll
-      for (int i = 0; i < NX; ++i) y[i] += hc[i * G + lane];
-    } else {
-      M::template Hxx_mul<true, LAY>(L, ox, y);
-      M::template Hxe_mul<true, LAY>(L, oe, y);
-    }
-    M::template Hxu_mul<true, LAY>(L, w, y);
-    __syncthreads();
-    if (lane < NZ) {
-#pragma unroll
-      for (int i = 0; i < NX; ++i) y[i] += ldsT[i * NZ + lane];
-    }
-    __syncthreads();
-  }
-  // non-stiff RK4 step of length h over nodes (n0, n1, n2)
-  LFSD_DEV void ric_rk4(T* z, int n0, int n1, int n2, T h) {
-    T k[NX], acc[NX], zs[NX];
-    ric_rhs(z, n0, k);
-#pragma unroll
-    for (int i = 0; i < NX; ++i) { acc[i] = k[i]; zs[i] = z[i] + T(0.5) * h * k[i]; }
-    ric_rhs(zs, n1, k);
-#pragma unroll
-    for (int i = 0; i < NX; ++i) { acc[i] += T(2) * k[i]; zs[i] = z[i] + T(0.5) * h * k[i]; }
-    ric_rhs(zs, n1, k);
-#pragma unroll
-    for (int i = 0; i < NX; ++i) { acc[i] += T(2) * k[i]; zs[i] = z[i] + h * k[i]; }
-    ric_rhs(zs, n2, k);
-#pragma unroll
-    for (int i = 0; i < NX; ++i) z[i] += h / T(6) * (acc[i] + k[i]);
-  }
-  // Strang step: stiff h/2, non-stiff h, stiff h/2
-  LFSD_DEV void ric_strang(T* z, int n0, int n1, int n2, T h) {
-    ric_stiff(z, node(n0), h * T(0.5));
-    ric_rk4(z, n0, n1, n2, h);
-    ric_stiff(z, node(n2), h * T(0.5));
-  }
-  // two Strang steps of length h/2 over nodes (0,1,2) and (2,3,4): the two adjacent stiff quarter-steps at the middle
-  // node are the exact flow of the same frozen system, so they compose exactly into one half-step
-  LFSD_DEV void ric_strang2(T* z, T h) {
-    ric_stiff(z, node(0), h * T(0.25));
-    ric_rk4(z, 0, 1, 2, h * T(0.5));
-    ric_stiff(z, node(2), h * T(0.5));
-    ric_rk4(z, 2, 3, 4, h * T(0.5));
-    ric_stiff(z, node(4), h * T(0.25));
-  }
-
-  // ---- forward auxiliary state -----------------------------------------------------------------
-  // lanes < NX carry P columns (interpolated); lanes < NP also carry one X = dx/dtheta column and its W column.
-  // stiff sub-flow  X' = -fu K X,  K = Huu^-1 fu^T P (frozen over the sub-step), solved exactly:
-  //   X(dt) = X - dt fu phi1(dt K fu) K X,   phi1(M) = M^-1 (I - e^-M)   (m x m matrix function).
-  // (An A-stable rational step is not enough here: with a cheap control cost dt*|K fu| reaches O(10^2).)
-  // fwd_prep: for the three stiff nodes (0, 2, 4) of a unit the P lanes gather K(t_node); then lanes 0..2
-  // each evaluate phi1 for ONE node (quarter and half step), so the matrix function costs one evaluation per unit.
-  LFSD_DEV void fwd_prep(const T* zA, const T* zB, T s0, T ds, T hq) {
-    T* ldsK = lds + Lay::LDS_KN;
-    T* ldsP = lds + Lay::LDS_PSI;
-    LFSD_FWD_NODE_LOOP
-    for (int r = 0; r < 3; ++r) {
-      const T* L = node(2 * r);
-      const T sr = s0 + T(2 * r) * ds;
-      T zt[NX], sv[NU], kj[NU];
-#pragma unroll
-      for (int i = 0; i < NX; ++i) zt[i] = zA[i] + sr * (zB[i] - zA[i]);
-      M::template fu_mulT<false, LAY>(L, zt, sv);
-      matvec<NU>(L + M::OFF_IHUU, sv, kj);
-      if (lane < NX) {
-#pragma unroll
-        for (int a = 0; a < NU; ++a) ldsK[(r * NX + lane) * NU + a] = kj[a];
-      }
-    }
-    __syncthreads();
-    if (lane < 3) {
-      T Mx[NU * NU], Pq[NU * NU], Ph[NU * NU];
-      M::template fu_gram<false, LAY>(node(2 * lane), ldsK + lane * NX * NU, Mx);       // K fu
-#pragma unroll
-      for (int i = 0; i < NU * NU; ++i) Mx[i] *= hq;
-      phi1_neg<NU>(Mx, Pq, Ph);
-#pragma unroll
-      for (int i = 0; i < NU * NU; ++i) { ldsP[lane * 2 * NU * NU + i] = Pq[i]; ldsP[(lane * 2 + 1) * NU * NU + i] = Ph[i]; }
-    }
-    __syncthreads();
-  }
-  // apply the prepared exact stiff step of node r (0..2); half = false: dt = hq, true: dt = 2 hq
-  LFSD_DEV void fwd_stiff(T* xa, int r, bool half, T hq) {
-    const T* Kn = lds + Lay::LDS_KN + r * NX * NU;
-    const T* Psi = lds + Lay::LDS_PSI + (r * 2 + (half ? 1 : 0)) * NU * NU;
-    T kx[NU], y[NU];
-#pragma unroll
-    for (int a = 0; a < NU; ++a) kx[a] = T(0);
-#pragma unroll
-    for (int i = 0; i < NX; ++i) {
-#pragma unroll
-      for (int a = 0; a < NU; ++a) kx[a] += Kn[i * NU + a] * xa[i];
-    }
-    matvec<NU>(Psi, kx, y);
-    const T dt = half ? T(2) * hq : hq;
-#pragma unroll
-    for (int a = 0; a < NU; ++a) y[a] *= -dt;
-    M::template fu_mul<true, LAY>(node(2 * r), y, xa);
-  }
-  // non-stiff part  X' = fx X + fe - fu Huu^-1 (Hux X + Hue + fu^T W).  Its X-independent part
-  //   b_j(t) = (fe - fu Huu^-1 (fu^T W(t) + Hue)) e_j
-  // is evaluated once per staged node (fwd_cols) and parked per lane; the 12 right-hand sides of a unit then cost
-  //   y = fx x - fu Huu^-1 Hux x + b_j.
-  LFSD_DEV void fwd_cols(const T* zA, const T* zB, T s0, T ds) {
-    T* bc = lds + Lay::LDS_END + NX * NP;
-    LFSD_FWD_NODE_LOOP
-    for (int nd = 0; nd < Lay::NNODE; ++nd) {
-      const T* L = node(nd);
-      const T sr = s0 + T(nd) * ds;
-      T wt[NX], sv[NU], v[NU], b[NX];
-#pragma unroll
-      for (int i = 0; i < NX; ++i) wt[i] = zA[i] + sr * (zB[i] - zA[i]);
-      M::template fu_mulT<false, LAY>(L, wt, sv);
-      M::template Hue_mul<true, LAY>(L, oe, sv);
-      matvec<NU>(L + M::OFF_IHUU, sv, v);
-#pragma unroll
-      for (int a = 0; a < NU; ++a) v[a] = -v[a];
-      M::template fe_mul<false, LAY>(L, oe, b);
-      M::template fu_mul<true, LAY>(L, v, b);
-      if (xlane) {
-#pragma unroll
-        for (int i = 0; i < NX; ++i) bc[(nd * NX + i) * NP + xcol] = b[i];
-      }
-    }
-  }
-  LFSD_DEV void fwd_rhs(const T* xa, int nd, T* y) {
-    const T* L = node(nd);
-    const T* bc = lds + Lay::LDS_END + NX * NP + nd * NX * NP;     // lanes without an X column read column 0; their result is dropped
-    T s[NU], v[NU];
-    M::template Hxu_mulT<false, LAY>(L, xa, s);
-    matvec<NU>(L + M::OFF_IHUU, s, v);
-#pragma unroll
-    for (int a = 0; a < NU; ++a) v[a] = -v[a];
-    M::template fx_mul<false, LAY>(L, xa, y);
-    M::template fu_mul<true, LAY>(L, v, y);
-#pragma unroll
-    for (int i = 0; i < NX; ++i) y[i] += bc[i * NP + xcol];
-  }
-  // non-stiff RK4 step of length h over nodes (n0, n1, n2)
-  LFSD_DEV void fwd_rk4(T* xa, int n0, int n1, int n2, T h) {
-    T k[NX], acc[NX], xs[NX];
-    fwd_rhs(xa, n0, k);
-#pragma unroll
-    for (int i = 0; i < NX; ++i) { acc[i] = k[i]; xs[i] = xa[i] + T(0.5) * h * k[i]; }
-    fwd_rhs(xs, n1, k);
-#pragma unroll
-    for (int i = 0; i < NX; ++i) { acc[i] += T(2) * k[i]; xs[i] = xa[i] + T(0.5) * h * k[i]; }
-    fwd_rhs(xs, n1, k);
-#pragma unroll
-    for (int i = 0; i < NX; ++i) { acc[i] += T(2) * k[i]; xs[i] = xa[i] + h * k[i]; }
-    fwd_rhs(xs, n2, k);
-#pragma unroll
-    for (int i = 0; i < NX; ++i) xa[i] += h / T(6) * (acc[i] + k[i]);
-  }
-  // auxiliary control at a grid point (CPDP.py:295):  U = -Huu^-1((Hux + fu^T P) X + fu^T W + Hue)
-  LFSD_DEV void aux_control(const T* xa, const T* pt, const T* wt, const T* L, T* uo) {
-    T* ldsS = lds + Lay::LDS_S;
-    const T* iH = L + M::OFF_IHUU;
-    T s[NU];
-    M::template fu_mulT<false, LAY>(L, pt, s);          // P role: row `lane` of (fu^T P)^T
-    if (lane < NX) {
-#pragma unroll
-      for (int a = 0; a < NU; ++a) ldsS[lane * NU + a] = s[a];
-    }
-    __syncthreads();
-    M::template fu_mulT<false, LAY>(L, wt, s);          // X role: s = fu^T w_j + Hue e_j + Hux x_j + fu^T P x_j
-    M::template Hue_mul<true, LAY>(L, oe, s);
-    M::template Hxu_mulT<true, LAY>(L, xa, s);
-#pragma unroll
-    for (int i = 0; i < NX; ++i) {
-#pragma unroll
-      for (int a = 0; a < NU; ++a) s[a] += ldsS[i * NU + a] * xa[i];
-    }
-    matvec<NU>(iH, s, uo);
-#pragma unroll
-    for (int a = 0; a < NU; ++a) uo[a] = -uo[a];
-    __syncthreads();
-  }
-};
-
-template <class M, typename T, int G, int LAY> LFSD_DEV void aux_setup(AuxCtx<M, T, G, LAY>& s, const AuxArgs<T>& a, long long traj,
-                                                            T* lds_all, int lds_stride = AuxLayout<M>::lds_elems()) {
-  constexpr int NX = M::NX, NP = M::NP, NC = M::NC;
-  using Lay = AuxLayout<M>;
-  const int gib = threadIdx.x / G;
-  s.lane = threadIdx.x % G;
-  s.xlane = (LAY == 1) && (s.lane < NP);
-  s.xcol = s.xlane ? s.lane : 0;
-  s.lds = lds_all + gib * lds_stride;
-  {
-    T* le = s.lds + Lay::LDS_E;
-    T* lc = s.lds + Lay::LDS_C;
-    for (int i = s.lane; i < NP; i += G) le[i] = a.auxvar[traj * NP + i];
-    for (int i = s.lane; i < NC; i += G) lc[i] = a.consts[traj * a.const_stride + i];
-    s.e = le; s.c = lc;
-  }
-  __syncthreads();
-  s.dgrid = a.horizon[traj] / T(a.n_grid);
-#pragma unroll
-  for (int i = 0; i < NX; ++i) s.ox[i] = (s.lane == i) ? T(1) : T(0);
-#pragma unroll
-  for (int i = 0; i < NP; ++i) s.oe[i] = (LAY == 1 ? (s.xlane && s.lane == i) : (s.lane == NX + i)) ? T(1) : T(0);
-}
-
-// Barriers in the two auxiliary sweeps: the number of split units per interval (`units`) follows each trajectory's own
-// stiffness, so lane groups of one workgroup pass different numbers of __syncthreads().  That is well defined here --
-// and only here -- because a workgroup is exactly ONE wavefront (launched with 64 threads, checked below): s_barrier is
-// a scalar instruction the wavefront executes as a whole whatever its EXEC mask, it has nobody to wait for, and what
-// remains of __syncthreads() is the LDS fence (s_waitcnt lgkmcnt(0)) every group needs for its own private LDS slice.
-// A port to multi-wave workgroups would have to make `units` block-uniform first (as oc_solve_kernel does with its votes).
-template <class M, typename T, int G>
-__global__ void __launch_bounds__(64, (sizeof(T) == 4 ? LFSD_WAVES_RIC : 1)) aux_riccati_kernel(AuxArgs<T> a) {
-  if (blockDim.x != 64) return;                   // one wavefront per workgroup: see the note on barriers above
-  using Ctx = AuxCtx<M, T, G, 0>;
-  using Lay = AuxLayout<M>;
-  constexpr int NX = M::NX, NP = M::NP, NZ = NX + NP;
-  constexpr int GPB = 64 / G;
-  static_assert(64 % G == 0 && G >= NZ && G >= Lay::NNODE, "lane group must hold one column of [P W] per lane");
-  __shared__ T lds_all[GPB * Lay::template lds_elems_ric<G>() + LFSD_AUX_LDS_PAD];
-  poison_lds(lds_all, GPB * Lay::template lds_elems_ric<G>());
-  const long long slot = (long long)blockIdx.x * GPB + threadIdx.x / G;
-  const bool valid = slot < a.batch;
-  const long long traj = valid ? slot : (long long)a.batch - 1;
-  Ctx s;
-  aux_setup<M, T, G, 0>(s, a, traj, lds_all, Lay::template lds_elems_ric<G>());
-  const int N = a.n_grid, Sa = a.substeps;
-  const int lane = s.lane;
-  T* Zt = a.Z_grid + traj * (long long)(N + 1) * NZ * NX;
-  T z[NX];
-  {
-    T xN[NX];
-    const T* xs = a.state_grid + (traj * (N + 1) + N) * NX;
-#pragma unroll
-    for (int i = 0; i < NX; ++i) xN[i] = xs[i];
-    const T tN = M::TIME_VARYING ? s.dgrid * T(N) : T(0);
-    M::final_hess_mul(tN, xN, s.e, s.c, s.ox, s.oe, z);      // [ddhxx ddhxe], CPDP.py:330-331
-    if (lane >= NZ) {
-#pragma unroll
-      for (int i = 0; i < NX; ++i) z[i] = T(0);
-    }
-    if (valid && lane < NZ) {
-#pragma unroll
-      for (int i = 0; i < NX; ++i) Zt[((long long)N * NZ + lane) * NX + i] = z[i];
-    }
-  }
-  T* ldsT = s.lds + Lay::LDS_T;
-  int units_hint = Sa;
-  for (int k = N - 1; k >= 0; --k) {
-    s.load_interval(a, traj, k, N);
-    // stiffness-aware sub-stepping: P is largest at the later end of the interval (terminal transient).  The coefficients
-    // are staged for the first unit of the expected unit count at once: node 0 sits at the interval end either way, and
-    // when the stiffness estimate confirms the count the first unit need not stage again
-    const int units_guess = units_hint;
-    s.stage_nodes(T(1), T(-1) / T(4 * units_guess));
-    int units = s.units_for(s.stiff_rate(z, s.node(0)), Sa, a.rate_max, a.max_refine);
-    // error-driven refinement stops at max_refine x the minimum units -- and as soon as a doubling fails to halve the
-    // estimate: next to a conjugate point (finite escape of the Riccati solution) no step size meets a relative tolerance,
-    // and one such trajectory must not stall the batch
-    const long long units_cap = (long long)Sa * a.max_refine;
-    if (units < units_hint) units = (int)t_min((long long)units_hint, units_cap);
-    T ratio_prev = T(-1);
-    bool staged = (units == units_guess);
-    // Error-controlled sub-stepping (a.rtol > 0): the Richardson pair gives |fine - coarse| / 3 as an estimate of the
-    // second-order error that the extrapolation removes; while it exceeds rtol relative to the column's size the interval
-    // is redone from its stored start value Z(t_k+1) with twice the units.  (solve_ivp's rtol of the reference, CPDP.py:335,
-    // is 1e-3 on the un-extrapolated estimate of its pair; the default here is 1e-4.)
-    for (;;) {
-      const T hc = s.dgrid / T(units);
-      const T ds = T(1) / T(4 * units);
-      T err_l = T(0), scl_l = T(0);
-      for (int unit = 0; unit < units; ++unit) {
-        const T s_hi = T(1) - T(unit) / T(units);
-        if (!(staged && unit == 0)) s.stage_nodes(s_hi, -ds);      // node i sits at fraction s_hi - i/(4 units)
-        staged = false;
-        s.ric_cols();
-        // coarse chain in place, then the fine chain in place from the parked start value (the barriers inside the chains
-        // keep the compiler from carrying the parked column in registers)
-        T* zpark = s.lds + Lay::template ric_park<G>();
-#pragma unroll
-        for (int i = 0; i < NX; ++i) zpark[i * G + lane] = z[i];
-        s.ric_strang(z, 0, 2, 4, hc);
-#pragma unroll
-        for (int i = 0; i < NX; ++i) { const T z0 = zpark[i * G + lane]; zpark[i * G + lane] = z[i]; z[i] = z0; }
-        s.ric_strang2(z, hc);
-#pragma unroll
-        for (int i = 0; i < NX; ++i) {
-          const T zc = zpark[i * G + lane];
-          err_l = t_max(err_l, t_abs(z[i] - zc));
-          z[i] = (T(4) * z[i] - zc) / T(3);     // Richardson (Strang is O(h^2), symmetric)
-          scl_l = t_max(scl_l, t_abs(z[i]));
-        }
-      }
-      if (!(a.rtol > T(0))) break;
-      // per block of columns (P: lanes < NX, W: the rest) the worst estimate against that block's magnitude
-      ldsT[lane] = err_l; ldsT[G + lane] = scl_l;
-      __syncthreads();
-      T eP = T(0), sP = T(0), eW = T(0), sW = T(0);
-      for (int l = 0; l < NZ; ++l) {
-        if (l < NX) { eP = t_max(eP, ldsT[l]); sP = t_max(sP, ldsT[G + l]); }
-        else { eW = t_max(eW, ldsT[l]); sW = t_max(sW, ldsT[G + l]); }
-      }
-      __syncthreads();
-      const T tolP = T(3) * a.rtol * sP, tolW = T(3) * a.rtol * (sW + T(1e-3) * sP);
-      const bool fine_enough = (eP <= tolP && eW <= tolW) || !(t_finite(eP) && t_finite(eW));
-      const T ratio = t_max(eP / t_max(tolP, T(1e-30)), eW / t_max(tolW, T(1e-30)));
-      const bool no_gain = ratio_prev >= T(0) && ratio > T(0.5) * ratio_prev;
-      ratio_prev = ratio;
-      if (fine_enough || no_gain || !valid || (long long)units * 2 > units_cap) {
-        // next interval: start from this interval's units, or half of them when the estimate had a 32-fold margin
-        units_hint = (eP * T(32) <= tolP && eW * T(32) <= tolW && units > Sa) ? units / 2 : units;
-        break;
-      }
-      units *= 2;
-      if (lane < NZ) {
-#pragma unroll
-        for (int i = 0; i < NX; ++i) z[i] = Zt[((long long)(k + 1) * NZ + lane) * NX + i];
-      }
-    }
-    // keep P symmetric (the closed-form stiff update relies on it) and store the grid value
-    if (lane < NX) {
-#pragma unroll
-      for (int i = 0; i < NX; ++i) ldsT[lane * NZ + i] = z[i];
-    }
-    __syncthreads();
-    if (lane < NX) {
-#pragma unroll
-      for (int i = 0; i < NX; ++i) z[i] = T(0.5) * (z[i] + ldsT[i * NZ + lane]);
-    }
-    __syncthreads();
-    if (valid && lane < NZ) {
-#pragma unroll
-      for (int i = 0; i < NX; ++i) Zt[((long long)k * NZ + lane) * NX + i] = z[i];
-    }
-  }
-}
-
-template <class M, typename T, int G>
-__global__ void __launch_bounds__(64, (sizeof(T) == 4 ? LFSD_WAVES_FWD : 1)) aux_forward_kernel(AuxArgs<T> a) {
-  if (blockDim.x != 64) return;                   // one wavefront per workgroup: see the note above aux_riccati_kernel
-  using Ctx = AuxCtx<M, T, G, 1>;
-  using Lay = AuxLayout<M>;
-  constexpr int NX = M::NX, NU = M::NU, NP = M::NP, NZ = NX + NP;
-  constexpr int GPB = 64 / G;
-  static_assert(64 % G == 0 && G >= NX && G >= NP && G >= Lay::NNODE, "forward lane group: one P column and one X column per lane");
-  __shared__ T lds_all[GPB * Lay::template lds_elems_fwd<G>() + LFSD_AUX_LDS_PAD];
-  poison_lds(lds_all, GPB * Lay::template lds_elems_fwd<G>());
-  const long long slot = (long long)blockIdx.x * GPB + threadIdx.x / G;
-  const bool valid = slot < a.batch;
-  const long long traj = valid ? slot : (long long)a.batch - 1;
-  Ctx s;
-  aux_setup<M, T, G, 1>(s, a, traj, lds_all, Lay::template lds_elems_fwd<G>());
-  const int N = a.n_grid, Sa = a.substeps;
-  const int lane = s.lane;
-  const bool xlane = s.xlane;
-  const T* Zt = a.Z_grid + traj * (long long)(N + 1) * NZ * NX;
-  T xa[NX], wA[NX], wB[NX];     // X column; W column at both ends of the interval (the P columns live in LDS)
-#pragma unroll
-  for (int i = 0; i < NX; ++i) { xa[i] = T(0); wA[i] = T(0); wB[i] = T(0); }     // X(0) = 0, CPDP.py:355
-  T* ldsPA = s.lds + Lay::LDS_END + Lay::FWD_P;
-  T* ldsPB = ldsPA + NX * NX;
-  T* ldsP0 = ldsPB + NX * NX;                                  // zero row
-  for (int i = lane; i < NX; i += G) ldsP0[i] = T(0);
-  const T* pA = (lane < NX) ? ldsPA + lane * NX : ldsP0;
-  const T* pB = (lane < NX) ? ldsPB + lane * NX : ldsP0;
-  T loss = T(0), gacc = T(0);
-  int units_hint = Sa;
-  T* Xo = a.auxX_grid ? a.auxX_grid + traj * (long long)(N + 1) * NP * NX : nullptr;
-  T* Uo = a.auxU_grid ? a.auxU_grid + traj * (long long)(N + 1) * NP * NU : nullptr;
-  if (valid && Xo && xlane) {
-#pragma unroll
-    for (int i = 0; i < NX; ++i) Xo[(long long)s.xcol * NX + i] = T(0);
-  }
-  for (int k = 0; k < N; ++k) {
-    s.load_interval(a, traj, k, N);
-    if (lane < NX) {           // (load_interval's barriers fence the previous interval's readers; stage_nodes' the writers)
-#pragma unroll
-      for (int i = 0; i < NX; ++i) { ldsPA[lane * NX + i] = Zt[((long long)k * NZ + lane) * NX + i]; ldsPB[lane * NX + i] = Zt[((long long)(k + 1) * NZ + lane) * NX + i]; }
-    }
-    if (xlane) {
-#pragma unroll
-      for (int i = 0; i < NX; ++i) { wA[i] = Zt[((long long)k * NZ + NX + lane) * NX + i]; wB[i] = Zt[((long long)(k + 1) * NZ + NX + lane) * NX + i]; }
-    }
-    T* xprev = s.lds + Lay::LDS_END;                 // this lane's X(t_k), parked in LDS until the loss needs it
-    if (xlane) {
-#pragma unroll
-      for (int i = 0; i < NX; ++i) xprev[i * NP + s.xcol] = xa[i];
-    }
-    s.stage_nodes(T(0), T(0.25));          // nodes at 0, 1/4 .. 1 of the interval: the stiffness at both ends -- and exactly
-    const T rate = t_max(s.stiff_rate(pA, s.node(0)), s.stiff_rate(pB, s.node(4)));      // the staging of a single unit
-    int units = s.units_for(rate, Sa, a.rate_max, a.max_refine);
-    const long long units_cap = (long long)Sa * a.max_refine;
-    if (units < units_hint) units = (int)t_min((long long)units_hint, units_cap);
-    T ratio_prev = T(-1);
-    bool staged = (units == 1);
-    for (;;) {                         // error-controlled sub-stepping, as in the Riccati sweep; the start value X(t_k) is `xprev`
-      const T hc = s.dgrid / T(units);
-      const T ds = T(1) / T(4 * units);
-      T err_l = T(0), scl_l = T(0);
-      for (int unit = 0; unit < units; ++unit) {
-        const T s_lo = T(unit) / T(units);
-        if (!(staged && unit == 0)) s.stage_nodes(s_lo, ds);
-        staged = false;
-        if (Uo && unit == 0) {
-          T uo[NU];
-          s.aux_control(xa, pA, wA, s.node(0), uo);
-          if (valid && xlane) {
-#pragma unroll
-            for (int b = 0; b < NU; ++b) Uo[((long long)k * NP + s.xcol) * NU + b] = uo[b];
-          }
-        }
-        T xc[NX], xf[NX];
-#pragma unroll
-        for (int i = 0; i < NX; ++i) { xc[i] = xa[i]; xf[i] = xa[i]; }
-        const T hq = hc * T(0.25);
-        s.fwd_prep(pA, pB, s_lo, ds, hq);
-        s.fwd_cols(wA, wB, s_lo, ds);
-        // coarse Strang step (stiff h/2, RK4 h, stiff h/2) and two fine ones; the two adjacent fine stiff
-        // quarter-steps at the middle node compose exactly into one half-step.  (Unlike the Riccati sweep, which runs its
-        // two chains in place with the other value parked in LDS, this one-wave-per-SIMD kernel is 20 % faster with both
-        // chains as independent instruction streams the compiler can interleave.)
-        s.fwd_stiff(xc, 0, true, hq);
-        s.fwd_rk4(xc, 0, 2, 4, hc);
-        s.fwd_stiff(xc, 2, true, hq);
-        s.fwd_stiff(xf, 0, false, hq);
-        s.fwd_rk4(xf, 0, 1, 2, hc * T(0.5));
-        s.fwd_stiff(xf, 1, true, hq);
-        s.fwd_rk4(xf, 2, 3, 4, hc * T(0.5));
-        s.fwd_stiff(xf, 2, false, hq);
-        __syncthreads();      // all reads of this unit's staged coefficients are done before the next staging
-#pragma unroll
-        for (int i = 0; i < NX; ++i) {
-          if (xlane) err_l = t_max(err_l, t_abs(xf[i] - xc[i]));
-          xa[i] = xlane ? (T(4) * xf[i] - xc[i]) / T(3) : T(0);
-          scl_l = t_max(scl_l, t_abs(xa[i]));
-        }
-        if (Uo && k == N - 1 && unit == units - 1) {
-          T uo[NU];
-          s.aux_control(xa, pB, wB, s.node(4), uo);
-          if (valid && xlane) {
-#pragma unroll
-            for (int b = 0; b < NU; ++b) Uo[((long long)N * NP + s.xcol) * NU + b] = uo[b];
-          }
-        }
-      }
-      if (!(a.rtol > T(0))) break;
-      T* ldsR = s.lds + Lay::LDS_T;           // (the feedback / phi1 images of the last unit are dead by now)
-      ldsR[lane] = err_l; ldsR[G + lane] = scl_l;
-      __syncthreads();
-      T eX = T(0), sX = T(0);
-      for (int l = 0; l < NP; ++l) { eX = t_max(eX, ldsR[l]); sX = t_max(sX, ldsR[G + l]); }
-      __syncthreads();
-      const T tolX = T(3) * a.rtol * (sX + T(1e-2));       // dx/dtheta starts from zero: absolute floor 1e-2 * rtol
-      const T ratio = eX / tolX;
-      const bool no_gain = ratio_prev >= T(0) && ratio > T(0.5) * ratio_prev;
-      ratio_prev = ratio;
-      if (eX <= tolX || no_gain || !t_finite(eX) || (long long)units * 2 > units_cap) {
-        units_hint = (eX * T(32) <= tolX && units > Sa) ? units / 2 : units;
-        break;
-      }
-      units *= 2;
-#pragma unroll
-      for (int i = 0; i < NX; ++i) xa[i] = xlane ? xprev[i * NP + s.xcol] : T(0);
-    }
-    if (valid && Xo && xlane) {
-#pragma unroll
-      for (int i = 0; i < NX; ++i) Xo[((long long)(k + 1) * NP + s.xcol) * NX + i] = xa[i];
-    }
-    // loss and gradient contributions of the waypoints that fall into this interval
-    // (linear interpolation of the grid values, exactly what opt_sol(t)/auxsys_sol(t) do: CPDP.py:386)
-    for (int w = 0; w < a.n_waypoints; ++w) {
-      const T tau = a.taus[traj * a.n_waypoints + w];
-      int kw = (int)t_floor(tau / s.dgrid);
-      kw = kw < 0 ? 0 : (kw > N - 1 ? N - 1 : kw);
-      if (kw != k) continue;
-      const T sw = (tau - T(k) * s.dgrid) / s.dgrid;
-      T rvec[NX];
-#pragma unroll
-      for (int i = 0; i < NX; ++i) rvec[i] = T(0);
-      for (int q = 0; q < a.n_iface; ++q) {
-        const int idx = a.iface_idx[q];
-        const T target = a.waypoints[(traj * a.n_waypoints + w) * a.n_iface + q];
-#pragma unroll
-        for (int i = 0; i < NX; ++i) {
-          if (i == idx) {
-            const T cur = s.xa_[i] + sw * (s.xb_[i] - s.xa_[i]);
-            const T r = cur - target;
-            rvec[i] += r;
-            loss += r * r;
-          }
-        }
-      }
-#pragma unroll
-      for (int i = 0; i < NX; ++i) { const T xp = xprev[i * NP + s.xcol]; gacc += rvec[i] * (xp + sw * (xa[i] - xp)); }
-    }
-  }
-  if (valid) {
-    if (lane == 0) a.loss[traj] = loss;
-    if (xlane) a.grad[traj * NP + s.xcol] = gacc;
-  }
-}
-
-// =====================================================================================
-//  Parameter update rules (lib/QuadAlgorithm.py:454-578), one thread per (trajectory, parameter)
-// =====================================================================================
-template <typename T> struct OptArgs {
-  int batch, n_param, method, iter_idx;      // iter_idx starts from 0 (QuadAlgorithm.py:507)
-  T lr, mu, beta1, beta2, eps;
-  T* theta;            // [B][p]  in/out
-  const T* grad;       // [B][p]
-  T* m;                // [B][p]  Nesterov velocity / first moment
-  T* v;                // [B][p]  second moment
-  T* vhat;             // [B][p]  AMSGrad running max
-  const T* proj_lo;    // [p] lower bound applied after the step (-inf = none); examples clamp theta[0] >= 1e-8
-  const int* row_active;   // [B] or nullptr: rows with 0 keep theta AND their optimizer state (a frozen trajectory)
-};
-
-template <typename T> __global__ void optimizer_kernel(OptArgs<T> a) {
-  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= (long long)a.batch * a.n_param) return;
-  if (a.row_active && !a.row_active[i / a.n_param]) return;
-  const int j = (int)(i % a.n_param);
-  const T g = a.grad[i];
-  T th = a.theta[i];
-  const T idx = T(a.iter_idx + 1);
-  if (a.method == OPT_VANILLA) {
-    th -= a.lr * g;
-  } else if (a.method == OPT_NESTEROV) {
-    // grad was evaluated at the look-ahead point theta + mu*v (QuadAlgorithm.py:478-486)
-    const T vel = a.mu * a.m[i] - a.lr * g;
-    a.m[i] = vel;
-    th += vel;
-  } else {
-    const T mm = a.beta1 * a.m[i] + (T(1) - a.beta1) * g;
-    const T vv = a.beta2 * a.v[i] + (T(1) - a.beta2) * g * g;
-    a.m[i] = mm; a.v[i] = vv;
-    if (a.method == OPT_AMSGRAD) {
-      const T vh = t_max(a.vhat[i], vv);
-      a.vhat[i] = vh;
-      th -= a.lr * mm / (t_sqrt(vh) + a.eps);
-    } else {
-      const T c1 = T(1) - t_pow(a.beta1, idx), c2 = T(1) - t_pow(a.beta2, idx);
-      const T mh = mm / c1, vh = vv / c2;
-      if (a.method == OPT_ADAM) th -= a.lr * mh / (t_sqrt(vh) + a.eps);
-      else th -= a.lr * (a.beta1 * mh + (T(1) - a.beta1) / c1 * g) / (t_sqrt(vh) + a.eps);
-    }
-  }
-  if (a.proj_lo) th = t_max(th, a.proj_lo[j]);
-  a.theta[i] = th;
-}
-
-// look-ahead point of Nesterov: out = theta + mu * v   (QuadAlgorithm.py:478)
-template <typename T> __global__ void lookahead_kernel(long long n, T mu, const T* theta, const T* v, T* out) {
-  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) out[i] = theta[i] + mu * v[i];
-}
-
-}  // namespace lfsd
+#include "cpdp_common.h"
+#include "cpdp_oc.h"
+#include "cpdp_aux.h"
+#include "cpdp_opt.h"

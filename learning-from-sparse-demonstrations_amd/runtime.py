@@ -102,14 +102,18 @@ def hipcc_commands(spec, out, extra=(), extra_capi=TUNED_CAPI, extra_riccati=TUN
              [find_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", o1, o2, "-o", out]], [o1, o2])
 
 
+# every hand-written file a model library is compiled from (rebuild when any of them is newer than the .so)
+KERNEL_SOURCES = ("cpdp_kernels.h", "cpdp_common.h", "cpdp_oc.h", "cpdp_aux.h", "cpdp_opt.h", "lfsd_capi.cpp", "lfsd_internal.h",
+                  "lfsd_riccati.inc", "lfsd_riccati.cpp")
+
+
 def build_library(spec, force=False, verbose=False):
     """Generate the model header and compile the gfx950 shared library in-tree (csrc/build/)."""
     os.makedirs(BUILD_DIR, exist_ok=True)
     out = library_path(spec.hash())
     write_header(spec, force=force)
     deps = [header_path(spec.hash()), os.path.join(INCLUDE_DIR, "lfsd_cpdp.h")] + \
-        [os.path.join(CSRC_DIR, f) for f in ("cpdp_kernels.h", "lfsd_capi.cpp", "lfsd_internal.h", "lfsd_riccati.inc",
-                                             "lfsd_riccati.cpp")]
+        [os.path.join(CSRC_DIR, f) for f in KERNEL_SOURCES]
     if not force and os.path.exists(out) and all(os.path.getmtime(out) >= os.path.getmtime(d) for d in deps):
         return out
     tmp = out + ".tmp%d" % os.getpid()

@@ -30,9 +30,8 @@ def build_emu_library(oc):
     runtime.write_header(spec)
     os.makedirs(EMU_BUILD, exist_ok=True)
     out = os.path.join(EMU_BUILD, "liblfsd_%s_emu.so" % spec.hash())
-    deps = [runtime.header_path(spec.hash()), os.path.join(runtime.CSRC_DIR, "cpdp_kernels.h"),
-            os.path.join(runtime.CSRC_DIR, "lfsd_capi.cpp"), os.path.join(runtime.CSRC_DIR, "lfsd_internal.h"),
-            os.path.join(runtime.CSRC_DIR, "lfsd_riccati.inc"), os.path.join(EMU_DIR, "simt_emu.h")]
+    deps = [runtime.header_path(spec.hash()), os.path.join(EMU_DIR, "simt_emu.h")] + \
+        [os.path.join(runtime.CSRC_DIR, f) for f in runtime.KERNEL_SOURCES]
     if os.path.exists(out) and all(os.path.getmtime(out) >= os.path.getmtime(d) for d in deps):
         return out
     g = runtime.lanes_for(spec.n, spec.m, spec.p)

@@ -5,6 +5,7 @@
 #include <cstdlib>
 #include <cmath>
 #include "../../learning-from-sparse-demonstrations_amd/csrc/cpdp_kernels.h"
+#define HIP_OK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { printf("%s: %s\n", #call, hipGetErrorString(e_)); exit(2); } } while (0)
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 __global__ void probe(float* out) {
@@ -38,10 +39,10 @@ static int check_chain() {
   srand(7);
   for (int i = 0; i < 64 * 13; ++i) { ha[i] = (float)(rand() % 17 - 8); hb[i] = (float)(rand() % 13 - 6); }      // exact in fp32
   float *da, *db, *dout;
-  hipMalloc(&da, sizeof(ha)); hipMalloc(&db, sizeof(hb)); hipMalloc(&dout, sizeof(ho));
-  hipMemcpy(da, ha, sizeof(ha), hipMemcpyHostToDevice); hipMemcpy(db, hb, sizeof(hb), hipMemcpyHostToDevice);
+  HIP_OK(hipMalloc(&da, sizeof(ha))); HIP_OK(hipMalloc(&db, sizeof(hb))); HIP_OK(hipMalloc(&dout, sizeof(ho)));
+  HIP_OK(hipMemcpy(da, ha, sizeof(ha), hipMemcpyHostToDevice)); HIP_OK(hipMemcpy(db, hb, sizeof(hb), hipMemcpyHostToDevice));
   hipLaunchKernelGGL(chain, dim3(1), dim3(64), 0, 0, da, db, dout);
-  hipMemcpy(ho, dout, sizeof(ho), hipMemcpyDeviceToHost);
+  HIP_OK(hipMemcpy(ho, dout, sizeof(ho), hipMemcpyDeviceToHost));
   int bad = 0;
   for (int blk = 0; blk < 4; ++blk) for (int j = 0; j < 16; ++j) for (int i = 0; i < 16; ++i) {
     float ref = 0.f;                                  // D_blk[i][j] = sum_k a(lane 16 blk + i)[k] * b(lane 16 blk + j)[k]
@@ -54,9 +55,9 @@ static int check_chain() {
 }
 int main() {
   check_chain();
-  float* d; hipMalloc(&d, 4096 * 4); hipMemset(d, 0, 4096 * 4);
+  float* d; HIP_OK(hipMalloc(&d, 4096 * 4)); HIP_OK(hipMemset(d, 0, 4096 * 4));
   hipLaunchKernelGGL(probe, dim3(1), dim3(64), 0, 0, d);
-  static float h[4096]; hipMemcpy(h, d, 4096 * 4, hipMemcpyDeviceToHost);
+  static float h[4096]; HIP_OK(hipMemcpy(h, d, 4096 * 4, hipMemcpyDeviceToHost));
   int bad = 0;
   for (int l = 0; l < 64; ++l) for (int r = 0; r < 16; ++r) {
     // hypothesis: register 4*b + (i%4), lane 16*(i/4) + j  holds  D_b[i][j]
