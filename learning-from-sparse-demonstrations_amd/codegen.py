@@ -26,7 +26,7 @@ import hashlib
 import sympy as sp
 from sympy.printing.c import C99CodePrinter
 
-CODEGEN_VERSION = 8
+CODEGEN_VERSION = 9
 
 
 class ModelSpec:
@@ -156,7 +156,45 @@ def _loads(spec, with_u=True, with_l=False):
         ins += [(s, 'l[%d]' % i) for i, s in enumerate(spec.L)]
     ins += [(s, 'e[%d]' % i) for i, s in enumerate(spec.E)]
     ins += [(s, 'c[%d]' % i) for i, s in enumerate(spec.C)]
+    ins += [(s, 'c[%d]' % (max(spec.nc, 1) + j)) for j, (s, _) in enumerate(getattr(spec, '_derived', ()))]
     return ins
+
+
+def _has_division(e):
+    return any(isinstance(q, sp.Pow) and q.exp.is_negative for q in sp.preorder_traversal(e))
+
+
+def _hoist_const_quotients(exprs, consts):
+    """Quotients of the model's run-time constants (1/m, (Jy - Jz)/Jx, ...) are the same for every call of a solve, but
+    the compiler cannot hoist them out of the kernels' loops (the constants live in LDS, across barriers), and an IEEE
+    division is a ten-instruction dependent sequence.  Every maximal sub-expression that depends on constants only and
+    contains a division is replaced by a DERIVED constant cd<j>; the kernels evaluate Model::derive_consts once per
+    trajectory when they stage the constants.  Returns (new expressions, [(symbol, expression)])."""
+    cset = set(consts)
+    table = {}
+
+    def sym_for(e):
+        if e not in table:
+            table[e] = sp.Symbol('cd%d' % len(table), real=True)
+        return table[e]
+
+    def rec(e):
+        if e.is_Atom:
+            return e
+        fs = e.free_symbols
+        if fs and fs <= cset:
+            return sym_for(e) if _has_division(e) else e
+        if isinstance(e, sp.Mul):
+            cargs = [a for a in e.args if a.free_symbols and a.free_symbols <= cset]
+            if cargs:
+                cm = sp.Mul(*cargs)
+                if _has_division(cm):
+                    rest = [a if not a.free_symbols else rec(a) for a in e.args if not (a.free_symbols and a.free_symbols <= cset)]
+                    return sp.Mul(sym_for(cm), *rest)
+        return e.func(*[rec(a) for a in e.args])
+
+    out = [x.applyfunc(rec) if isinstance(x, sp.MatrixBase) else rec(sp.sympify(x)) for x in exprs]
+    return out, [(v, k) for k, v in sorted(table.items(), key=lambda kv: int(str(kv[1])[2:]))]
 
 
 def _nz(e):
@@ -219,7 +257,8 @@ _ORDERS = {'fx': 'cr', 'fu': 'cr', 'fe': 'cr', 'Hxx': 'rr', 'Hxu': 'rc', 'Hxe': 
 def emit_header(spec):
     n, m, p, nc = spec.n, spec.m, spec.p, spec.nc
     X, U, E, L = sp.Matrix(spec.X), sp.Matrix(spec.U), sp.Matrix(spec.E), sp.Matrix(spec.L)
-    f, c, h = spec.f, spec.c, spec.h
+    (f, c, h), derived = _hoist_const_quotients([spec.f, spec.c, spec.h], spec.C)
+    spec._derived = derived
     fx, fu, fe = f.jacobian(X), f.jacobian(U), f.jacobian(E)
     cx, cu = sp.Matrix([c]).jacobian(X), sp.Matrix([c]).jacobian(U)
     H = c + (f.T * L)[0, 0]
@@ -247,6 +286,15 @@ def emit_header(spec):
     S.append('struct Model {')
     S.append('  static constexpr int NX = %d, NU = %d, NP = %d, NC = %d;' % (n, m, p, max(nc, 1)))
     S.append('  static constexpr int NC_REAL = %d;' % nc)
+    S.append('  // derived constants (quotients of the run-time constants): c[NC .. NCX), filled by derive_consts at staging')
+    S.append('  static constexpr int ND = %d, NCX = NC + ND;' % len(derived))
+    S.append('  template<class T> static LFSD_DEV void derive_consts(T* c) {')
+    if derived:
+        S.append(_body([(s_, 'c[%d]' % i) for i, s_ in enumerate(spec.C)],
+                       [('c[%d]' % (max(nc, 1) + j), ex) for j, (_, ex) in enumerate(derived)]))
+    else:
+        S.append('    (void)c;')
+    S.append('  }')
     S.append('  static constexpr bool TIME_VARYING = %s;' % ('true' if spec.time_varying else 'false'))
     S.append('  static const char* name() { return "%s"; }' % spec.name)
     S.append('  static const char* hash() { return "%s"; }' % spec.hash())

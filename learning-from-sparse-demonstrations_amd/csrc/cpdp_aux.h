@@ -46,7 +46,7 @@ template <class M> struct AuxLayout {
   static constexpr int LDS_E = LDS_T + LDS_TSZ;
                                                               // cold per-trajectory state: auxvar, consts,
   static constexpr int LDS_C = LDS_E + NP;                    // and the (x,u,lambda) grid values at both interval ends
-  static constexpr int LDS_GA = LDS_C + M::NC;                // [x_k u_k l_k]
+  static constexpr int LDS_GA = LDS_C + M::NCX;               // [x_k u_k l_k]
   static constexpr int LDS_GB = LDS_GA + 2 * NX + NU;         // [x_k+1 u_k+1 l_k+1]
   static constexpr int LDS_END = LDS_GB + 2 * NX + NU;
   static constexpr int lds_elems() { return ((LDS_END + 3) / 4) * 4; }
@@ -438,6 +438,7 @@ template <class M, typename T, int G, int LAY> LFSD_DEV void aux_setup(AuxCtx<M,
     T* lc = s.lds + Lay::LDS_C;
     for (int i = s.lane; i < NP; i += G) le[i] = a.auxvar[traj * NP + i];
     for (int i = s.lane; i < NC; i += G) lc[i] = a.consts[traj * a.const_stride + i];
+    if constexpr (M::ND > 0) { __syncthreads(); if (s.lane == 0) M::derive_consts(lc); }
     s.e = le; s.c = lc;
   }
   __syncthreads();
@@ -509,7 +510,7 @@ __global__ void __launch_bounds__(64, (sizeof(T) == 4 ? LFSD_WAVES_RIC : 1)) aux
     // Error-controlled sub-stepping (a.rtol > 0): the Richardson pair gives |fine - coarse| / 3 as an estimate of the
     // second-order error that the extrapolation removes; while it exceeds rtol relative to the column's size the interval
     // is redone from its stored start value Z(t_k+1) with twice the units.  (solve_ivp's rtol of the reference, CPDP.py:335,
-    // is 1e-3 on the un-extrapolated estimate of its pair; the default here is 1e-4.)
+    // is 1e-3 on the un-extrapolated estimate of its pair, and so is the default here.)
     for (;;) {
       const T hc = s.dgrid / T(units);
       const T ds = T(1) / T(4 * units);
@@ -550,10 +551,13 @@ __global__ void __launch_bounds__(64, (sizeof(T) == 4 ? LFSD_WAVES_RIC : 1)) aux
       const bool fine_enough = (eP <= tolP && eW <= tolW) || !(t_finite(eP) && t_finite(eW));
       const T ratio = t_max(eP / t_max(tolP, T(1e-30)), eW / t_max(tolW, T(1e-30)));
       const bool no_gain = ratio_prev >= T(0) && ratio > T(0.5) * ratio_prev;
+#if defined(LFSD_AUX_TRACE)
+      if (lane == 0 && slot < LFSD_AUX_TRACE) printf("ric traj %d k %d units %d ratio %.3e (P %.3e W %.3e) prior %d\n", (int)slot, k, units, (double)ratio, (double)(eP / t_max(tolP, T(1e-30))), (double)(eW / t_max(tolW, T(1e-30))), units_guess);
+#endif
       ratio_prev = ratio;
       if (fine_enough || no_gain || !valid || (long long)units * 2 > units_cap) {
-        // next interval: start from this interval's units, or half of them when the estimate had a 32-fold margin
-        units_hint = (eP * T(32) <= tolP && eW * T(32) <= tolW && units > Sa) ? units / 2 : units;
+        // next interval: start from this interval's units, or half of them when the estimate leaves room for it
+        units_hint = (eP * T(LFSD_AUX_DOWN) <= tolP && eW * T(LFSD_AUX_DOWN) <= tolW && units > Sa) ? units / 2 : units;
         break;
       }
       units *= 2;
@@ -698,9 +702,12 @@ __global__ void __launch_bounds__(64, (sizeof(T) == 4 ? LFSD_WAVES_FWD : 1)) aux
       const T tolX = T(3) * a.rtol * (sX + T(1e-2));       // dx/dtheta starts from zero: absolute floor 1e-2 * rtol
       const T ratio = eX / tolX;
       const bool no_gain = ratio_prev >= T(0) && ratio > T(0.5) * ratio_prev;
+#if defined(LFSD_AUX_TRACE)
+      if (lane == 0 && slot < LFSD_AUX_TRACE) printf("fwd traj %d k %d units %d ratio %.3e\n", (int)slot, k, units, (double)ratio);
+#endif
       ratio_prev = ratio;
       if (eX <= tolX || no_gain || !t_finite(eX) || (long long)units * 2 > units_cap) {
-        units_hint = (eX * T(32) <= tolX && units > Sa) ? units / 2 : units;
+        units_hint = (eX * T(LFSD_AUX_DOWN) <= tolX && units > Sa) ? units / 2 : units;
         break;
       }
       units *= 2;

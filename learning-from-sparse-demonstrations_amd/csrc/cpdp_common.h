@@ -47,6 +47,14 @@
 #ifndef LFSD_AUX_LDS_PAD
 #define LFSD_AUX_LDS_PAD 0
 #endif
+// Error-controlled sub-stepping of the auxiliary sweeps: the next interval starts with HALF the units of this one when
+// this one's worst per-unit estimate is at most 1/LFSD_AUX_DOWN of its tolerance.  The estimate is the local error of
+// one split unit, O(h^3): measured on the headline workload it grows 7.4-8x when the units are halved
+// (profiles/r02_h_aux_units.txt), so a 10-fold margin predicts <= 0.8 of the tolerance after the halving.  (It was 32
+// until that trace showed every trajectory integrating at 2-4x the units its tolerance asked for.)
+#ifndef LFSD_AUX_DOWN
+#define LFSD_AUX_DOWN 10
+#endif
 // Riccati kernel: which Z-independent columns are parked per lane in LDS (0 none, 1 [Hxx Hxe] and Huu^-1 [Hux Hue],
 // 2 only Huu^-1 [Hux Hue]).  Mode 2 leaves 16 KB of LDS per workgroup, which admits the second wave per SIMD below.
 #ifndef LFSD_RIC_CACHE
@@ -245,7 +253,9 @@ LFSD_DEV float t_pow(float a, float b) { return powf(a, b); }
 LFSD_DEV double t_pow(double a, double b) { return pow(a, b); }
 
 // ---- tiny dense helpers on group-uniform n x n matrices (row-major, in registers) -----------
-// Cholesky A = L L^T in place (lower); false if not positive definite.
+// Cholesky A = L L^T in place (lower); false if not positive definite.  The DIAGONAL of the result holds 1 / L_jj: the
+// substitutions of chol_solve then multiply instead of divide (an IEEE fp32 division is a ten-instruction dependent
+// sequence on this hardware, and the backward sweep of the OC solve runs two solves per stage on every lane).
 template <int n, typename T> LFSD_DEV bool chol_factor(T* A, T& dmin) {
   bool ok = true;
 #pragma unroll
@@ -255,8 +265,8 @@ template <int n, typename T> LFSD_DEV bool chol_factor(T* A, T& dmin) {
     for (int k = 0; k < j; ++k) d -= A[j * n + k] * A[j * n + k];
     if (!(d > T(0))) { if (ok && d < dmin) dmin = d; ok = false; d = T(1); }    // only the first failing pivot is meaningful
     d = t_sqrt(d);
-    A[j * n + j] = d;
     const T inv = T(1) / d;
+    A[j * n + j] = inv;
 #pragma unroll
     for (int i = j + 1; i < n; ++i) {
       T s = A[i * n + j];
@@ -273,14 +283,14 @@ template <int n, typename T> LFSD_DEV void chol_solve(const T* Lm, T* b) {
     T s = b[i];
 #pragma unroll
     for (int k = 0; k < i; ++k) s -= Lm[i * n + k] * b[k];
-    b[i] = s / Lm[i * n + i];
+    b[i] = s * Lm[i * n + i];
   }
 #pragma unroll
   for (int i = n - 1; i >= 0; --i) {
     T s = b[i];
 #pragma unroll
     for (int k = i + 1; k < n; ++k) s -= Lm[k * n + i] * b[k];
-    b[i] = s / Lm[i * n + i];
+    b[i] = s * Lm[i * n + i];
   }
 }
 // Box-constrained stage problem of the control-limited backward sweep (finite control_lb / control_ub of
@@ -340,11 +350,13 @@ template <int n, typename T> LFSD_DEV bool box_qp(const T* Q, const T* q, const 
   }
   return ok;
 }
-// LU without pivoting, in place (unit lower + upper).  For I + small and SPD-like matrices.
+// LU without pivoting, in place (unit lower + upper).  For I + small and SPD-like matrices.  As in chol_factor the
+// diagonal of the result holds the RECIPROCAL pivots, and lu_solve multiplies by them.
 template <int n, typename T> LFSD_DEV void lu_factor(T* A) {
 #pragma unroll
   for (int j = 0; j < n; ++j) {
     const T inv = T(1) / A[j * n + j];
+    A[j * n + j] = inv;
 #pragma unroll
     for (int i = j + 1; i < n; ++i) {
       const T f = A[i * n + j] * inv;
@@ -364,7 +376,7 @@ template <int n, typename T> LFSD_DEV void lu_solve(const T* A, T* b) {
   for (int i = n - 1; i >= 0; --i) {
 #pragma unroll
     for (int k = i + 1; k < n; ++k) b[i] -= A[i * n + k] * b[k];
-    b[i] /= A[i * n + i];
+    b[i] *= A[i * n + i];
   }
 }
 template <int n, typename T> LFSD_DEV void mat_inverse(const T* A, T* Ainv) {

@@ -71,7 +71,7 @@ template <class M> struct OcLayout {
   // cold per-trajectory state kept in LDS rather than in (spilling) registers
   template <int G> static constexpr int lds_e() { return LDS_RED + G; }
   template <int G> static constexpr int lds_c() { return lds_e<G>() + M::NP; }
-  template <int G> static constexpr int lds_x0() { return lds_c<G>() + M::NC; }
+  template <int G> static constexpr int lds_x0() { return lds_c<G>() + M::NCX; }
   // exact-Hessian sweep: per-lane slots for the 4 RK4 stage points (uniform copy + this lane's tangent)
   template <int G> static constexpr int lds_ex() { return lds_x0<G>() + NX; }
   template <int G> static constexpr int lds_elems() { return ((lds_ex<G>() + 8 * NX * G + 3) / 4) * 4; }
@@ -575,6 +575,24 @@ template <class M, typename T, int G, bool EXACT, bool BND = false> struct OcSol
   static constexpr int NCL = (NXU < 16) ? NXU : 16;      // columns carried by lanes
   static constexpr int NUL = NCL - NX;                   // ... of them control columns
   static constexpr int NEXT = NXU - NCL;                 // columns carried in LDS (0 or 1)
+  LFSD_DEV void mf_load_stage(int cur, int k, T* m, T& mq, T& me, T* xk, T* uk) const {
+    const T* Mk = Mwp(cur) + (long long)k * Lay::M_ELEMS;
+    if (lane < NCL) {
+#pragma unroll
+      for (int i = 0; i < NX; ++i) m[i] = Mk[i * Lay::NXUP + lane];
+      mq = Mk[NX * Lay::NXUP + lane];
+    } else {
+#pragma unroll
+      for (int i = 0; i < NX; ++i) m[i] = T(0);
+      mq = T(0);
+    }
+    me = (NEXT && lane <= NX) ? Mk[lane * Lay::NXUP + NCL] : T(0);
+    const T* xp = xbp(cur) + k * NX;  const T* up = ubp(cur) + k * NU;
+#pragma unroll
+    for (int i = 0; i < NX; ++i) xk[i] = xp[i];
+#pragma unroll
+    for (int a = 0; a < NU; ++a) uk[a] = up[a];
+  }
   LFSD_DEV bool backward_mf(int cur, int mode, T mu, bool live, T& gnorm, T& dV1, T& dV2, T& dmin) {
     static_assert(G == 16 && NX <= 16 && NEXT <= 1, "MFMA backward sweep: 16-lane groups, at most one column beyond 16");
     T* ldsV = lds + Lay::LDS_V;  T* ldsK = lds + Lay::LDS_K;
@@ -602,27 +620,16 @@ template <class M, typename T, int G, bool EXACT, bool BND = false> struct OcSol
         for (int i = 0; i < NX; ++i) lam_out[N * NX + i] = lam[i];
       }
     }
+    // this lane's column of [A B; q], its row of the LDS-carried column and the nominal (x_k, u_k) of one interval: the
+    // loads of interval k-1 are issued while interval k is being processed (one wave per SIMD: nothing else would hide
+    // the latency of the workspace, which does not fit the caches)
+    T m[NX], mq = T(0), me = T(0), mN[NX], mqN = T(0), meN = T(0), xkN[NX], ukN[NU];
+    mf_load_stage(cur, N - 1, m, mq, me, xk, uk);
     for (int k = N - 1; k >= 0; --k) {
-      T m[NX], mq = T(0);
-      const T* Mk = Mwp(cur) + (long long)k * Lay::M_ELEMS;
-      if (lane < NCL) {
-#pragma unroll
-        for (int i = 0; i < NX; ++i) m[i] = Mk[i * Lay::NXUP + lane];
-        mq = Mk[NX * Lay::NXUP + lane];
-      } else {
-#pragma unroll
-        for (int i = 0; i < NX; ++i) m[i] = T(0);
-      }
       if (NEXT) {                                  // column NCL of [A B; q]: row `lane` of it, parked in LDS
-        if (lane <= NX) ldsME[lane] = Mk[lane * Lay::NXUP + NCL];
+        if (lane <= NX) ldsME[lane] = me;
       }
-      {
-        const T* xp = xbp(cur) + k * NX;  const T* up = ubp(cur) + k * NU;
-#pragma unroll
-        for (int i = 0; i < NX; ++i) xk[i] = xp[i];
-#pragma unroll
-        for (int a = 0; a < NU; ++a) uk[a] = up[a];
-      }
+      if (LFSD_BW_PREFETCH) { if (k > 0) mf_load_stage(cur, k - 1, mN, mqN, meN, xkN, ukN); }
       // Y = V_xx [A B](:, 0..15)
       f32x16 acc;
 #pragma unroll
@@ -766,6 +773,17 @@ template <class M, typename T, int G, bool EXACT, bool BND = false> struct OcSol
 #pragma unroll
       for (int i = 0; i < NX; ++i) vcol[i] = (lane < NX) ? T(0.5) * (vcol[i] + ldsV[i * NX + lane]) : T(0);
       __syncthreads();
+      if (k > 0) {
+        if (LFSD_BW_PREFETCH) {
+#pragma unroll
+          for (int i = 0; i < NX; ++i) { m[i] = mN[i]; xk[i] = xkN[i]; }
+#pragma unroll
+          for (int a = 0; a < NU; ++a) uk[a] = ukN[a];
+          mq = mqN; me = meN;
+        } else {
+          mf_load_stage(cur, k - 1, m, mq, me, xk, uk);
+        }
+      }
     }
     ldsRed[lane] = gl_max;
     __syncthreads();
@@ -1040,6 +1058,7 @@ __global__ void __launch_bounds__(64, LFSD_WAVES_OC) oc_solve_kernel(OcArgs<T> a
     for (int i = s.lane; i < NP; i += GR) le[i] = a.auxvar[traj * NP + i];
     for (int i = s.lane; i < NC; i += GR) lc[i] = a.consts[traj * a.const_stride + i];
     for (int i = s.lane; i < NX; i += GR) lx[i] = a.ini_state[traj * NX + i];
+    if constexpr (M::ND > 0) { __syncthreads(); if (s.lane == 0) M::derive_consts(lc); }
   }
   __syncthreads();
   const int N = s.N;
@@ -1104,6 +1123,12 @@ __global__ void __launch_bounds__(64, LFSD_WAVES_OC) oc_solve_kernel(OcArgs<T> a
     s.ub[1][i] = a.resume ? a.control_grid[traj * (N + 1) * NU + i] : (a.u_init ? a.u_init[traj * N * NU + i] : T(0));
   __syncthreads();
   int cur = 0;
+#if defined(LFSD_OC_CLOCK)
+  long long clk_bw = 0, clk_ro = 0, clk_ls = 0, clk_t0 = clock64();
+#define LFSD_CLK(acc, stmt) { const long long c0_ = clock64(); stmt; acc += clock64() - c0_; }
+#else
+#define LFSD_CLK(acc, stmt) { stmt; }
+#endif
   T J = do_rollout(1, 0, T(0), false);
   __syncthreads();
   T mu = T(0);
@@ -1138,7 +1163,9 @@ __global__ void __launch_bounds__(64, LFSD_WAVES_OC) oc_solve_kernel(OcArgs<T> a
     T dmin = T(0);
     bool bw_ok = false;
     s.reuse_hess = EXACT && mode == 2 && hess_ok;
-    if (do_backward(cur, mode, mu, status == ST_RUNNING, gnorm, dV1, dV2, dmin, bw_ok)) { need_bw = false; hess_ok = EXACT && mode == 2; }
+    bool bw_ran = false;
+    LFSD_CLK(clk_bw, bw_ran = do_backward(cur, mode, mu, status == ST_RUNNING, gnorm, dV1, dV2, dmin, bw_ok));
+    if (bw_ran) { need_bw = false; hess_ok = EXACT && mode == 2; }
     bool try_step = false;
     if (status == ST_RUNNING) {
       my_iters = it + 1 + it_off;
@@ -1172,7 +1199,7 @@ __global__ void __launch_bounds__(64, LFSD_WAVES_OC) oc_solve_kernel(OcArgs<T> a
     __syncthreads();
     const bool any_ls = vote[1] != 0;
     __syncthreads();
-    if (any_ls) ia = s.linesearch(cur, J, dV1, dV2, alpha, Jmin, flat_full);
+    if (any_ls) LFSD_CLK(clk_ls, ia = s.linesearch(cur, J, dV1, dV2, alpha, Jmin, flat_full));
     bool accept = false;
     if (ls_try) {
       if (ia >= 0) {
@@ -1200,7 +1227,8 @@ __global__ void __launch_bounds__(64, LFSD_WAVES_OC) oc_solve_kernel(OcArgs<T> a
     if (roll) vote[1] = 1;
     __syncthreads();
     if (vote[1]) {
-      const T Jn = do_rollout(cur, cur ^ 1, opt_try ? T(1) : (accept ? alpha : T(0)), roll);
+      T Jn;
+      LFSD_CLK(clk_ro, Jn = do_rollout(cur, cur ^ 1, opt_try ? T(1) : (accept ? alpha : T(0)), roll));
       if (opt_try) {
         const T flat = T(8) * Eps<T>::v() * t_abs(J);
         const bool fin = t_finite(Jn);
@@ -1247,7 +1275,12 @@ __global__ void __launch_bounds__(64, LFSD_WAVES_OC) oc_solve_kernel(OcArgs<T> a
   __syncthreads();
   if (need_bw) vote[0] = 1;
   __syncthreads();
-  { T dmin = T(0); bool okf = false; if (vote[0]) do_backward(cur, 0, T(0), need_bw, gnorm, dV1, dV2, dmin, okf); }   // refresh costates on the final nominal
+  { T dmin = T(0); bool okf = false; if (vote[0]) LFSD_CLK(clk_bw, do_backward(cur, 0, T(0), need_bw, gnorm, dV1, dV2, dmin, okf)); }   // refresh costates on the final nominal
+#if defined(LFSD_OC_CLOCK)
+  if (threadIdx.x == 0 && blockIdx.x < LFSD_OC_CLOCK)
+    printf("oc clock wave %d: iterations %d total %lld backward %lld rollout %lld linesearch %lld (shader clocks)\n", (int)blockIdx.x, it, clock64() - clk_t0, clk_bw, clk_ro, clk_ls);
+#endif
+#undef LFSD_CLK
   __syncthreads();
   if (valid) {
     T* xo = a.state_grid + traj * (N + 1) * NX;
@@ -1286,6 +1319,7 @@ __global__ void __launch_bounds__(64, 1) oc_solve_wide_kernel(OcArgs<T> a) {
     for (int i = s.lane; i < NP; i += 64) le[i] = a.auxvar[traj * NP + i];
     for (int i = s.lane; i < NC; i += 64) lc[i] = a.consts[traj * a.const_stride + i];
     for (int i = s.lane; i < NX; i += 64) lx[i] = a.ini_state[traj * NX + i];
+    if constexpr (M::ND > 0) { __syncthreads(); if (s.lane == 0) M::derive_consts(lc); }
   }
   T* ldsRed = s.lds + Lay::LDS_RED;
   if constexpr (BND) {
