@@ -533,7 +533,7 @@ __global__ void __launch_bounds__(64, (sizeof(T) == 4 ? LFSD_WAVES_RIC : 1)) aux
         for (int i = 0; i < NX; ++i) {
           const T zc = zpark[i * G + lane];
           err_l = t_max(err_l, t_abs(z[i] - zc));
-          z[i] = (T(4) * z[i] - zc) / T(3);     // Richardson (Strang is O(h^2), symmetric)
+          z[i] = (T(4) * z[i] - zc) * (T(1) / T(3));     // Richardson (Strang is O(h^2), symmetric); constant reciprocal: no division
           scl_l = t_max(scl_l, t_abs(z[i]));
         }
       }
@@ -680,7 +680,7 @@ __global__ void __launch_bounds__(64, (sizeof(T) == 4 ? LFSD_WAVES_FWD : 1)) aux
 #pragma unroll
         for (int i = 0; i < NX; ++i) {
           if (xlane) err_l = t_max(err_l, t_abs(xf[i] - xc[i]));
-          xa[i] = xlane ? (T(4) * xf[i] - xc[i]) / T(3) : T(0);
+          xa[i] = xlane ? (T(4) * xf[i] - xc[i]) * (T(1) / T(3)) : T(0);
           scl_l = t_max(scl_l, t_abs(xa[i]));
         }
         if (Uo && k == N - 1 && unit == units - 1) {

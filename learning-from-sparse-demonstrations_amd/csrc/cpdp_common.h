@@ -247,6 +247,18 @@ template <typename T> LFSD_DEV T t_min(T a, T b) { return a < b ? a : b; }
 template <typename T> LFSD_DEV bool t_finite(T a) { return (a - a) == T(0); }
 LFSD_DEV float t_sqrt(float a) { return sqrtf(a); }
 LFSD_DEV double t_sqrt(double a) { return sqrt(a); }
+// Reciprocal and reciprocal square root of a PIVOT (positive, well inside the normal range): the hardware estimate
+// (v_rcp_f32 / v_rsq_f32, 1 ulp) refined by one Newton step -- three to four instructions where the IEEE division and
+// square root of the compiler are ten-instruction dependent sequences each.  fp64 and the CPU emulator divide.
+#if defined(LFSD_EMU)
+LFSD_DEV float t_rcp(float a) { return 1.0f / a; }
+LFSD_DEV float t_rsqrt(float a) { return 1.0f / sqrtf(a); }
+#else
+LFSD_DEV float t_rcp(float a) { float r = __builtin_amdgcn_rcpf(a); return fmaf(fmaf(-a, r, 1.0f), r, r); }
+LFSD_DEV float t_rsqrt(float a) { float r = __builtin_amdgcn_rsqf(a); return r * fmaf(-0.5f * a * r, r, 1.5f); }
+#endif
+LFSD_DEV double t_rcp(double a) { return 1.0 / a; }
+LFSD_DEV double t_rsqrt(double a) { return 1.0 / sqrt(a); }
 LFSD_DEV float t_floor(float a) { return floorf(a); }
 LFSD_DEV double t_floor(double a) { return floor(a); }
 LFSD_DEV float t_pow(float a, float b) { return powf(a, b); }
@@ -264,8 +276,7 @@ template <int n, typename T> LFSD_DEV bool chol_factor(T* A, T& dmin) {
 #pragma unroll
     for (int k = 0; k < j; ++k) d -= A[j * n + k] * A[j * n + k];
     if (!(d > T(0))) { if (ok && d < dmin) dmin = d; ok = false; d = T(1); }    // only the first failing pivot is meaningful
-    d = t_sqrt(d);
-    const T inv = T(1) / d;
+    const T inv = t_rsqrt(d);
     A[j * n + j] = inv;
 #pragma unroll
     for (int i = j + 1; i < n; ++i) {
@@ -355,7 +366,7 @@ template <int n, typename T> LFSD_DEV bool box_qp(const T* Q, const T* q, const 
 template <int n, typename T> LFSD_DEV void lu_factor(T* A) {
 #pragma unroll
   for (int j = 0; j < n; ++j) {
-    const T inv = T(1) / A[j * n + j];
+    const T inv = t_rcp(A[j * n + j]);
     A[j * n + j] = inv;
 #pragma unroll
     for (int i = j + 1; i < n; ++i) {
