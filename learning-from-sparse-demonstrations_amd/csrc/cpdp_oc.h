@@ -1008,17 +1008,23 @@ LFSD_DEV void oc_bind(Sol& s, const OcArgs<T>& a, T* region, long long slot, boo
 }
 
 // The gradient test  |Q_u|_inf < tol (1 + |J|)  sits at the rounding floor of the gradient in fp32 (tol 1e-6).  Measured on the
-// benchmark (profiles/r02_h_oc_straggler.txt): a trajectory whose gradient norm stops at 1.0-1.2e-5 against a threshold of
-// 0.8e-5 wandered through every fall-back of the step control for 6 more iterations, and one such trajectory holds its
-// whole launch.  Second test, for the Newton-like models without a Levenberg shift: the last accepted step did NOT
-// contract the gradient (g > g_last / 2: Newton's quadratic contraction has ended), the decrease the next full step
-// predicts (half the squared Newton decrement) is below the resolution of the cost itself, 2 eps |J|, and the gradient is
-// within a factor 32 of the tolerance -- the gradient has reached its rounding floor and no step can improve the iterate
-// measurably.  Reported as ST_STALLED ("converged to working precision").  (The decrement alone is not enough: it stops
-// at sqrt(eps) accuracy of the iterate, which the fp32 parity tests do see.)
-template <typename T> LFSD_DEV bool at_working_precision(int mode, T mu, T gnorm, T g_last, T dV1, T dV2, T J, T tol) {
-  return mode >= 1 && mu == T(0) && g_last >= T(0) && gnorm > T(0.5) * g_last &&
-         -(dV1 + dV2) <= T(2) * Eps<T>::v() * t_abs(J) && gnorm < T(32) * tol * (T(1) + t_abs(J));
+// benchmark (profiles/r02_h_oc_straggler.txt): the typical trajectory reaches 1.2e-5 against a threshold of 1.1e-5 after
+// five steps and pays a sixth for 0.5e-5; one whose gradient norm stops at 1.0-1.2e-5 against 0.8e-5 wandered through
+// every fall-back of the step control for 6 more iterations -- and one such trajectory holds its whole launch.
+// Second test, for the Newton-like models without a Levenberg shift.  `dec` = the decrease the full step predicts = half
+// the squared Newton decrement; below 2 eps |J| it is under the resolution of the cost itself.  The iterate is at working
+// precision when that holds now AND either
+//   - it already held at the nominal the last accepted step left: the first such step leaves an error of sqrt(eps) size
+//     in the iterate (which the fp32 parity tests do see), the Newton step after it squares that; or
+//     -- accepted when the gradient is within a factor 2 of the tolerance (flat problems such as the robot arm reach a
+//     small decrement long before their iterate has settled: there the gradient test stays in charge); or
+//   - the last accepted step did not contract the gradient (g > g_last / 2): the quadratic phase has ended at the floor
+//     -- accepted when the gradient is within a factor 32 of the tolerance.
+// Reported as ST_STALLED ("converged to working precision").
+template <typename T> LFSD_DEV bool at_working_precision(int mode, T mu, T gnorm, T g_last, T dec_last, T dV1, T dV2, T J, T tol) {
+  const T res = T(2) * Eps<T>::v() * t_abs(J), gtol = tol * (T(1) + t_abs(J));
+  if (!(mode >= 1 && mu == T(0) && g_last >= T(0) && -(dV1 + dV2) <= res)) return false;
+  return (dec_last <= res && gnorm < T(2) * gtol) || (gnorm > T(0.5) * g_last && gnorm < T(32) * gtol);
 }
 
 // EXACT = false: lean instantiation without the exact-Hessian code (Gauss-Newton / Hamiltonian models only);
@@ -1155,6 +1161,7 @@ __global__ void __launch_bounds__(64, LFSD_WAVES_OC) oc_solve_kernel(OcArgs<T> a
   T gnorm = T(0), dV1 = T(0), dV2 = T(0);
   T g_flat = T(-1);         // gradient norm at the last accepted noise-level ("flat") step; <0: none yet
   T g_last = T(-1);         // gradient norm of the nominal the last accepted step left; <0: none yet
+  T dec_last = T(1e30);     // ... and the decrease its full step predicted
   T J_ref = J;              // cost 4 accepted steps ago (stagnation window)
   int n_acc = 0;
   bool hess_ok = false;     // Hws holds the exact stage Hessians of nominal `cur`
@@ -1197,7 +1204,7 @@ __global__ void __launch_bounds__(64, LFSD_WAVES_OC) oc_solve_kernel(OcArgs<T> a
         }
       } else if (gnorm < a.tol * (T(1) + t_abs(J))) {
         status = ST_CONVERGED;
-      } else if (at_working_precision(mode, mu, gnorm, g_last, dV1, dV2, J, a.tol)) {
+      } else if (at_working_precision(mode, mu, gnorm, g_last, dec_last, dV1, dV2, J, a.tol)) {
         status = ST_STALLED;
       } else {
         try_step = true;
@@ -1260,7 +1267,7 @@ __global__ void __launch_bounds__(64, LFSD_WAVES_OC) oc_solve_kernel(OcArgs<T> a
       }
       if (accept) {
         cur ^= 1;
-        g_last = gnorm;
+        g_last = gnorm; dec_last = (mode >= 1 && mu == T(0)) ? -(dV1 + dV2) : T(1e30);
         need_bw = true;
         hess_ok = false;
         optimistic = (ia == 0);
@@ -1368,7 +1375,7 @@ __global__ void __launch_bounds__(64, 1) oc_solve_wide_kernel(OcArgs<T> a) {
   int mode = (EXACT && a.exact_after == 0) ? 2 : 0;
   bool ham_ok = true, hess_ok = false, gn_crawl = false, costates_ok = false;
   int status = t_finite(J) ? ST_RUNNING : ST_FAILED, it = 0;
-  T gnorm = T(0), dV1 = T(0), dV2 = T(0), g_flat = T(-1), g_last = T(-1), J_ref = J, mu_bad = T(-1);
+  T gnorm = T(0), dV1 = T(0), dV2 = T(0), g_flat = T(-1), g_last = T(-1), dec_last = T(1e30), J_ref = J, mu_bad = T(-1);
   int n_acc = 0, mu_hold = 0;
   const int mu_hold_need = LFSD_MU_HOLD;
   for (; it < a.max_iter && status == ST_RUNNING; ++it) {
@@ -1393,7 +1400,7 @@ __global__ void __launch_bounds__(64, 1) oc_solve_wide_kernel(OcArgs<T> a) {
       continue;
     }
     if (gnorm < a.tol * (T(1) + t_abs(J))) { status = ST_CONVERGED; break; }
-    if (at_working_precision(mode, mu, gnorm, g_last, dV1, dV2, J, a.tol)) { status = ST_STALLED; ++it; break; }      // (this iteration's sweep counts)
+    if (at_working_precision(mode, mu, gnorm, g_last, dec_last, dV1, dV2, J, a.tol)) { status = ST_STALLED; ++it; break; }      // (this iteration's sweep counts)
     // all step lengths at once; the largest one that passes the Armijo test is taken
     const T Ja = s.rollout_alphas(cur, true, alpha_l);
     ldsRed[s.lane] = Ja;
@@ -1433,7 +1440,7 @@ __global__ void __launch_bounds__(64, 1) oc_solve_wide_kernel(OcArgs<T> a) {
       s.adopt_alpha(ia, cur ^ 1);
       s.linearise_parallel(cur ^ 1);
       cur ^= 1;
-      g_last = gnorm;
+      g_last = gnorm; dec_last = (mode >= 1 && mu == T(0)) ? -(dV1 + dV2) : T(1e30);
       hess_ok = false; costates_ok = false;
       if (ia == 0) {
         const T mu_next = (mu > T(1e-8)) ? mu * T(LFSD_MU_DOWN) : T(0);
