@@ -33,7 +33,8 @@ extern "C" {
 
 /* status[] values written by lfsd_coc_solve */
 #define LFSD_ST_CONVERGED 1   /* max |dJ/du| < tol * (1 + |J|)                         */
-#define LFSD_ST_STALLED   2   /* no step improves J beyond rounding: converged to precision */
+#define LFSD_ST_STALLED   2   /* converged to working precision: no step improves J beyond rounding, or the Newton
+                                 decrement is below the resolution of J with the gradient at its rounding floor */
 #define LFSD_ST_MAXITER   3
 #define LFSD_ST_FAILED    4   /* non-finite cost / regularisation exhausted            */
 
