@@ -149,6 +149,37 @@ def test_full_size_properties_quadrotor_batch4096():
     assert np.all(np.abs(g32 - g64).max(axis=1) < 2e-2 * np.abs(g64).max(axis=1))
 
 
+def test_headline_workload_has_no_stragglers_and_stops_at_the_fp64_answer():
+    """The benchmark's own learner (bench.build_learner: 4096 seeds, Nesterov), 12 outer iterations.  A launch lasts as long
+    as its slowest wavefront, so one trajectory wandering at the fp32 gradient floor used to double oc_solve's time
+    (profiles/r02_h_oc_straggler.txt): the working-precision test must end every solve within 8 iterations at every outer
+    iteration -- and what it accepts must be the fp64 solve's answer: loss 5e-4, gradient 1e-2 (the stated fp32 tolerance of
+    the pipeline) on a random subset at the parameters of the last outer iteration."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    args = bench.parse_args(["--no-cpu-baseline"])
+    oc, env, d = models.quadrotor(n_grid=args.n_grid)
+    oc = gpu_prepare(oc, torch.float32)
+    L, theta0, x0 = bench.build_learner(args, oc, d, oc.compile(), 0, 1, "independent")
+    L.count_unconverged = False
+    for k in range(12):
+        th = oc.compile().lookahead(L.theta, L.m, L.mu).clone()
+        L.step()
+        it, st = L._sol["iters"].cpu().numpy(), L._sol["status"].cpu().numpy()
+        assert np.isin(st, (1, 2)).all(), (k, np.bincount(st, minlength=5))
+        assert it.max() <= 8, (k, np.bincount(it))
+    sub = np.random.default_rng(3).choice(args.batch, 48, replace=False)
+    oc64, _, _ = models.quadrotor(n_grid=args.n_grid)
+    oc64 = gpu_prepare(oc64, torch.float64)
+    sol64 = oc64.cocSolverBatch(x0[sub], d["horizon"], th[sub].double())
+    aux64 = oc64.auxSysSolverBatch(sol64, d["taus"], d["waypoints"], d["interface"])
+    l32, l64 = L._aux["loss"][sub].double().cpu().numpy(), aux64["loss"].cpu().numpy()
+    g32, g64 = L._aux["grad"][sub].double().cpu().numpy(), aux64["grad"].cpu().numpy()
+    assert np.all(np.abs(l32 - l64) < 5e-4 * np.maximum(1.0, l64)), np.abs(l32 - l64).max()
+    assert np.all(np.abs(g32 - g64).max(axis=1) < 1e-2 * np.abs(g64).max(axis=1)), (np.abs(g32 - g64).max(axis=1) / np.abs(g64).max(axis=1)).max()
+
+
 def test_shared_theta_gradient_is_sum_over_demonstrations():
     oc, d = gpu_model("pendulum", torch.float64, 10, substeps=8)
     B = 37                                            # ragged: not a multiple of the 8 groups per wavefront
