@@ -795,6 +795,63 @@ template <class M, typename T, int G, bool EXACT, bool BND = false> struct OcSol
     return ok;
   }
 
+  // Costates and gradient norm of nominal `cur` WITHOUT the value recursion (16-lane groups of the lean fp32 kernel):
+  //   lam_k = A_k^T lam_k+1 + l_x,   dJ/du_k = B_k^T lam_k+1 + l_u
+  // from the stored [A B; q] alone -- two dot products per lane and stage where the full sweep (backward_mf) does two
+  // matrix products, a factorisation and two solves.  A solve that is about to pass its convergence test needs nothing
+  // else from its last sweep: oc_solve_kernel tries this first when the previous Newton step already predicted a decrease
+  // below the resolution of the cost, and pays for the full sweep only if the gradient test then fails.
+  LFSD_DEV void costate_sweep_mf(int cur, bool live, T& gnorm) {
+    static_assert(G == 16 && NX <= 16 && NEXT <= 1, "16-lane groups, at most one column beyond 16");
+    T* ldsME = lds + Lay::LDS_M;  T* ldsLam = lds + Lay::LDS_LAM;  T* ldsRed = lds + Lay::LDS_RED;
+    T lam[NX], xk[NX], uk[NU];
+    {
+      const T* xN = xbp(cur) + N * NX;
+#pragma unroll
+      for (int i = 0; i < NX; ++i) xk[i] = xN[i];
+      M::final_grad(tk(N), xk, e, c, lam);
+      if (lane == 0 && live) {
+#pragma unroll
+        for (int i = 0; i < NX; ++i) lam_out[N * NX + i] = lam[i];
+      }
+    }
+    T gl_max = T(0);
+    T m[NX], mq = T(0), me = T(0), mN[NX], mqN = T(0), meN = T(0);
+    mf_load_stage(cur, N - 1, m, mq, me, xk, uk);
+    for (int k = N - 1; k >= 0; --k) {
+      if (NEXT) { if (lane <= NX) ldsME[lane] = me; }
+      if (k > 0) mf_load_stage(cur, k - 1, mN, mqN, meN, xk, uk);
+      T gl = mq;
+#pragma unroll
+      for (int i = 0; i < NX; ++i) gl += m[i] * lam[i];
+      if (lane < NX) ldsLam[lane] = gl;
+      else if (lane < NCL) gl_max = t_max(gl_max, t_abs(gl));
+      __syncthreads();
+      if (NEXT) {
+        T gl_e = ldsME[NX];
+#pragma unroll
+        for (int kk = 0; kk < NX; ++kk) gl_e += ldsME[kk] * lam[kk];
+        gl_max = t_max(gl_max, (lane == NX) ? t_abs(gl_e) : T(0));
+      }
+#pragma unroll
+      for (int i = 0; i < NX; ++i) lam[i] = ldsLam[i];
+      if (lane == 0 && live) {
+#pragma unroll
+        for (int i = 0; i < NX; ++i) lam_out[k * NX + i] = lam[i];
+      }
+      __syncthreads();
+#pragma unroll
+      for (int i = 0; i < NX; ++i) m[i] = mN[i];
+      mq = mqN; me = meN;
+    }
+    ldsRed[lane] = gl_max;
+    __syncthreads();
+    gnorm = T(0);
+#pragma unroll
+    for (int a = 0; a < NUL; ++a) gnorm = t_max(gnorm, ldsRed[NX + a]);
+    __syncthreads();
+  }
+
   // Lane l tries step length 2^-l (all candidate roll-outs run concurrently in the group).
   // Returns the index of the largest accepted step (or -1) and the best cost seen.
   LFSD_DEV int linesearch(int cur, T J, T dV1, T dV2, T& alpha_out, T& Jmin, bool& flat_full) {
@@ -1176,6 +1233,29 @@ __global__ void __launch_bounds__(64, LFSD_WAVES_OC) oc_solve_kernel(OcArgs<T> a
     __syncthreads();
     if (!vote[0]) break;
     __syncthreads();
+    if constexpr (MF) {
+      // A solve whose last Newton step already predicted a decrease below the resolution of the cost is about to pass its
+      // convergence test: try the costate-only sweep (gradient norm + costates, a few per cent of a full sweep) first.
+      // Accepted on the gradient test itself, or on the first clause of at_working_precision (the decrement of the nominal
+      // just left stands in for this one's, which only the full sweep knows: the gradient must not have grown).
+      const bool want_c = status == ST_RUNNING && mode >= 1 && mu == T(0) && g_last >= T(0) && dec_last <= T(2) * Eps<T>::v() * t_abs(J);
+      if (threadIdx.x == 0) vote[1] = 0;
+      __syncthreads();
+      if (want_c) vote[1] = 1;
+      __syncthreads();
+      const bool any_c = vote[1] != 0;
+      __syncthreads();
+      if (any_c) {
+        T gc = T(0);
+        s.costate_sweep_mf(cur, want_c, gc);
+        if (want_c) {
+          const T gtol = a.tol * (T(1) + t_abs(J));
+          if (gc < gtol) status = ST_CONVERGED;
+          else if (gc < T(2) * gtol && gc < g_last) status = ST_STALLED;
+          if (status != ST_RUNNING) { gnorm = gc; need_bw = false; my_iters = it + 1 + it_off; }
+        }
+      }
+    }
     // hand over to the exact stage Hessians at the iteration limit of the cheap models.  (Measured: handing over
     // earlier, e.g. after three full Gauss-Newton steps, costs more regularised Newton steps than it saves.)
     // ... or as soon as Gauss-Newton is reduced to crawling (the oracle's "close: switch to Newton" rule)
