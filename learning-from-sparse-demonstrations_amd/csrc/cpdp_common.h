@@ -113,6 +113,12 @@
 #ifndef LFSD_MFMA_BACKWARD
 #define LFSD_MFMA_BACKWARD 1
 #endif
+// Gauss-Newton -> Hamiltonian (cheap Newton-like) stage-Hessian model: after the first accepted full step whose gain is
+// below this fraction of the new cost ("past the first big drops").  Measured on the benchmark: 0.9 changes nothing (6
+// iterations per solve either way), 3.0 -- switching right after the first step -- costs 2 % of the trajectories a 7th.
+#ifndef LFSD_HAM_SWITCH
+#define LFSD_HAM_SWITCH 0.3
+#endif
 #ifndef LFSD_REG_CONSISTENT
 #define LFSD_REG_CONSISTENT 1
 #endif

@@ -1362,7 +1362,7 @@ __global__ void __launch_bounds__(64, LFSD_WAVES_OC) oc_solve_kernel(OcArgs<T> a
             if (LFSD_MU_HOLD_BACKOFF && mu > T(0) && mu_bad >= T(0) && mu_next <= mu_bad) mu_hold_need = mu_hold_need < 16 ? 2 * mu_hold_need : 16;
             mu = mu_next; mu_hold = 0;
           }
-          if (mode == 0 && ham_ok && (J - Jn) < T(0.3) * t_abs(Jn)) mode = 1;      // past the first big drops: Newton-like
+          if (mode == 0 && ham_ok && (J - Jn) < T(LFSD_HAM_SWITCH) * t_abs(Jn)) mode = 1;      // past the first big drops: Newton-like
           else if (LFSD_GN_CRAWL && mode == 0 && !ham_ok && (J - Jn) < T(1e-2) * t_abs(Jn)) gn_crawl = true;
         }
         J = Jn;
@@ -1526,7 +1526,7 @@ __global__ void __launch_bounds__(64, 1) oc_solve_wide_kernel(OcArgs<T> a) {
         const T mu_next = (mu > T(1e-8)) ? mu * T(LFSD_MU_DOWN) : T(0);
         if (mu > T(0) && mu_bad >= T(0) && mu_next <= mu_bad && mu_hold < mu_hold_need) ++mu_hold;
         else { mu = mu_next; mu_hold = 0; }
-        if (mode == 0 && ham_ok && (J - Jn) < T(0.3) * t_abs(Jn)) mode = 1;
+        if (mode == 0 && ham_ok && (J - Jn) < T(LFSD_HAM_SWITCH) * t_abs(Jn)) mode = 1;
         else if (LFSD_GN_CRAWL && mode == 0 && !ham_ok && (J - Jn) < T(1e-2) * t_abs(Jn)) gn_crawl = true;
       }
       J = Jn;
