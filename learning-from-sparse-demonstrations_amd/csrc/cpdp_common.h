@@ -50,10 +50,12 @@
 // Error-controlled sub-stepping of the auxiliary sweeps: the next interval starts with HALF the units of this one when
 // this one's worst per-unit estimate is at most 1/LFSD_AUX_DOWN of its tolerance.  The estimate is the local error of
 // one split unit, O(h^3): measured on the headline workload it grows 7.4-8x when the units are halved
-// (profiles/r02_h_aux_units.txt), so a 10-fold margin predicts <= 0.8 of the tolerance after the halving.  (It was 32
-// until that trace showed every trajectory integrating at 2-4x the units its tolerance asked for.)
+// (profiles/r02_h_aux_units.txt), so an 8-fold margin predicts <= 0.93-1.0 of the tolerance after the halving.  (It was
+// 32 until that trace showed every trajectory integrating at 2-4x the units its tolerance asked for.  Measured on the
+// benchmark: 10 -> Riccati 2.28 ms, 8 -> 2.14 ms, 6 -> 2.28 ms again: below 8 the halved intervals fail their test and are
+// redone.)
 #ifndef LFSD_AUX_DOWN
-#define LFSD_AUX_DOWN 10
+#define LFSD_AUX_DOWN 8
 #endif
 // Riccati kernel: which Z-independent columns are parked per lane in LDS (0 none, 1 [Hxx Hxe] and Huu^-1 [Hux Hue],
 // 2 only Huu^-1 [Hux Hue]).  Mode 2 leaves 16 KB of LDS per workgroup, which admits the second wave per SIMD below.
