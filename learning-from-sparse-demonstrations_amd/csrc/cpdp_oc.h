@@ -1072,7 +1072,7 @@ LFSD_DEV void oc_bind(Sol& s, const OcArgs<T>& a, T* region, long long slot, boo
 // the squared Newton decrement; below 2 eps |J| it is under the resolution of the cost itself.  The iterate is at working
 // precision when that holds now AND either
 //   - it already held at the nominal the last accepted step left: the first such step leaves an error of sqrt(eps) size
-//     in the iterate (which the fp32 parity tests do see), the Newton step after it squares that; or
+//     in the iterate (which the fp32 parity tests do see), the Newton step after it squares that
 //     -- accepted when the gradient is within a factor 2 of the tolerance (flat problems such as the robot arm reach a
 //     small decrement long before their iterate has settled: there the gradient test stays in charge); or
 //   - the last accepted step did not contract the gradient (g > g_last / 2): the quadratic phase has ended at the floor
