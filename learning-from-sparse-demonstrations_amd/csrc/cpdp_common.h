@@ -54,6 +54,10 @@
 // 32 until that trace showed every trajectory integrating at 2-4x the units its tolerance asked for.  Measured on the
 // benchmark: 10 -> Riccati 2.28 ms, 8 -> 2.14 ms, 6 -> 2.28 ms again: below 8 the halved intervals fail their test and are
 // redone.)
+// non-stiff part of a split unit: 4 = classical RK4 (shipped), 2 = explicit midpoint (experiment)
+#ifndef LFSD_AUX_RK
+#define LFSD_AUX_RK 2
+#endif
 #ifndef LFSD_AUX_DOWN
 #define LFSD_AUX_DOWN 8
 #endif
