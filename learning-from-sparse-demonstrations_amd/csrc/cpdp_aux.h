@@ -260,17 +260,18 @@ template <class M, typename T, int G, int LAY> struct AuxCtx {
   // non-stiff RK4 step of length h over nodes (n0, n1, n2)
   LFSD_DEV void ric_rk4(T* z, int n0, int n1, int n2, T h) {
     T k[NX], acc[NX], zs[NX];
-#if LFSD_AUX_RK == 2
-    // experiment: explicit midpoint rule (the Strang splitting around it is second order anyway)
-    (void)n2; (void)acc;
-    ric_rhs(z, n0, k);
+    if constexpr (aux_rk<T>() == 2) {
+      // explicit midpoint rule: the Strang splitting around it is second order anyway, and in fp32 the rounding floor of
+      // the sweep hides the two orders the Richardson pair gains with RK4 (cpdp_common.h, LFSD_AUX_RK32)
+      (void)n2; (void)acc;
+      ric_rhs(z, n0, k);
 #pragma unroll
-    for (int i = 0; i < NX; ++i) zs[i] = z[i] + T(0.5) * h * k[i];
-    ric_rhs(zs, n1, k);
+      for (int i = 0; i < NX; ++i) zs[i] = z[i] + T(0.5) * h * k[i];
+      ric_rhs(zs, n1, k);
 #pragma unroll
-    for (int i = 0; i < NX; ++i) z[i] += h * k[i];
-    return;
-#endif
+      for (int i = 0; i < NX; ++i) z[i] += h * k[i];
+      return;
+    }
     ric_rhs(z, n0, k);
 #pragma unroll
     for (int i = 0; i < NX; ++i) { acc[i] = k[i]; zs[i] = z[i] + T(0.5) * h * k[i]; }
@@ -396,16 +397,16 @@ template <class M, typename T, int G, int LAY> struct AuxCtx {
   // non-stiff RK4 step of length h over nodes (n0, n1, n2)
   LFSD_DEV void fwd_rk4(T* xa, int n0, int n1, int n2, T h) {
     T k[NX], acc[NX], xs[NX];
-#if LFSD_AUX_RK == 2
-    (void)n2; (void)acc;
-    fwd_rhs(xa, n0, k);
+    if constexpr (aux_rk<T>() == 2) {
+      (void)n2; (void)acc;
+      fwd_rhs(xa, n0, k);
 #pragma unroll
-    for (int i = 0; i < NX; ++i) xs[i] = xa[i] + T(0.5) * h * k[i];
-    fwd_rhs(xs, n1, k);
+      for (int i = 0; i < NX; ++i) xs[i] = xa[i] + T(0.5) * h * k[i];
+      fwd_rhs(xs, n1, k);
 #pragma unroll
-    for (int i = 0; i < NX; ++i) xa[i] += h * k[i];
-    return;
-#endif
+      for (int i = 0; i < NX; ++i) xa[i] += h * k[i];
+      return;
+    }
     fwd_rhs(xa, n0, k);
 #pragma unroll
     for (int i = 0; i < NX; ++i) { acc[i] = k[i]; xs[i] = xa[i] + T(0.5) * h * k[i]; }

@@ -54,9 +54,19 @@
 // 32 until that trace showed every trajectory integrating at 2-4x the units its tolerance asked for.  Measured on the
 // benchmark: 10 -> Riccati 2.28 ms, 8 -> 2.14 ms, 6 -> 2.28 ms again: below 8 the halved intervals fail their test and are
 // redone.)
-// non-stiff part of a split unit: 4 = classical RK4 (shipped), 2 = explicit midpoint (experiment)
-#ifndef LFSD_AUX_RK
-#define LFSD_AUX_RK 2
+// Non-stiff part of a split unit of the auxiliary sweeps: 4 = classical RK4, 2 = explicit midpoint rule.  The Strang
+// splitting around it is second order either way; with RK4 the Richardson pair is (nearly) symmetric and the extrapolation
+// gains two orders, with the midpoint rule one -- at half the right-hand sides per unit.  Measured on MI355X
+// (profiles/r02_m_substeps_accuracy.txt, r02_m_*): in fp32 the sweeps' rounding floor (1e-5 relative) hides the
+// difference -- gradient error vs the tight oracle 1.2e-4 at rtol 1e-3 with both, Riccati 2.12 -> 1.47 ms, forward
+// 1.08 -> 0.91 ms on the benchmark -- so the fp32 kernels use the midpoint rule.  In fp64 (parity reference; the rocket's
+// auxiliary pass) RK4 stays: the midpoint rule cost the robot arm's large-sensitivity seeds a factor 3 in accuracy and
+// the rocket 12 % in time (more units).
+#ifndef LFSD_AUX_RK32
+#define LFSD_AUX_RK32 2
+#endif
+#ifndef LFSD_AUX_RK64
+#define LFSD_AUX_RK64 4
 #endif
 #ifndef LFSD_AUX_DOWN
 #define LFSD_AUX_DOWN 8
@@ -252,6 +262,8 @@ LFSD_DEV void tile_transpose(f32x16& acc) {
 template <typename T> struct Eps;
 template <> struct Eps<float> { static LFSD_DEV float v() { return 1.1920929e-07f; } };
 template <> struct Eps<double> { static LFSD_DEV double v() { return 2.220446049250313e-16; } };
+
+template <typename T> LFSD_HD constexpr int aux_rk() { return sizeof(T) == 4 ? LFSD_AUX_RK32 : LFSD_AUX_RK64; }
 
 template <typename T> LFSD_DEV T t_abs(T a) { return a < T(0) ? -a : a; }
 template <typename T> LFSD_DEV T t_max(T a, T b) { return a > b ? a : b; }

@@ -63,11 +63,10 @@ def test_pendulum_full_pipeline_vs_oracle(emu, dtype, oc_mapping):
         assert rel(aux["grad"][b], r["grad"]) < t["grad"]
 
 
-def test_aux_sweeps_converge_at_third_order(emu):
-    """Halving the split-step size must cut the gradient error ~8x: Strang splitting around the explicit midpoint rule is
-    second order, the Richardson pair removes the h^2 term.  (With classical RK4 inside -- LFSD_AUX_RK 4 -- the pair is
-    symmetric and the extrapolation gains two orders, at 1.5x the price per unit; the error-controlled default needs the
-    same units either way)"""
+def test_aux_sweeps_converge_at_fourth_order(emu):
+    """fp64 (classical RK4 inside the Strang split): halving the split-step size must cut the gradient error ~16x (Strang +
+    Richardson) until round-off.  (The fp32 kernels use the explicit midpoint rule, LFSD_AUX_RK32: third order, below
+    their rounding floor either way.)"""
     thetas, taus, wps = [[2.0, 1.0, 1.0]], [0.1, 0.3, 0.6, 0.7, 0.9], [[0.4], [1.2], [2.1], [2.4], [2.9]]
     o = make_oracle("pendulum", 10)
     r = None
@@ -76,7 +75,7 @@ def test_aux_sweeps_converge_at_third_order(emu):
         oc, d, sol, aux = run_case(emu, "pendulum", torch.float64, thetas, taus, wps, 10, substeps=sub, rtol=0.0)   # fixed units
         r = r or oracle_loss_grad(o, d["ini_state"], d["horizon"], thetas[0], taus, wps, d["interface"])
         errs.append(rel(aux["grad"][0], r["grad"]))
-    assert errs[0] / errs[1] > 6 and errs[1] / errs[2] > 6 and errs[2] < 5e-5, errs
+    assert errs[0] / errs[1] > 8 and errs[1] / errs[2] > 8 and errs[2] < 2e-5, errs
 
 
 def test_error_controlled_substepping_beats_fixed_units(emu):
@@ -344,7 +343,7 @@ def test_rocket_newton_mode_vs_oracle(emu):
     assert r["defect"] < 1e-9 and r["gmax"] < 1e-6 and r["lmax"] < 1e-6 * np.abs(Lm).max(), (r["defect"], r["gmax"], r["lmax"])
     aux = oc.auxSysSolverBatch(sol, taus, wps, d["interface"])
     assert abs(aux["loss"][0].item() - r["loss"]) < 1e-7 * max(1.0, r["loss"])
-    assert rel(aux["grad"][0], r["grad"]) < 2e-3
+    assert rel(aux["grad"][0], r["grad"]) < 1e-3
     # the oracle's cold-start KKT point, handed over as the initial guess, is where the kernel stays
     r0 = o.cocSolver(d["ini_state"], d["horizon"], th, return_grids=True, exact_after=0, max_iter=400)
     assert o.last_info["converged"]

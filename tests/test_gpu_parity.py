@@ -51,7 +51,7 @@ def test_reference_shaped_single_trajectory_api(kind):
 
 
 @pytest.mark.parametrize("substeps", [0, 4])        # 0: the library default bench.py runs (error-controlled, rtol 1e-3); 4: fixed units
-@pytest.mark.parametrize("dtype,ltol,gtol,xtol", [(torch.float64, 1e-6, 2e-4, 1e-6), (torch.float32, 5e-4, 2e-3, 5e-3)])
+@pytest.mark.parametrize("dtype,ltol,gtol,xtol", [(torch.float64, 1e-6, 1e-4, 1e-6), (torch.float32, 5e-4, 2e-3, 5e-3)])
 def test_quadrotor_bench_seeds_vs_tight_oracle(dtype, ltol, gtol, xtol, substeps):
     """The headline configuration itself (n_grid 50, the first seeds bench.py draws, aux_substeps 4) against the TIGHT oracle
     (Radau, rtol 1e-10), so the floor of the shipped fp32 path is known apart from the reference integrator's own 5e-3:
@@ -235,7 +235,7 @@ def test_rocket_newton_mode_vs_oracle(oc_mapping):
     aux = oc.auxSysSolverBatch(sol, taus, wps, d["interface"])
     r = oracle_check_solution(o, d["ini_state"], d["horizon"], th, X, U, Lm, taus, wps, d["interface"])
     assert r["defect"] < 1e-9 and r["gmax"] < 1e-6 and r["lmax"] < 1e-6 * np.abs(Lm).max(), (r["defect"], r["gmax"], r["lmax"])
-    assert abs(aux["loss"][1].item() - r["loss"]) < 1e-7 * max(1.0, r["loss"]) and rel(aux["grad"][1], r["grad"]) < 2e-3
+    assert abs(aux["loss"][1].item() - r["loss"]) < 1e-7 * max(1.0, r["loss"]) and rel(aux["grad"][1], r["grad"]) < 1e-3
     r0 = o.cocSolver(d["ini_state"], d["horizon"], th, return_grids=True, exact_after=0, max_iter=400)
     assert o.last_info["converged"]
     u0 = torch.as_tensor(r0[3][None, :-1].copy(), device="cuda:0")
