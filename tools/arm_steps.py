@@ -1,6 +1,6 @@
 """BASELINE configs[1] (robot arm, n_grid 50, 1024 random seeds): OC status histogram at theta_0, at theta_1 = theta_0 - lr*grad_0
 and along 12 Vanilla steps at the example's learning rate 0.1 (Examples/robotarm_random.py:60-73) with every gradient
-applied (skip_unconverged=False).  A seed is *admissible* while its parameters keep the problem well posed: finite and
+applied (skip_unconverged=False), library-default auxiliary sweeps (error-controlled from one unit per interval).  A seed is *admissible* while its parameters keep the problem well posed: finite and
 below 1e3, time-warp beta > 0 and both quadratic state weights > 0.05 (convex running cost); the few seeds whose (correct, oracle-checked)
 sensitivity at theta_1 is 20-100x the typical one are thrown out of that region by the fixed learning rate."""
 import os, sys, time
@@ -29,7 +29,6 @@ if __name__ == "__main__":
     for dt in (torch.float32, torch.float64):
         oc, env, d = models.ZOO["robotarm"](n_grid=50)
         oc.setDevice(dev, dt)
-        oc.setSolverOptions(aux_substeps=4)
         x0 = np.tile(d["ini_state"], (B, 1))
         L = CPDP.SparseDemoLearner(oc, x0, d["horizon"], d["taus"], d["waypoints"], d["interface"], th0, method="Vanilla",
                                    learning_rate=d["lr"], skip_unconverged=False)
