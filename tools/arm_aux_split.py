@@ -1,5 +1,7 @@
-import sys, time
-sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tools")
+"""Robot arm (configs[1]) learner step split by kernel (HIP events), library-default auxiliary sweeps vs a forced
+minimum of four units per interval."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import numpy as np, torch
 import lfsd_amd
 from lfsd_amd import models, CPDP
