@@ -72,9 +72,12 @@
 #define LFSD_AUX_DOWN 8
 #endif
 // Riccati kernel: which Z-independent columns are parked per lane in LDS (0 none, 1 [Hxx Hxe] and Huu^-1 [Hux Hue],
-// 2 only Huu^-1 [Hux Hue]).  Mode 2 leaves 16 KB of LDS per workgroup, which admits the second wave per SIMD below.
+// 2 only Huu^-1 [Hux Hue]).  Mode 2 leaves 16 KB of LDS per workgroup, which admits the second wave per SIMD below; it
+// paid while a unit evaluated 12 right-hand sides per node set.  With the midpoint rule (6, LFSD_AUX_RK32) recomputing
+// the columns costs less than parking them: measured on the benchmark, Riccati 1.47 ms (mode 2) / 2.30 ms (mode 1) /
+// 1.37 ms (mode 0).
 #ifndef LFSD_RIC_CACHE
-#define LFSD_RIC_CACHE 2
+#define LFSD_RIC_CACHE 0
 #endif
 // outer per-node loops of the once-per-unit preparation (ric_cols; fwd_prep, fwd_cols): rolled.  Measured: 6 % faster in
 // the Riccati sweep; the forward sweep preferred them unrolled (7 %) until it was compiled with the max-ILP scheduler,
