@@ -169,31 +169,47 @@ def cpu_baseline(d, n_grid, thetas, n_sample, timeout=240.0):
                        "and cannot be (no network)" % (n_sample, len(thetas), workers, cores, dt)), results
 
 
-def build_learner(args, oc, d, lib, rank, world, mode, pg=None):
-    """The benchmark's problem set: rank r draws its own 4096 trajectories (weak scaling)."""
+def demo_set(args, d, rank, mode):
+    """The problem set rank `rank` draws (weak scaling: every rank its own `--batch` trajectories, seeded by the rank)."""
     import numpy as np
-    from lfsd_amd import CPDP
     B = args.batch
     rng = np.random.default_rng(1234 + rank)
-    if mode == "independent":
-        theta0 = np.array(d["theta0"])[None, :] + 0.05 * rng.standard_normal((B, lib.n_auxvar))
-        theta0[:, 0] = np.abs(theta0[:, 0]) + 0.5
-        x0 = np.tile(d["ini_state"], (B, 1))
-        L = CPDP.SparseDemoLearner(oc, x0, d["horizon"], d["taus"], d["waypoints"], d["interface"], theta0,
-                                   method="Nesterov", learning_rate=1e-2, mu=0.9, warm_start=args.warm_start)
-        return L, theta0, x0
-    # shared theta, random demonstrations: start position, goal and waypoints perturbed per trajectory
     x0 = np.tile(d["ini_state"], (B, 1))
+    if mode == "independent":
+        theta0 = np.array(d["theta0"])[None, :] + 0.05 * rng.standard_normal((B, len(d["theta0"])))
+        theta0[:, 0] = np.abs(theta0[:, 0]) + 0.5
+        return dict(x0=x0, theta0=theta0)
+    # shared theta, random demonstrations: start position, goal and waypoints perturbed per trajectory
     x0[:, 0:3] += 0.2 * rng.standard_normal((B, 3))
     goal = np.array([3.0, 3.0, 1.5])[None, :] + 0.2 * rng.standard_normal((B, 3))
     wps = np.array(d["waypoints"])[None, :, :] + 0.1 * rng.standard_normal((B, len(d["waypoints"]), 3))
+    return dict(x0=x0, goal=goal, wps=wps, theta0=np.array(d["theta0"], dtype=np.float64))
+
+
+def shared_learner(oc, d, demos, n_total, pg=None, warm_start=False):
+    """SparseDemoLearner(mode='shared') over `demos` (one rank's demo_set, or the concatenation of several ranks');
+    n_total = demonstrations over ALL ranks: lr 1e-2 is the example's rate for ONE demonstration, the summed gradient
+    is scaled back by it."""
+    import numpy as np
+    from lfsd_amd import CPDP
+    x0, goal, wps = demos["x0"], demos["goal"], demos["wps"]
+    B = x0.shape[0]
     consts = oc.consts_tensor(batch=B, overrides=dict(goal_r0=goal[:, 0], goal_r1=goal[:, 1], goal_r2=goal[:, 2]))
-    theta0 = np.array(d["theta0"], dtype=np.float64)
-    # lr 1e-2 is the example's rate for ONE demonstration; the summed gradient of B*world demonstrations is scaled back
-    L = CPDP.SparseDemoLearner(oc, x0, d["horizon"], np.tile(d["taus"], (B, 1)), wps, d["interface"], theta0,
-                               method="Nesterov", learning_rate=1e-2 / (B * world), mu=0.9, consts=consts,
-                               mode="shared", process_group=pg, warm_start=args.warm_start)
-    return L, theta0[None, :], x0
+    return CPDP.SparseDemoLearner(oc, x0, d["horizon"], np.tile(d["taus"], (B, 1)), wps, d["interface"], demos["theta0"],
+                                  method="Nesterov", learning_rate=1e-2 / n_total, mu=0.9, consts=consts,
+                                  mode="shared", process_group=pg, warm_start=warm_start)
+
+
+def build_learner(args, oc, d, lib, rank, world, mode, pg=None):
+    """The benchmark's learner for rank `rank`."""
+    from lfsd_amd import CPDP
+    demos = demo_set(args, d, rank, mode)
+    if mode == "independent":
+        L = CPDP.SparseDemoLearner(oc, demos["x0"], d["horizon"], d["taus"], d["waypoints"], d["interface"], demos["theta0"],
+                                   method="Nesterov", learning_rate=1e-2, mu=0.9, warm_start=args.warm_start)
+        return L, demos["theta0"], demos["x0"]
+    L = shared_learner(oc, d, demos, args.batch * world, pg=pg, warm_start=args.warm_start)
+    return L, demos["theta0"][None, :], demos["x0"]
 
 
 def main(argv=None):
@@ -336,7 +352,11 @@ def main(argv=None):
                                           ("fixed %d units per interval" % (args.substeps or 4)),
                        "oc_status_hist": np.bincount(st, minlength=5).tolist(), "oc_iters_mean": float(it.mean()),
                        "oc_iters_max": int(it.max()), "loss_mean": float(loss.mean().item()) / (1 if mode == "independent" else B * world),
-                       "kernel_ms": {k: round(v, 3) for k, v in ktime.items()}},
+                       "kernel_ms": {k: round(v, 3) for k, v in ktime.items()},
+                       # shared mode: the one parameter vector every rank holds after warmup + steps iterations (17 digits: the
+                       # N>1 test compares it with a single-process run over the union of the ranks' demonstrations)
+                       "theta": [float(x) for x in L.theta.double().cpu().numpy().ravel()] if mode == "shared" else None,
+                       "n_unconverged_last_step": (int(round(float(L.n_bad_device.item()))) if (mode == "shared" and L.n_bad_device is not None) else None)},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": abytes, "avg_launch_ms": ktime[dom],

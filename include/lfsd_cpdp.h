@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define LFSD_ABI_VERSION 5
+#define LFSD_ABI_VERSION 6
 #define LFSD_F32 0
 #define LFSD_F64 1
 #define LFSD_EINVAL (-1)   /* bad argument (null pointer, non-positive size, unknown enum) */
@@ -64,8 +64,9 @@ int lfsd_get_model_info(lfsd_model_info* out);
 /* default value of runtime constant i (the number the reference would have baked into the CasADi graph) */
 double lfsd_const_default(int i);
 
-/* bytes of device scratch lfsd_coc_solve needs for `batch` trajectories */
-size_t lfsd_coc_workspace_bytes(int dtype, int batch, int n_grid);
+/* bytes of device scratch lfsd_coc_solve needs for `batch` trajectories when called with the same exact_after / mapping
+ * and with (bounded != 0) or without control bounds: the two mappings of the solve lay their scratch out differently */
+size_t lfsd_coc_workspace_bytes(int dtype, int batch, int n_grid, int exact_after, int mapping, int bounded);
 
 /* Solve `batch` independent optimal-control problems (the NLP of CPDP.py:110-175:
  * n_grid shooting intervals, steps_per_grid RK4 steps each, piecewise-constant control).

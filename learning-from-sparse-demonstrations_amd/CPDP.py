@@ -31,6 +31,9 @@ from .runtime import LfsdError, ModelLibrary
 
 class COCSys:
     time_varying = False
+    # tests / tuning tools: force one mapping of the OC solve for every instance ("lockstep" | "wide"), whatever the
+    # instance or the batch size would pick (the C ABI takes the choice as an argument; nothing reads the environment)
+    mapping_override = None
 
     def __init__(self, project_name="myOc"):
         self.sys_name = project_name
@@ -249,7 +252,8 @@ class COCSys:
         clb, cub = self._control_bounds()
         sol = lib.coc_solve(x0, hz, th, consts, self.n_grid, self.steps_per_grid, u_init=u_init,
                             max_iter=self.max_iter, tol=self.tol, workspace=workspace, out=out,
-                            exact_after=self.exact_after, control_lb=clb, control_ub=cub, mapping=self.mapping)
+                            exact_after=self.exact_after, control_lb=clb, control_ub=cub,
+                            mapping=COCSys.mapping_override or self.mapping)
         sol.update(horizon=hz, auxvar=th, consts=consts, ini_state=x0, n_grid=self.n_grid)
         return sol
 
@@ -350,8 +354,9 @@ class SparseDemoLearner:
     ``mode='shared'``: one theta for all demonstrations; the gradient is summed over the batch and
     all-reduced over ``process_group`` (RCCL) before a single update.
 
-    ``skip_unconverged`` (default OFF = the reference's behaviour: every gradient is applied; since round 2 the OC
-    solve converges on every seed of the BASELINE configurations, tests/test_gpu_parity.py).  When switched on, a
+    ``skip_unconverged`` (default: OFF in ``independent`` mode = the reference's behaviour, every gradient is applied
+    to its own seed; ON in ``shared`` mode, where ONE non-finite or unconverged demonstration would otherwise be summed,
+    all-reduced and applied to the single theta of every rank).  When switched on, a
     trajectory whose optimal-control solve ended at the iteration limit or failed, or whose loss / gradient is not
     finite, is frozen for that step: its row is masked out of the update kernel (parameters AND optimizer state stay
     untouched, for every update rule), in shared mode it is left out of the summed loss / gradient, and the number of
@@ -366,7 +371,7 @@ class SparseDemoLearner:
     def __init__(self, oc, ini_state, horizon, taus, waypoints, interface_idx, theta0, method="Vanilla",
                  learning_rate=1e-2, mu=0.9, beta_1=0.9, beta_2=0.999, epsilon=1e-8, proj_lo=None, consts=None,
                  mode="independent", process_group=None, true_loss_print_flag=False, warm_start=False,
-                 skip_unconverged=False):
+                 skip_unconverged=None):
         self.oc, self.method, self.lr, self.mu = oc, method, learning_rate, mu
         self.b1, self.b2, self.eps = beta_1, beta_2, epsilon
         if method not in runtime.OPT_METHODS:
@@ -404,9 +409,10 @@ class SparseDemoLearner:
         # warm_start: start every OC solve from the previous iteration's controls (theta moves little per step).
         # The reference cold-starts IPOPT every time; the converged KKT point is the same, only the path to it is shorter.
         self.warm_start = warm_start
-        self.skip_unconverged = skip_unconverged
+        self.skip_unconverged = (mode == "shared") if skip_unconverged is None else bool(skip_unconverged)
         self.count_unconverged = True      # one small device->host read per step; switch off inside timed loops
         self.n_unconverged = 0
+        self.n_bad_device = None
         self.event_hook = None
         self._ok = None
         self._ws = None
@@ -483,6 +489,7 @@ class SparseDemoLearner:
                 torch.distributed.all_reduce(buf, group=self.pg)              # RCCL over xGMI on the GPU
                 g, l, n_bad = buf[:-2].reshape(1, -1), buf[-2:-1], buf[-1:]
             grad_used, loss_out = g.contiguous(), l
+            self.n_bad_device = n_bad                                         # (device tensor: read it outside timed loops)
             if self.skip_unconverged and self.count_unconverged:
                 self.n_unconverged = int(round(n_bad.item()))                 # over all ranks
         else:

@@ -94,12 +94,12 @@ template <class M, typename T, int G, int LAY> struct AuxCtx {
     const T* ls = a.costate_grid + (traj * (N + 1) + k) * NX;
     T* ga = lds + Lay::LDS_GA;
     T* gb = lds + Lay::LDS_GB;
-    __syncthreads();                         // previous interval's readers are done
+    LFSD_WAVE_SYNC();                         // previous interval's readers are done
     for (int i = lane; i < NX; i += G) { ga[i] = xs[i]; gb[i] = xs[NX + i]; ga[NX + NU + i] = ls[i]; gb[NX + NU + i] = ls[NX + i]; }
     for (int i = lane; i < NU; i += G) { ga[NX + i] = us[i]; gb[NX + i] = us[NU + i]; }
     xa_ = ga; ua_ = ga + NX; la_ = ga + NX + NU; xb_ = gb; ub_ = gb + NX; lb_ = gb + NX + NU;
     t_a = M::TIME_VARYING ? dgrid * T(k) : T(0);
-    __syncthreads();
+    LFSD_WAVE_SYNC();
   }
   // Lane `node` (< 5) evaluates the packed PMP coefficients at its own time node s (fraction of the
   // interval) on the reference's linear interpolant of (x,u,lambda) (CPDP.py:320-323) and stages them in LDS.
@@ -120,7 +120,7 @@ template <class M, typename T, int G, int LAY> struct AuxCtx {
 #pragma unroll
       for (int i = 0; i < NU * NU; ++i) L[M::OFF_IHUU + i] = iH[i];
     }
-    __syncthreads();
+    LFSD_WAVE_SYNC();
   }
   LFSD_DEV const T* node(int i) const { return lds + Lay::LDS_L + i * M::NCOEF; }
 
@@ -135,7 +135,7 @@ template <class M, typename T, int G, int LAY> struct AuxCtx {
 #pragma unroll
       for (int a = 0; a < NU; ++a) ldsS[lane * NU + a] = kj[a];
     }
-    __syncthreads();
+    LFSD_WAVE_SYNC();
     T Mx[NU * NU];
     M::template fu_gram<false, LAY>(L, ldsS, Mx);
     T nrm = T(0);
@@ -146,7 +146,7 @@ template <class M, typename T, int G, int LAY> struct AuxCtx {
       for (int b = 0; b < NU; ++b) r += t_abs(Mx[a * NU + b]);
       nrm = t_max(nrm, r);
     }
-    __syncthreads();
+    LFSD_WAVE_SYNC();
     return nrm;
   }
   LFSD_DEV int units_for(T rate, int Sa, T rate_max, int max_refine) const {
@@ -167,7 +167,7 @@ template <class M, typename T, int G, int LAY> struct AuxCtx {
 #pragma unroll
       for (int a = 0; a < NU; ++a) ldsS[lane * NU + a] = s[a];
     }
-    __syncthreads();
+    LFSD_WAVE_SYNC();
     T Gm[NU * NU];
     const T idt = T(1) / dt;
 #pragma unroll
@@ -182,7 +182,7 @@ template <class M, typename T, int G, int LAY> struct AuxCtx {
       for (int a = 0; a < NU; ++a) d += ldsS[i * NU + a] * s[a];
       z[i] -= d;
     }
-    __syncthreads();
+    LFSD_WAVE_SYNC();
   }
   // The columns of [Hxx Hxe] and Huu^-1 [Hux Hue] this lane needs do not depend on Z: once per staged node
   // instead of once per right-hand-side evaluation (12 per unit).  Parked per lane at [(node*(NX+NU)+r)*G + lane].
@@ -250,12 +250,12 @@ template <class M, typename T, int G, int LAY> struct AuxCtx {
       M::template Hxe_mul<true, LAY>(L, oe, y);
     }
     M::template Hxu_mul<true, LAY>(L, w, y);
-    __syncthreads();
+    LFSD_WAVE_SYNC();
     if (lane < NZ) {
 #pragma unroll
       for (int i = 0; i < NX; ++i) y[i] += ldsT[i * NZ + lane];
     }
-    __syncthreads();
+    LFSD_WAVE_SYNC();
   }
   // non-stiff RK4 step of length h over nodes (n0, n1, n2)
   LFSD_DEV void ric_rk4(T* z, int n0, int n1, int n2, T h) {
@@ -325,7 +325,7 @@ template <class M, typename T, int G, int LAY> struct AuxCtx {
         for (int a = 0; a < NU; ++a) ldsK[(r * NX + lane) * NU + a] = kj[a];
       }
     }
-    __syncthreads();
+    LFSD_WAVE_SYNC();
     if (lane < 3) {
       T Mx[NU * NU], Pq[NU * NU], Ph[NU * NU];
       M::template fu_gram<false, LAY>(node(2 * lane), ldsK + lane * NX * NU, Mx);       // K fu
@@ -335,7 +335,7 @@ template <class M, typename T, int G, int LAY> struct AuxCtx {
 #pragma unroll
       for (int i = 0; i < NU * NU; ++i) { ldsP[lane * 2 * NU * NU + i] = Pq[i]; ldsP[(lane * 2 + 1) * NU * NU + i] = Ph[i]; }
     }
-    __syncthreads();
+    LFSD_WAVE_SYNC();
   }
   // apply the prepared exact stiff step of node r (0..2); half = false: dt = hq, true: dt = 2 hq
   LFSD_DEV void fwd_stiff(T* xa, int r, bool half, T hq) {
@@ -430,7 +430,7 @@ template <class M, typename T, int G, int LAY> struct AuxCtx {
 #pragma unroll
       for (int a = 0; a < NU; ++a) ldsS[lane * NU + a] = s[a];
     }
-    __syncthreads();
+    LFSD_WAVE_SYNC();
     M::template fu_mulT<false, LAY>(L, wt, s);          // X role: s = fu^T w_j + Hue e_j + Hux x_j + fu^T P x_j
     M::template Hue_mul<true, LAY>(L, oe, s);
     M::template Hxu_mulT<true, LAY>(L, xa, s);
@@ -442,7 +442,7 @@ template <class M, typename T, int G, int LAY> struct AuxCtx {
     matvec<NU>(iH, s, uo);
 #pragma unroll
     for (int a = 0; a < NU; ++a) uo[a] = -uo[a];
-    __syncthreads();
+    LFSD_WAVE_SYNC();
   }
 };
 
@@ -460,10 +460,10 @@ template <class M, typename T, int G, int LAY> LFSD_DEV void aux_setup(AuxCtx<M,
     T* lc = s.lds + Lay::LDS_C;
     for (int i = s.lane; i < NP; i += G) le[i] = a.auxvar[traj * NP + i];
     for (int i = s.lane; i < NC; i += G) lc[i] = a.consts[traj * a.const_stride + i];
-    if constexpr (M::ND > 0) { __syncthreads(); if (s.lane == 0) M::derive_consts(lc); }
+    if constexpr (M::ND > 0) { LFSD_WAVE_SYNC(); if (s.lane == 0) M::derive_consts(lc); }
     s.e = le; s.c = lc;
   }
-  __syncthreads();
+  LFSD_WAVE_SYNC();
   s.dgrid = a.horizon[traj] / T(a.n_grid);
 #pragma unroll
   for (int i = 0; i < NX; ++i) s.ox[i] = (s.lane == i) ? T(1) : T(0);
@@ -471,12 +471,14 @@ template <class M, typename T, int G, int LAY> LFSD_DEV void aux_setup(AuxCtx<M,
   for (int i = 0; i < NP; ++i) s.oe[i] = (LAY == 1 ? (s.xlane && s.lane == i) : (s.lane == NX + i)) ? T(1) : T(0);
 }
 
-// Barriers in the two auxiliary sweeps: the number of split units per interval (`units`) follows each trajectory's own
-// stiffness, so lane groups of one workgroup pass different numbers of __syncthreads().  That is well defined here --
-// and only here -- because a workgroup is exactly ONE wavefront (launched with 64 threads, checked below): s_barrier is
-// a scalar instruction the wavefront executes as a whole whatever its EXEC mask, it has nobody to wait for, and what
-// remains of __syncthreads() is the LDS fence (s_waitcnt lgkmcnt(0)) every group needs for its own private LDS slice.
-// A port to multi-wave workgroups would have to make `units` block-uniform first (as oc_solve_kernel does with its votes).
+// Synchronisation in the two auxiliary sweeps: the number of split units per interval (`units`) follows each trajectory's
+// own stiffness, so the lane groups of one wavefront pass DIFFERENT numbers of synchronisation points.  A workgroup barrier
+// (__syncthreads / s_barrier) under such data-dependent control flow is undefined; what the sweeps need is less than a
+// barrier anyway: a workgroup is exactly ONE wavefront (launched with 64 threads, checked on entry), every lane group
+// works on its own private LDS slice, and the only hand-over is between lanes of the same wavefront.  LFSD_WAVE_SYNC
+// (cpdp_common.h) is exactly that: an LDS-scoped release/acquire fence pair (s_waitcnt lgkmcnt(0) -- the DS queue of a
+// wavefront is in order) around a wave_barrier (a scheduling fence for the compiler, no instruction).  A port to multi-wave
+// workgroups would have to make `units` block-uniform first (as oc_solve_kernel does with its votes).
 template <class M, typename T, int G>
 __global__ void __launch_bounds__(64, (sizeof(T) == 4 ? LFSD_WAVES_RIC : 1)) aux_riccati_kernel(AuxArgs<T> a) {
   if (blockDim.x != 64) return;                   // one wavefront per workgroup: see the note on barriers above
@@ -562,13 +564,13 @@ __global__ void __launch_bounds__(64, (sizeof(T) == 4 ? LFSD_WAVES_RIC : 1)) aux
       if (!(a.rtol > T(0))) break;
       // per block of columns (P: lanes < NX, W: the rest) the worst estimate against that block's magnitude
       ldsT[lane] = err_l; ldsT[G + lane] = scl_l;
-      __syncthreads();
+      LFSD_WAVE_SYNC();
       T eP = T(0), sP = T(0), eW = T(0), sW = T(0);
       for (int l = 0; l < NZ; ++l) {
         if (l < NX) { eP = t_max(eP, ldsT[l]); sP = t_max(sP, ldsT[G + l]); }
         else { eW = t_max(eW, ldsT[l]); sW = t_max(sW, ldsT[G + l]); }
       }
-      __syncthreads();
+      LFSD_WAVE_SYNC();
       const T tolP = T(3) * a.rtol * sP, tolW = T(3) * a.rtol * (sW + T(1e-3) * sP);
       const bool fine_enough = (eP <= tolP && eW <= tolW) || !(t_finite(eP) && t_finite(eW));
       const T ratio = t_max(eP / t_max(tolP, T(1e-30)), eW / t_max(tolW, T(1e-30)));
@@ -593,12 +595,12 @@ __global__ void __launch_bounds__(64, (sizeof(T) == 4 ? LFSD_WAVES_RIC : 1)) aux
 #pragma unroll
       for (int i = 0; i < NX; ++i) ldsT[lane * NZ + i] = z[i];
     }
-    __syncthreads();
+    LFSD_WAVE_SYNC();
     if (lane < NX) {
 #pragma unroll
       for (int i = 0; i < NX; ++i) z[i] = T(0.5) * (z[i] + ldsT[i * NZ + lane]);
     }
-    __syncthreads();
+    LFSD_WAVE_SYNC();
     if (valid && lane < NZ) {
 #pragma unroll
       for (int i = 0; i < NX; ++i) Zt[((long long)k * NZ + lane) * NX + i] = z[i];
@@ -698,7 +700,7 @@ __global__ void __launch_bounds__(64, (sizeof(T) == 4 ? LFSD_WAVES_FWD : 1)) aux
         s.fwd_stiff(xf, 1, true, hq);
         s.fwd_rk4(xf, 2, 3, 4, hc * T(0.5));
         s.fwd_stiff(xf, 2, false, hq);
-        __syncthreads();      // all reads of this unit's staged coefficients are done before the next staging
+        LFSD_WAVE_SYNC();      // all reads of this unit's staged coefficients are done before the next staging
 #pragma unroll
         for (int i = 0; i < NX; ++i) {
           if (xlane) err_l = t_max(err_l, t_abs(xf[i] - xc[i]));
@@ -717,10 +719,10 @@ __global__ void __launch_bounds__(64, (sizeof(T) == 4 ? LFSD_WAVES_FWD : 1)) aux
       if (!(a.rtol > T(0))) break;
       T* ldsR = s.lds + Lay::LDS_T;           // (the feedback / phi1 images of the last unit are dead by now)
       ldsR[lane] = err_l; ldsR[G + lane] = scl_l;
-      __syncthreads();
+      LFSD_WAVE_SYNC();
       T eX = T(0), sX = T(0);
       for (int l = 0; l < NP; ++l) { eX = t_max(eX, ldsR[l]); sX = t_max(sX, ldsR[G + l]); }
-      __syncthreads();
+      LFSD_WAVE_SYNC();
       const T tolX = T(3) * a.rtol * (sX + T(1e-2));       // dx/dtheta starts from zero: absolute floor 1e-2 * rtol
       const T ratio = eX / tolX;
       const bool no_gain = ratio_prev >= T(0) && ratio > T(0.5) * ratio_prev;

@@ -153,6 +153,22 @@
 #define LFSD_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 #endif
 
+// LFSD_WAVE_SYNC: LDS hand-over between lanes of ONE wavefront (kernels whose workgroup is a single wavefront: the
+// auxiliary sweeps).  Release/acquire fences restricted to the LDS address space (s_waitcnt lgkmcnt(0); global loads in
+// flight are not drained) around a wave_barrier, which emits nothing and only keeps the compiler from moving LDS accesses
+// across it.  Unlike __syncthreads() it is well defined under control flow that differs between the lanes of the wavefront.
+// The CPU emulator runs every lane as a fiber and needs a real rendez-vous there.
+#if defined(LFSD_EMU)
+#define LFSD_WAVE_SYNC() __syncthreads()
+#else
+#define LFSD_WAVE_SYNC()                                            \
+  do {                                                              \
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local"); \
+    __builtin_amdgcn_wave_barrier();                                \
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local"); \
+  } while (0)
+#endif
+
 namespace lfsd {
 
 // debug aid for the emulator build: start every kernel with NaN-filled LDS so that a read of

@@ -1400,7 +1400,7 @@ __global__ void __launch_bounds__(64, LFSD_WAVES_OC) oc_solve_kernel(OcArgs<T> a
 // step control as oc_solve_kernel (one backward sweep = one iteration; the step lengths 2^0..2^-15 are all rolled out at
 // once, so "optimistic full step, then line search" is a single phase: the largest step length that passes the Armijo
 // test is taken).  Control flow is uniform per workgroup -- no votes, no lock-step partners.  lfsd_coc_solve picks this
-// kernel when the lock-step mapping would leave most SIMDs without a wavefront (LFSD_OC_WIDE overrides).
+// kernel when the lock-step mapping would leave most SIMDs without a wavefront (the `mapping` argument overrides).
 template <class M, typename T, bool EXACT, bool BND = false>
 __global__ void __launch_bounds__(64, 1) oc_solve_wide_kernel(OcArgs<T> a) {
   using Sol = OcWide<M, T, EXACT, BND>;

@@ -3,7 +3,6 @@
 //         hipcc -x hip --offload-arch=gfx950 -DLFSD_MODEL_HEADER='"gen/<hash>.h"' -DLFSD_G=<lanes> ...
 // (tests/emu builds the same file with g++ -DLFSD_EMU for the CPU SIMT emulator.)
 #include "lfsd_internal.h"
-#include <cstdlib>
 #ifndef LFSD_WIDE_MAX_BATCH
 #define LFSD_WIDE_MAX_BATCH 1536
 #endif
@@ -45,29 +44,26 @@ static long long padded_batch(int batch) { return ((long long)(batch + OC_GPB - 
 // mapping from a few thousand trajectories up, the fp32 packed / MFMA lean kernel at every batch size; models that spend
 // most iterations on exact stage Hessians are faster on the wide mapping at every batch size measured (robot arm 4096:
 // 113 -> 41 ms, 8192: 202 -> 75 ms; rocket 4096: 1315 -> 525 ms; profiles/r02_d_wide_vs_lockstep.txt).  The caller can say
-// so (`mapping`: LFSD_MAP_AUTO / _LOCKSTEP / _WIDE; lfsd_amd.models does for the robot arm); LFSD_OC_WIDE=0/1 in the
-// environment overrides everything.
-template <typename T> static bool use_wide(int batch, int exact_after, int mapping) {
-  if (const char* ev = getenv("LFSD_OC_WIDE")) return atoi(ev) != 0;
+// so (`mapping`: LFSD_MAP_AUTO / _LOCKSTEP / _WIDE; lfsd_amd.models does for the robot arm).  A bounded problem
+// (control_lb / control_ub) always runs the wide kernel.
+static bool use_wide(int dtype, int batch, int exact_after, int mapping, bool bounded) {
+  if (bounded) return true;
   if (mapping == LFSD_MAP_LOCKSTEP) return false;
   if (mapping == LFSD_MAP_WIDE) return true;
   if (exact_after == 0) return true;      // Newton from the first iteration (rocket): wide wins at every batch size measured
-  const bool lean_mfma = OC_PK && sizeof(T) == 4;
+  const bool lean_mfma = OC_PK && dtype == LFSD_F32;
   return batch <= LFSD_WIDE_MAX_BATCH && !lean_mfma;
 }
-// (the workspace query does not know exact_after: it returns the larger of the two layouts where wide is possible)
-static bool wide_possible(int batch) {
-  if (const char* ev = getenv("LFSD_OC_WIDE")) return atoi(ev) != 0;
-  return batch <= LFSD_WIDE_MAX_BATCH;
-}
 
-LFSD_API size_t lfsd_coc_workspace_bytes(int dtype, int batch, int n_grid) {
+// exactly what lfsd_coc_solve needs for the mapping the same arguments select (ABI 6; ABI 5 returned the larger of the two
+// layouts whatever the batch: 9.6 GB instead of 6.4 GB at 32768 quadrotor trajectories)
+LFSD_API size_t lfsd_coc_workspace_bytes(int dtype, int batch, int n_grid, int exact_after, int mapping, int bounded) {
   if (batch <= 0 || n_grid <= 0 || (dtype != LFSD_F32 && dtype != LFSD_F64)) return 0;
+  if (mapping < LFSD_MAP_AUTO || mapping > LFSD_MAP_WIDE) return 0;
   const size_t es = dtype == LFSD_F32 ? 4 : 8;
-  const size_t lock = (size_t)padded_batch(batch) * (size_t)lfsd::OcLayout<Model>::template ws_elems<G>(n_grid) * es;
-  const size_t wide = (size_t)batch * (size_t)lfsd::OcLayout<Model>::ws_elems_wide(n_grid) * es;
-  (void)wide_possible;
-  return wide > lock ? wide : lock;      // (a bounded problem runs the wide kernel at any batch size)
+  if (use_wide(dtype, batch, exact_after, mapping, bounded != 0))
+    return (size_t)batch * (size_t)lfsd::OcLayout<Model>::ws_elems_wide(n_grid) * es;
+  return (size_t)padded_batch(batch) * (size_t)lfsd::OcLayout<Model>::template ws_elems<G>(n_grid) * es;
 }
 
 template <typename T>
@@ -89,7 +85,7 @@ static int coc_solve_t(int batch, int n_grid, int steps_per_grid, const void* in
   a.ws = (T*)workspace; a.ws_stride = lfsd::OcLayout<Model>::template ws_elems<G>(n_grid);
   a.tol = (T)tol;
   a.exact_after = exact_after;
-  if (control_lb || use_wide<T>(batch, exact_after, mapping)) {       // bounded problems: the wide kernel at every batch size
+  if (use_wide(sizeof(T) == 4 ? LFSD_F32 : LFSD_F64, batch, exact_after, mapping, control_lb != nullptr)) {       // bounded problems: the wide kernel at every batch size
     a.ws_stride = lfsd::OcLayout<Model>::ws_elems_wide(n_grid);
     if (workspace_bytes < (size_t)batch * (size_t)a.ws_stride * sizeof(T)) return LFSD_ENOSPC;
     a.it_start = 0; a.resume = 0; a.max_iter_total = max_iter;

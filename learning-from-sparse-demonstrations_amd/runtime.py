@@ -163,7 +163,7 @@ class ModelLibrary:
         L.lfsd_get_model_info.argtypes = [ctypes.POINTER(_ModelInfo)]
         L.lfsd_const_default.argtypes = [ci]
         L.lfsd_const_default.restype = cd
-        L.lfsd_coc_workspace_bytes.argtypes = [ci, ci, ci]
+        L.lfsd_coc_workspace_bytes.argtypes = [ci, ci, ci, ci, ci, ci]
         L.lfsd_coc_workspace_bytes.restype = ctypes.c_size_t
         L.lfsd_coc_solve.argtypes = [ci, ci, ci, ci, vp, vp, vp, vp, ci, vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, cd, ci, ci, vp,
                                      ctypes.c_size_t, vp]
@@ -176,7 +176,7 @@ class ModelLibrary:
         L.lfsd_lookahead.argtypes = [ci, ctypes.c_longlong, cd, vp, vp, vp, vp]
         info = _ModelInfo()
         rc = L.lfsd_get_model_info(ctypes.byref(info))
-        if rc != 0 or info.abi_version != 5:
+        if rc != 0 or info.abi_version != 6:
             raise LfsdError("ABI mismatch in %s" % path)
         self.n_state, self.n_control, self.n_auxvar, self.n_const = (info.n_state, info.n_control, info.n_auxvar,
                                                                       info.n_const)
@@ -228,8 +228,9 @@ class ModelLibrary:
             raise LfsdError("%s failed with code %d" % (what, rc))
 
     # ---- entry points ----------------------------------------------------------------------
-    def coc_workspace_bytes(self, dtype, batch, n_grid):
-        return int(self.lib.lfsd_coc_workspace_bytes(_DT[dtype], batch, n_grid))
+    def coc_workspace_bytes(self, dtype, batch, n_grid, exact_after=16, mapping="auto", bounded=False):
+        return int(self.lib.lfsd_coc_workspace_bytes(_DT[dtype], batch, n_grid, int(exact_after), MAPPINGS[mapping],
+                                                      1 if bounded else 0))
 
     def coc_solve(self, ini_state, horizon, auxvar, consts, n_grid, steps_per_grid=4, u_init=None, max_iter=100,
                   tol=None, workspace=None, out=None, exact_after=16, control_lb=None, control_ub=None, mapping="auto"):
@@ -263,7 +264,7 @@ class ModelLibrary:
                        cost=torch.empty((B,), dtype=dt, device=dev),
                        iters=torch.zeros((B,), dtype=torch.int32, device=dev),
                        status=torch.zeros((B,), dtype=torch.int32, device=dev))
-        need = self.coc_workspace_bytes(dt, B, n_grid)
+        need = self.coc_workspace_bytes(dt, B, n_grid, exact_after, mapping, control_lb is not None)
         if workspace is None or workspace.numel() * workspace.element_size() < need:
             workspace = torch.empty((need + 7) // 8, dtype=torch.int64, device=dev)
         if tol is None:

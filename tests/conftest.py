@@ -48,8 +48,10 @@ def build_emu_library(oc):
 def oc_mapping(request, monkeypatch):
     """Both mappings of the OC solve: several trajectories per wavefront with the intervals in sequence (lfsd_coc_solve's
     choice from a few thousand trajectories up) and one trajectory per wavefront with the intervals in parallel (its choice
-    below that).  LFSD_OC_WIDE forces one or the other whatever the batch size."""
-    monkeypatch.setenv("LFSD_OC_WIDE", "1" if request.param == "wide" else "0")
+    below that).  COCSys.mapping_override forces one or the other whatever the instance or the batch size asks for (it is
+    handed to lfsd_coc_solve as its `mapping` argument)."""
+    from lfsd_amd import CPDP
+    monkeypatch.setattr(CPDP.COCSys, "mapping_override", request.param)
     return request.param
 
 
@@ -193,6 +195,18 @@ def oracle_parallel(jobs, timeout=1500.0):
     return out
 
 
+def parity_record(what, metric, measured, asserted):
+    """Every parity comparison leaves its measured error beside the asserted bound: in the failure message, and -- when
+    LFSD_PARITY_REPORT names a file -- as one JSON line per comparison (profiles/*_parity_floors.jsonl are such runs on the
+    GPU; the asserted bounds of the fp32 cases are set from them with a stated margin, not chosen blanket)."""
+    import json
+    path = os.environ.get("LFSD_PARITY_REPORT")
+    if path:
+        with open(path, "a") as f:
+            f.write(json.dumps(dict(what=what, metric=metric, measured=float(measured), asserted=float(asserted))) + "\n")
+    assert measured < asserted, "%s: %s measured %.3e, asserted < %.1e" % (what, metric, measured, asserted)
+
+
 def assert_grids_match(sol, aux, b, r, n, m, p, tol, what=""):
     """Every output of the path vs the oracle: state / control / costate grids (CPDP.py:186-196), Riccati pair [P W]
     (CPDP.py:329-338), dx/dtheta and du/dtheta (CPDP.py:352-381), loss and gradient.  tol: dict(grid, costate, aux, loss, grad)."""
@@ -202,19 +216,16 @@ def assert_grids_match(sol, aux, b, r, n, m, p, tol, what=""):
         a = a.detach().double().cpu().numpy() if hasattr(a, "detach") else np.asarray(a, dtype=np.float64)
         ref = np.asarray(ref, dtype=np.float64)
         return np.abs(a - ref).max() / max(np.abs(ref).max(), 1e-300)
-    assert rel(sol["state_grid"][b], r["X"]) < tol["grid"], (what, "state", rel(sol["state_grid"][b], r["X"]))
-    assert rel(sol["control_grid"][b], r["U"]) < tol["grid"], (what, "control", rel(sol["control_grid"][b], r["U"]))
-    assert rel(sol["costate_grid"][b], r["L"]) < tol["costate"], (what, "costate", rel(sol["costate_grid"][b], r["L"]))
-    N1 = r["PW"].shape[0]
-    Zo = np.concatenate([r["PW"][:, :n * n].reshape(N1, n, n), r["PW"][:, n * n:].reshape(N1, n, p)], axis=2)
-    e = rel(aux["Z_grid"][b].permute(0, 2, 1), Zo)
-    assert e < tol["aux"], (what, "Z_grid", e)
-    e = rel(aux["auxX_grid"][b].permute(0, 2, 1).reshape(N1, n * p), r["vX"])
-    assert e < tol["aux"], (what, "auxX_grid", e)
-    # du/dtheta(T) = -Huu^-1 (fu^T h_xx) dx/dtheta(T) + ...  amplifies the error of dx/dtheta by |Huu^-1 fu^T h_xx| (10^3 for the
-    # arm's final-cost weight 100), hence its own tolerance
-    e = rel(aux["auxU_grid"][b].permute(0, 2, 1).reshape(N1, m * p), r["vU"])
-    assert e < tol.get("auxU", tol["aux"]), (what, "auxU_grid", e)
-    assert abs(float(aux["loss"][b]) - r["loss"]) < tol["loss"] * max(1.0, r["loss"]), (what, "loss", float(aux["loss"][b]), r["loss"])
-    e = rel(aux["grad"][b], r["grad"])
-    assert e < tol["grad"], (what, "grad", e)
+    parity_record(what, "state", rel(sol["state_grid"][b], r["X"]), tol["grid"])
+    parity_record(what, "control", rel(sol["control_grid"][b], r["U"]), tol["grid"])
+    parity_record(what, "costate", rel(sol["costate_grid"][b], r["L"]), tol["costate"])
+    if aux.get("auxX_grid") is not None:
+        N1 = r["PW"].shape[0]
+        Zo = np.concatenate([r["PW"][:, :n * n].reshape(N1, n, n), r["PW"][:, n * n:].reshape(N1, n, p)], axis=2)
+        parity_record(what, "Z_grid", rel(aux["Z_grid"][b].permute(0, 2, 1), Zo), tol["aux"])
+        parity_record(what, "auxX_grid", rel(aux["auxX_grid"][b].permute(0, 2, 1).reshape(N1, n * p), r["vX"]), tol["aux"])
+        # du/dtheta(T) = -Huu^-1 (fu^T h_xx) dx/dtheta(T) + ...  amplifies the error of dx/dtheta by |Huu^-1 fu^T h_xx| (10^3 for
+        # the arm's final-cost weight 100), hence its own tolerance
+        parity_record(what, "auxU_grid", rel(aux["auxU_grid"][b].permute(0, 2, 1).reshape(N1, m * p), r["vU"]), tol.get("auxU", tol["aux"]))
+    parity_record(what, "loss", abs(float(aux["loss"][b]) - r["loss"]) / max(1.0, r["loss"]), tol["loss"])
+    parity_record(what, "grad", rel(aux["grad"][b], r["grad"]), tol["grad"])

@@ -8,7 +8,7 @@ int main() {
   const int B = 5, N = 6, n = mi.n_state, m = mi.n_control, p = mi.n_auxvar, nc = mi.n_const, nw = 2, ni = 1;
   for (int pass = 0; pass < 4; ++pass) {         // both arithmetic types x both mappings of the OC solve (lock-step, wide)
     const int dtype = pass & 1;
-    setenv("LFSD_OC_WIDE", (pass & 2) ? "1" : "0", 1);
+    const int mapping = (pass & 2) ? LFSD_MAP_WIDE : LFSD_MAP_LOCKSTEP;
     const size_t es = dtype ? 8 : 4;
     auto buf = [&](size_t cnt) { return std::vector<char>(cnt * es); };
     auto x0 = buf(B * n), hz = buf(B), th = buf(B * p), cs = buf(nc ? nc : 1), X = buf(B * (N + 1) * n), U = buf(B * (N + 1) * m),
@@ -20,10 +20,10 @@ int main() {
       for (int w = 0; w < nw; ++w) { set(taus, b * nw + w, 0.3 + 0.4 * w); set(wps, b * nw + w, 0.5); } }
     for (int i = 0; i < nc; ++i) set(cs, i, lfsd_const_default(i));
     std::vector<int> it(B), st(B), iface = {0};
-    size_t wsb = lfsd_coc_workspace_bytes(dtype, B, N);
+    size_t wsb = lfsd_coc_workspace_bytes(dtype, B, N, 3, mapping, 0);
     std::vector<char> ws(wsb);
     int rc = lfsd_coc_solve(dtype, B, N, 4, x0.data(), hz.data(), th.data(), nc ? cs.data() : nullptr, 0, nullptr, nullptr, nullptr, X.data(), U.data(), L.data(),
-                            cost.data(), it.data(), st.data(), 40, dtype ? 1e-9 : 1e-6, 3, LFSD_MAP_AUTO, ws.data(), wsb, nullptr);
+                            cost.data(), it.data(), st.data(), 40, dtype ? 1e-9 : 1e-6, 3, mapping, ws.data(), wsb, nullptr);
     printf("dtype %d coc rc %d status %d iters %d\n", dtype, rc, st[0], it[0]);
     rc = lfsd_aux_solve(dtype, B, N, hz.data(), th.data(), nc ? cs.data() : nullptr, 0, X.data(), U.data(), L.data(), Z.data(), nw, ni, iface.data(),
                         taus.data(), wps.data(), loss.data(), grad.data(), aX.data(), aU.data(), (pass & 2) ? 1 : 4, (pass & 2) ? 1e-3 : 0.0, nullptr);

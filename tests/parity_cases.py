@@ -91,6 +91,32 @@ def single_trajectory_api(prepare, kind="robotarm", dtype=torch.float64):
     assert np.allclose(auxsys_sol(tm), 0.5 * (a[3] + a[4]), rtol=1e-12, atol=1e-14)
 
 
+def configs0_pendulum(prepare, dtype=torch.float64):
+    """BASELINE configs[0]: "SinglePendulum (JinEnv) CPDP, horizon 50, 1 seed" -- Examples/pendulum_groundtruth.py's system at
+    n_grid 50, one trajectory, against the tight oracle: every output grid through the batch API (batch of ONE: seven of
+    the eight lane groups of the wavefront are padding), then the reference-shaped calls."""
+    oc, env, d = models.pendulum(n_grid=50)
+    prepare(oc, dtype)
+    oc.setSolverOptions(aux_substeps=8)
+    th = [1.0, 0.5, 1.5]                                   # pendulum_random.py's initial guess
+    taus, wps = [0.1, 0.3, 0.6, 0.7, 0.9], [[0.4], [1.2], [2.1], [2.4], [2.9]]
+    sol = oc.cocSolverBatch([d["ini_state"]], d["horizon"], [th])
+    aux = oc.auxSysSolverBatch(sol, taus, wps, d["interface"], want_grids=True)
+    assert sol["status"].tolist() == [1]
+    r = oracle_parallel([dict(kind="pendulum", n_grid=50, ini_state=d["ini_state"], horizon=d["horizon"], theta=th, taus=taus,
+                              wps=wps, iface=d["interface"])])[0]
+    assert_grids_match(sol, aux, 0, r, 2, 1, 3, TOL[dtype], what="configs[0] pendulum n_grid 50")
+    time_grid, opt_sol = oc.cocSolver(d["ini_state"], d["horizon"], th)
+    auxsys_sol = oc.auxSysSolver(time_grid, opt_sol, th)
+    assert time_grid.shape == (51,)
+    g = opt_sol(time_grid)
+    ref = np.concatenate((r["X"], r["U"], r["L"]), axis=1)
+    assert np.abs(g - ref).max() < 10 * TOL[dtype]["grid"] * np.abs(ref).max()
+    a = auxsys_sol(time_grid)
+    assert np.abs(a[:, :6] - r["vX"]).max() < TOL[dtype]["aux"] * np.abs(r["vX"]).max()
+    assert np.abs(a[:, 6:] - r["vU"]).max() < TOL[dtype]["auxU"] * np.abs(r["vU"]).max()
+
+
 def rocket_mixed_precision(prepare, n_grid=15):
     """BASELINE configs[4]'s arithmetic: fp32 optimal-control solve + fp64 auxiliary (Riccati / sensitivity) pass
     (COCSys.setDevice(aux_dtype=float64)).  The rocket has several local minima, so the check is basin-independent: the

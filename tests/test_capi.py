@@ -41,8 +41,12 @@ def test_hip_library_exports_all_symbols(name):
     assert lib.lfsd_coc_solve(7, 1, 10, 4, None, None, None, None, 0, None, None, None, None, None, None, None, None, None,
                               10, ctypes.c_double(1e-6), 10, 0, None, ctypes.c_size_t(0), None) == -1
     lib.lfsd_coc_workspace_bytes.restype = ctypes.c_size_t
-    assert lib.lfsd_coc_workspace_bytes(0, 4096, 50) > 0
-    assert lib.lfsd_coc_workspace_bytes(3, 4096, 50) == 0
+    assert lib.lfsd_coc_workspace_bytes(0, 4096, 50, 16, 0, 0) > 0
+    assert lib.lfsd_coc_workspace_bytes(3, 4096, 50, 16, 0, 0) == 0
+    assert lib.lfsd_coc_workspace_bytes(0, 4096, 50, 16, 7, 0) == 0        # unknown mapping
+    # the wide mapping (forced, or implied by control bounds) needs more scratch per trajectory than the lock-step one
+    lock, wide = lib.lfsd_coc_workspace_bytes(0, 4096, 50, 16, 1, 0), lib.lfsd_coc_workspace_bytes(0, 4096, 50, 16, 2, 0)
+    assert 0 < lock < wide and lib.lfsd_coc_workspace_bytes(0, 4096, 50, 16, 1, 1) == wide
 
 
 def test_product_refuses_cpu_tensors():

@@ -146,7 +146,7 @@ def test_quadrotor_fp32_packed_rollout_matches_fp64(emu, monkeypatch):
     (oc_solve_kernel<..., PK=true>, four trajectories per workgroup, backward sweep on the (emulated) matrix cores); fp64 keeps the
     one-column-per-lane mapping.  Same inputs, ragged batch of 5 (one full workgroup + one partial), stated fp32
     tolerances: loss 5e-4, gradient 2e-2, grids 5e-3."""
-    monkeypatch.setenv("LFSD_OC_WIDE", "0")          # this test is about the lock-step kernels
+    monkeypatch.setattr(CPDP.COCSys, "mapping_override", "lockstep")          # this test is about the lock-step kernels
     oc, env, d = models.quadrotor(n_grid=int(G["n_grid"]))
     emu(oc)
     consts = oc.consts_tensor(overrides=dict(goal_r0=G["goal_r"][0], goal_r1=G["goal_r"][1], goal_r2=G["goal_r"][2]))
@@ -403,7 +403,7 @@ def test_warm_start_and_mixed_precision(emu, monkeypatch):
     """u_init warm start reaches the same KKT point in fewer iterations; fp32 solve + fp64 auxiliary pass
     (BASELINE configs[4]) returns fp64-accurate sweeps on the fp32 trajectory.  Robot arm on the lock-step kernels (the other
     robot-arm tests run the wide mapping, lfsd_coc_solve's choice for small batches)."""
-    monkeypatch.setenv("LFSD_OC_WIDE", "0")
+    monkeypatch.setattr(CPDP.COCSys, "mapping_override", "lockstep")
     oc, env, d = models.robotarm(n_grid=12)
     emu(oc)
     th = [[3., 0.5, 2, 1.5, 0.2]]
@@ -482,6 +482,31 @@ def test_learner_skips_unconverged_trajectories(emu):
     assert L3.n_unconverged == 0 and torch.equal(L3.theta, L4.theta)
 
 
+def test_shared_mode_masks_a_bad_demonstration_by_default(emu):
+    """mode='shared' sums every demonstration's gradient into ONE theta (and all-reduces it): a single failed solve or
+    non-finite gradient would destroy the whole job, so the status / finiteness mask is ON by default there.  A batch
+    with one poisoned demonstration must take exactly the step of the batch without it, and count it."""
+    from lfsd_amd import CPDP
+    oc, env, d = models.ZOO["pendulum"](n_grid=10)
+    emu(oc)
+    oc.setDevice(dtype=torch.float64)
+    x0 = np.array([[0.0, 0.0], [0.1, 0.0], [np.nan, 0.0]])
+    taus, wps, th0 = [0.3, 0.6], [[0.5], [1.0]], [1.5, 0.8, 1.2]
+    L = CPDP.SparseDemoLearner(oc, x0, d["horizon"], taus, wps, d["interface"], th0, learning_rate=1e-2, mode="shared")
+    assert L.skip_unconverged is True
+    Lg = CPDP.SparseDemoLearner(oc, x0[:2], d["horizon"], taus, wps, d["interface"], th0, learning_rate=1e-2, mode="shared")
+    for _ in range(2):
+        loss, grad = L.step()
+        loss_g, grad_g = Lg.step()
+        assert L.n_unconverged == 1 and Lg.n_unconverged == 0
+        assert torch.isfinite(L.theta).all() and torch.equal(L.theta, Lg.theta)
+        assert torch.equal(loss, loss_g) and torch.equal(grad, grad_g)
+    Lu = CPDP.SparseDemoLearner(oc, x0, d["horizon"], taus, wps, d["interface"], th0, learning_rate=1e-2, mode="shared",
+                                skip_unconverged=False)            # the unguarded sum is what the default protects against
+    Lu.step()
+    assert not torch.isfinite(Lu.theta).all()
+
+
 def test_waypoints_outside_the_horizon_raise_like_interp1d(emu):
     """The reference's opt_sol(t) is scipy's interp1d (CPDP.py:386): a tau outside [0, horizon] raises ValueError there;
     the kernels would extrapolate silently, so the host checks.  Same for an interface index that selects no state."""
@@ -511,6 +536,17 @@ def test_control_bounds_vs_independent_bounded_solve(emu):
         oc.setDevice(dtype=dtype)
         return oc
     pc.control_bounds(prepare, torch.float64)
+
+
+def test_configs0_pendulum_horizon50_single_seed(emu):
+    """BASELINE configs[0] (SinglePendulum, horizon 50, 1 seed) on the emulated kernels; the -m gpu tier repeats it."""
+    import parity_cases as pc
+
+    def prepare(oc, dtype):
+        emu(oc)
+        oc.setDevice(dtype=dtype)
+        return oc
+    pc.configs0_pendulum(prepare)
 
 
 def test_state_bounds_are_refused():

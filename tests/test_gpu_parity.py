@@ -180,6 +180,95 @@ def test_headline_workload_has_no_stragglers_and_stops_at_the_fp64_answer():
     assert np.all(np.abs(g32 - g64).max(axis=1) < 1e-2 * np.abs(g64).max(axis=1)), (np.abs(g32 - g64).max(axis=1) / np.abs(g64).max(axis=1)).max()
 
 
+def test_headline_defaults_vs_tight_oracle_at_outer_iteration_12():
+    """Where the work-saving shortcuts of the shipped fp32 path act -- the working-precision stop of the OC solve (status 2,
+    cpdp_oc.h at_working_precision / the costate-only last sweep), the error-controlled unit count and the midpoint rule
+    of the auxiliary sweeps (library defaults: rtol 1e-3 from one unit) -- they are compared with the TIGHT ORACLE, not
+    with fp64 HIP: the benchmark's own learner runs 12 outer iterations, and at the parameters of the 12th (later
+    iterations need more split units than theta_0) six trajectories that ended CONVERGED and six that ended at WORKING
+    PRECISION go through the fp64 oracle (IPOPT-equivalent solve, Radau rtol 1e-10 sweeps).
+    Measured floors (profiles/r03_parity_floors.jsonl): state 2e-5, loss 3e-6, gradient 3e-4; asserted with a margin of
+    ~5x: state 2e-4, costate 5e-3, loss 5e-5, gradient 2e-3."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    args = bench.parse_args(["--no-cpu-baseline"])
+    oc, env, d = models.quadrotor(n_grid=args.n_grid)
+    oc = gpu_prepare(oc, torch.float32)
+    oc.setSolverOptions(aux_substeps=args.substeps, aux_rtol=args.aux_rtol)        # the library defaults bench.py runs
+    L, theta0, x0 = bench.build_learner(args, oc, d, oc.compile(), 0, 1, "independent")
+    for k in range(12):
+        th = oc.compile().lookahead(L.theta, L.m, L.mu).clone()
+        L.step()
+    st = L._sol["status"].cpu().numpy()
+    assert np.isin(st, (1, 2)).all(), np.bincount(st, minlength=5)
+    rng = np.random.default_rng(12)
+    pick = []
+    for code in (1, 2):
+        idx = np.where(st == code)[0]
+        assert len(idx) >= 6, (code, np.bincount(st, minlength=5))        # both exits are really taken on this workload
+        pick += list(rng.choice(idx, 6, replace=False))
+    th64 = th.double().cpu().numpy()
+    refs = oracle_parallel([dict(kind="quadrotor", n_grid=args.n_grid, ini_state=d["ini_state"], horizon=d["horizon"],
+                                 theta=list(th64[b]), taus=d["taus"], wps=d["waypoints"], iface=d["interface"]) for b in pick])
+    tol = dict(grid=2e-4, costate=5e-3, loss=5e-5, grad=2e-3)
+    for b, r in zip(pick, refs):
+        assert_grids_match(L._sol, L._aux, int(b), r, 13, 4, 7, tol,
+                           what="headline fp32 defaults, outer iteration 12, seed %d, status %d" % (b, st[b]))
+
+
+def test_configs0_pendulum_horizon50_single_seed():
+    """BASELINE configs[0]: SinglePendulum (JinEnv), horizon (n_grid) 50, ONE seed -- the reference's own CPU-runnable
+    case -- in fp64 against the tight oracle, through the batch API and through the reference-shaped calls."""
+    pc.configs0_pendulum(gpu_prepare)
+
+
+@pytest.mark.parametrize("backend", ["gloo", "nccl"])
+def test_bench_two_ranks_share_theta_through_the_allreduce(backend):
+    """N > 1 on hardware: `bench.py --gpus 2` as a FRESH child process (its parent never touches a GPU and starts
+    torch.distributed.run; nothing is re-executed from this pytest process).  With gloo both ranks land on the one GPU of
+    the box (local_rank % device_count); with nccl (= RCCL) the test needs two GPUs and is skipped otherwise.  Rank 0's
+    JSON line must say n_gpus 2 / mode shared, and the single theta every rank holds after warmup + steps iterations must
+    equal a single-process mode='shared' run over the UNION of the two ranks' demonstrations (fp64, 1e-10): the summed
+    gradient really went through the all-reduce and drove the update (QuadAlgorithm.py:469-495 / robotarm_random.py:60-73
+    is the loop being sharded)."""
+    import json
+    import subprocess
+    import sys
+    if backend == "nccl" and torch.cuda.device_count() < 2:
+        pytest.skip("RCCL run needs two GPUs (the driver's SCALE run covers it)")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    argv = ["--gpus", "2", "--backend", backend, "--batch", "256", "--steps", "2", "--warmup", "1", "--dtype", "f64",
+            "--no-cpu-baseline"]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + argv, capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["config"]["mode"] == "shared" and out["scaling"] == "weak"
+    assert out["config"]["n_unconverged_last_step"] == 0
+    assert out["value"] > 0 and abs(out["value"] - 2 * 256 * 2 / (out["ms_per_step"] * 2e-3)) < 1e-6 * out["value"]
+    # single process, union of the two shards, the same three iterations
+    args = bench.parse_args(argv)
+    oc, env_, d = models.quadrotor(n_grid=args.n_grid)
+    oc = gpu_prepare(oc, torch.float64)
+    oc.setSolverOptions(aux_substeps=args.substeps, aux_rtol=args.aux_rtol)
+    parts = [bench.demo_set(args, d, rk, "shared") for rk in (0, 1)]
+    union = dict(x0=np.concatenate([p_["x0"] for p_ in parts]), goal=np.concatenate([p_["goal"] for p_ in parts]),
+                 wps=np.concatenate([p_["wps"] for p_ in parts]), theta0=parts[0]["theta0"])
+    L = bench.shared_learner(oc, d, union, 2 * args.batch)
+    for _ in range(args.warmup + args.steps):
+        L.step()
+    th = L.theta.double().cpu().numpy().ravel()
+    assert L.n_unconverged == 0
+    assert np.abs(np.array(out["config"]["theta"]) - th).max() < 1e-10 * np.abs(th).max(), (out["config"]["theta"], th.tolist())
+
+
 def test_shared_theta_gradient_is_sum_over_demonstrations():
     oc, d = gpu_model("pendulum", torch.float64, 10, substeps=8)
     B = 37                                            # ragged: not a multiple of the 8 groups per wavefront

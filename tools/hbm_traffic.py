@@ -1,58 +1,90 @@
 #!/usr/bin/env python3
-"""Fold two rocprofv3 `--pmc` passes (FETCH_SIZE, WRITE_SIZE) into profiles/<round>_hbm_traffic.json.
+"""Fold two rocprofv3 `--pmc` passes (FETCH_SIZE, WRITE_SIZE) into profiles/<round>_hbm_traffic.json, PER DISPATCH.
 
-usage: tools/hbm_traffic.py FETCH_counter_collection.csv WRITE_counter_collection.csv OUT.json [launches_per_step...]
+usage: tools/hbm_traffic.py FETCH_counter_collection.csv WRITE_counter_collection.csv OUT.json
 
-The counters are reported by rocprofv3 in KB per dispatch. bench.py reads `hbm_bytes_per_step` of the dominant kernel
-for the `roofline.traffic` field. `oc_solve` is launched twice per outer iteration (lean kernel + Newton-capable
-kernel), the two auxiliary sweeps once.
+rocprofv3 reports both counters in KB per dispatch.  One outer iteration of the benchmark launches
+    oc_solve (lean kernel, full batch)  ->  oc_solve (exact-capable kernel, resumes what the lean one left: normally
+    nothing, every workgroup returns at once)  ->  aux_riccati  ->  aux_forward,
+and bench.py adds a 4-trajectory parity solve before the loop.  Only FULL-BATCH dispatches describe the timed launch:
+they are selected by the largest Grid_Size of each kernel, the lean OC kernel apart from the resume kernel by its
+template arguments, and every one is listed (`dispatches`) beside the mean the bench line quotes (`hbm_bytes_per_launch`).
+The k-th selected dispatch of the FETCH pass is paired with the k-th of the WRITE pass (same command, same order).
+
+Calibration (MI355X_MICROARCH.md, HBM): FETCH_SIZE tallies 128-B requests at 64 B for wide coalesced reads (x2 there);
+for the 4-8-byte-per-lane accesses of these kernels it is uncalibrated, so the raw figure is a LOWER bound of the bytes
+read; WRITE_SIZE is exact for streaming stores.  Both count Infinity-Cache hits: this is memory-side traffic, not DRAM.
 """
 import csv
 import json
+import re
 import sys
 from collections import defaultdict
 
-KERNELS = {"oc_solve": "oc_solve_kernel", "aux_riccati": "aux_riccati_kernel", "aux_forward": "aux_forward_kernel"}
-LAUNCHES_PER_STEP = {"oc_solve": 2, "aux_riccati": 1, "aux_forward": 1}
-NOTE = ("raw rocprofv3 counters (KB) from separate --pmc passes of `bench.py --steps 2 --warmup 1 --no-cpu-baseline` "
-        "(3 steps); oc_solve is two launches per step (lean + Newton-capable kernel); accesses are 4-B-per-lane "
-        "scalar loads/stores for which MI355X_MICROARCH.md gives no FETCH_SIZE calibration (its x2 correction is for "
-        "16-B-per-lane streams)")
+KERNELS = {"oc_solve": "oc_solve_kernel", "oc_solve_resume": "oc_solve_kernel", "oc_solve_wide": "oc_solve_wide_kernel",
+           "aux_riccati": "aux_riccati_kernel", "aux_forward": "aux_forward_kernel"}
 
 
-def per_kernel(path, counter):
-    tot, cnt = defaultdict(float), defaultdict(int)
+def classify(name):
+    """bench key of a kernel name, or None."""
+    if "oc_solve_wide_kernel" in name:
+        return "oc_solve_wide"
+    if "oc_solve_kernel" in name:
+        # oc_solve_kernel<Model, T, G, EXACT, PK>: EXACT = true is the resume launch of the two-launch solve
+        m = re.search(r"oc_solve_kernel<.*?,\s*(float|double),\s*\d+,\s*(true|false)", name)
+        return "oc_solve_resume" if (m and m.group(2) == "true") else "oc_solve"
+    if "aux_riccati_kernel" in name:
+        return "aux_riccati"
+    if "aux_forward_kernel" in name:
+        return "aux_forward"
+    return None
+
+
+def dispatches(path, counter):
+    """{key: [(dispatch_id, grid_size, KB)]} in dispatch order."""
+    out = defaultdict(list)
     with open(path, newline="") as f:
         for row in csv.DictReader(f):
             if row["Counter_Name"] != counter:
                 continue
-            for key, pat in KERNELS.items():
-                if pat in row["Kernel_Name"]:
-                    tot[key] += float(row["Counter_Value"])
-                    cnt[key] += 1
-    return tot, cnt
+            key = classify(row["Kernel_Name"])
+            if key:
+                out[key].append((int(row["Dispatch_Id"]), int(row["Grid_Size"]), float(row["Counter_Value"])))
+    for v in out.values():
+        v.sort()
+    return out
+
+
+def full_batch(rows):
+    g = max(r[1] for r in rows)
+    return [r for r in rows if r[1] == g]
 
 
 def main(argv):
     fetch_csv, write_csv, out = argv[1:4]
-    ft, fc = per_kernel(fetch_csv, "FETCH_SIZE")
-    wt, wc = per_kernel(write_csv, "WRITE_SIZE")
+    fd, wd = dispatches(fetch_csv, "FETCH_SIZE"), dispatches(write_csv, "WRITE_SIZE")
     res = {}
-    for key in KERNELS:
-        if not fc[key] or not wc[key]:
+    for key in sorted(set(fd) & set(wd)):
+        ff, ww = full_batch(fd[key]), full_batch(wd[key])
+        n = min(len(ff), len(ww))
+        if n == 0:
             continue
-        f_kb, w_kb = ft[key] / fc[key], wt[key] / wc[key]
-        per_launch = (f_kb + w_kb) * 1024.0
-        res[key] = {
-            "FETCH_SIZE_KB_per_launch": f_kb, "launches_fetch": fc[key],
-            "WRITE_SIZE_KB_per_launch": w_kb, "launches_write": wc[key],
-            "hbm_bytes_per_launch": per_launch,
-            "hbm_bytes_per_step": per_launch * LAUNCHES_PER_STEP[key],
-            "note": NOTE,
-        }
+        per = [{"grid_threads": ff[i][1], "FETCH_SIZE_KB": ff[i][2], "WRITE_SIZE_KB": ww[i][2],
+                "bytes": (ff[i][2] + ww[i][2]) * 1024.0} for i in range(n)]
+        mean = sum(p["bytes"] for p in per) / n
+        res[key] = {"full_batch_launches": n, "dispatches_of_this_kernel_in_the_run": len(fd[key]),
+                    "hbm_bytes_per_launch": mean,
+                    "FETCH_SIZE_KB_per_launch": sum(p["FETCH_SIZE_KB"] for p in per) / n,
+                    "WRITE_SIZE_KB_per_launch": sum(p["WRITE_SIZE_KB"] for p in per) / n,
+                    "dispatches": per}
+    res["_note"] = ("raw rocprofv3 FETCH_SIZE / WRITE_SIZE (KB) of separate --pmc passes, per full-batch dispatch; "
+                    "FETCH_SIZE is uncalibrated (a lower bound) for 4-8-byte-per-lane accesses and both include "
+                    "Infinity-Cache hits (MI355X_MICROARCH.md, HBM)")
     with open(out, "w") as f:
         json.dump(res, f, indent=1)
-    print(json.dumps({k: round(v["hbm_bytes_per_step"] / 1e6, 1) for k, v in res.items()}), "MB/step")
+    print(json.dumps({k: {"launches": v["full_batch_launches"], "MB_per_launch": round(v["hbm_bytes_per_launch"] / 1e6, 1),
+                          "each_MB": [round(p["bytes"] / 1e6, 1) for p in v["dispatches"]]}
+                      for k, v in res.items() if not k.startswith("_")}))
 
 
 if __name__ == "__main__":

@@ -6,8 +6,8 @@ import numpy as np, torch
 import lfsd_amd
 from lfsd_amd import models
 kind, lib, dt, B, N = sys.argv[1], sys.argv[2], torch.float32 if sys.argv[3] == "f32" else torch.float64, int(sys.argv[4]), int(sys.argv[5])
-os.environ["LFSD_OC_WIDE"] = "1" if len(sys.argv) > 6 else "0"
 oc, env, d = models.ZOO[kind](n_grid=N)
+oc.setSolverOptions(mapping="wide" if len(sys.argv) > 6 else "lockstep")
 if lib != "default":
     oc.use_library(lib)
 oc.setDevice("cuda:0", dt)

@@ -1,4 +1,4 @@
-"""Lock-step vs wide mapping of the OC solve (LFSD_OC_WIDE=0/1) on the small-batch BASELINE configurations:
+"""Lock-step vs wide mapping of the OC solve (setSolverOptions(mapping=...)) on the small-batch BASELINE configurations:
 kernel time of one cold-started solve, status histogram, iteration counts."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -8,8 +8,8 @@ from lfsd_amd import models
 
 def run(kind, n_grid, B, dtype, reps=3):
     for wide in ("0", "1"):
-        os.environ["LFSD_OC_WIDE"] = wide
         oc, env, d = models.ZOO[kind](n_grid=n_grid)
+        oc.setSolverOptions(mapping="wide" if wide == "1" else "lockstep")
         oc.setDevice("cuda:0", dtype)
         p = oc.compile().n_auxvar
         rng = np.random.default_rng(0)
@@ -24,7 +24,6 @@ def run(kind, n_grid, B, dtype, reps=3):
         print("%-9s n_grid %3d batch %5d %s %-9s: %8.2f ms | status %s | iters mean %.1f max %d | cost mean %.6f" %
               (kind, n_grid, B, str(dtype)[6:], "wide" if wide == "1" else "lock-step", min(ts), np.bincount(st, minlength=5).tolist(),
                it.mean(), it.max(), sol["cost"].double().mean().item()), flush=True)
-    os.environ.pop("LFSD_OC_WIDE")
 
 if __name__ == "__main__":
     run("robotarm", 50, 1024, torch.float32)
