@@ -111,7 +111,11 @@ int lfsd_coc_solve(int dtype, int batch, int n_grid, int steps_per_grid,
  *           |fine - coarse| / 3 of a block of columns exceeds rtol x that block's magnitude (the reference integrates the
  *           same ODEs with scipy's solve_ivp at its default rtol 1e-3, CPDP.py:335, 368, which is the host side's default here too:
  *           measured gradient error 1e-5..1e-4 of the exact ODE solution against the reference integrator's 2.6e-3).
- *           0: fixed `substeps`.                                                                */
+ *           0: fixed `substeps`.
+ *   stats   [B][4] int32 or NULL: per trajectory, {split units executed by the Riccati sweep (rejected attempts included),
+ *           intervals of it that were accepted ABOVE rtol because refinement stopped gaining (next to a conjugate point) or hit
+ *           its cap, the same two numbers of the forward sweep}.  A non-zero second or fourth entry marks a loss / gradient
+ *           whose error estimate exceeds the tolerance asked for.                                */
 int lfsd_aux_solve(int dtype, int batch, int n_grid,
                    const void* horizon, const void* auxvar, const void* consts, int const_per_traj,
                    const void* state_grid, const void* control_grid, const void* costate_grid,
@@ -119,7 +123,7 @@ int lfsd_aux_solve(int dtype, int batch, int n_grid,
                    int n_waypoints, int n_iface, const int* iface_idx,
                    const void* taus, const void* waypoints,
                    void* loss, void* grad, void* auxX_grid, void* auxU_grid,
-                   int substeps, double rtol, void* stream);
+                   int substeps, double rtol, int* stats, void* stream);
 
 /* The two phases of lfsd_aux_solve as separate launches (same arguments; lfsd_aux_solve == riccati then forward):
  *   lfsd_aux_riccati  CPDP/CPDP.py:316-338  backward Riccati sweep, fills Z_grid
@@ -127,7 +131,7 @@ int lfsd_aux_solve(int dtype, int batch, int n_grid,
 int lfsd_aux_riccati(int dtype, int batch, int n_grid,
                      const void* horizon, const void* auxvar, const void* consts, int const_per_traj,
                      const void* state_grid, const void* control_grid, const void* costate_grid,
-                     void* Z_grid, int substeps, double rtol, void* stream);
+                     void* Z_grid, int substeps, double rtol, int* stats, void* stream);
 int lfsd_aux_forward(int dtype, int batch, int n_grid,
                      const void* horizon, const void* auxvar, const void* consts, int const_per_traj,
                      const void* state_grid, const void* control_grid, const void* costate_grid,
@@ -135,7 +139,7 @@ int lfsd_aux_forward(int dtype, int batch, int n_grid,
                      int n_waypoints, int n_iface, const int* iface_idx,
                      const void* taus, const void* waypoints,
                      void* loss, void* grad, void* auxX_grid, void* auxU_grid,
-                     int substeps, double rtol, void* stream);
+                     int substeps, double rtol, int* stats, void* stream);
 
 /* theta <- update(theta, grad) for every trajectory; m/v/vhat are optimizer state [B][n_param]
  * (m: Nesterov velocity or first moment; v: second moment; vhat: AMSGrad max; unused ones may be NULL).

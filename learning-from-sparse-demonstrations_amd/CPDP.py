@@ -467,7 +467,7 @@ class SparseDemoLearner:
     def _aux_out(self):
         if self._aux is None:
             return None
-        return {k: self._aux[k] for k in ("loss", "grad")}
+        return {k: self._aux[k] for k in ("loss", "grad", "stats")}
 
     def step(self):
         """One outer iteration; returns (loss, grad) evaluated where the update rule needs them."""

@@ -26,7 +26,7 @@ import hashlib
 import sympy as sp
 from sympy.printing.c import C99CodePrinter
 
-CODEGEN_VERSION = 9
+CODEGEN_VERSION = 11
 
 
 class ModelSpec:
@@ -302,6 +302,33 @@ def emit_header(spec):
              % (max(nc, 1), ', '.join(repr(float(v)) for v in (spec.const_defaults or [0.0])) if nc else '0.0'))
 
     sig_xu = 'T t, const T* x, const T* u, const T* e, const T* c'
+    # 0. structurally constant tangent columns.  The leading NZC state components enter neither the dynamics (f_x e_i == 0:
+    #    position of the quadrotor / rocket, cart position) nor any mixed second derivative of the running cost with the
+    #    other variables.  Their columns of the shooting sensitivity [A_k B_k] are exact unit vectors through every RK4
+    #    stage -- only their entry of the cost row q_k is non-trivial, and that is an RK4 quadrature of dc/dx_i along the
+    #    nominal (cost_grad_zc) -- and their rows / columns of the stage Hessian couple to nothing else.  The lean OC kernel
+    #    neither propagates nor stores nor multiplies them (cpdp_oc.h, backward_sc).
+    nzc = 0
+    for i in range(n):
+        if any(_nz(fx[r, i]) for r in range(n)):
+            break
+        nzc += 1
+    cxx, cxu = cx.jacobian(X), cx.jacobian(U)
+
+    def _separable(k):
+        return all(not _nz(cxx[i, j]) for i in range(k) for j in range(k, n)) and \
+            all(not _nz(cxu[i, a]) for i in range(k) for a in range(m))
+    while nzc > 0 and not _separable(nzc):
+        nzc -= 1
+    S.append('  // leading state components with f_x e_i == 0 and no mixed cost curvature with the rest: structurally constant tangent columns')
+    S.append('  static constexpr int NZC = %d;' % nzc)
+    S.append('  // cz[i] = dc/dx_i, i < NZC')
+    S.append('  template<class T> static LFSD_DEV void cost_grad_zc(%s, T* cz) {' % sig_xu)
+    if nzc:
+        S.append(_body(_loads(spec), [('cz[%d]' % i, cx[0, i]) for i in range(nzc)]))
+    else:
+        S.append('    (void)t; (void)x; (void)u; (void)e; (void)c; (void)cz;')
+    S.append('  }')
     # 1. dynamics + running cost
     S.append('  template<class T> static LFSD_DEV void dyn_cost(%s, T* f, T& q) {' % sig_xu)
     S.append(_body(_loads(spec), [('f[%d]' % i, f[i]) for i in range(n)] + [('q', c)]))
@@ -365,8 +392,9 @@ def emit_header(spec):
         off = sm.end
     off_huu = (off + 3) // 4 * 4
     off_ihuu = (off_huu + m * m + 3) // 4 * 4
-    ncoef = ((off_ihuu + m * m + 3) // 4) * 4
-    S.append('  static constexpr int OFF_HUU = %d, OFF_IHUU = %d, NCOEF = %d;' % (off_huu, off_ihuu, ncoef))
+    off_zero = off_ihuu + m * m                 # one word that always holds 0 (gather target of structural zeros)
+    ncoef = ((off_zero + 1 + 3) // 4) * 4
+    S.append('  static constexpr int OFF_HUU = %d, OFF_IHUU = %d, OFF_ZERO = %d, NCOEF = %d;' % (off_huu, off_ihuu, off_zero, ncoef))
     S.append('  // packed (16-byte aligned starts): ' + ', '.join('%s[%d..%d)' % (sm.name, sm.off, sm.end) for sm in mats) +
              ', Huu dense, Huu^-1 dense (filled by the kernel)')
     S.append('  template<int LAY, class T> static LFSD_DEV void pmp_coeffs(%s, T* L) {' % sig_xul)
@@ -375,12 +403,21 @@ def emit_header(spec):
         for sm in mats:
             outs += sm.stores(lay)
         outs += [('L[%d]' % (off_huu + a * m + b), Huu[a, b]) for a in range(m) for b in range(m)]
+        outs += [('L[%d]' % off_zero, sp.Integer(0))]
         S.append('    %s (LAY == %d) {' % ('if constexpr' if lay == 0 else '} else', lay) if lay == 0 else '    } else {')
         S.append(_body(_loads(spec, with_l=True), outs, indent='      '))
     S.append('    }')
     S.append('  }')
     for sm in mats:
         S.append(sm.emit_ops())
+    # packed offset of fx[r][c] per layout, OFF_ZERO for a structural zero: lets a lane gather ITS column of fx as a dense
+    # vector -- the operand layout of the matrix-core experiment in the Riccati sweep (cpdp_aux.h, LFSD_RIC_MFMA)
+    for lay in (0, 1):
+        tab = [off_zero] * (n * n)
+        for (r, cc, o, _) in mats[0].lay[lay]:
+            tab[r * n + cc] = o
+        S.append('  static LFSD_DEV int fx_off%d(int r, int c) { constexpr short tab[%d] = {%s}; return tab[r * %d + c]; }'
+                 % (lay, n * n, ', '.join(map(str, tab)), n))
     # G[a*NU+b] (+)= sum_i S[i*NU+a] * fu[i][b]    (S = rows of B^T P gathered in LDS)
     fu_sm = mats[1]
     S.append('  // G = S^T fu  with S an NX x NU row-major matrix (e.g. S = P fu  ->  G = fu^T P fu)')

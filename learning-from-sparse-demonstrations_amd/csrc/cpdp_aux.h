@@ -8,6 +8,15 @@ namespace lfsd {
 // =====================================================================================
 //  Auxiliary control system (differentiated maximum principle)
 // =====================================================================================
+// EXPERIMENT (round 3, profiles/r03_mfma_aux.txt): the Z-dependent product  A^T Z = fx^T Z (+ ...)  of the Riccati right-hand
+// side on the matrix cores -- v_mfma_f32_16x16x1_4b_f32 rank-1 updates with this lane's column of fx gathered dense from
+// the staged coefficients -- instead of the generated sparse operator (43 of 169 entries for the quadrotor).  Needs all
+// 64 lanes (EXEC is ignored by the matrix pipe and the result is spread over the wavefront), so it only runs where the
+// two trajectories of the wavefront are in step; otherwise the sparse operator.  Off in every shipped build.
+#ifndef LFSD_RIC_MFMA
+#define LFSD_RIC_MFMA 0
+#endif
+
 template <typename T> struct AuxArgs {
   int batch, n_grid, substeps;    // substeps = minimum coarse split-steps per grid interval (fine = 2x, Richardson)
   T rate_max;                     // refine an interval until  dt * |Huu^-1 fu^T P fu|_inf <= rate_max
@@ -30,6 +39,7 @@ template <typename T> struct AuxArgs {
   T* grad;                        // [B][NP]
   T* auxX_grid;                   // [B][N+1][NP][NX] or nullptr  (dx/dtheta, column-major)
   T* auxU_grid;                   // [B][N+1][NP][NU] or nullptr
+  int* stats;                     // [B][4] or nullptr: split units executed and intervals accepted ABOVE rtol, Riccati | forward sweep
 };
 
 template <class M> struct AuxLayout {
@@ -87,6 +97,7 @@ template <class M, typename T, int G, int LAY> struct AuxCtx {
   T t_a, dgrid;
   T* lds;
   T ox[NX], oe[NP];    // one-hot selectors of this lane's column
+  int fxo[(LFSD_RIC_MFMA != 0) ? NX : 1];      // experiment: offsets of column (lane % 16) of fx in the packed coefficients
 
   LFSD_DEV void load_interval(const AuxArgs<T>& a, long long traj, int k, int N) {
     const T* xs = a.state_grid + (traj * (N + 1) + k) * NX;
@@ -229,7 +240,28 @@ template <class M, typename T, int G, int LAY> struct AuxCtx {
     matvec<NU>(iH, s, v);
 #pragma unroll
     for (int a = 0; a < NU; ++a) { nv[a] = -v[a]; w[a] = -(wq[a] + v[a]); }
+#if LFSD_RIC_MFMA && !defined(LFSD_EMU)
+    bool on_matrix_cores = false;
+    if constexpr (sizeof(T) == 4 && LAY == 0 && G >= 16 && NX <= 16) {
+      if (__builtin_amdgcn_read_exec() == ~0ull) {
+        on_matrix_cores = true;
+        T ac[NX];
+#pragma unroll
+        for (int kk = 0; kk < NX; ++kk) ac[kk] = L[fxo[kk]];          // fx[kk][lane % 16]: row kk of this lane's column
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+        for (int kk = 0; kk < NX; ++kk) mfma4b(ac[kk], z[kk], acc);   // D_b[i][j] = sum_kk fx[kk][i] z_j[kk] = (fx^T z_j)[i]
+        tile_transpose(acc);
+#pragma unroll
+        for (int i = 0; i < NX; ++i) y[i] = acc[i];
+      }
+    }
+    if (!on_matrix_cores) M::template fx_mulT<false, LAY>(L, z, y);
+#else
     M::template fx_mulT<false, LAY>(L, z, y);
+#endif
     if (lane < NX) {
       T tv[NX];
 #pragma unroll
@@ -496,6 +528,10 @@ __global__ void __launch_bounds__(64, (sizeof(T) == 4 ? LFSD_WAVES_RIC : 1)) aux
   aux_setup<M, T, G, 0>(s, a, traj, lds_all, Lay::template lds_elems_ric<G>());
   const int N = a.n_grid, Sa = a.substeps;
   const int lane = s.lane;
+#if LFSD_RIC_MFMA && !defined(LFSD_EMU)
+#pragma unroll
+  for (int kk = 0; kk < NX; ++kk) s.fxo[kk] = ((lane & 15) < NX) ? M::fx_off0(kk, lane & 15) : M::OFF_ZERO;
+#endif
   T* Zt = a.Z_grid + traj * (long long)(N + 1) * NZ * NX;
   T z[NX];
   {
@@ -516,6 +552,7 @@ __global__ void __launch_bounds__(64, (sizeof(T) == 4 ? LFSD_WAVES_RIC : 1)) aux
   }
   T* ldsT = s.lds + Lay::LDS_T;
   int units_hint = Sa;
+  int n_units = 0, n_unmet = 0;      // (group-uniform) units executed incl. rejected attempts; intervals accepted above tolerance
   for (int k = N - 1; k >= 0; --k) {
     s.load_interval(a, traj, k, N);
     // stiffness-aware sub-stepping: P is largest at the later end of the interval (terminal transient).  The coefficients
@@ -561,6 +598,7 @@ __global__ void __launch_bounds__(64, (sizeof(T) == 4 ? LFSD_WAVES_RIC : 1)) aux
           scl_l = t_max(scl_l, t_abs(z[i]));
         }
       }
+      n_units += units;
       if (!(a.rtol > T(0))) break;
       // per block of columns (P: lanes < NX, W: the rest) the worst estimate against that block's magnitude
       ldsT[lane] = err_l; ldsT[G + lane] = scl_l;
@@ -580,6 +618,7 @@ __global__ void __launch_bounds__(64, (sizeof(T) == 4 ? LFSD_WAVES_RIC : 1)) aux
 #endif
       ratio_prev = ratio;
       if (fine_enough || no_gain || !valid || (long long)units * 2 > units_cap) {
+        if (!fine_enough) ++n_unmet;       // refinement gave up (next to a conjugate point, or at the cap): reported, not hidden
         // next interval: start from this interval's units, or half of them when the estimate leaves room for it
         units_hint = (eP * T(LFSD_AUX_DOWN) <= tolP && eW * T(LFSD_AUX_DOWN) <= tolW && units > Sa) ? units / 2 : units;
         break;
@@ -606,6 +645,7 @@ __global__ void __launch_bounds__(64, (sizeof(T) == 4 ? LFSD_WAVES_RIC : 1)) aux
       for (int i = 0; i < NX; ++i) Zt[((long long)k * NZ + lane) * NX + i] = z[i];
     }
   }
+  if (valid && a.stats && lane == 0) { a.stats[traj * 4 + 0] = n_units; a.stats[traj * 4 + 1] = n_unmet; }
 }
 
 template <class M, typename T, int G>
@@ -638,6 +678,7 @@ __global__ void __launch_bounds__(64, (sizeof(T) == 4 ? LFSD_WAVES_FWD : 1)) aux
   const T* pB = (lane < NX) ? ldsPB + lane * NX : ldsP0;
   T loss = T(0), gacc = T(0);
   int units_hint = Sa;
+  int n_units = 0, n_unmet = 0;
   T* Xo = a.auxX_grid ? a.auxX_grid + traj * (long long)(N + 1) * NP * NX : nullptr;
   T* Uo = a.auxU_grid ? a.auxU_grid + traj * (long long)(N + 1) * NP * NU : nullptr;
   if (valid && Xo && xlane) {
@@ -716,6 +757,7 @@ __global__ void __launch_bounds__(64, (sizeof(T) == 4 ? LFSD_WAVES_FWD : 1)) aux
           }
         }
       }
+      n_units += units;
       if (!(a.rtol > T(0))) break;
       T* ldsR = s.lds + Lay::LDS_T;           // (the feedback / phi1 images of the last unit are dead by now)
       ldsR[lane] = err_l; ldsR[G + lane] = scl_l;
@@ -731,6 +773,7 @@ __global__ void __launch_bounds__(64, (sizeof(T) == 4 ? LFSD_WAVES_FWD : 1)) aux
 #endif
       ratio_prev = ratio;
       if (eX <= tolX || no_gain || !t_finite(eX) || (long long)units * 2 > units_cap) {
+        if (!(eX <= tolX)) ++n_unmet;
         units_hint = (eX * T(LFSD_AUX_DOWN) <= tolX && units > Sa) ? units / 2 : units;
         break;
       }
@@ -773,6 +816,7 @@ __global__ void __launch_bounds__(64, (sizeof(T) == 4 ? LFSD_WAVES_FWD : 1)) aux
   if (valid) {
     if (lane == 0) a.loss[traj] = loss;
     if (xlane) a.grad[traj * NP + s.xcol] = gacc;
+    if (a.stats && lane == 0) { a.stats[traj * 4 + 2] = n_units; a.stats[traj * 4 + 3] = n_unmet; }
   }
 }
 

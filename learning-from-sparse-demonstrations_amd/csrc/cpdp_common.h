@@ -138,6 +138,26 @@
 #ifndef LFSD_HAM_SWITCH
 #define LFSD_HAM_SWITCH 0.3
 #endif
+// lean fp32 kernel of the 32-lane models: leave the structurally constant tangent columns of the model (Model::NZC, e.g.
+// the quadrotor's position) out of the roll-out, the workspace and the matrix products (1), or treat every column alike (0)
+#ifndef LFSD_STRUCT_COLS
+#define LFSD_STRUCT_COLS 1
+#endif
+// Mesh continuation of the lean fp32 OC kernel (cpdp_oc.h, oc_solve_kernel): one RK4 step per grid interval while full
+// steps gain more than LFSD_COARSE_SWITCH of the cost, then the reference's steps_per_grid.  LFSD_COARSE_START 0 switches it
+// off.  Measured on the benchmark (profiles/r03_d_ab_coarse_exit.txt, r03_e_ab_coarse_switch.txt), oc_solve per launch: off
+// 3.79 ms; switch at 3.0 (after the first step) 3.20; 0.3 (with the Gauss-Newton -> Hamiltonian hand-over) 2.93; 1e-2 2.94;
+// 1e-3 (one Newton-like step more on the coarse grid) 2.85; 1e-4 2.98; 0 (only when the coarse problem has converged) 3.66.
+#ifndef LFSD_COARSE_START
+#define LFSD_COARSE_START 1
+#endif
+#ifndef LFSD_COARSE_SWITCH
+#define LFSD_COARSE_SWITCH 1e-3
+#endif
+// leaving the coarse grid: 1 = always by a roll-out + linearisation of the nominal without a step, 0 = with the next full step
+#ifndef LFSD_COARSE_RELIN
+#define LFSD_COARSE_RELIN 0
+#endif
 #ifndef LFSD_REG_CONSISTENT
 #define LFSD_REG_CONSISTENT 1
 #endif

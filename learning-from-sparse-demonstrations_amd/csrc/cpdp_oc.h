@@ -45,6 +45,14 @@ template <class M> struct OcLayout {
   static constexpr int NXUP = (NXU + 1) / 2 * 2;
   static constexpr int M_ELEMS = (NX + 1) * NXUP;                // [A B] rows + the cost-gradient row q, per interval
   static constexpr int H_ELEMS = NXU * NXUP;
+  // Lean kernel with structurally constant tangent columns (M::NZC leading state components the dynamics do not depend
+  // on, codegen.py): only the LIVE = NXU - ZC columns are propagated and stored -- rows 0..NX of them, then the cost-row
+  // entries q of the constant columns -- inside the same scratch region (MS_ELEMS <= M_ELEMS words per interval).
+  static constexpr int ZC = M::NZC, LIVE = NXU - ZC, LIVEP = (LIVE + 1) / 2 * 2, ZCP = (ZC + 1) / 2 * 2;
+  static constexpr int MS_ELEMS = (NX + 1) * LIVEP + ZCP;
+  // (the lean kernel takes this path only where MS_ELEMS <= M_ELEMS, 16-lane groups hold the live columns, and the
+  //  constant states find a lane among the control lanes: sc_ok)
+  static constexpr bool sc_ok = ZC > 0 && MS_ELEMS <= M_ELEMS && LIVE <= 16 && ZC <= NU && NX <= 16;
   template <int G> LFSD_HD static long long ws_elems(int N) {
     const long long n = 2LL * (N + 1) * NX + 2LL * N * NU + 2LL * N * M_ELEMS + 1LL * N * NX * NU + 1LL * N * NU +
            1LL * (N + 1) * NX + 1LL * SMAX * NX * (1 + G) +     // + sub-step start states (uniform | per lane)
@@ -100,29 +108,51 @@ template <class M, typename T, int G, bool EXACT, bool BND = false> struct OcSol
 
   // One RK4 step of (x, q) with frozen control; optionally with the per-lane tangent (m, mq).
   // V: tangent type -- T (one column per lane) or pk2<T> (two columns per lane, packed math)
-  template <bool SENS, class V = T>
-  LFSD_DEV void rk4_step(T t, T* x, T& q, const T* u, V* m, V& mq, const V* du) const {
+  // NZ > 0 (lean kernel with structurally constant columns): qz[i] += RK4 quadrature of dc/dx_i along the stages, i < NZ
+  template <bool SENS, class V = T, int NZ = 0>
+  LFSD_DEV void rk4_step(T t, T* x, T& q, const T* u, V* m, V& mq, const V* du, T* qz = nullptr) const {
     T xs[NX], ax[NX], f[NX], cq, aq;
     V ms[NX], am[NX], d[NX], dq, adq;
+    T cz[NZ ? NZ : 1], az[NZ ? NZ : 1];
     const T hh = DT * T(0.5);
     if (SENS) M::dyn_cost_jvp(t, x, u, e, c, m, du, f, cq, d, dq); else M::dyn_cost(t, x, u, e, c, f, cq);
     aq = cq; if (SENS) adq = dq;
+    if (NZ) {
+      M::cost_grad_zc(t, x, u, e, c, cz);
+#pragma unroll
+      for (int i = 0; i < NZ; ++i) az[i] = cz[i];
+    }
 #pragma unroll
     for (int i = 0; i < NX; ++i) { ax[i] = f[i]; xs[i] = x[i] + hh * f[i]; if (SENS) { am[i] = d[i]; ms[i] = m[i] + hh * d[i]; } }
     LFSD_SCHED_FENCE();
     if (SENS) M::dyn_cost_jvp(t, xs, u, e, c, ms, du, f, cq, d, dq); else M::dyn_cost(t, xs, u, e, c, f, cq);
     aq += T(2) * cq; if (SENS) adq += T(2) * dq;
+    if (NZ) {
+      M::cost_grad_zc(t, xs, u, e, c, cz);
+#pragma unroll
+      for (int i = 0; i < NZ; ++i) az[i] += T(2) * cz[i];
+    }
 #pragma unroll
     for (int i = 0; i < NX; ++i) { ax[i] += T(2) * f[i]; xs[i] = x[i] + hh * f[i]; if (SENS) { am[i] += T(2) * d[i]; ms[i] = m[i] + hh * d[i]; } }
     LFSD_SCHED_FENCE();
     if (SENS) M::dyn_cost_jvp(t, xs, u, e, c, ms, du, f, cq, d, dq); else M::dyn_cost(t, xs, u, e, c, f, cq);
     aq += T(2) * cq; if (SENS) adq += T(2) * dq;
+    if (NZ) {
+      M::cost_grad_zc(t, xs, u, e, c, cz);
+#pragma unroll
+      for (int i = 0; i < NZ; ++i) az[i] += T(2) * cz[i];
+    }
 #pragma unroll
     for (int i = 0; i < NX; ++i) { ax[i] += T(2) * f[i]; xs[i] = x[i] + DT * f[i]; if (SENS) { am[i] += T(2) * d[i]; ms[i] = m[i] + DT * d[i]; } }
     LFSD_SCHED_FENCE();
     if (SENS) M::dyn_cost_jvp(t, xs, u, e, c, ms, du, f, cq, d, dq); else M::dyn_cost(t, xs, u, e, c, f, cq);
     aq += cq; if (SENS) adq += dq;
     const T h6 = DT / T(6);
+    if (NZ) {
+      M::cost_grad_zc(t, xs, u, e, c, cz);
+#pragma unroll
+      for (int i = 0; i < NZ; ++i) qz[i] += h6 * (az[i] + cz[i]);
+    }
 #pragma unroll
     for (int i = 0; i < NX; ++i) { x[i] += h6 * (ax[i] + f[i]); if (SENS) m[i] += h6 * (am[i] + d[i]); }
     q += h6 * aq; if (SENS) mq += h6 * adq;
@@ -409,7 +439,7 @@ template <class M, typename T, int G, bool EXACT, bool BND = false> struct OcSol
             for (int a = 0; a < NU; ++a) hcol[(NX + a) * Lay::NXUP] = hu[a];
           }
         }
-#if defined(LFSD_TRACE)
+#if defined(LFSD_TRACE_HCOL)
         if (lane < NXU && blockIdx.x == 0 && threadIdx.x < G) {
           printf("HCOL k %d lane %d x", k, lane); for (int i = 0; i < NX; ++i) printf(" %.17g", (double)xk[i]);
           printf(" u"); for (int a = 0; a < NU; ++a) printf(" %.17g", (double)uk[a]);
@@ -852,6 +882,332 @@ template <class M, typename T, int G, bool EXACT, bool BND = false> struct OcSol
     __syncthreads();
   }
 
+  // =====================================================================================================================
+  //  Lean fp32 kernel with STRUCTURALLY CONSTANT tangent columns (M::NZC > 0: quadrotor / rocket position, round 3)
+  // =====================================================================================================================
+  // The dynamics do not depend on the leading ZC state components, so their columns of [A_k B_k] are exact unit vectors
+  // through every RK4 stage: they are neither propagated (the packed roll-out carries the LIVE = NXU - ZC other columns, 7
+  // lanes of 16 for the quadrotor instead of 9), nor stored (14 x 14 + 4 words per interval instead of 14 x 18), nor
+  // multiplied: with  M = [E_Z  M_live]
+  //     Y = V M       ->  Y(:, Z) = V(:, Z)                      (free)
+  //     Q = M^T Y     ->  Q(Z, live) = Y(Z, live),  Q(Z, Z) = V(Z, Z)      (free; rows of what the live lanes hold anyway)
+  // and all 17 columns of the quadrotor fit the 16 lanes of a group WITHOUT the LDS-carried 17th column of backward_mf:
+  //     lane L < LX = NX - ZC     M-role: live state column ZC + L       V-role: the same state
+  //     lane LX + a, a < NU       M-role: control column a               V-role (a < ZC): constant state a
+  // A lane's two roles share every instruction; the constant state's column of Q is gathered from the rows Y(Z, :) the
+  // other lanes publish in LDS.  The stage Hessian of a constant state couples to nothing outside Z (codegen checks), so
+  // one ham_hess_mul with BOTH one-hots set returns the control column's entries and the constant state's side by side.
+  static constexpr int ZC = Lay::ZC, LIVE = Lay::LIVE, LX = NX - Lay::ZC, MS = Lay::MS_ELEMS, LIVEP = Lay::LIVEP;
+  LFSD_DEV T rollout_sens_sc(int cur, int nxt, T alpha, bool gains) {
+    using V = pk2<T>;
+    T x[NX], u[NU], J = T(0);
+#pragma unroll
+    for (int i = 0; i < NX; ++i) x[i] = x0[i];
+    const int c0 = ZC + 2 * lane, c1 = c0 + 1;             // original column indices of this lane's pair of live columns
+    for (int k = 0; k < N; ++k) {
+      control(cur, k, x, alpha, gains, u);
+      if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < NX; ++i) xbp(nxt)[k * NX + i] = x[i];
+#pragma unroll
+        for (int a = 0; a < NU; ++a) ubp(nxt)[k * NU + a] = u[a];
+      }
+      V m[NX], du[NU], mq = V(T(0));
+      T q = T(0), qz[ZC ? ZC : 1];
+#pragma unroll
+      for (int i = 0; i < ZC; ++i) qz[i] = T(0);
+#pragma unroll
+      for (int i = 0; i < NX; ++i) m[i] = mk2<T>((c0 == i) ? T(1) : T(0), (c1 == i) ? T(1) : T(0));
+#pragma unroll
+      for (int a = 0; a < NU; ++a) du[a] = mk2<T>((c0 == NX + a) ? T(1) : T(0), (c1 == NX + a) ? T(1) : T(0));
+      const T t = tk(k);
+      for (int s = 0; s < S; ++s) rk4_step<true, V, ZC>(t, x, q, u, m, mq, du, qz);
+      J += q;
+      T* Mk = Mwp(nxt) + (long long)k * MS;
+      if (c0 < NXU) {          // live columns 2 lane, 2 lane + 1 of every row as one 8-byte store
+        V* Mv = reinterpret_cast<V*>(Mk + 2 * lane);
+#pragma unroll
+        for (int i = 0; i < NX; ++i) Mv[i * (LIVEP / 2)] = m[i];
+        Mv[NX * (LIVEP / 2)] = mq;
+      }
+      if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < ZC; ++i) Mk[(NX + 1) * LIVEP + i] = qz[i];
+      }
+    }
+    if (lane == 0) {
+#pragma unroll
+      for (int i = 0; i < NX; ++i) xbp(nxt)[N * NX + i] = x[i];
+    }
+    J += M::final_cost(tk(N), x, e, c);
+    return J;
+  }
+  // this lane's live column of [A B; q], the cost-row entry of its constant state, the nominal of one interval
+  LFSD_DEV void sc_load_stage(int cur, int k, T* m, T& mq, T& qzl, T* xk, T* uk) const {
+    const T* Mk = Mwp(cur) + (long long)k * MS;
+    if (lane < LIVE) {
+#pragma unroll
+      for (int i = 0; i < NX; ++i) m[i] = Mk[i * LIVEP + lane];
+      mq = Mk[NX * LIVEP + lane];
+    } else {
+#pragma unroll
+      for (int i = 0; i < NX; ++i) m[i] = T(0);
+      mq = T(0);
+    }
+    qzl = (lane >= LX && lane < NX) ? Mk[(NX + 1) * LIVEP + (lane - LX)] : T(0);
+    const T* xp = xbp(cur) + k * NX;  const T* up = ubp(cur) + k * NU;
+#pragma unroll
+    for (int i = 0; i < NX; ++i) xk[i] = xp[i];
+#pragma unroll
+    for (int a = 0; a < NU; ++a) uk[a] = up[a];
+  }
+  LFSD_DEV bool backward_sc(int cur, int mode, T mu, bool live, T& gnorm, T& dV1, T& dV2, T& dmin) {
+    static_assert(!Lay::sc_ok || (G == 16 && LIVE <= 16 && ZC <= NU && NX <= 16), "structural sweep: 16-lane groups");
+    T* ldsV = lds + Lay::LDS_V;  T* ldsK = lds + Lay::LDS_K;
+    T* ldsQux = lds + Lay::LDS_QUX;  T* ldsQuu = lds + Lay::LDS_QUU;  T* ldsQu = lds + Lay::LDS_QU;
+    T* ldsVx = lds + Lay::LDS_VX;  T* ldsLam = lds + Lay::LDS_LAM;  T* ldsRed = lds + Lay::LDS_RED;
+    T* ldsYZ = lds + Lay::LDS_M;              // [16 lanes][ZC] rows Y(Z, column of the lane)   (LDS_M region: NXU*NX words)
+    const bool has_v = lane < NX;                       // V-role: lanes < LX live state ZC + lane, lanes LX.. constant state lane - LX
+    const bool st_zc = lane >= LX && lane < NX;
+    const int sv = has_v ? (lane < LX ? ZC + lane : lane - LX) : 0;       // natural state index of the V-role
+    const int zi = st_zc ? lane - LX : 0;
+    const bool ctl = lane >= LX && lane < LIVE;         // M-role: control column lane - LX
+    T Vx[NX], lam[NX], vcol[NX], xk[NX], uk[NU];
+    bool ok = true;
+    T gl_max = T(0);
+    dV1 = T(0); dV2 = T(0); dmin = T(0);
+    {
+      const T* xN = xbp(cur) + N * NX;
+#pragma unroll
+      for (int i = 0; i < NX; ++i) xk[i] = xN[i];
+      M::final_grad(tk(N), xk, e, c, Vx);
+      T ox[NX], oe[NP];
+#pragma unroll
+      for (int i = 0; i < NX; ++i) { ox[i] = (has_v && sv == i) ? T(1) : T(0); lam[i] = Vx[i]; }
+#pragma unroll
+      for (int i = 0; i < NP; ++i) oe[i] = T(0);
+      M::final_hess_mul(tk(N), xk, e, c, ox, oe, vcol);      // lanes >= NX: ox = 0  ->  vcol = 0
+      if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < NX; ++i) { ldsVx[i] = Vx[i]; ldsLam[i] = lam[i]; }
+        if (live) {
+#pragma unroll
+          for (int i = 0; i < NX; ++i) lam_out[N * NX + i] = lam[i];
+        }
+      }
+    }
+    __syncthreads();
+    T m[NX], mq = T(0), qzl = T(0), mN[NX], mqN = T(0), qzN = T(0), xkN[NX], ukN[NU];
+    sc_load_stage(cur, N - 1, m, mq, qzl, xk, uk);
+    for (int k = N - 1; k >= 0; --k) {
+      if (LFSD_BW_PREFETCH) { if (k > 0) sc_load_stage(cur, k - 1, mN, mqN, qzN, xkN, ukN); }
+      // Y(V-lane r, live column of this lane) = sum_kk V[kk][state of lane r] M[kk][column]
+      f32x16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+      for (int kk = 0; kk < NX; ++kk) mfma4b(vcol[kk], m[kk], acc);
+      // stage-Hessian column(s) of this lane on the vector pipe, beside the products in flight on the matrix pipe
+      T hx[NX], hu[NU];
+      {
+        T ox[NX], ou[NU], ls[NX];          // one-hots of BOTH roles: the V-role's state and the M-role's control
+        const T HL = (mode == 1) ? T(1) : T(0);
+#pragma unroll
+        for (int i = 0; i < NX; ++i) { ox[i] = (has_v && sv == i) ? T(1) : T(0); ls[i] = HL * lam[i]; }
+#pragma unroll
+        for (int a = 0; a < NU; ++a) ou[a] = (lane == LX + a) ? T(1) : T(0);
+        M::ham_hess_mul(tk(k), xk, uk, ls, e, c, ox, ou, hx, hu);
+      }
+      tile_transpose(acc);
+      T yn[NX];                                    // Y(:, column of this lane) in NATURAL row order
+#pragma unroll
+      for (int s_ = 0; s_ < NX; ++s_) yn[s_] = acc[s_ < ZC ? LX + s_ : s_ - ZC];
+      if (lane < LIVE) {
+#pragma unroll
+        for (int z = 0; z < ZC; ++z) ldsYZ[lane * ZC + z] = yn[z];
+      }
+      // Q(live, live) = M_live^T Y
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+      for (int kk = 0; kk < NX; ++kk) mfma4b(m[kk], yn[kk], acc);
+      T Qg = mq, gl = mq;
+#pragma unroll
+      for (int i = 0; i < NX; ++i) { Qg += m[i] * Vx[i]; gl += m[i] * lam[i]; }
+      tile_transpose(acc);
+      __syncthreads();                             // ldsYZ visible
+      // column of Q (natural row order) of this lane's V-role, control rows of its M-role
+      T Qcol[NX], mu_rows[NU], Quxj[NU];
+#pragma unroll
+      for (int a = 0; a < NU; ++a) mu_rows[a] = acc[LX + a] + dgrid * hu[a];
+#pragma unroll
+      for (int j = 0; j < LX; ++j) {
+        const T gz = ldsYZ[j * ZC + zi];           // Q(live state ZC + j, constant state zi) = Y(zi, that column)
+        Qcol[ZC + j] = st_zc ? gz : acc[j] + dgrid * hx[ZC + j];
+      }
+#pragma unroll
+      for (int z = 0; z < ZC; ++z) Qcol[z] = st_zc ? vcol[z] + dgrid * hx[z] : yn[z];      // Q(Z, Z) = V(Z, Z) + H_ZZ ; Q(Z, live) = Y(Z, live)
+#pragma unroll
+      for (int a = 0; a < NU; ++a) Quxj[a] = st_zc ? ldsYZ[(LX + a) * ZC + zi] : mu_rows[a];
+      // (Vx and the costate of the constant state: from their LDS images -- still the incoming values here; a per-lane
+      //  select over the register copies makes the compiler park both arrays in scratch)
+      const T Qg_v = st_zc ? qzl + ldsVx[zi] : Qg;
+      const T gl_v = st_zc ? qzl + ldsLam[zi] : gl;
+      if (has_v) {
+#pragma unroll
+        for (int a = 0; a < NU; ++a) ldsQux[sv * NU + a] = Quxj[a];
+      }
+      if (ctl) {
+        const int b = lane - LX;
+#pragma unroll
+        for (int a = 0; a < NU; ++a) ldsQuu[b * NU + a] = mu_rows[a];
+        ldsQu[b] = Qg;
+        gl_max = t_max(gl_max, t_abs(gl));
+      }
+      __syncthreads();
+      T Quu0[NU * NU], Lc[NU * NU], Qu[NU], kff[NU], Kj[NU], t1[NU];
+#pragma unroll
+      for (int a = 0; a < NU; ++a) {
+        Qu[a] = ldsQu[a];
+#pragma unroll
+        for (int b = 0; b < NU; ++b) Quu0[a * NU + b] = T(0.5) * (ldsQuu[b * NU + a] + ldsQuu[a * NU + b]);
+      }
+#pragma unroll
+      for (int i = 0; i < NU * NU; ++i) Lc[i] = Quu0[i];
+#pragma unroll
+      for (int a = 0; a < NU; ++a) Lc[a * NU + a] += mu;
+      if (ok) ok = chol_factor<NU>(Lc, dmin); else { T dd = T(0); chol_factor<NU>(Lc, dd); }
+      if (LFSD_REG_CONSISTENT) {
+#pragma unroll
+        for (int a = 0; a < NU; ++a) Quu0[a * NU + a] += mu;
+      }
+#pragma unroll
+      for (int a = 0; a < NU; ++a) { kff[a] = -Qu[a]; Kj[a] = -Quxj[a]; }
+      chol_solve<NU>(Lc, kff);
+      chol_solve<NU>(Lc, Kj);
+      T qk[NU];
+      matvec<NU>(Quu0, kff, qk);
+#pragma unroll
+      for (int a = 0; a < NU; ++a) { dV1 += kff[a] * Qu[a]; dV2 += T(0.5) * kff[a] * qk[a]; }
+      T Vxj = Qg_v;
+#pragma unroll
+      for (int a = 0; a < NU; ++a) Vxj += Kj[a] * (qk[a] + Qu[a]) + Quxj[a] * kff[a];
+      if (has_v) {
+#pragma unroll
+        for (int a = 0; a < NU; ++a) ldsK[sv * NU + a] = Kj[a];
+        ldsVx[sv] = Vxj;
+        ldsLam[sv] = gl_v;
+        if (live) {
+          T* Kout = Kws + ((long long)k * NX + sv) * NU;
+#pragma unroll
+          for (int a = 0; a < NU; ++a) Kout[a] = Kj[a];
+        }
+      }
+      if (lane == 0 && live) {
+#pragma unroll
+        for (int a = 0; a < NU; ++a) kws[k * NU + a] = kff[a];
+      }
+      __syncthreads();
+      matvec<NU>(Quu0, Kj, t1);
+#pragma unroll
+      for (int a = 0; a < NU; ++a) t1[a] += Quxj[a];
+#pragma unroll
+      for (int i = 0; i < NX; ++i) {
+        T sacc = Qcol[i];
+#pragma unroll
+        for (int a = 0; a < NU; ++a) sacc += ldsK[i * NU + a] * t1[a] + ldsQux[i * NU + a] * Kj[a];
+        vcol[i] = sacc;
+        Vx[i] = ldsVx[i];
+        lam[i] = ldsLam[i];
+      }
+      if (lane == 0 && live) {
+#pragma unroll
+        for (int i = 0; i < NX; ++i) lam_out[k * NX + i] = lam[i];
+      }
+      // symmetrise V_xx through LDS (the rank-1 feeds rely on row i == column i)
+      if (has_v) {
+#pragma unroll
+        for (int i = 0; i < NX; ++i) ldsV[sv * NX + i] = vcol[i];
+      }
+      __syncthreads();
+#pragma unroll
+      for (int i = 0; i < NX; ++i) vcol[i] = has_v ? T(0.5) * (vcol[i] + ldsV[i * NX + sv]) : T(0);
+      __syncthreads();
+      if (k > 0) {
+        if (LFSD_BW_PREFETCH) {
+#pragma unroll
+          for (int i = 0; i < NX; ++i) { m[i] = mN[i]; xk[i] = xkN[i]; }
+#pragma unroll
+          for (int a = 0; a < NU; ++a) uk[a] = ukN[a];
+          mq = mqN; qzl = qzN;
+        } else {
+          sc_load_stage(cur, k - 1, m, mq, qzl, xk, uk);
+        }
+      }
+    }
+    ldsRed[lane] = gl_max;
+    __syncthreads();
+    gnorm = T(0);
+#pragma unroll
+    for (int a = 0; a < NU; ++a) gnorm = t_max(gnorm, ldsRed[LX + a]);
+    __syncthreads();
+    if (!t_finite(gnorm) || !t_finite(dV1) || !t_finite(dV2)) ok = false;
+    return ok;
+  }
+  // costates and gradient norm without the value recursion (see costate_sweep_mf), structural layout
+  LFSD_DEV void costate_sweep_sc(int cur, bool live, T& gnorm) {
+    T* ldsLam = lds + Lay::LDS_LAM;  T* ldsRed = lds + Lay::LDS_RED;
+    const bool has_v = lane < NX, st_zc = lane >= LX && lane < NX, ctl = lane >= LX && lane < LIVE;
+    const int sv = has_v ? (lane < LX ? ZC + lane : lane - LX) : 0;
+    const int zi = st_zc ? lane - LX : 0;
+    T lam[NX], xk[NX], uk[NU];
+    {
+      const T* xN = xbp(cur) + N * NX;
+#pragma unroll
+      for (int i = 0; i < NX; ++i) xk[i] = xN[i];
+      M::final_grad(tk(N), xk, e, c, lam);
+      if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < NX; ++i) ldsLam[i] = lam[i];
+        if (live) {
+#pragma unroll
+          for (int i = 0; i < NX; ++i) lam_out[N * NX + i] = lam[i];
+        }
+      }
+    }
+    __syncthreads();
+    T gl_max = T(0);
+    T m[NX], mq = T(0), qzl = T(0), mN[NX], mqN = T(0), qzN = T(0);
+    sc_load_stage(cur, N - 1, m, mq, qzl, xk, uk);
+    for (int k = N - 1; k >= 0; --k) {
+      if (k > 0) sc_load_stage(cur, k - 1, mN, mqN, qzN, xk, uk);
+      T gl = mq;
+#pragma unroll
+      for (int i = 0; i < NX; ++i) gl += m[i] * lam[i];
+      if (ctl) gl_max = t_max(gl_max, t_abs(gl));
+      const T glz = qzl + ldsLam[zi];              // (incoming costate of the constant state, from its LDS image)
+      __syncthreads();
+      if (has_v) ldsLam[sv] = st_zc ? glz : gl;
+      __syncthreads();
+#pragma unroll
+      for (int i = 0; i < NX; ++i) lam[i] = ldsLam[i];
+      if (lane == 0 && live) {
+#pragma unroll
+        for (int i = 0; i < NX; ++i) lam_out[k * NX + i] = lam[i];
+      }
+      __syncthreads();
+#pragma unroll
+      for (int i = 0; i < NX; ++i) m[i] = mN[i];
+      mq = mqN; qzl = qzN;
+    }
+    ldsRed[lane] = gl_max;
+    __syncthreads();
+    gnorm = T(0);
+#pragma unroll
+    for (int a = 0; a < NU; ++a) gnorm = t_max(gnorm, ldsRed[LX + a]);
+    __syncthreads();
+  }
+
   // Lane l tries step length 2^-l (all candidate roll-outs run concurrently in the group).
   // Returns the index of the largest accepted step (or -1) and the best cost seen.
   LFSD_DEV int linesearch(int cur, T J, T dV1, T dV2, T& alpha_out, T& Jmin, bool& flat_full) {
@@ -1102,6 +1458,8 @@ __global__ void __launch_bounds__(64, LFSD_WAVES_OC) oc_solve_kernel(OcArgs<T> a
   constexpr int GPB = 64 / GR;
   // backward sweep of the packed kernel on the matrix cores (OcSolver::backward_mf) where the model fits 16-lane groups
   constexpr bool MF = PK && (LFSD_MFMA_BACKWARD != 0) && sizeof(T) == 4 && NX <= 16 && NX + NU <= 17;
+  // ... without the structurally constant tangent columns of the model (OcSolver::backward_sc, rollout_sens_sc)
+  constexpr bool SC = MF && (LFSD_STRUCT_COLS != 0) && Lay::sc_ok;
   constexpr int RS = EXACT ? Lay::template lds_elems<G>() : ((Lay::template lds_ex<G>() + 3) / 4) * 4;
   constexpr int MB = 12;                          // mailbox floats per trajectory
   static_assert(64 % G == 0 && G >= NX + NU, "lane group must hold one column of [A B] per lane");
@@ -1154,7 +1512,9 @@ __global__ void __launch_bounds__(64, LFSD_WAVES_OC) oc_solve_kernel(OcArgs<T> a
       __syncthreads();
       if (!any) return false;
       T g_, d1_, d2_, dm_;
-      const bool okb = s.backward_mf(cur_, mode_, mu_, want_, g_, d1_, d2_, dm_);
+      bool okb;
+      if constexpr (SC) okb = s.backward_sc(cur_, mode_, mu_, want_, g_, d1_, d2_, dm_);
+      else okb = s.backward_mf(cur_, mode_, mu_, want_, g_, d1_, d2_, dm_);
       if (want_) { ok_ = okb; gnorm_ = g_; dV1_ = d1_; dV2_ = d2_; dmin_ = dm_; }
       return want_;
     } else if constexpr (!PK) {
@@ -1191,7 +1551,8 @@ __global__ void __launch_bounds__(64, LFSD_WAVES_OC) oc_solve_kernel(OcArgs<T> a
     }
   };
   auto do_rollout = [&](int cur_, int nxt_, T alpha_, bool gains_) LFSD_LAMBDA_RO -> T {
-    if constexpr (PK) return s.rollout_sens_pk(cur_, nxt_, alpha_, gains_);
+    if constexpr (SC) return s.rollout_sens_sc(cur_, nxt_, alpha_, gains_);
+    else if constexpr (PK) return s.rollout_sens_pk(cur_, nxt_, alpha_, gains_);
     else return s.rollout_sens(cur_, nxt_, alpha_, gains_);
   };
 
@@ -1206,6 +1567,19 @@ __global__ void __launch_bounds__(64, LFSD_WAVES_OC) oc_solve_kernel(OcArgs<T> a
 #else
 #define LFSD_CLK(acc, stmt) { stmt; }
 #endif
+  // Mesh continuation (lean fp32 kernel of the 32-lane models, round 3).  The first iterations of a cold start only have to
+  // get near the optimum -- the zero-control roll-out of the quadrotor starts at J = 2.5e4 for an optimum of 10 -- and do
+  // not need the reference's 4 RK4 steps per grid interval for that: while full steps keep gaining more than
+  // LFSD_COARSE_SWITCH of the cost, roll-outs and linearisations run with ONE RK4 step per interval (a quarter of the work
+  // of the phase that is 53 % of the kernel).  Then the nominal is rolled out and linearised once on the reference's
+  // discretisation (`relin`, an iteration without a backward sweep) and the solve continues there: every convergence
+  // test, every returned number belongs to the NLP of CPDP.py:110-175 with steps_per_grid sub-steps; the coarse phase only
+  // changes the path to its KKT point, as the choice of DDP over IPOPT does.
+  constexpr bool CS = PK && !EXACT && (LFSD_COARSE_START != 0);
+  bool coarse = CS && a.steps_per_grid > 1 && !a.resume && a.max_iter > 4;
+  bool relin = false;       // leave the coarse grid at the next iteration ...
+  bool relin_hard = LFSD_COARSE_RELIN != 0;      // ... by a roll-out + linearisation of the nominal without a step (else: with the step)
+  if (coarse) { s.S = 1; s.DT = s.dgrid; }
   T J = do_rollout(1, 0, T(0), false);
   __syncthreads();
   T mu = T(0);
@@ -1233,12 +1607,20 @@ __global__ void __launch_bounds__(64, LFSD_WAVES_OC) oc_solve_kernel(OcArgs<T> a
     __syncthreads();
     if (!vote[0]) break;
     __syncthreads();
+    if (coarse && it + 3 >= a.max_iter) relin = true;      // never leave a launch on the coarse grid
+    // Leaving the coarse grid.  Normally WITH this iteration's step (`fine_step`): the backward sweep still runs on the coarse
+    // linearisation, its full step is rolled out and linearised on the reference's discretisation and taken unless the cost
+    // rises beyond what the two discretisations can differ by (their costs differ by ~1e-5 relative, about the gain a
+    // Newton-like step predicts at this point, so the Armijo test cannot referee this one step).  Otherwise -- the full step
+    // was refused, or a line search is due -- WITHOUT a step (`relin_now`): the nominal is rolled out and linearised again.
+    const bool fine_step = CS && relin && !relin_hard && optimistic && status == ST_RUNNING;
+    const bool relin_now = CS && relin && !fine_step && status == ST_RUNNING;
     if constexpr (MF) {
       // A solve whose last Newton step already predicted a decrease below the resolution of the cost is about to pass its
       // convergence test: try the costate-only sweep (gradient norm + costates, a few per cent of a full sweep) first.
       // Accepted on the gradient test itself, or on the first clause of at_working_precision (the decrement of the nominal
       // just left stands in for this one's, which only the full sweep knows: the gradient must not have grown).
-      const bool want_c = status == ST_RUNNING && mode >= 1 && mu == T(0) && g_last >= T(0) && dec_last <= T(2) * Eps<T>::v() * t_abs(J);
+      const bool want_c = status == ST_RUNNING && !coarse && mode >= 1 && mu == T(0) && g_last >= T(0) && dec_last <= T(2) * Eps<T>::v() * t_abs(J);
       if (threadIdx.x == 0) vote[1] = 0;
       __syncthreads();
       if (want_c) vote[1] = 1;
@@ -1247,7 +1629,8 @@ __global__ void __launch_bounds__(64, LFSD_WAVES_OC) oc_solve_kernel(OcArgs<T> a
       __syncthreads();
       if (any_c) {
         T gc = T(0);
-        s.costate_sweep_mf(cur, want_c, gc);
+        if constexpr (SC) s.costate_sweep_sc(cur, want_c, gc);
+        else s.costate_sweep_mf(cur, want_c, gc);
         if (want_c) {
           const T gtol = a.tol * (T(1) + t_abs(J));
           if (gc < gtol) status = ST_CONVERGED;
@@ -1266,10 +1649,11 @@ __global__ void __launch_bounds__(64, LFSD_WAVES_OC) oc_solve_kernel(OcArgs<T> a
     bool bw_ok = false;
     s.reuse_hess = EXACT && mode == 2 && hess_ok;
     bool bw_ran = false;
-    LFSD_CLK(clk_bw, bw_ran = do_backward(cur, mode, mu, status == ST_RUNNING, gnorm, dV1, dV2, dmin, bw_ok));
+    LFSD_CLK(clk_bw, bw_ran = do_backward(cur, mode, mu, status == ST_RUNNING && !relin_now, gnorm, dV1, dV2, dmin, bw_ok));
     if (bw_ran) { need_bw = false; hess_ok = EXACT && mode == 2; }
     bool try_step = false;
-    if (status == ST_RUNNING) {
+    if (relin_now) my_iters = it + 1 + it_off;
+    if (status == ST_RUNNING && !relin_now) {
       my_iters = it + 1 + it_off;
       if (!bw_ok) {
         // indefinite Q_uu: the cheap Newton-like model hands over to the exact one; otherwise Levenberg shift
@@ -1288,6 +1672,11 @@ __global__ void __launch_bounds__(64, LFSD_WAVES_OC) oc_solve_kernel(OcArgs<T> a
         status = ST_STALLED;
       } else {
         try_step = true;
+      }
+      if (coarse) {
+        // convergence is only ever declared on the reference's discretisation; a failed sweep is retried there as well
+        if (status == ST_CONVERGED || status == ST_STALLED) { status = ST_RUNNING; relin = true; try_step = fine_step; }
+        else if (!bw_ok) { relin = true; relin_hard = true; }
       }
     }
     // Step selection.  Optimistic groups roll the full step (alpha = 1) out together with its linearisation and
@@ -1328,12 +1717,28 @@ __global__ void __launch_bounds__(64, LFSD_WAVES_OC) oc_solve_kernel(OcArgs<T> a
     const bool roll = accept || opt_try;
     if (threadIdx.x == 0) vote[1] = 0;
     __syncthreads();
-    if (roll) vote[1] = 1;
+    if (roll || relin_now) vote[1] = 1;
     __syncthreads();
     if (vote[1]) {
       T Jn;
+      if (relin_now || (fine_step && opt_try)) { s.S = a.steps_per_grid; s.DT = s.dgrid / T(s.S); coarse = false; }
       LFSD_CLK(clk_ro, Jn = do_rollout(cur, cur ^ 1, opt_try ? T(1) : (accept ? alpha : T(0)), roll));
-      if (opt_try) {
+      if (relin_now) {
+        // the same controls on the reference's discretisation: new nominal, new cost, fresh linearisation; the histories of
+        // the convergence tests start over
+        cur ^= 1; J = Jn; relin = false;
+        need_bw = true; hess_ok = false;
+        g_last = T(-1); dec_last = T(1e30); g_flat = T(-1); J_ref = J; n_acc = 0;
+        if (!t_finite(J)) status = ST_FAILED;
+      }
+      if (opt_try && fine_step) {
+        relin = false;
+        if (t_finite(Jn) && Jn <= J + T(1e-3) * t_abs(J)) {
+          accept = true; ia = 0;
+        } else {
+          relin = true; relin_hard = true;      // refused: re-linearise the (coarse) nominal on the fine grid, then carry on there
+        }
+      } else if (opt_try) {
         const T flat = T(8) * Eps<T>::v() * t_abs(J);
         const bool fin = t_finite(Jn);
         if (fin && (J - Jn) >= T(1e-4) * (-(dV1 + dV2)) - flat && Jn < J) {
@@ -1343,11 +1748,14 @@ __global__ void __launch_bounds__(64, LFSD_WAVES_OC) oc_solve_kernel(OcArgs<T> a
           accept = true; ia = 0; g_flat = gnorm;
         } else {
           optimistic = false;     // same gains, parallel line search next round
+          if (coarse) { relin = true; relin_hard = true; }      // ... on the fine grid
         }
       }
       if (accept) {
+        if (coarse && (ia != 0 || (J - Jn) < T(LFSD_COARSE_SWITCH) * t_abs(Jn))) { relin = true; if (ia != 0) relin_hard = true; }      // past the first big drops
         cur ^= 1;
         g_last = gnorm; dec_last = (mode >= 1 && mu == T(0)) ? -(dV1 + dV2) : T(1e30);
+        if (fine_step) { g_last = T(-1); dec_last = T(1e30); g_flat = T(-1); J_ref = Jn; n_acc = 0; }      // histories start over on the fine grid
         need_bw = true;
         hess_ok = false;
         optimistic = (ia == 0);

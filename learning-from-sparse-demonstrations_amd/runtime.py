@@ -168,10 +168,10 @@ class ModelLibrary:
         L.lfsd_coc_solve.argtypes = [ci, ci, ci, ci, vp, vp, vp, vp, ci, vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, cd, ci, ci, vp,
                                      ctypes.c_size_t, vp]
         L.lfsd_aux_solve.argtypes = [ci, ci, ci, vp, vp, vp, ci, vp, vp, vp, vp, ci, ci, vp, vp, vp, vp, vp, vp, vp,
-                                     ci, cd, vp]
-        L.lfsd_aux_riccati.argtypes = [ci, ci, ci, vp, vp, vp, ci, vp, vp, vp, vp, ci, cd, vp]
+                                     ci, cd, vp, vp]
+        L.lfsd_aux_riccati.argtypes = [ci, ci, ci, vp, vp, vp, ci, vp, vp, vp, vp, ci, cd, vp, vp]
         L.lfsd_aux_forward.argtypes = [ci, ci, ci, vp, vp, vp, ci, vp, vp, vp, vp, ci, ci, vp, vp, vp, vp, vp, vp, vp,
-                                       ci, cd, vp]
+                                       ci, cd, vp, vp]
         L.lfsd_optimizer_step.argtypes = [ci, ci, ci, ci, ci, cd, cd, cd, cd, cd, vp, vp, vp, vp, vp, vp, vp, vp]
         L.lfsd_lookahead.argtypes = [ci, ctypes.c_longlong, cd, vp, vp, vp, vp]
         info = _ModelInfo()
@@ -315,6 +315,10 @@ class ModelLibrary:
             Z_grid = torch.empty((B, N + 1, n + p, n), dtype=dt, device=dev)
         if out is None:
             out = dict(loss=torch.zeros((B,), dtype=dt, device=dev), grad=torch.zeros((B, p), dtype=dt, device=dev))
+        if out.get("stats") is None:
+            # [B][4]: split units executed / intervals accepted above rtol, Riccati sweep | forward sweep (include/lfsd_cpdp.h)
+            out["stats"] = torch.zeros((B, 4), dtype=torch.int32, device=dev)
+        self._check(out["stats"], (B, 4), torch.int32, "stats")
         auxX = auxU = None
         if want_grids:
             auxX = torch.empty((B, N + 1, p, n), dtype=dt, device=dev)
@@ -322,14 +326,15 @@ class ModelLibrary:
         common = (_DT[dt], B, N, self._p(horizon), self._p(auxvar), self._p(consts), per_traj,
                   self._p(state_grid), self._p(control_grid), self._p(costate_grid), self._p(Z_grid))
         tail = (nw, ni, self._p(iface_idx), self._p(taus), self._p(waypoints), self._p(out["loss"]),
-                self._p(out["grad"]), self._p(auxX), self._p(auxU), int(substeps), float(rtol), self._stream(state_grid))
+                self._p(out["grad"]), self._p(auxX), self._p(auxU), int(substeps), float(rtol), self._p(out["stats"]),
+                self._stream(state_grid))
         with self._on(state_grid):
             if phase_hook is None:
                 self._rc(self.lib.lfsd_aux_solve(*common, *tail), "lfsd_aux_solve")
             else:
                 phase_hook("riccati")
-                self._rc(self.lib.lfsd_aux_riccati(*common, int(substeps), float(rtol), self._stream(state_grid)),
-                         "lfsd_aux_riccati")
+                self._rc(self.lib.lfsd_aux_riccati(*common, int(substeps), float(rtol), self._p(out["stats"]),
+                                                   self._stream(state_grid)), "lfsd_aux_riccati")
                 phase_hook("forward")
                 self._rc(self.lib.lfsd_aux_forward(*common, *tail), "lfsd_aux_forward")
                 phase_hook("end")

@@ -19,14 +19,15 @@ int main() {
     for (int b = 0; b < B; ++b) { set(hz, b, 1.0); for (int i = 0; i < p; ++i) set(th, b * p + i, 1.0 + 0.1 * i + 0.05 * b);
       for (int w = 0; w < nw; ++w) { set(taus, b * nw + w, 0.3 + 0.4 * w); set(wps, b * nw + w, 0.5); } }
     for (int i = 0; i < nc; ++i) set(cs, i, lfsd_const_default(i));
-    std::vector<int> it(B), st(B), iface = {0};
+    std::vector<int> it(B), st(B), iface = {0}, stats(4 * B);
     size_t wsb = lfsd_coc_workspace_bytes(dtype, B, N, 3, mapping, 0);
     std::vector<char> ws(wsb);
     int rc = lfsd_coc_solve(dtype, B, N, 4, x0.data(), hz.data(), th.data(), nc ? cs.data() : nullptr, 0, nullptr, nullptr, nullptr, X.data(), U.data(), L.data(),
                             cost.data(), it.data(), st.data(), 40, dtype ? 1e-9 : 1e-6, 3, mapping, ws.data(), wsb, nullptr);
     printf("dtype %d coc rc %d status %d iters %d\n", dtype, rc, st[0], it[0]);
     rc = lfsd_aux_solve(dtype, B, N, hz.data(), th.data(), nc ? cs.data() : nullptr, 0, X.data(), U.data(), L.data(), Z.data(), nw, ni, iface.data(),
-                        taus.data(), wps.data(), loss.data(), grad.data(), aX.data(), aU.data(), (pass & 2) ? 1 : 4, (pass & 2) ? 1e-3 : 0.0, nullptr);
+                        taus.data(), wps.data(), loss.data(), grad.data(), aX.data(), aU.data(), (pass & 2) ? 1 : 4, (pass & 2) ? 1e-3 : 0.0, stats.data(), nullptr);
+    printf("dtype %d aux units %d / %d unmet %d / %d\n", dtype, stats[0], stats[2], stats[1], stats[3]);
     printf("dtype %d aux rc %d\n", dtype, rc);
     for (int meth = 0; meth < 5; ++meth)
       rc |= lfsd_optimizer_step(dtype, meth, B, p, 0, 0.01, 0.9, 0.9, 0.999, 1e-8, th.data(), grad.data(), mm.data(), mv.data(), mvh.data(), nullptr, nullptr, nullptr);

@@ -2,16 +2,12 @@
 comparison code runs on both, so a case that is green on the emulator and red on the GPU isolates a device-side
 problem.  `prepare(oc, dtype)` binds the model to its backend (emulator library / cuda:0) and returns it.
 
-Stated tolerances (relative to the largest component of the compared array):
-
-                       fp64                                   fp32 (fp64 -> fp32 tolerance of the pipeline)
-  state/control grids  1e-6                                   5e-3
-  costate grid         1e-5                                   2e-2  (flat-cost problems: arm, cart-pole)
-  Z = [P W], dx/dth,   2e-3 at 16 sub-steps                   2e-2
-  du/dth               (4th-order split-step sweeps vs Radau rtol 1e-10); du/dth 2e-2 / 5e-2: its value at t = T is
-                       -Huu^-1 fu^T h_xx dx/dth(T), which multiplies the error of dx/dth by ~10^3 on the robot arm
-  loss                 1e-6                                   2e-3
-  gradient             1e-4                                   2e-2
+Tolerances (relative to the largest component of the compared array).  fp64: the discretisation class of the sweeps
+(state/control 1e-6, costate 1e-5, [P W] / dx/dth 2e-3 at 16 sub-steps, du/dth 2e-2 -- its value at t = T is
+-Huu^-1 fu^T h_xx dx/dth(T), which multiplies the error of dx/dth by ~10^3 on the robot arm -- loss 1e-6, gradient 1e-4).
+fp32: per model, about 10x the LARGEST error measured on MI355X over both mappings and every seed of the case
+(profiles/r03_a_parity_floors.jsonl, written by conftest.parity_record; measured maxima in the comment of each row) --
+not one blanket figure: a regression by a factor of ten in any single output fails.
 """
 import numpy as np
 import torch
@@ -20,8 +16,25 @@ import lfsd_amd  # noqa: F401
 from lfsd_amd import models
 from conftest import oracle_parallel, assert_grids_match
 
-TOL = {torch.float64: dict(grid=1e-6, costate=1e-5, aux=2e-3, auxU=2e-2, loss=1e-6, grad=1e-4),
-       torch.float32: dict(grid=5e-3, costate=2e-2, aux=2e-2, auxU=5e-2, loss=2e-3, grad=2e-2)}
+TOL64 = dict(grid=1e-6, costate=1e-5, aux=2e-3, auxU=2e-2, loss=1e-6, grad=1e-4)
+TOL32 = {
+    # measured fp32 maxima (r03):  state/control  costate   [P W]    dx/dth   du/dth   loss     gradient
+    #   pendulum                   2.8e-4         3.4e-4    1.4e-3   1.0e-3   9.2e-4   1.6e-5   9.5e-4
+    "pendulum": dict(grid=3e-3, costate=3e-3, aux=1e-2, auxU=1e-2, loss=2e-4, grad=1e-2),
+    #   robot arm                  1.5e-6         1.5e-4    1.7e-4   1.7e-3   1.2e-2*  1.5e-6   6.5e-4    (* the fp64 figure too: discretisation at t = T)
+    "robotarm": dict(grid=1e-4, costate=2e-3, aux=1e-2, auxU=5e-2, loss=5e-5, grad=6e-3),
+    #   cart-pole                  3.6e-4         2.3e-4    1.8e-4   4.3e-4   7.0e-4   2.3e-5   1.8e-4
+    "cartpole": dict(grid=3e-3, costate=2e-3, aux=4e-3, auxU=7e-3, loss=2e-4, grad=2e-3),
+    #   quadrotor (n_grid 10)      1.9e-4         5.2e-5    9.5e-5   8.3e-5   1.2e-4   6.7e-6   3.0e-5
+    "quadrotor": dict(grid=2e-3, costate=5e-4, aux=1e-3, auxU=1e-3, loss=1e-4, grad=3e-4),
+}
+
+
+def tol_for(kind, dtype):
+    return TOL64 if dtype == torch.float64 else TOL32[kind]
+
+
+TOL = {torch.float64: TOL64, torch.float32: dict(grid=5e-3, costate=2e-2, aux=2e-2, auxU=5e-2, loss=2e-3, grad=2e-2)}   # (loosest fp32 class; single_trajectory_api)
 
 G_CASES = {
     "pendulum": dict(n_grid=10, thetas=[[1.0, 0.5, 1.5], [2.0, 1.0, 1.0], [0.7, 1.3, 0.6]],
@@ -53,7 +66,7 @@ def all_grids_vs_oracle(prepare, kind, dtype, substeps=16, tol=None):
                                  theta=list(t), taus=taus, wps=wps, iface=d["interface"]) for t in th])
     lib = oc.compile()
     for b in range(B):
-        assert_grids_match(sol, aux, b, refs[b], lib.n_state, lib.n_control, lib.n_auxvar, tol or TOL[dtype],
+        assert_grids_match(sol, aux, b, refs[b], lib.n_state, lib.n_control, lib.n_auxvar, tol or tol_for(kind, dtype),
                            what="%s %s seed %d" % (kind, dtype, b))
     return oc, d, sol, aux, refs
 

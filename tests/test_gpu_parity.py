@@ -7,7 +7,7 @@ import torch
 
 import lfsd_amd  # noqa: F401
 from lfsd_amd import CPDP, models, runtime
-from conftest import make_oracle, oracle_loss_grad, oracle_parallel, oracle_check_solution, assert_grids_match
+from conftest import make_oracle, oracle_loss_grad, oracle_parallel, oracle_check_solution, assert_grids_match, parity_record
 import parity_cases as pc
 
 pytestmark = pytest.mark.gpu
@@ -51,11 +51,14 @@ def test_reference_shaped_single_trajectory_api(kind):
 
 
 @pytest.mark.parametrize("substeps", [0, 4])        # 0: the library default bench.py runs (error-controlled, rtol 1e-3); 4: fixed units
-@pytest.mark.parametrize("dtype,ltol,gtol,xtol", [(torch.float64, 1e-6, 1e-4, 1e-6), (torch.float32, 5e-4, 2e-3, 5e-3)])
+@pytest.mark.parametrize("dtype,ltol,gtol,xtol", [(torch.float64, 1e-6, 1e-4, 2e-6), (torch.float32, 5e-5, 1e-3, 3e-4)])
 def test_quadrotor_bench_seeds_vs_tight_oracle(dtype, ltol, gtol, xtol, substeps):
-    """The headline configuration itself (n_grid 50, the first seeds bench.py draws, aux_substeps 4) against the TIGHT oracle
-    (Radau, rtol 1e-10), so the floor of the shipped fp32 path is known apart from the reference integrator's own 5e-3:
-    fp64 isolates the discretisation error of the sweeps, fp32 adds the arithmetic (measured: 5e-7 / 4e-6 on the gradient)."""
+    """The headline configuration itself (n_grid 50, the first seeds bench.py draws; library defaults and fixed 4 units)
+    against the TIGHT oracle (Radau, rtol 1e-10), so the floor of the shipped fp32 path is known apart from the reference
+    integrator's own 5e-3.  Measured on MI355X (profiles/r03_a_parity_floors.jsonl), fp64 / fp32: state 9e-7 / 1.1e-5, control
+    4e-7 / 2.9e-5, costate 3e-7 / 9e-6, [P W] 1e-5 / 1.4e-4, dx/dth 2.7e-4 / 2.7e-4, loss 2e-8 / 3.6e-6, gradient 5e-7 / 1.1e-4;
+    asserted at about 10x (fp64 grids at 2x: they sit at the solver's tolerance): see `tol` below.  du/dth 1.6e-2 in both
+    precisions -- the discretisation of its value at t = T, 10^3 x the error of dx/dth."""
     oc, d = gpu_model("quadrotor", dtype, 50, substeps=substeps)
     oc.setSolverOptions(aux_rtol=1e-3 if substeps == 0 else 0.0)
     rng = np.random.default_rng(1234)
@@ -67,8 +70,7 @@ def test_quadrotor_bench_seeds_vs_tight_oracle(dtype, ltol, gtol, xtol, substeps
     assert set(sol["status"].tolist()) <= {1, 2}
     refs = oracle_parallel([dict(kind="quadrotor", n_grid=50, ini_state=d["ini_state"], horizon=d["horizon"], theta=list(t),
                                  taus=d["taus"], wps=d["waypoints"], iface=d["interface"]) for t in th])
-    tol = dict(grid=xtol, costate=10 * xtol, aux=2e-3 if dtype == torch.float64 else 2e-2, auxU=5e-2,      # du/dtheta(T): x10^3 of dx/dtheta
-               loss=ltol, grad=gtol)
+    tol = dict(grid=xtol, costate=10 * xtol, aux=3e-3, auxU=5e-2, loss=ltol, grad=gtol)
     for b in range(4):
         assert_grids_match(sol, aux, b, refs[b], 13, 4, 7, tol, what="bench seed %d %s" % (b, dtype))
 
@@ -176,8 +178,10 @@ def test_headline_workload_has_no_stragglers_and_stops_at_the_fp64_answer():
     aux64 = oc64.auxSysSolverBatch(sol64, d["taus"], d["waypoints"], d["interface"])
     l32, l64 = L._aux["loss"][sub].double().cpu().numpy(), aux64["loss"].cpu().numpy()
     g32, g64 = L._aux["grad"][sub].double().cpu().numpy(), aux64["grad"].cpu().numpy()
-    assert np.all(np.abs(l32 - l64) < 5e-4 * np.maximum(1.0, l64)), np.abs(l32 - l64).max()
-    assert np.all(np.abs(g32 - g64).max(axis=1) < 1e-2 * np.abs(g64).max(axis=1)), (np.abs(g32 - g64).max(axis=1) / np.abs(g64).max(axis=1)).max()
+    # (the comparison with the ORACLE at these parameters is test_headline_defaults_vs_tight_oracle_at_outer_iteration_12;
+    #  this one covers 48 more seeds against fp64 HIP.  Measured r03: loss 3e-6, gradient 4e-4)
+    parity_record("headline fp32 vs fp64 HIP, 48 seeds at outer iteration 12", "loss", (np.abs(l32 - l64) / np.maximum(1.0, l64)).max(), 5e-5)
+    parity_record("headline fp32 vs fp64 HIP, 48 seeds at outer iteration 12", "grad", (np.abs(g32 - g64).max(axis=1) / np.abs(g64).max(axis=1)).max(), 3e-3)
 
 
 def test_headline_defaults_vs_tight_oracle_at_outer_iteration_12():
@@ -187,7 +191,7 @@ def test_headline_defaults_vs_tight_oracle_at_outer_iteration_12():
     with fp64 HIP: the benchmark's own learner runs 12 outer iterations, and at the parameters of the 12th (later
     iterations need more split units than theta_0) six trajectories that ended CONVERGED and six that ended at WORKING
     PRECISION go through the fp64 oracle (IPOPT-equivalent solve, Radau rtol 1e-10 sweeps).
-    Measured floors (profiles/r03_parity_floors.jsonl): state 2e-5, loss 3e-6, gradient 3e-4; asserted with a margin of
+    Measured floors (profiles/r03_a_parity_floors.jsonl): state 2e-5, loss 3e-6, gradient 3e-4; asserted with a margin of
     ~5x: state 2e-4, costate 5e-3, loss 5e-5, gradient 2e-3."""
     import sys
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -409,16 +413,19 @@ def test_robotarm_batch1024_random_seeds_configs1():
             thetas["theta1"] = th1
         l32, g32 = res[(torch.float32, name)]
         l64, g64 = res[(torch.float64, name)]
-        assert (np.abs(l32 - l64) < 2e-3 * np.maximum(1.0, l64)).all(), name
+        parity_record("robot arm 1024 seeds fp32 vs fp64 HIP at " + name, "loss", (np.abs(l32 - l64) / np.maximum(1.0, l64)).max(), 2e-3)
         gerr = np.abs(g32 - g64).max(1) / np.abs(g64).max(1)
+        parity_record("robot arm 1024 seeds fp32 vs fp64 HIP at " + name, "grad, median over seeds", float(np.median(gerr)), 2e-3)
         if name == "theta0":
-            assert (gerr < 2e-2).all(), (name, gerr.max())
+            parity_record("robot arm 1024 seeds fp32 vs fp64 HIP at theta0", "grad, worst seed", gerr.max(), 2e-2)
         else:
+            parity_record("robot arm 1024 seeds fp32 vs fp64 HIP at theta1", "share of seeds with grad error > 2e-2", float((gerr >= 2e-2).mean()), 0.02)
             # theta_1: about 1 % of the seeds sit next to a conjugate point of the optimal-control problem (the tight oracle's
             # Riccati integration has a finite escape there, next test); the same KKT point is found (loss above), but its
             # sensitivity is ill-conditioned with respect to the trajectory itself: fp32 round-off of the SOLVE moves it by
             # O(1), whichever precision the auxiliary pass runs in.  Stated: >= 98 % of the seeds within 2e-2.
             assert (gerr < 2e-2).mean() >= 0.98, (name, (gerr < 2e-2).mean())
+            parity_record("robot arm 1024 seeds fp32 vs fp64 HIP at theta1", "grad, 95th percentile", float(np.quantile(gerr, 0.95)), 2e-2)
 
 
 def test_robotarm_theta1_vs_oracle_16_seeds():
@@ -462,7 +469,8 @@ def test_robotarm_theta1_vs_oracle_16_seeds():
         # fp32: 2e-2 where the sensitivity is of typical size; the seeds picked for their large gradients sit next to a
         # conjugate point, where fp32 round-off of the solve itself moves the gradient by tens of percent
         typical = np.abs(r["grad"]).max() < 3 * np.median(gmax)
-        assert rel(aux32["grad"][k], r["grad"]) < (2e-2 if typical else 7e-1), (b, aux32["grad"][k], r["grad"])
+        parity_record("robot arm theta1 seed %d fp32 vs oracle (%s sensitivity)" % (b, "typical" if typical else "large"), "grad",
+                      rel(aux32["grad"][k], r["grad"]), 2e-2 if typical else 7e-1)
     assert compared >= 16, compared
 
 

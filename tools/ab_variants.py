@@ -25,6 +25,14 @@ VARIANTS = {
     "dual": (("-DLFSD_OC_DUAL=1",), None, False),
     "nodual": (("-DLFSD_OC_DUAL=0",), None, False),
     "nostruct": (("-DLFSD_STRUCT_COLS=0",), None, False),
+    "nocoarse": (("-DLFSD_COARSE_START=0",), None, False),
+    "r02like": (("-DLFSD_COARSE_START=0", "-DLFSD_STRUCT_COLS=0"), None, False),
+    "relinhard": (("-DLFSD_COARSE_RELIN=1",), None, False),
+    "cs1e2": (("-DLFSD_COARSE_SWITCH=0.01",), None, False),
+    "cs1e3": (("-DLFSD_COARSE_SWITCH=0.001",), None, False),
+    "cs3": (("-DLFSD_COARSE_SWITCH=3.0",), None, False),
+    "cs1e4": (("-DLFSD_COARSE_SWITCH=0.0001",), None, False),
+    "cs0": (("-DLFSD_COARSE_SWITCH=0.0",), None, False),
 }
 
 
