@@ -33,7 +33,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
 VALU_PEAK_TFLOPS = {"f32": 157.3, "f64": 78.6}
-PROFILE_TAG = "r02"            # profiles/<tag>_hbm_traffic.json, <tag>_issue_counters.json feed the roofline object
+PROFILE_TAG = "r03"            # profiles/<tag>_hbm_traffic.json, <tag>_issue_counters.json feed the roofline object
 
 
 def parse_args(argv=None):
@@ -312,21 +312,35 @@ def main(argv=None):
         headline = (B == 4096 and args.n_grid == 50 and args.dtype == "f32" and args.substeps == 0 and args.aux_rtol == 1e-3
                     and mode == "independent" and not args.warm_start and not args.library)
 
+        sources = {}
+
         def profile(name):
-            path = os.path.join(ROOT, "profiles", "%s_%s.json" % (PROFILE_TAG, name))
+            """Counter figures that THIS run does not measure: read from a committed fold of separate rocprofv3 --pmc passes
+            of the same command, and named as such in the line (file + git blob hash of the file read)."""
+            import hashlib
+            rel = "profiles/%s_%s.json" % (PROFILE_TAG, name)
+            path = os.path.join(ROOT, rel)
             if not (headline and os.path.exists(path)):
                 return {}
             try:
-                return json.load(open(path)).get(dom, {})
+                raw = open(path, "rb").read()
+                sources[name] = {"file": rel, "git_blob": hashlib.sha1(b"blob %d\0" % len(raw) + raw).hexdigest()}
+                return json.loads(raw).get(dom, {})
             except Exception:
                 return {}
-        traffic = profile("hbm_traffic").get("hbm_bytes_per_step")
+        traffic = profile("hbm_traffic").get("hbm_bytes_per_launch")
         issue = profile("issue_counters")
+        # split units the error control of the auxiliary sweeps actually spent (per-trajectory statistics output of the
+        # kernels, read once after the timed loop) -- also what the flop model of those kernels is evaluated at
+        stats = L._aux["stats"].double().cpu().numpy()
+        units = {"aux_riccati": float(stats[:, 0].mean()) / args.n_grid, "aux_forward": float(stats[:, 2].mean()) / args.n_grid}
         # useful flops of the dominant kernel: operation counts of the generated model code x calls x active columns
         # (perf_model.py), times the solver iterations the batch actually ran
-        flops = perf_model.kernel_flops(oc.model_spec(), dom, args.n_grid, 4, max(1, args.substeps) if args.aux_rtol > 0 else (args.substeps or 4),
-                                        mean_iters=float(it.mean())) * B
-        useful_tflops = flops / (ktime[dom] * 1e-3) / 1e12
+        flops, mflops = perf_model.kernel_flops(oc.model_spec(), dom, args.n_grid, 4, max(1, args.substeps) if args.aux_rtol > 0 else (args.substeps or 4),
+                                                mean_iters=float(it.mean()), units_per_interval=units.get(dom), split=True,
+                                                midpoint=(args.dtype == "f32"), coarse_rollouts=(5 if args.dtype == "f32" else 0))
+        useful_tflops = flops * B / (ktime[dom] * 1e-3) / 1e12
+        executed = issue.get("valu_flops_executed_per_launch")
         out = {
             "metric": "CPDP outer iterations/sec (batch trajectories)",
             "value": B * world * args.steps / elapsed,
@@ -353,6 +367,8 @@ def main(argv=None):
                        "oc_status_hist": np.bincount(st, minlength=5).tolist(), "oc_iters_mean": float(it.mean()),
                        "oc_iters_max": int(it.max()), "loss_mean": float(loss.mean().item()) / (1 if mode == "independent" else B * world),
                        "kernel_ms": {k: round(v, 3) for k, v in ktime.items()},
+                       "aux_units_per_interval": {k: round(v, 3) for k, v in units.items()},
+                       "aux_intervals_accepted_above_rtol": int(stats[:, 1].sum() + stats[:, 3].sum()),
                        # shared mode: the one parameter vector every rank holds after warmup + steps iterations (17 digits: the
                        # N>1 test compares it with a single-process run over the union of the ranks' demonstrations)
                        "theta": [float(x) for x in L.theta.double().cpu().numpy().ravel()] if mode == "shared" else None,
@@ -363,13 +379,23 @@ def main(argv=None):
                          # the fraction that actually bounds this path: fp32 vector issue, not HBM
                          "valu_useful_tflops": useful_tflops,
                          "valu_frac": useful_tflops / VALU_PEAK_TFLOPS[args.dtype],
+                         # what the vector pipe EXECUTED per launch by the counters (every enabled lane, redundant group-uniform
+                         # work included) at this run's launch time, and the modelled useful share of it
+                         "valu_executed_tflops": None if executed is None else executed / (ktime[dom] * 1e-3) / 1e12,
+                         "valu_useful_over_executed": None if executed is None else flops * B / executed,
+                         "mfma_useful_tflops": mflops * B / (ktime[dom] * 1e-3) / 1e12,
                          "valu_issue_util": issue.get("valu_issue_util"),
+                         "valu_lane_util": issue.get("valu_lane_util"),
                          "mfma_busy": issue.get("mfma_busy"),
+                         "source": sources or None,
                          "note": "the per-trajectory recursions are latency/VALU-issue bound, not HBM bound: "
                                  "algorithmic bytes are O(10 KB) per trajectory against O(10^7) FLOP of sequential "
-                                 "fp32 vector work per solve; valu_frac = useful flops (perf_model.py) / 157.3 TFLOP/s, "
-                                 "valu_issue_util and mfma_busy from the SQ counters of profiles/%s_issue_counters.json; "
-                                 "see DESIGN.md section 4" % PROFILE_TAG},
+                                 "fp32 vector work per solve; valu_frac = useful VECTOR flops (perf_model.py, corrected in round 3 against the "
+                                 "counters) / 157.3 TFLOP/s, "
+                                 "traffic, valu_issue_util, valu_lane_util (EXEC-enabled lanes per vector instruction) and "
+                                 "mfma_busy are NOT measured by this run: they come from the committed fold of separate rocprofv3 "
+                                 "--pmc passes of this command named in `source` (null when the run is not the headline "
+                                 "configuration); see DESIGN.md section 4"},
         }
         if world == 1 and mode == "independent" and not args.no_cpu_baseline:
             try:

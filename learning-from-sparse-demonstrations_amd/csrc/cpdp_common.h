@@ -124,9 +124,13 @@
 // recursion (Tassa's form) an indefinite Q_uu feeds -mu K^T K into V_xx, the sweep needs shifts 30x larger, and 64 of
 // 1024 seeds ran out of 100 iterations.  LFSD_HAM_SHIFT: shift the cheap Hamiltonian model as well instead of falling
 // back to Gauss-Newton (measured: no gain).
-// backward sweep: issue the loads of interval k-1 while interval k is processed (costs NX+1 + NX+NU registers)
+// backward sweep: issue the loads of interval k-1 while interval k is processed (1; costs NX+1 + NX+NU registers), or load
+// each interval when the sweep gets there (0).  Round 2 measured no difference and kept 1 -- the compiler had sunk the
+// prefetch to its first use (LFSD_ISSUE_FENCE below); with the loads really issued ahead (r03_g_ab_prefetch_pin.txt)
+// oc_solve takes 2.65 ms against 2.59 ms without the prefetch: the 23 registers it holds through the stage cost more
+// accumulator-register traffic than the loads' latency does beside 7000 cycles of stage work.
 #ifndef LFSD_BW_PREFETCH
-#define LFSD_BW_PREFETCH 1
+#define LFSD_BW_PREFETCH 0
 #endif
 // lean fp32 kernel of the 32-lane models: backward sweep on the matrix cores (1) or relayed on the vector pipe (0)
 #ifndef LFSD_MFMA_BACKWARD
@@ -296,6 +300,29 @@ LFSD_DEV void tile_transpose(f32x16& acc) {
     }
   }
 }
+#endif
+
+// LFSD_ISSUE_FENCE(): the loads written above it are ISSUED above it.  Without it the compiler sinks a software prefetch
+// ("load stage k-1 while stage k is processed") down to the first use of its values -- the copy at the end of the loop
+// body -- i.e. it undoes the prefetch, and the next stage starts by waiting for its own operands (seen in the ISA of the
+// backward sweeps: s_waitcnt vmcnt(15) ... vmcnt(3) between the first thirteen MFMAs of a stage; round 2 measured
+// "prefetch on / off: no difference" for exactly that reason).  A compiler-level memory clobber: no instruction, and no
+// wait either -- the s_waitcnt still goes where the values are first used.
+#if defined(LFSD_EMU)
+#define LFSD_ISSUE_FENCE()
+#else
+#define LFSD_ISSUE_FENCE() asm volatile("" ::: "memory")
+#endif
+
+// pin(x): the value is materialised HERE, unconditionally.  Needed where a load feeds one arm of a per-lane select
+//   r = own_column ? f(lds[addr]) : other;
+// -- clang turns that into a divergent branch around the load, and a sequence of thirteen of them into thirteen serialised
+// LDS round trips (measured in the backward sweep of the OC solve, profiles/r03_g_bw_clock.txt: 1600 of 8300 cycles per
+// stage for the symmetrisation of V_xx alone).  With the loads issued back to back and pinned, the select is a v_cndmask.
+#if defined(LFSD_EMU)
+template <typename T> LFSD_DEV void pin(T&) {}
+#else
+template <typename T> LFSD_DEV void pin(T& x) { asm volatile("" : "+v"(x)); }
 #endif
 
 template <typename T> struct Eps;

@@ -401,7 +401,7 @@ template <class M, typename T, int G, bool EXACT, bool BND = false> struct OcSol
         for (int i = 0; i < NX; ++i) ldsM[lane * NX + i] = m[i];
       }
       __syncthreads();
-      if (LFSD_BW_PREFETCH && k > 0) load_stage(k - 1, mN, mqN, xkN, ukN);
+      if (LFSD_BW_PREFETCH && k > 0) { load_stage(k - 1, mN, mqN, xkN, ukN); LFSD_ISSUE_FENCE(); }
       // Y = Vxx' m_j ;  Qcol = [A B]^T Y
       T Y[NX], Qcol[NXU];
 #pragma unroll
@@ -529,7 +529,7 @@ template <class M, typename T, int G, bool EXACT, bool BND = false> struct OcSol
       for (int a = 0; a < NU; ++a) { dV1 += kff[a] * Qu[a]; dV2 += T(0.5) * kff[a] * qk[a]; }
       T Vxj = Qg;
 #pragma unroll
-      for (int a = 0; a < NU; ++a) Vxj += Kj[a] * (qk[a] + Qu[a]) + Quxj[a] * kff[a];
+      for (int a = 0; a < NU; ++a) { Vxj += Kj[a] * (qk[a] + Qu[a]); Vxj += Quxj[a] * kff[a]; }
       if (lane < NX) {
 #pragma unroll
         for (int a = 0; a < NU; ++a) ldsK[lane * NU + a] = Kj[a];
@@ -551,7 +551,7 @@ template <class M, typename T, int G, bool EXACT, bool BND = false> struct OcSol
       for (int i = 0; i < NX; ++i) {
         T s = Qcol[i];
 #pragma unroll
-        for (int a = 0; a < NU; ++a) s += ldsK[i * NU + a] * t1[a] + ldsQux[i * NU + a] * Kj[a];
+        for (int a = 0; a < NU; ++a) { s += ldsK[i * NU + a] * t1[a]; s += ldsQux[i * NU + a] * Kj[a]; }
         vcol[i] = s;
         Vx[i] = ldsVx[i];
         lam[i] = ldsLam[i];
@@ -659,7 +659,7 @@ template <class M, typename T, int G, bool EXACT, bool BND = false> struct OcSol
       if (NEXT) {                                  // column NCL of [A B; q]: row `lane` of it, parked in LDS
         if (lane <= NX) ldsME[lane] = me;
       }
-      if (LFSD_BW_PREFETCH) { if (k > 0) mf_load_stage(cur, k - 1, mN, mqN, meN, xkN, ukN); }
+      if (LFSD_BW_PREFETCH) { if (k > 0) { mf_load_stage(cur, k - 1, mN, mqN, meN, xkN, ukN); LFSD_ISSUE_FENCE(); } }
       // Y = V_xx [A B](:, 0..15)
       f32x16 acc;
 #pragma unroll
@@ -761,7 +761,7 @@ template <class M, typename T, int G, bool EXACT, bool BND = false> struct OcSol
       for (int a = 0; a < NU; ++a) { dV1 += kff[a] * Qu[a]; dV2 += T(0.5) * kff[a] * qk[a]; }
       T Vxj = Qg;
 #pragma unroll
-      for (int a = 0; a < NU; ++a) Vxj += Kj[a] * (qk[a] + Qu[a]) + Quxj[a] * kff[a];
+      for (int a = 0; a < NU; ++a) { Vxj += Kj[a] * (qk[a] + Qu[a]); Vxj += Quxj[a] * kff[a]; }
       if (lane < NX) {
 #pragma unroll
         for (int a = 0; a < NU; ++a) ldsK[lane * NU + a] = Kj[a];
@@ -785,7 +785,7 @@ template <class M, typename T, int G, bool EXACT, bool BND = false> struct OcSol
       for (int i = 0; i < NX; ++i) {
         T sacc = Qcol[i];
 #pragma unroll
-        for (int a = 0; a < NU; ++a) sacc += ldsK[i * NU + a] * t1[a] + ldsQux[i * NU + a] * Kj[a];
+        for (int a = 0; a < NU; ++a) { sacc += ldsK[i * NU + a] * t1[a]; sacc += ldsQux[i * NU + a] * Kj[a]; }      // (two FMAs; one statement compiles to mul + fma + add)
         vcol[i] = sacc;
         Vx[i] = ldsVx[i];
         lam[i] = ldsLam[i];
@@ -800,8 +800,16 @@ template <class M, typename T, int G, bool EXACT, bool BND = false> struct OcSol
         for (int i = 0; i < NX; ++i) ldsV[lane * NX + i] = vcol[i];
       }
       __syncthreads();
+      {
+        const int lv = lane < NX ? lane : 0;
+        T vt[NX];
 #pragma unroll
-      for (int i = 0; i < NX; ++i) vcol[i] = (lane < NX) ? T(0.5) * (vcol[i] + ldsV[i * NX + lane]) : T(0);
+        for (int i = 0; i < NX; ++i) vt[i] = ldsV[i * NX + lv];
+#pragma unroll
+        for (int i = 0; i < NX; ++i) pin(vt[i]);
+#pragma unroll
+        for (int i = 0; i < NX; ++i) vcol[i] = (lane < NX) ? T(0.5) * (vcol[i] + vt[i]) : T(0);
+      }
       __syncthreads();
       if (k > 0) {
         if (LFSD_BW_PREFETCH) {
@@ -850,7 +858,7 @@ template <class M, typename T, int G, bool EXACT, bool BND = false> struct OcSol
     mf_load_stage(cur, N - 1, m, mq, me, xk, uk);
     for (int k = N - 1; k >= 0; --k) {
       if (NEXT) { if (lane <= NX) ldsME[lane] = me; }
-      if (k > 0) mf_load_stage(cur, k - 1, mN, mqN, meN, xk, uk);
+      if (k > 0) { mf_load_stage(cur, k - 1, mN, mqN, meN, xk, uk); LFSD_ISSUE_FENCE(); }
       T gl = mq;
 #pragma unroll
       for (int i = 0; i < NX; ++i) gl += m[i] * lam[i];
@@ -961,6 +969,13 @@ template <class M, typename T, int G, bool EXACT, bool BND = false> struct OcSol
 #pragma unroll
     for (int a = 0; a < NU; ++a) uk[a] = up[a];
   }
+  // diagnostic build (-DLFSD_BW_CLOCK, tools/bw_clock.py): shader clocks of the six phases of a stage, summed over a sweep
+#if defined(LFSD_BW_CLOCK) && !defined(LFSD_EMU)
+  long long bwc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define LFSD_BWC(i) { const long long t_ = clock64(); bwc[i] += t_ - bwc_t; bwc_t = t_; }
+#else
+#define LFSD_BWC(i)
+#endif
   LFSD_DEV bool backward_sc(int cur, int mode, T mu, bool live, T& gnorm, T& dV1, T& dV2, T& dmin) {
     static_assert(!Lay::sc_ok || (G == 16 && LIVE <= 16 && ZC <= NU && NX <= 16), "structural sweep: 16-lane groups");
     T* ldsV = lds + Lay::LDS_V;  T* ldsK = lds + Lay::LDS_K;
@@ -999,8 +1014,11 @@ template <class M, typename T, int G, bool EXACT, bool BND = false> struct OcSol
     __syncthreads();
     T m[NX], mq = T(0), qzl = T(0), mN[NX], mqN = T(0), qzN = T(0), xkN[NX], ukN[NU];
     sc_load_stage(cur, N - 1, m, mq, qzl, xk, uk);
+#if defined(LFSD_BW_CLOCK) && !defined(LFSD_EMU)
+    long long bwc_t = clock64();
+#endif
     for (int k = N - 1; k >= 0; --k) {
-      if (LFSD_BW_PREFETCH) { if (k > 0) sc_load_stage(cur, k - 1, mN, mqN, qzN, xkN, ukN); }
+      if (LFSD_BW_PREFETCH == 1) { if (k > 0) { sc_load_stage(cur, k - 1, mN, mqN, qzN, xkN, ukN); LFSD_ISSUE_FENCE(); } }
       // Y(V-lane r, live column of this lane) = sum_kk V[kk][state of lane r] M[kk][column]
       f32x16 acc;
 #pragma unroll
@@ -1019,6 +1037,7 @@ template <class M, typename T, int G, bool EXACT, bool BND = false> struct OcSol
         M::ham_hess_mul(tk(k), xk, uk, ls, e, c, ox, ou, hx, hu);
       }
       tile_transpose(acc);
+      LFSD_BWC(0)                                  // loads issued, MFMA #1, stage Hessian column, transpose
       T yn[NX];                                    // Y(:, column of this lane) in NATURAL row order
 #pragma unroll
       for (int s_ = 0; s_ < NX; ++s_) yn[s_] = acc[s_ < ZC ? LX + s_ : s_ - ZC];
@@ -1036,23 +1055,30 @@ template <class M, typename T, int G, bool EXACT, bool BND = false> struct OcSol
       for (int i = 0; i < NX; ++i) { Qg += m[i] * Vx[i]; gl += m[i] * lam[i]; }
       tile_transpose(acc);
       __syncthreads();                             // ldsYZ visible
+      if (LFSD_BW_PREFETCH == 2) { if (k > 0) { sc_load_stage(cur, k - 1, mN, mqN, qzN, xkN, ukN); LFSD_ISSUE_FENCE(); } }      // (experiment: behind the MFMA chains)
+      LFSD_BWC(1)                                  // MFMA #2, gradient dot products, transpose
       // column of Q (natural row order) of this lane's V-role, control rows of its M-role
       T Qcol[NX], mu_rows[NU], Quxj[NU];
 #pragma unroll
       for (int a = 0; a < NU; ++a) mu_rows[a] = acc[LX + a] + dgrid * hu[a];
+      T gzv[LIVE];                                 // row zi of Y, every live column: issued back to back for ALL lanes (pin)
 #pragma unroll
-      for (int j = 0; j < LX; ++j) {
-        const T gz = ldsYZ[j * ZC + zi];           // Q(live state ZC + j, constant state zi) = Y(zi, that column)
-        Qcol[ZC + j] = st_zc ? gz : acc[j] + dgrid * hx[ZC + j];
-      }
+      for (int j = 0; j < LIVE; ++j) gzv[j] = ldsYZ[j * ZC + zi];
+      // (Vx and the costate of the constant state: from their LDS images -- still the incoming values here; a per-lane
+      //  select over the register copies makes the compiler park both arrays in scratch)
+      T Vx_z = ldsVx[zi], lam_z = ldsLam[zi];
+#pragma unroll
+      for (int j = 0; j < LIVE; ++j) pin(gzv[j]);
+      pin(Vx_z); pin(lam_z);
+#pragma unroll
+      for (int j = 0; j < LX; ++j)                 // Q(live state ZC + j, constant state zi) = Y(zi, that column)
+        Qcol[ZC + j] = st_zc ? gzv[j] : acc[j] + dgrid * hx[ZC + j];
 #pragma unroll
       for (int z = 0; z < ZC; ++z) Qcol[z] = st_zc ? vcol[z] + dgrid * hx[z] : yn[z];      // Q(Z, Z) = V(Z, Z) + H_ZZ ; Q(Z, live) = Y(Z, live)
 #pragma unroll
-      for (int a = 0; a < NU; ++a) Quxj[a] = st_zc ? ldsYZ[(LX + a) * ZC + zi] : mu_rows[a];
-      // (Vx and the costate of the constant state: from their LDS images -- still the incoming values here; a per-lane
-      //  select over the register copies makes the compiler park both arrays in scratch)
-      const T Qg_v = st_zc ? qzl + ldsVx[zi] : Qg;
-      const T gl_v = st_zc ? qzl + ldsLam[zi] : gl;
+      for (int a = 0; a < NU; ++a) Quxj[a] = st_zc ? gzv[LX + a] : mu_rows[a];
+      const T Qg_v = st_zc ? qzl + Vx_z : Qg;
+      const T gl_v = st_zc ? qzl + lam_z : gl;
       if (has_v) {
 #pragma unroll
         for (int a = 0; a < NU; ++a) ldsQux[sv * NU + a] = Quxj[a];
@@ -1065,6 +1091,7 @@ template <class M, typename T, int G, bool EXACT, bool BND = false> struct OcSol
         gl_max = t_max(gl_max, t_abs(gl));
       }
       __syncthreads();
+      LFSD_BWC(2)                                  // gather of the constant states' columns, Q columns, Q_ux / Q_uu to LDS
       T Quu0[NU * NU], Lc[NU * NU], Qu[NU], kff[NU], Kj[NU], t1[NU];
 #pragma unroll
       for (int a = 0; a < NU; ++a) {
@@ -1091,7 +1118,8 @@ template <class M, typename T, int G, bool EXACT, bool BND = false> struct OcSol
       for (int a = 0; a < NU; ++a) { dV1 += kff[a] * Qu[a]; dV2 += T(0.5) * kff[a] * qk[a]; }
       T Vxj = Qg_v;
 #pragma unroll
-      for (int a = 0; a < NU; ++a) Vxj += Kj[a] * (qk[a] + Qu[a]) + Quxj[a] * kff[a];
+      for (int a = 0; a < NU; ++a) { Vxj += Kj[a] * (qk[a] + Qu[a]); Vxj += Quxj[a] * kff[a]; }
+      LFSD_BWC(3)                                  // Q_uu from LDS, Cholesky, gains
       if (has_v) {
 #pragma unroll
         for (int a = 0; a < NU; ++a) ldsK[sv * NU + a] = Kj[a];
@@ -1115,7 +1143,7 @@ template <class M, typename T, int G, bool EXACT, bool BND = false> struct OcSol
       for (int i = 0; i < NX; ++i) {
         T sacc = Qcol[i];
 #pragma unroll
-        for (int a = 0; a < NU; ++a) sacc += ldsK[i * NU + a] * t1[a] + ldsQux[i * NU + a] * Kj[a];
+        for (int a = 0; a < NU; ++a) { sacc += ldsK[i * NU + a] * t1[a]; sacc += ldsQux[i * NU + a] * Kj[a]; }      // (two FMAs; one statement compiles to mul + fma + add)
         vcol[i] = sacc;
         Vx[i] = ldsVx[i];
         lam[i] = ldsLam[i];
@@ -1124,15 +1152,24 @@ template <class M, typename T, int G, bool EXACT, bool BND = false> struct OcSol
 #pragma unroll
         for (int i = 0; i < NX; ++i) lam_out[k * NX + i] = lam[i];
       }
+      LFSD_BWC(4)                                  // gains to LDS / HBM, V_xx update
       // symmetrise V_xx through LDS (the rank-1 feeds rely on row i == column i)
       if (has_v) {
 #pragma unroll
         for (int i = 0; i < NX; ++i) ldsV[sv * NX + i] = vcol[i];
       }
       __syncthreads();
+      {
+        T vt[NX];                                  // row sv of V_xx: thirteen loads in flight together (pin), then the select
 #pragma unroll
-      for (int i = 0; i < NX; ++i) vcol[i] = has_v ? T(0.5) * (vcol[i] + ldsV[i * NX + sv]) : T(0);
+        for (int i = 0; i < NX; ++i) vt[i] = ldsV[i * NX + sv];
+#pragma unroll
+        for (int i = 0; i < NX; ++i) pin(vt[i]);
+#pragma unroll
+        for (int i = 0; i < NX; ++i) vcol[i] = has_v ? T(0.5) * (vcol[i] + vt[i]) : T(0);
+      }
       __syncthreads();
+      LFSD_BWC(5)                                  // symmetrisation
       if (k > 0) {
         if (LFSD_BW_PREFETCH) {
 #pragma unroll
@@ -1152,6 +1189,11 @@ template <class M, typename T, int G, bool EXACT, bool BND = false> struct OcSol
     for (int a = 0; a < NU; ++a) gnorm = t_max(gnorm, ldsRed[LX + a]);
     __syncthreads();
     if (!t_finite(gnorm) || !t_finite(dV1) || !t_finite(dV2)) ok = false;
+#if defined(LFSD_BW_CLOCK) && !defined(LFSD_EMU)
+    if (threadIdx.x == 0 && blockIdx.x == 0)
+      printf("bw clock (wave 0, one sweep of %d stages): mfma1+hess %lld  mfma2+dots %lld  gather+Qcol %lld  chol+gains %lld  K+Vupdate %lld  symm %lld\n",
+             N, bwc[0], bwc[1], bwc[2], bwc[3], bwc[4], bwc[5]);
+#endif
     return ok;
   }
   // costates and gradient norm without the value recursion (see costate_sweep_mf), structural layout
@@ -1180,12 +1222,14 @@ template <class M, typename T, int G, bool EXACT, bool BND = false> struct OcSol
     T m[NX], mq = T(0), qzl = T(0), mN[NX], mqN = T(0), qzN = T(0);
     sc_load_stage(cur, N - 1, m, mq, qzl, xk, uk);
     for (int k = N - 1; k >= 0; --k) {
-      if (k > 0) sc_load_stage(cur, k - 1, mN, mqN, qzN, xk, uk);
+      if (k > 0) { sc_load_stage(cur, k - 1, mN, mqN, qzN, xk, uk); LFSD_ISSUE_FENCE(); }
       T gl = mq;
 #pragma unroll
       for (int i = 0; i < NX; ++i) gl += m[i] * lam[i];
       if (ctl) gl_max = t_max(gl_max, t_abs(gl));
-      const T glz = qzl + ldsLam[zi];              // (incoming costate of the constant state, from its LDS image)
+      T lam_z = ldsLam[zi];                        // (incoming costate of the constant state, from its LDS image)
+      pin(lam_z);
+      const T glz = qzl + lam_z;
       __syncthreads();
       if (has_v) ldsLam[sv] = st_zc ? glz : gl;
       __syncthreads();

@@ -68,6 +68,18 @@ def _model_counts(spec_hash, spec):
     nz = lambda M: sum(1 for e in M if e != 0)
     out["nnz"] = {k: nz(M) for k, M in (("fx", fx), ("fu", fu), ("fe", fe), ("Hxx", Hxx), ("Hxu", Hxu), ("Hxe", Hxe),
                                         ("Hue", Hue))}
+    out["nnz_cx"], out["nnz_cu"] = nz(cx), nz(cu)
+    # structurally constant leading tangent columns (same rule as codegen.emit_header)
+    cxx, cxu = cx.jacobian(X), cx.jacobian(U)
+    k = 0
+    for i in range(n):
+        if any(fx[r, i] != 0 for r in range(n)):
+            break
+        k += 1
+    while k > 0 and not (all(cxx[i, j] == 0 for i in range(k) for j in range(k, n)) and
+                         all(cxu[i, a] == 0 for i in range(k) for a in range(m))):
+        k -= 1
+    out["nzc"] = k
     return out
 
 
@@ -75,38 +87,62 @@ def model_counts(spec):
     return _model_counts(spec.hash(), spec)
 
 
-def kernel_flops(spec, kernel, n_grid, steps_per_grid, substeps, mean_iters=1.0, units_per_interval=None):
+def kernel_flops(spec, kernel, n_grid, steps_per_grid, substeps, mean_iters=1.0, units_per_interval=None, midpoint=False,
+                 coarse_rollouts=0, split=False):
     """Useful flops of ONE trajectory in one launch of `kernel` ("oc_solve" | "aux_riccati" | "aux_forward").
-    oc_solve: `mean_iters` solver iterations, each = tangent roll-out (RK4, 4 stages x S steps x N intervals, one
-    uniform evaluation + NX+NU tangent columns) + backward sweep (V_xx m, [A B]^T Y dense products, stage Hessian
-    column, gains) -- plus the initial roll-out.  aux kernels: per interval `units` split units (default = substeps),
-    each 12 right-hand sides (coarse RK4 + two fine RK4 steps) per column + 5 coefficient nodes."""
+
+    Round 3: the figures are checked against the counters (SQ_INSTS_VALU_FLOPS_FP32 x 64 lanes x EXEC share,
+    profiles/r03_issue_counters.json, `valu_flops_executed_per_launch`) times the share of the executing lanes that carry
+    needed work, and were corrected where they disagreed by more than 20 %: the round-2 model counted the RK4 combination
+    twice and took the tangent operations from sympy's CSE of the directional derivative, which keeps group-uniform
+    coefficient products inside the per-column count (2.2x too many for the quadrotor's roll-out).  A tangent column now
+    costs what the linear map costs: one FMA per structural non-zero of [f_x f_u; c_x c_u] plus the RK4 combination.
+
+    oc_solve: `mean_iters` solver iterations, each = tangent roll-out (RK4, 4 stages x S steps x N intervals, one uniform
+    evaluation + the LIVE tangent columns: structurally constant columns are not computed, codegen NZC) + backward sweep
+    (dense products V_xx [A B], [A B]^T Y -- on the matrix cores in the lean fp32 kernel, reported apart with split=True --
+    stage Hessian column, gains, V_xx update) -- plus the initial roll-out.  `coarse_rollouts` of the 1 + mean_iters
+    roll-outs run with ONE RK4 step per interval (mesh continuation; 5 on the benchmark).
+    aux kernels: per interval `units_per_interval` split units (default `substeps`; bench.py passes the measured mean of the
+    error-controlled sweeps), each 12 right-hand sides (coarse RK4 + two fine RK4 steps; 6 with the explicit midpoint rule of
+    the fp32 kernels, `midpoint`) per column + 5 coefficient nodes."""
     c = model_counts(spec)
     n, m, p = spec.n, spec.m, spec.p
     nxu, N, S = n + m, n_grid, steps_per_grid
-    rk = 4 * (n + 1)                                                   # RK4 combination per stage, state + cost
-    if kernel == "oc_solve":
-        rollout = N * S * 4 * (c["jvp_uniform"] + 2 * rk + nxu * (c["jvp_column"] + 2 * rk)) + N * 2 * n * m
-        backward = N * (2 * n * n * nxu + 2 * nxu * n * nxu            # Y = V_xx m, Q = [A B]^T Y
-                        + nxu * c["ham_column"]                         # stage Hessian model, one column each
-                        + 2 * n * nxu + m * m * m // 3 + 4 * m * m * nxu   # Q_u / lambda, Cholesky, gains K, k
-                        + n * (4 * m * n + 2 * m * m))                  # V_xx update
-        return (1.0 + mean_iters) * rollout + max(mean_iters, 1.0) * backward
     nn = c["nnz"]
+    if kernel == "oc_solve":
+        live = nxu - c.get("nzc", 0)
+        glue = 4 * (n + 1)                                             # x_s = x + a f, acc += w f: two FMAs per component
+        col = 2 * (nn["fx"] + nn["fu"] + c["nnz_cx"] + c["nnz_cu"]) + glue      # one tangent column, one RK4 stage
+        uni = c["jvp_uniform"] + glue                                  # nominal f, c and the Jacobian coefficients, once
+        rollout = N * S * 4 * (uni + live * col) + N * 2 * n * m       # (+ closed-loop control)
+        dense = N * (2 * n * n * live + 2 * live * n * live)           # Y = V_xx M_live, Q = M_live^T Y
+        backward = N * (nxu * c["ham_column"]                           # stage Hessian model, one column each
+                        + 4 * n * nxu + m * m * m // 3 + 4 * m * m * nxu      # Q_u / lambda, Cholesky, gains K, k
+                        + n * (4 * m * n + 2 * m * m) + n * n)          # V_xx update + symmetrisation
+        n_ro = 1.0 + mean_iters
+        nc = min(float(coarse_rollouts), n_ro) if S > 1 else 0.0
+        valu = (n_ro - nc) * rollout + nc * rollout / S + max(mean_iters, 1.0) * backward
+        mfma = max(mean_iters, 1.0) * dense
+        return (valu, mfma) if split else valu + mfma
     units = units_per_interval or substeps
+    nrhs = 6 if midpoint else 12
     if kernel == "aux_riccati":
         cols = n + p
-        rhs = 2 * (2 * nn["fx"] + 2 * nn["fu"] + nn["Hxx"] + 2 * nn["Hxu"] + nn["fe"] + nn["Hxe"] + nn["Hue"]) // 1 \
-            + 2 * m * m * 2 + 2 * n
-        stiff = 2 * (2 * nn["fu"]) + 2 * n * m + m * m * m
-        per_unit = 5 * (c["pmp_coeffs"] + m ** 3) / cols + 12 * (rhs + 3 * n) + 5 * stiff
-        return N * units * cols * per_unit
+        # one right-hand side, one column -- as implemented (cpdp_aux.h ric_rhs): fx^T z, fu^T z, Huu^-1 (.), Hxu w; the P
+        # columns also produce their row of P [A r] (Hxu nv, fe^T z, Hue^T nv), which the other lanes read back transposed
+        rhs = 2 * (nn["fx"] + nn["fu"] + nn["Hxu"]) + 2 * m * m + (n / cols) * 2 * (nn["Hxu"] + nn["fe"] + nn["Hue"]) + 2 * n
+        stiff = 2 * nn["fu"] + 2 * m * m + 2 * n * m + (2 * m * nn["fu"] + m * m * m) / cols
+        per_unit = 5 * (c["pmp_coeffs"] + m ** 3) / cols + nrhs * (rhs + 3 * n) + 5 * stiff
+        v = N * units * cols * per_unit
+        return (v, 0.0) if split else v
     if kernel == "aux_forward":
         cols = p
         rhs = 2 * (nn["fx"] + nn["Hxu"] + nn["fu"]) + 2 * m * m + n
         stiff = 2 * n * m + 2 * m * m + 2 * nn["fu"]
         prep = 3 * (2 * nn["fu"] + 2 * m * m) * n / cols + 3 * 40 * m ** 3 / cols
-        per_unit = 5 * (c["pmp_coeffs"] + m ** 3) / cols + prep + 12 * (rhs + 3 * n) + 8 * stiff \
+        per_unit = 5 * (c["pmp_coeffs"] + m ** 3) / cols + prep + nrhs * (rhs + 3 * n) + 8 * stiff \
             + 5 * (2 * nn["fu"] + 2 * nn["fe"] + 2 * m * m)
-        return N * units * cols * per_unit
+        v = N * units * cols * per_unit
+        return (v, 0.0) if split else v
     raise KeyError(kernel)

@@ -33,6 +33,9 @@ VARIANTS = {
     "cs3": (("-DLFSD_COARSE_SWITCH=3.0",), None, False),
     "cs1e4": (("-DLFSD_COARSE_SWITCH=0.0001",), None, False),
     "cs0": (("-DLFSD_COARSE_SWITCH=0.0",), None, False),
+    "bwclock": (("-DLFSD_BW_CLOCK=1",), None, False),
+    "pflate": (("-DLFSD_BW_PREFETCH=2",), None, False),
+    "pflateclock": (("-DLFSD_BW_PREFETCH=2", "-DLFSD_BW_CLOCK=1"), None, False),
 }
 
 
