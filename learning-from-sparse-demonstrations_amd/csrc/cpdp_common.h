@@ -317,8 +317,10 @@ LFSD_DEV void tile_transpose(f32x16& acc) {
 // pin(x): the value is materialised HERE, unconditionally.  Needed where a load feeds one arm of a per-lane select
 //   r = own_column ? f(lds[addr]) : other;
 // -- clang turns that into a divergent branch around the load, and a sequence of thirteen of them into thirteen serialised
-// LDS round trips (measured in the backward sweep of the OC solve, profiles/r03_g_bw_clock.txt: 1600 of 8300 cycles per
-// stage for the symmetrisation of V_xx alone).  With the loads issued back to back and pinned, the select is a v_cndmask.
+// LDS round trips (measured in the backward sweep of the OC solve, profiles/r03_g_ab_prefetch_pin.txt: 1600 of 8300 cycles
+// per stage for the symmetrisation of V_xx alone).  With the loads issued back to back and pinned, the select is a v_cndmask.
+// (Tried and dropped in the forward auxiliary sweep, which runs at 256 + 256 registers with spills: batching the loads of
+// its stiff steps this way doubled its scratch traffic, 1.01 -> 2.13 ms; batching only its node staging cost 3 %.)
 #if defined(LFSD_EMU)
 template <typename T> LFSD_DEV void pin(T&) {}
 #else

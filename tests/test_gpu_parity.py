@@ -413,11 +413,11 @@ def test_robotarm_batch1024_random_seeds_configs1():
             thetas["theta1"] = th1
         l32, g32 = res[(torch.float32, name)]
         l64, g64 = res[(torch.float64, name)]
-        parity_record("robot arm 1024 seeds fp32 vs fp64 HIP at " + name, "loss", (np.abs(l32 - l64) / np.maximum(1.0, l64)).max(), 2e-3)
+        parity_record("robot arm 1024 seeds fp32 vs fp64 HIP at " + name, "loss", (np.abs(l32 - l64) / np.maximum(1.0, l64)).max(), 5e-4)      # measured 4e-5 / 8e-5
         gerr = np.abs(g32 - g64).max(1) / np.abs(g64).max(1)
-        parity_record("robot arm 1024 seeds fp32 vs fp64 HIP at " + name, "grad, median over seeds", float(np.median(gerr)), 2e-3)
+        parity_record("robot arm 1024 seeds fp32 vs fp64 HIP at " + name, "grad, median over seeds", float(np.median(gerr)), 1e-3)      # measured 8e-5 / 1.4e-4
         if name == "theta0":
-            parity_record("robot arm 1024 seeds fp32 vs fp64 HIP at theta0", "grad, worst seed", gerr.max(), 2e-2)
+            parity_record("robot arm 1024 seeds fp32 vs fp64 HIP at theta0", "grad, worst seed", gerr.max(), 2e-2)      # measured 3.7e-3
         else:
             parity_record("robot arm 1024 seeds fp32 vs fp64 HIP at theta1", "share of seeds with grad error > 2e-2", float((gerr >= 2e-2).mean()), 0.02)
             # theta_1: about 1 % of the seeds sit next to a conjugate point of the optimal-control problem (the tight oracle's
@@ -470,7 +470,7 @@ def test_robotarm_theta1_vs_oracle_16_seeds():
         # conjugate point, where fp32 round-off of the solve itself moves the gradient by tens of percent
         typical = np.abs(r["grad"]).max() < 3 * np.median(gmax)
         parity_record("robot arm theta1 seed %d fp32 vs oracle (%s sensitivity)" % (b, "typical" if typical else "large"), "grad",
-                      rel(aux32["grad"][k], r["grad"]), 2e-2 if typical else 7e-1)
+                      rel(aux32["grad"][k], r["grad"]), 5e-3 if typical else 7e-1)      # measured 4.3e-4 / 0.45 (next to a conjugate point)
     assert compared >= 16, compared
 
 
