@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define LFSD_ABI_VERSION 6
+#define LFSD_ABI_VERSION 7
 #define LFSD_F32 0
 #define LFSD_F64 1
 #define LFSD_EINVAL (-1)   /* bad argument (null pointer, non-positive size, unknown enum) */
@@ -84,12 +84,21 @@ size_t lfsd_coc_workspace_bytes(int dtype, int batch, int n_grid, int exact_afte
  *   setControlVariable(control, control_lb, control_ub) -> lbw / ubw of the NLP (CPDP.py:33-46, 150-153).  Both or
  *   neither; entries beyond +-1e19 mean "unbounded in that direction".  Solved by a control-limited backward sweep
  *   (box QP per stage, zero feedback gain on clamped components, clamped roll-out); the initial guess is the midpoint of
- *   finite bounds as in the reference.  State bounds are not supported.
+ *   finite bounds as in the reference.
+ *   state_lb / state_ub [n_state] (shared by the batch), state_mult [B][n_grid][2][n_state], state_rho > 0, or all NULL:
+ *   finite STATE bounds, the reference's setStateVariable(state, state_lb, state_ub) -> lbw / ubw of the shooting nodes
+ *   X_1..X_N (CPDP.py:20-31, 140-147).  One call solves ONE augmented-Lagrangian subproblem: the nodes' terms
+ *   [max(0, lu + rho (x - ub))^2 - lu^2 + max(0, ll + rho (lb - x))^2 - ll^2] / (2 rho) with the multipliers lu = state_mult
+ *   [b][k-1][0][:], ll = [b][k-1][1][:] of node k are added to the cost; the caller updates the multipliers
+ *   (lu <- max(0, lu + rho (x_k - ub)), ll likewise) and the penalty between calls until the nodes are feasible -- the outer
+ *   loop is host code (COCSys.cocSolverBatch).  The returned costates include the bound multipliers, as IPOPT's lam_g
+ *   do.  With state bounds the control-bound arrays must be given too (entries of +-1e20 where there is none).
  *   mapping: LFSD_MAP_AUTO, or force one of the two mappings of the same algorithm (same KKT points either way).   */
 int lfsd_coc_solve(int dtype, int batch, int n_grid, int steps_per_grid,
                    const void* ini_state, const void* horizon, const void* auxvar,
                    const void* consts, int const_per_traj, const void* u_init,
                    const void* control_lb, const void* control_ub,
+                   const void* state_lb, const void* state_ub, const void* state_mult, double state_rho,
                    void* state_grid, void* control_grid, void* costate_grid,
                    void* cost, int* iters, int* status,
                    int max_iter, double tol, int exact_after, int mapping,

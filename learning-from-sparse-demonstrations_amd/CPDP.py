@@ -50,6 +50,9 @@ class COCSys:
         self.exact_after = 16            # iteration from which the exact stage Hessian is forced
         self.aux_dtype = None            # None: same as dtype; torch.float64: fp64 auxiliary (Riccati/sensitivity) pass
         self.mapping = "auto"            # "auto" | "lockstep" | "wide": mapping of the OC solve onto the machine
+        # state bounds (augmented Lagrangian): first penalty, its growth, feasibility tolerance (None: 1e-7 fp64 / 1e-4 fp32,
+        # relative to 1 + the largest finite bound), limit of outer iterations
+        self.state_rho0, self.state_rho_growth, self.state_tol, self.state_max_outer = 10.0, 10.0, None, 40
 
     # ---- model definition (CPDP.py:15-87) ------------------------------------------------------
     def setAuxvarVariable(self, auxvar=None):
@@ -60,15 +63,26 @@ class COCSys:
         self._lib = None
 
     def setStateVariable(self, state, state_lb=[], state_ub=[]):
-        """CPDP.py:20-31.  Finite state bounds are NLP variable bounds on the shooting nodes in the reference (IPOPT's
-        interior point handles them); the DDP solver here has no counterpart and refuses them."""
+        """CPDP.py:20-31: bounds are used only when their length equals n_state (otherwise +-1e20, as the reference).
+        Finite state bounds are the variable bounds lbw / ubw of the shooting nodes X_1..X_N in the reference's NLP
+        (CPDP.py:140-147; X_0 is pinned to ini_state, :131-134), which IPOPT's interior point handles; here they are
+        enforced by an augmented-Lagrangian outer loop around the batched solve (cocSolverBatch): every node gets a
+        multiplier pair and a quadratic penalty, the kernels solve the subproblem, the host updates multipliers and penalty
+        until the nodes are feasible to `state_tol`."""
         self.state = symbolic._flat([state])
         self.n_state = len(self.state)
-        if len(state_lb) == self.n_state and len(state_ub) == self.n_state and \
-                any(np.isfinite(v) and abs(v) < 1e19 for v in list(state_lb) + list(state_ub)):
-            raise NotImplementedError("finite state bounds are not supported by the HIP solver (the reference's "
-                                      "examples never set them)")
+        self.state_lb = [float(v) for v in state_lb] if len(state_lb) == self.n_state else self.n_state * [-1e20]
+        self.state_ub = [float(v) for v in state_ub] if len(state_ub) == self.n_state else self.n_state * [1e20]
+        if any(l > u for l, u in zip(self.state_lb, self.state_ub)):
+            raise ValueError("state_lb > state_ub")
         self._lib = None
+
+    def _state_bounds(self):
+        """(lb, ub) device tensors, or (None, None) when no bound is finite."""
+        lb, ub = getattr(self, "state_lb", None), getattr(self, "state_ub", None)
+        if lb is None or not any(abs(v) < 1e19 for v in lb + ub):
+            return None, None
+        return self._t(lb), self._t(ub)
 
     def setControlVariable(self, control, control_lb=[], control_ub=[]):
         """CPDP.py:33-46: bounds are used only when their length equals n_control (otherwise +-1e20, as the reference).
@@ -250,11 +264,57 @@ class COCSys:
         if consts is None:
             consts = self.consts_tensor()
         clb, cub = self._control_bounds()
-        sol = lib.coc_solve(x0, hz, th, consts, self.n_grid, self.steps_per_grid, u_init=u_init,
-                            max_iter=self.max_iter, tol=self.tol, workspace=workspace, out=out,
-                            exact_after=self.exact_after, control_lb=clb, control_ub=cub,
-                            mapping=COCSys.mapping_override or self.mapping)
+        slb, sub = self._state_bounds()
+        kw = dict(max_iter=self.max_iter, tol=self.tol, exact_after=self.exact_after,
+                  mapping=COCSys.mapping_override or self.mapping)
+        if slb is None:
+            sol = lib.coc_solve(x0, hz, th, consts, self.n_grid, self.steps_per_grid, u_init=u_init, workspace=workspace,
+                                out=out, control_lb=clb, control_ub=cub, **kw)
+        else:
+            sol = self._solve_state_bounded(lib, x0, hz, th, consts, u_init, workspace, out, clb, cub, slb, sub, kw)
         sol.update(horizon=hz, auxvar=th, consts=consts, ini_state=x0, n_grid=self.n_grid)
+        return sol
+
+    def _solve_state_bounded(self, lib, x0, hz, th, consts, u_init, workspace, out, clb, cub, slb, sub, kw):
+        """Augmented-Lagrangian outer loop for finite state bounds on the shooting nodes X_1..X_N (CPDP.py:140-147).
+        Subproblem k (one lfsd_coc_solve, warm-started from the controls of subproblem k-1): the NLP plus, per node and state
+        component, [max(0, lu + rho (x - ub))^2 - lu^2 + max(0, ll + rho (lb - x))^2 - ll^2] / (2 rho).  Then
+        lu <- max(0, lu + rho (x - ub)), ll <- max(0, ll + rho (lb - x)); rho grows when the worst violation of the batch
+        shrinks by less than 4x.  Done when every node of every trajectory is feasible to `state_tol` and the multipliers
+        have stopped moving: the last subproblem's stationarity is then the KKT condition of the bounded NLP, with
+        lu - ll the bound multipliers (IPOPT's lam_x) and the returned costates the dynamics multipliers (lam_g)."""
+        B, n, N = x0.shape[0], lib.n_state, self.n_grid
+        if clb is None:                     # the bounded kernel reads both boxes
+            clb, cub = self._t(lib.n_control * [-1e20]), self._t(lib.n_control * [1e20])
+        mult = torch.zeros((B, N, 2, n), dtype=x0.dtype, device=x0.device)
+        rho = float(self.state_rho0)
+        finite = torch.cat([slb[slb.abs() < 1e19], sub[sub.abs() < 1e19]])
+        scale = 1.0 + float(finite.abs().max())
+        tol = self.state_tol if self.state_tol is not None else (1e-7 if x0.dtype == torch.float64 else 1e-4)
+        viol_prev, iters_total, sol = None, None, None
+        for outer in range(int(self.state_max_outer)):
+            sol = lib.coc_solve(x0, hz, th, consts, self.n_grid, self.steps_per_grid, u_init=u_init, workspace=workspace,
+                                out=out, control_lb=clb, control_ub=cub, state_lb=slb, state_ub=sub, state_mult=mult,
+                                state_rho=rho, **kw)
+            workspace, out = sol["workspace"], {k: sol[k] for k in ("state_grid", "control_grid", "costate_grid", "cost",
+                                                                   "iters", "status")}
+            iters_total = sol["iters"].clone() if iters_total is None else iters_total + sol["iters"]
+            X = sol["state_grid"][:, 1:, :]
+            gu, gl = X - sub, slb - X                                        # <= 0 when feasible
+            new_u = torch.clamp(mult[:, :, 0] + rho * gu, min=0.0)
+            new_l = torch.clamp(mult[:, :, 1] + rho * gl, min=0.0)
+            moved = max(float((new_u - mult[:, :, 0]).abs().max()), float((new_l - mult[:, :, 1]).abs().max()))
+            mult = torch.stack((new_u, new_l), dim=2).contiguous()
+            viol = float(torch.clamp(torch.maximum(gu, gl), min=0.0).max())
+            solved = bool(((sol["status"] == 1) | (sol["status"] == 2)).all())
+            if solved and viol <= tol * scale and moved <= tol * scale * rho:
+                break
+            if viol_prev is not None and viol > 0.25 * viol_prev and rho < 1e8:
+                rho *= float(self.state_rho_growth)
+            viol_prev = viol
+            u_init = sol["control_grid"][:, :-1].contiguous()
+        sol["iters"] = iters_total
+        sol["state_mult"], sol["state_rho"], sol["al_outer"], sol["state_violation"] = mult, rho, outer + 1, viol
         return sol
 
     def check_waypoints(self, taus, horizon, interface_idx):

@@ -31,6 +31,13 @@ template <typename T> struct OcArgs {
   int resume;           // 1: continue only trajectories whose status is ST_MAXITER, warm-started from control_grid
   const T* u_lb;        // [NU] finite control bounds (CPDP.py:33-46) or nullptr; handled by the wide kernel
   const T* u_ub;
+  // state bounds on the shooting nodes 1..N (CPDP.py:20-31, 140-147: lbw / ubw of the X_k), as the augmented-Lagrangian
+  // term of ONE outer iteration (the host updates multipliers and penalty between solves, COCSys.cocSolverBatch):
+  //   sum_k sum_i [ max(0, lu + rho (x_i - ub_i))^2 - lu^2 + max(0, ll + rho (lb_i - x_i))^2 - ll^2 ] / (2 rho)
+  const T* x_lb;        // [NX] or nullptr (no state bounds); entries beyond +-1e19: unbounded in that direction
+  const T* x_ub;
+  const T* x_mult;      // [B][N][2][NX] multipliers lu (upper), ll (lower) of node k = 1..N at index k-1
+  T x_rho;
 };
 
 template <class M> struct OcLayout {
@@ -88,6 +95,29 @@ template <class M> struct OcLayout {
 template <class M, typename T, int G, bool EXACT, bool BND = false> struct OcSolver {
   static constexpr int NX = M::NX, NU = M::NU, NP = M::NP, NC = M::NC, NXU = NX + NU;
   T ulb[BND ? NU : 1], uub[BND ? NU : 1];      // BND: box on the controls (clamped roll-out, box-QP backward sweep)
+  // BND, state bounds: augmented-Lagrangian node terms (OcArgs::x_lb ...); xm == nullptr: none
+  T xlb[BND ? NX : 1], xub[BND ? NX : 1], xrho = T(1);
+  const T* xm = nullptr;
+  // value of the node term at node k (1..N) for the state x
+  LFSD_DEV T node_pen(int k, const T* x) const {
+    if (!BND || xm == nullptr) return T(0);
+    const T* mk = xm + (long long)(k - 1) * 2 * NX;
+    T sacc = T(0);
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+      const T lu = mk[i], ll = mk[NX + i];
+      const T tu = t_max(lu + xrho * (x[i] - xub[i]), T(0)), tl = t_max(ll + xrho * (xlb[i] - x[i]), T(0));
+      sacc += (tu * tu - lu * lu) + (tl * tl - ll * ll);
+    }
+    return sacc * (T(0.5) / xrho);
+  }
+  // its gradient and (diagonal, Gauss-Newton) Hessian with respect to component i
+  LFSD_DEV void node_pen_d(int k, int i, T xi, T lbi, T ubi, T& g, T& h) const {
+    const T* mk = xm + (long long)(k - 1) * 2 * NX;
+    const T tu = t_max(mk[i] + xrho * (xi - ubi), T(0)), tl = t_max(mk[NX + i] + xrho * (lbi - xi), T(0));
+    g = tu - tl;
+    h = xrho * ((tu > T(0) ? T(1) : T(0)) + (tl > T(0) ? T(1) : T(0)));
+  }
   static constexpr int NALPHA = (G < 10) ? G : 10;
   using Lay = OcLayout<M>;
 
@@ -365,6 +395,15 @@ template <class M, typename T, int G, bool EXACT, bool BND = false> struct OcSol
 #pragma unroll
       for (int i = 0; i < NP; ++i) oe[i] = T(0);
       M::final_hess_mul(tk(N), xk, e, c, ox, oe, vcol);
+      if (BND && xm != nullptr) {            // state-bound term of node N: gradient into V_x and the costate, Hessian onto the diagonal
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+          T g_, h_;
+          node_pen_d(N, i, xk[i], xlb[i], xub[i], g_, h_);
+          Vx[i] += g_; lam[i] += g_;
+          if (lane == i) vcol[i] += h_;
+        }
+      }
       if (lane == 0) {
 #pragma unroll
         for (int i = 0; i < NX; ++i) lam_out[N * NX + i] = lam[i];
@@ -555,6 +594,15 @@ template <class M, typename T, int G, bool EXACT, bool BND = false> struct OcSol
         vcol[i] = s;
         Vx[i] = ldsVx[i];
         lam[i] = ldsLam[i];
+      }
+      if (BND && xm != nullptr && k > 0) {   // state-bound term of node k (x_0 is given, not bounded: CPDP.py:131-134)
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+          T g_, h_;
+          node_pen_d(k, i, xk[i], xlb[i], xub[i], g_, h_);
+          Vx[i] += g_; lam[i] += g_;
+          if (lane == i) vcol[i] += h_;
+        }
       }
       if (lane == 0) {
 #pragma unroll
@@ -1326,6 +1374,7 @@ template <class M, typename T, bool EXACT, bool BND = false> struct OcWide : OcS
       const T t = this->tk(k);
       for (int s = 0; s < S; ++s) this->template rk4_step<false>(t, x, q, u, x, dummy, u);
       Ja += q;
+      if (BND) Ja += this->node_pen(k + 1, x);          // state bounds on node k+1 (augmented-Lagrangian term)
     }
     if (lane < NAL) {
 #pragma unroll
@@ -1386,6 +1435,10 @@ template <class M, typename T, bool EXACT, bool BND = false> struct OcWide : OcS
 #pragma unroll
     for (int i = 0; i < NX; ++i) xN[i] = xbp(cur)[N * NX + i];
     M::final_grad(this->tk(N), xN, e, c, lam);
+    if (BND && this->xm != nullptr) {
+#pragma unroll
+      for (int i = 0; i < NX; ++i) { T g_, h_; this->node_pen_d(N, i, xN[i], this->xlb[i], this->xub[i], g_, h_); lam[i] += g_; }
+    }
     if (lane == 0) {
 #pragma unroll
       for (int i = 0; i < NX; ++i) lam_out[N * NX + i] = lam[i];
@@ -1398,6 +1451,13 @@ template <class M, typename T, bool EXACT, bool BND = false> struct OcWide : OcS
         gl = Mk[NX * Lay::NXUP];
 #pragma unroll
         for (int i = 0; i < NX; ++i) gl += Mk[i * Lay::NXUP] * lam[i];
+        if (BND && this->xm != nullptr && k > 0 && lane < NX) {      // + the state-bound term of node k
+          T xi = T(0), lbi = T(0), ubi = T(0), g_, h_;
+#pragma unroll
+          for (int i = 0; i < NX; ++i) { if (lane == i) { xi = xbp(cur)[k * NX + i]; lbi = this->xlb[i]; ubi = this->xub[i]; } }
+          this->node_pen_d(k, lane, xi, lbi, ubi, g_, h_);
+          gl += g_;
+        }
         if (lane < NX) { ldsLam[lane] = gl; lam_out[k * NX + lane] = gl; }
         else gl_max = t_max(gl_max, t_abs(gl));
       }
@@ -1882,6 +1942,12 @@ __global__ void __launch_bounds__(64, 1) oc_solve_wide_kernel(OcArgs<T> a) {
   if constexpr (BND) {
 #pragma unroll
     for (int b = 0; b < NU; ++b) { s.ulb[b] = a.u_lb[b]; s.uub[b] = a.u_ub[b]; }
+    if (a.x_lb != nullptr) {
+#pragma unroll
+      for (int i = 0; i < NX; ++i) { s.xlb[i] = a.x_lb[i]; s.xub[i] = a.x_ub[i]; }
+      s.xm = a.x_mult + traj * (long long)N * 2 * NX;
+      s.xrho = a.x_rho;
+    }
   }
   // initial guess into buffer 1 (the reference's w0: zero, or the midpoint of finite control bounds, CPDP.py:153), rolled out
   // without gains into buffer 0, linearised

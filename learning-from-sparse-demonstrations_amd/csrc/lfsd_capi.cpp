@@ -70,6 +70,7 @@ template <typename T>
 static int coc_solve_t(int batch, int n_grid, int steps_per_grid, const void* ini_state, const void* horizon,
                        const void* auxvar, const void* consts, int const_per_traj, const void* u_init,
                        const void* control_lb, const void* control_ub,
+                       const void* state_lb, const void* state_ub, const void* state_mult, double state_rho,
                        void* state_grid, void* control_grid, void* costate_grid, void* cost, int* iters, int* status,
                        int max_iter, double tol, int exact_after, int mapping, void* workspace, size_t workspace_bytes,
                        void* stream) {
@@ -80,6 +81,7 @@ static int coc_solve_t(int batch, int n_grid, int steps_per_grid, const void* in
   a.const_stride = (consts && const_per_traj) ? Model::NC : 0;
   a.u_init = (const T*)u_init;
   a.u_lb = (const T*)control_lb; a.u_ub = (const T*)control_ub;
+  a.x_lb = (const T*)state_lb; a.x_ub = (const T*)state_ub; a.x_mult = (const T*)state_mult; a.x_rho = (T)state_rho;
   a.state_grid = (T*)state_grid; a.control_grid = (T*)control_grid; a.costate_grid = (T*)costate_grid;
   a.cost = (T*)cost; a.iters = iters; a.status = status;
   a.ws = (T*)workspace; a.ws_stride = lfsd::OcLayout<Model>::template ws_elems<G>(n_grid);
@@ -122,8 +124,9 @@ static int coc_solve_t(int batch, int n_grid, int steps_per_grid, const void* in
 
 LFSD_API int lfsd_coc_solve(int dtype, int batch, int n_grid, int steps_per_grid, const void* ini_state,
                               const void* horizon, const void* auxvar, const void* consts, int const_per_traj,
-                              const void* u_init, const void* control_lb, const void* control_ub, void* state_grid,
-                              void* control_grid, void* costate_grid, void* cost,
+                              const void* u_init, const void* control_lb, const void* control_ub,
+                              const void* state_lb, const void* state_ub, const void* state_mult, double state_rho,
+                              void* state_grid, void* control_grid, void* costate_grid, void* cost,
                               int* iters, int* status, int max_iter, double tol, int exact_after, int mapping,
                               void* workspace, size_t workspace_bytes, void* stream) {
   if (batch <= 0 || n_grid <= 0 || steps_per_grid <= 0 || max_iter < 0 || !(tol >= 0)) return LFSD_EINVAL;
@@ -134,14 +137,19 @@ LFSD_API int lfsd_coc_solve(int dtype, int batch, int n_grid, int steps_per_grid
     return LFSD_EINVAL;
   if (Model::NC_REAL > 0 && !consts) return LFSD_EINVAL;
   if ((control_lb == nullptr) != (control_ub == nullptr)) return LFSD_EINVAL;
+  // state bounds: all three arrays or none, a positive penalty, and the control-bound arrays beside them (the bounded
+  // kernel reads both boxes; entries of +-1e20 mean "no bound")
+  if (state_lb || state_ub || state_mult) {
+    if (!state_lb || !state_ub || !state_mult || !control_lb || !(state_rho > 0)) return LFSD_EINVAL;
+  }
   if (dtype == LFSD_F32)
     return coc_solve_t<float>(batch, n_grid, steps_per_grid, ini_state, horizon, auxvar, consts, const_per_traj, u_init,
-                              control_lb, control_ub, state_grid, control_grid, costate_grid, cost, iters, status, max_iter, tol, exact_after,
-                              mapping, workspace, workspace_bytes, stream);
+                              control_lb, control_ub, state_lb, state_ub, state_mult, state_rho, state_grid, control_grid, costate_grid,
+                              cost, iters, status, max_iter, tol, exact_after, mapping, workspace, workspace_bytes, stream);
   if (dtype == LFSD_F64)
     return coc_solve_t<double>(batch, n_grid, steps_per_grid, ini_state, horizon, auxvar, consts, const_per_traj,
-                               u_init, control_lb, control_ub, state_grid, control_grid, costate_grid, cost, iters, status, max_iter, tol,
-                               exact_after, mapping, workspace, workspace_bytes, stream);
+                               u_init, control_lb, control_ub, state_lb, state_ub, state_mult, state_rho, state_grid, control_grid,
+                               costate_grid, cost, iters, status, max_iter, tol, exact_after, mapping, workspace, workspace_bytes, stream);
   return LFSD_EINVAL;
 }
 

@@ -165,8 +165,8 @@ class ModelLibrary:
         L.lfsd_const_default.restype = cd
         L.lfsd_coc_workspace_bytes.argtypes = [ci, ci, ci, ci, ci, ci]
         L.lfsd_coc_workspace_bytes.restype = ctypes.c_size_t
-        L.lfsd_coc_solve.argtypes = [ci, ci, ci, ci, vp, vp, vp, vp, ci, vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, cd, ci, ci, vp,
-                                     ctypes.c_size_t, vp]
+        L.lfsd_coc_solve.argtypes = [ci, ci, ci, ci, vp, vp, vp, vp, ci, vp, vp, vp, vp, vp, vp, cd, vp, vp, vp, vp, vp, vp, ci, cd, ci,
+                                     ci, vp, ctypes.c_size_t, vp]
         L.lfsd_aux_solve.argtypes = [ci, ci, ci, vp, vp, vp, ci, vp, vp, vp, vp, ci, ci, vp, vp, vp, vp, vp, vp, vp,
                                      ci, cd, vp, vp]
         L.lfsd_aux_riccati.argtypes = [ci, ci, ci, vp, vp, vp, ci, vp, vp, vp, vp, ci, cd, vp, vp]
@@ -176,7 +176,7 @@ class ModelLibrary:
         L.lfsd_lookahead.argtypes = [ci, ctypes.c_longlong, cd, vp, vp, vp, vp]
         info = _ModelInfo()
         rc = L.lfsd_get_model_info(ctypes.byref(info))
-        if rc != 0 or info.abi_version != 6:
+        if rc != 0 or info.abi_version != 7:
             raise LfsdError("ABI mismatch in %s" % path)
         self.n_state, self.n_control, self.n_auxvar, self.n_const = (info.n_state, info.n_control, info.n_auxvar,
                                                                       info.n_const)
@@ -233,7 +233,10 @@ class ModelLibrary:
                                                       1 if bounded else 0))
 
     def coc_solve(self, ini_state, horizon, auxvar, consts, n_grid, steps_per_grid=4, u_init=None, max_iter=100,
-                  tol=None, workspace=None, out=None, exact_after=16, control_lb=None, control_ub=None, mapping="auto"):
+                  tol=None, workspace=None, out=None, exact_after=16, control_lb=None, control_ub=None, mapping="auto",
+                  state_lb=None, state_ub=None, state_mult=None, state_rho=0.0):
+        """state_lb / state_ub [n], state_mult [B][n_grid][2][n], state_rho: ONE augmented-Lagrangian subproblem of the
+        state-bounded NLP (include/lfsd_cpdp.h); the multiplier loop is COCSys.cocSolverBatch."""
         dt = ini_state.dtype
         B = ini_state.shape[0]
         n, m, p, nc = self.n_state, self.n_control, self.n_auxvar, self.n_const
@@ -256,6 +259,12 @@ class ModelLibrary:
         self._check(control_ub, (m,), dt, "control_ub", optional=True)
         if (control_lb is None) != (control_ub is None):
             raise LfsdError("control_lb and control_ub go together")
+        if state_lb is not None:
+            self._check(state_lb, (n,), dt, "state_lb")
+            self._check(state_ub, (n,), dt, "state_ub")
+            self._check(state_mult, (B, n_grid, 2, n), dt, "state_mult")
+            if control_lb is None:
+                raise LfsdError("state bounds need the control-bound arrays beside them (+-1e20 where there is none)")
         dev = ini_state.device
         if out is None:
             out = dict(state_grid=torch.empty((B, n_grid + 1, n), dtype=dt, device=dev),
@@ -271,6 +280,7 @@ class ModelLibrary:
             tol = 1e-6 if dt == torch.float32 else 1e-9
         args = (_DT[dt], B, n_grid, steps_per_grid, self._p(ini_state), self._p(horizon), self._p(auxvar),
                 self._p(consts), per_traj, self._p(u_init), self._p(control_lb), self._p(control_ub),
+                self._p(state_lb), self._p(state_ub), self._p(state_mult), float(state_rho),
                 self._p(out["state_grid"]), self._p(out["control_grid"]),
                 self._p(out["costate_grid"]), self._p(out["cost"]), self._p(out["iters"]), self._p(out["status"]),
                 int(max_iter), float(tol), int(exact_after), MAPPINGS[mapping], self._p(workspace),

@@ -387,6 +387,67 @@ class COCSys:
         self.last_cost = float(J)
         return tg, np.asarray(X), np.vstack([U, U[-1:]]), lam, float(J)
 
+    def cocSolverStateBounded(self, ini_state, horizon, auxvar_value, state_lb, state_ub, control_lb=None, control_ub=None,
+                              U_init=None, tol=1e-12):
+        """The NLP of CPDP.py:110-175 with finite STATE bounds on the shooting nodes X_1..X_N (lbw / ubw of the X_k,
+        CPDP.py:140-147; X_0 is pinned to ini_state) -- and optionally control bounds -- solved in single-shooting form by
+        scipy's SLSQP: objective and node states from the plain RK4 roll-out, all derivatives by complex steps.  No code
+        shared with the HIP solver's augmented-Lagrangian loop or with this oracle's own DDP.
+        Returns (time_grid, state_grid, control_grid [N+1, last row repeated], J)."""
+        from scipy.optimize import minimize
+        self.diffPMP()
+        n, m, N = self.n_state, self.n_control, self.n_grid
+        e = np.asarray(auxvar_value, dtype=float).ravel()
+        x0 = np.asarray(ini_state, dtype=float).ravel()
+        xlb, xub = np.asarray(state_lb, dtype=float), np.asarray(state_ub, dtype=float)
+        idx_l = [i for i in range(n) if abs(xlb[i]) < 1e19]
+        idx_u = [i for i in range(n) if abs(xub[i]) < 1e19]
+        tg = np.linspace(0, horizon, N + 1)
+
+        def roll(u):
+            J, X = self.rollout_cost(x0, horizon, e, u.reshape(N, m))
+            return J, np.asarray(X)
+
+        def cons_of(X):
+            X = np.asarray(X)[1:]
+            return np.concatenate([(X[:, idx_l] - xlb[idx_l]).ravel(), (xub[idx_u] - X[:, idx_u]).ravel()])
+
+        def fun(u):
+            return float(roll(u)[0])
+
+        def both_jac(u):
+            g = np.zeros(N * m)
+            nc = N * (len(idx_l) + len(idx_u))
+            Jc = np.zeros((nc, N * m))
+            for i in range(N * m):
+                uc = u.astype(complex)
+                uc[i] += 1e-30j
+                J, X = roll(uc)
+                g[i] = J.imag / 1e-30
+                Jc[:, i] = cons_of(X).imag / 1e-30
+            return g, Jc
+        cache = {}
+
+        def cached(u):
+            key = u.tobytes()
+            if key not in cache:
+                cache.clear()
+                cache[key] = both_jac(u)
+            return cache[key]
+        bounds = None
+        if control_lb is not None:
+            bounds = list(zip(np.tile(np.asarray(control_lb, dtype=float), N), np.tile(np.asarray(control_ub, dtype=float), N)))
+        u0 = np.zeros(N * m) if U_init is None else np.asarray(U_init, dtype=float).ravel()
+        r = minimize(fun, u0, jac=lambda u: cached(u)[0], method="SLSQP", bounds=bounds,
+                     constraints=[dict(type="ineq", fun=lambda u: cons_of(roll(u)[1]).real, jac=lambda u: cached(u)[1])],
+                     options=dict(maxiter=2000, ftol=tol))
+        if not r.success:
+            raise RuntimeError("SLSQP: %s" % r.message)
+        U = r.x.reshape(N, m)
+        J, X = roll(r.x)
+        self.last_cost = float(J)
+        return tg, np.asarray(X), np.vstack([U, U[-1:]]), float(J)
+
     def kkt_certificate(self, ini_state, horizon, e, state_grid, control_grid, costate_grid, h=1e-30):
         """Solver-independent check that (X,U,lambda) is the KKT point of the NLP at CPDP.py:126-179.
 

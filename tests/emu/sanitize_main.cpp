@@ -22,7 +22,7 @@ int main() {
     std::vector<int> it(B), st(B), iface = {0}, stats(4 * B);
     size_t wsb = lfsd_coc_workspace_bytes(dtype, B, N, 3, mapping, 0);
     std::vector<char> ws(wsb);
-    int rc = lfsd_coc_solve(dtype, B, N, 4, x0.data(), hz.data(), th.data(), nc ? cs.data() : nullptr, 0, nullptr, nullptr, nullptr, X.data(), U.data(), L.data(),
+    int rc = lfsd_coc_solve(dtype, B, N, 4, x0.data(), hz.data(), th.data(), nc ? cs.data() : nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0.0, X.data(), U.data(), L.data(),
                             cost.data(), it.data(), st.data(), 40, dtype ? 1e-9 : 1e-6, 3, mapping, ws.data(), wsb, nullptr);
     printf("dtype %d coc rc %d status %d iters %d\n", dtype, rc, st[0], it[0]);
     rc = lfsd_aux_solve(dtype, B, N, hz.data(), th.data(), nc ? cs.data() : nullptr, 0, X.data(), U.data(), L.data(), Z.data(), nw, ni, iface.data(),

@@ -36,9 +36,11 @@ def test_hip_library_exports_all_symbols(name):
     assert ml.hash == spec.hash() and ml.lanes == runtime.lanes_for(spec.n, spec.m, spec.p)
     assert ml.time_varying == spec.time_varying
     # argument validation happens before any launch
-    assert lib.lfsd_coc_solve(0, 0, 10, 4, None, None, None, None, 0, None, None, None, None, None, None, None, None, None,
+    assert lib.lfsd_coc_solve(0, 0, 10, 4, None, None, None, None, 0, None, None, None, None, None, None, ctypes.c_double(0.0),
+                              None, None, None, None, None, None,
                               10, ctypes.c_double(1e-6), 10, 0, None, ctypes.c_size_t(0), None) == -1
-    assert lib.lfsd_coc_solve(7, 1, 10, 4, None, None, None, None, 0, None, None, None, None, None, None, None, None, None,
+    assert lib.lfsd_coc_solve(7, 1, 10, 4, None, None, None, None, 0, None, None, None, None, None, None, ctypes.c_double(0.0),
+                              None, None, None, None, None, None,
                               10, ctypes.c_double(1e-6), 10, 0, None, ctypes.c_size_t(0), None) == -1
     lib.lfsd_coc_workspace_bytes.restype = ctypes.c_size_t
     assert lib.lfsd_coc_workspace_bytes(0, 4096, 50, 16, 0, 0) > 0

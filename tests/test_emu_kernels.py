@@ -247,8 +247,10 @@ def test_error_behaviour_matches_reference(emu):
     x, u = SX.sym('x'), SX.sym('u')
     with pytest.raises(AssertionError, match="Define the state variable first!"):
         oc.model_spec()
-    with pytest.raises(NotImplementedError):
-        oc.setStateVariable(x, state_lb=[-1.0], state_ub=[1.0])                                  # state bounds: not supported
+    oc.setStateVariable(x, state_lb=[-1.0], state_ub=[1.0])                                      # state bounds: supported (round 3)
+    assert oc.state_lb == [-1.0] and oc.state_ub == [1.0]
+    with pytest.raises(ValueError):
+        oc.setStateVariable(x, state_lb=[1.0], state_ub=[-1.0])
     oc.setControlVariable(u, control_lb=[-1.0], control_ub=[1.0])                                 # control bounds: supported
     assert oc.control_lb == [-1.0] and oc.control_ub == [1.0]
     with pytest.raises(ValueError):
@@ -549,9 +551,18 @@ def test_configs0_pendulum_horizon50_single_seed(emu):
     pc.configs0_pendulum(prepare)
 
 
-def test_state_bounds_are_refused():
+def test_state_bounds_vs_independent_bounded_solve(emu):
+    """Finite state_lb / state_ub (CPDP.py:20-31, 140-147): augmented-Lagrangian loop around the (emulated) kernels vs the
+    oracle's SLSQP solve of the same bounded NLP (tests/parity_cases.state_bounds)."""
+    import parity_cases as pc
+
+    def prepare(oc, dtype):
+        emu(oc)
+        oc.setDevice(dtype=dtype)
+        return oc
+    pc.state_bounds(prepare, torch.float64)
     oc, env, d = models.pendulum(n_grid=10)
-    with pytest.raises(NotImplementedError):
-        oc.setStateVariable(env.X, [-1.0, -5.0], [1.0, 5.0])
-    oc.setStateVariable(env.X, [-1e20, -1e20], [1e20, 1e20])          # the reference's defaults are fine
-    oc.setStateVariable(env.X, [-1.0], [1.0])                          # wrong length: ignored, as in the reference (CPDP.py:23-31)
+    oc.setStateVariable(env.X, [-1e20, -1e20], [1e20, 1e20])          # the reference's defaults: no bounded path
+    assert oc._lib is None and oc.state_lb == [-1e20, -1e20]
+    with pytest.raises(ValueError):
+        oc.setStateVariable(env.X, [1.0, 0.0], [0.0, 1.0])
