@@ -1679,7 +1679,10 @@ __global__ void __launch_bounds__(64, LFSD_WAVES_OC) oc_solve_kernel(OcArgs<T> a
   // discretisation (`relin`, an iteration without a backward sweep) and the solve continues there: every convergence
   // test, every returned number belongs to the NLP of CPDP.py:110-175 with steps_per_grid sub-steps; the coarse phase only
   // changes the path to its KKT point, as the choice of DDP over IPOPT does.
-  constexpr bool CS = PK && !EXACT && (LFSD_COARSE_START != 0);
+  // (also the fp64 lean kernel of the same 32-lane models -- the reference-precision path of the benchmark; smaller models
+  //  keep the reference's grid throughout: their parity cases include problems with several local minima, cart-pole swing-up,
+  //  where another path may end in another KKT point than the oracle's)
+  constexpr bool CS = !EXACT && (PK || (G == 32 && sizeof(T) == 8)) && (LFSD_COARSE_START != 0);
   bool coarse = CS && a.steps_per_grid > 1 && !a.resume && a.max_iter > 4;
   bool relin = false;       // leave the coarse grid at the next iteration ...
   bool relin_hard = LFSD_COARSE_RELIN != 0;      // ... by a roll-out + linearisation of the nominal without a step (else: with the step)
