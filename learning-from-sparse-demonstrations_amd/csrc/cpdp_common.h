@@ -158,6 +158,10 @@
 #ifndef LFSD_COARSE_SWITCH
 #define LFSD_COARSE_SWITCH 1e-3
 #endif
+// wide kernel (one trajectory per wavefront): smallest n_grid with a coarse phase
+#ifndef LFSD_COARSE_MIN_GRID
+#define LFSD_COARSE_MIN_GRID 40
+#endif
 // leaving the coarse grid: 1 = always by a roll-out + linearisation of the nominal without a step, 0 = with the next full step
 #ifndef LFSD_COARSE_RELIN
 #define LFSD_COARSE_RELIN 0

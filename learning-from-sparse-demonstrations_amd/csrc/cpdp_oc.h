@@ -1683,7 +1683,7 @@ __global__ void __launch_bounds__(64, LFSD_WAVES_OC) oc_solve_kernel(OcArgs<T> a
   //  keep the reference's grid throughout: their parity cases include problems with several local minima, cart-pole swing-up,
   //  where another path may end in another KKT point than the oracle's)
   constexpr bool CS = !EXACT && (PK || (G == 32 && sizeof(T) == 8)) && (LFSD_COARSE_START != 0);
-  bool coarse = CS && a.steps_per_grid > 1 && !a.resume && a.max_iter > 4;
+  bool coarse = CS && a.steps_per_grid > 1 && !a.resume && a.max_iter > 4 && a.u_init == nullptr;      // (a caller's initial guess starts next to its answer)
   bool relin = false;       // leave the coarse grid at the next iteration ...
   bool relin_hard = LFSD_COARSE_RELIN != 0;      // ... by a roll-out + linearisation of the nominal without a step (else: with the step)
   if (coarse) { s.S = 1; s.DT = s.dgrid; }
@@ -1966,10 +1966,32 @@ __global__ void __launch_bounds__(64, 1) oc_solve_wide_kernel(OcArgs<T> a) {
   __syncthreads();
   int cur = 0;
   T alpha_l = T(0);
+  // Mesh continuation (see oc_solve_kernel): the 32-lane models only (quadrotor, rocket -- the rocket's cold start needs
+  // ~40-100 regularised Newton iterations of 2-5 % gain each before its last five quadratic ones, profiles/
+  // r03_f_rocket_trace_head.txt, and every one of them pays a second-order adjoint sweep through S x 4 RK4 stages per
+  // interval); never with an initial guess from the caller or with bounds (warm-started subproblems start next to their
+  // answer).  Smaller models keep the reference's grid: their parity cases follow the oracle's path into one of several minima.
+  constexpr bool CSW = !BND && (LFSD_COARSE_START != 0) && (NX + (NU > NP ? NU : NP) > 16);
+  // ... and only where the coarse grid still has as many RK4 steps as the reference's example grids have in all (n_grid
+  // 10-15 x 4): at n_grid 15 the rocket's coarse path ends in ANOTHER stationary point than the fine one (one with a
+  // conjugate point inside the horizon, where the Riccati sweep of the auxiliary pass has a finite escape; emulator tier,
+  // test_rocket_newton_mode_vs_oracle) -- a step of 0.2 s is too long for its attitude dynamics under aggressive controls.
+  bool coarse = CSW && a.steps_per_grid > 1 && a.u_init == nullptr && a.max_iter > 8 && a.n_grid >= LFSD_COARSE_MIN_GRID;
+  bool relin = false;
+  if (coarse) { s.S = 1; s.DT = s.dgrid; }
   T J = s.rollout_alphas(1, false, alpha_l);             // (every lane rolls the same controls out; lane 0's copy is adopted)
   ldsRed[s.lane] = J;
   __syncthreads();
   J = ldsRed[0];
+  __syncthreads();
+  if (coarse && !t_finite(J)) {                          // the coarse grid cannot even integrate the initial guess: reference grid
+    coarse = false; s.S = a.steps_per_grid; s.DT = s.dgrid / T(s.S);
+    J = s.rollout_alphas(1, false, alpha_l);
+    ldsRed[s.lane] = J;
+    __syncthreads();
+    J = ldsRed[0];
+    __syncthreads();
+  }
   s.adopt_alpha(0, 0);
   s.linearise_parallel(0);
   T mu = T(0);
@@ -1980,6 +2002,24 @@ __global__ void __launch_bounds__(64, 1) oc_solve_wide_kernel(OcArgs<T> a) {
   int n_acc = 0, mu_hold = 0;
   const int mu_hold_need = LFSD_MU_HOLD;
   for (; it < a.max_iter && status == ST_RUNNING; ++it) {
+    if (coarse && (relin || it + 4 >= a.max_iter)) {
+      // leave the coarse grid: the same controls rolled out (open loop) and linearised on the reference's discretisation; an
+      // iteration without a sweep.  Every convergence test below only ever passes on this grid.
+      coarse = false; relin = false;
+      s.S = a.steps_per_grid; s.DT = s.dgrid / T(s.S);
+      const T Jr = s.rollout_alphas(cur, false, alpha_l);
+      ldsRed[s.lane] = Jr;
+      __syncthreads();
+      J = ldsRed[0];
+      __syncthreads();
+      s.adopt_alpha(0, cur ^ 1);
+      s.linearise_parallel(cur ^ 1);
+      cur ^= 1;
+      hess_ok = false; costates_ok = false;
+      g_last = T(-1); dec_last = T(1e30); g_flat = T(-1); J_ref = J; n_acc = 0;
+      if (!t_finite(J)) { status = ST_FAILED; break; }
+      continue;
+    }
     if (EXACT && a.exact_after >= 0 && mode < 2 && (it >= a.exact_after || gn_crawl)) mode = 2;
     if (EXACT && mode == 2 && !hess_ok) {
       s.costate_sweep(cur);
@@ -2000,8 +2040,11 @@ __global__ void __launch_bounds__(64, 1) oc_solve_wide_kernel(OcArgs<T> a) {
       }
       continue;
     }
-    if (gnorm < a.tol * (T(1) + t_abs(J))) { status = ST_CONVERGED; break; }
-    if (at_working_precision(mode, mu, gnorm, g_last, dec_last, dV1, dV2, J, a.tol)) { status = ST_STALLED; ++it; break; }      // (this iteration's sweep counts)
+    if (gnorm < a.tol * (T(1) + t_abs(J))) { if (coarse) { relin = true; continue; } status = ST_CONVERGED; break; }
+    if (at_working_precision(mode, mu, gnorm, g_last, dec_last, dV1, dV2, J, a.tol)) {
+      if (coarse) { relin = true; continue; }
+      status = ST_STALLED; ++it; break;      // (this iteration's sweep counts)
+    }
     // all step lengths at once; the largest one that passes the Armijo test is taken
     const T Ja = s.rollout_alphas(cur, true, alpha_l);
     ldsRed[s.lane] = Ja;
@@ -2028,7 +2071,7 @@ __global__ void __launch_bounds__(64, 1) oc_solve_wide_kernel(OcArgs<T> a) {
       } else if (mu > T(1e10) || ((J - Jmin) <= T(8) * Eps<T>::v() * t_abs(J) && ((mode == 0 && !BND) || flat_full || mu > T(1e6)))) {
         // (with a box on the controls the clamped closed loop can fail every step length although the Gauss-Newton
         //  direction is a descent direction of the unclamped model: that is a reason to shorten the step, not to stop)
-        status = ST_STALLED;
+        if (coarse) relin = true; else status = ST_STALLED;
       } else {
         mu_bad = mu; mu_hold = 0;
         mu = t_max(mu * T(LFSD_MU_UP), mode == 2 ? T(1e-4) : T(1e-6));
@@ -2050,9 +2093,10 @@ __global__ void __launch_bounds__(64, 1) oc_solve_wide_kernel(OcArgs<T> a) {
         if (mode == 0 && ham_ok && (J - Jn) < T(LFSD_HAM_SWITCH) * t_abs(Jn)) mode = 1;
         else if (LFSD_GN_CRAWL && mode == 0 && !ham_ok && (J - Jn) < T(1e-2) * t_abs(Jn)) gn_crawl = true;
       }
+      if (coarse && (J - Jn) < T(LFSD_COARSE_SWITCH) * t_abs(Jn)) relin = true;      // past the big drops: the reference's grid
       J = Jn;
       if (++n_acc >= 4) {
-        if (J_ref - J <= T(16) * Eps<T>::v() * t_abs(J)) status = ST_STALLED;
+        if (J_ref - J <= T(16) * Eps<T>::v() * t_abs(J)) { if (coarse) relin = true; else status = ST_STALLED; }
         J_ref = J; n_acc = 0;
       }
     }

@@ -26,6 +26,7 @@ VARIANTS = {
     "nodual": (("-DLFSD_OC_DUAL=0",), None, False),
     "nostruct": (("-DLFSD_STRUCT_COLS=0",), None, False),
     "nocoarse": (("-DLFSD_COARSE_START=0",), None, False),
+    "nowidecoarse": (("-DLFSD_COARSE_MIN_GRID=100000",), None, False),
     "r02like": (("-DLFSD_COARSE_START=0", "-DLFSD_STRUCT_COLS=0"), None, False),
     "relinhard": (("-DLFSD_COARSE_RELIN=1",), None, False),
     "cs1e2": (("-DLFSD_COARSE_SWITCH=0.01",), None, False),
