@@ -1661,8 +1661,23 @@ __global__ void __launch_bounds__(64, LFSD_WAVES_OC) oc_solve_kernel(OcArgs<T> a
   };
 
   // initial guess into buffer 1, then "roll out" 1 -> 0 without gains
-  for (int i = s.lane; i < N * NU; i += GR)
-    s.ub[1][i] = a.resume ? a.control_grid[traj * (N + 1) * NU + i] : (a.u_init ? a.u_init[traj * N * NU + i] : T(0));
+  // (`warm`: the caller's initial guess of THIS trajectory is not all zero -- an all-zero row of u_init is the cold start, e.g.
+  //  the rows of a learner that only continues the solves that ran out of iterations)
+  bool warm = false;
+  {
+    T umax = T(0);
+    for (int i = s.lane; i < N * NU; i += GR) {
+      const T u0 = a.resume ? a.control_grid[traj * (N + 1) * NU + i] : (a.u_init ? a.u_init[traj * N * NU + i] : T(0));
+      s.ub[1][i] = u0;
+      umax = t_max(umax, t_abs(u0));
+    }
+    if (a.u_init != nullptr && !a.resume) {
+      T* ldsRed0 = s.lds + Lay::LDS_RED;
+      ldsRed0[s.lane] = umax;
+      __syncthreads();
+      for (int l = 0; l < GR; ++l) warm = warm || !(ldsRed0[l] == T(0));
+    }
+  }
   __syncthreads();
   int cur = 0;
 #if defined(LFSD_OC_CLOCK)
@@ -1683,7 +1698,7 @@ __global__ void __launch_bounds__(64, LFSD_WAVES_OC) oc_solve_kernel(OcArgs<T> a
   //  keep the reference's grid throughout: their parity cases include problems with several local minima, cart-pole swing-up,
   //  where another path may end in another KKT point than the oracle's)
   constexpr bool CS = !EXACT && (PK || (G == 32 && sizeof(T) == 8)) && (LFSD_COARSE_START != 0);
-  bool coarse = CS && a.steps_per_grid > 1 && !a.resume && a.max_iter > 4 && a.u_init == nullptr;      // (a caller's initial guess starts next to its answer)
+  bool coarse = CS && a.steps_per_grid > 1 && !a.resume && a.max_iter > 4 && !warm;      // (a caller's initial guess starts next to its answer)
   bool relin = false;       // leave the coarse grid at the next iteration ...
   bool relin_hard = LFSD_COARSE_RELIN != 0;      // ... by a roll-out + linearisation of the nominal without a step (else: with the step)
   if (coarse) { s.S = 1; s.DT = s.dgrid; }
