@@ -508,11 +508,15 @@ class SparseDemoLearner:
         return loss, grad
 
     def mask_unconverged(self, status, loss, grad):
-        """Rows whose OC solve neither converged (1) nor stalled at working precision (2), or whose loss / gradient is
+        """Rows whose OC solve neither converged (1) nor stalled at working precision (2), whose loss / gradient is
         not finite (parameters that have left the region where the problem is well posed, e.g. a cost weight driven
-        negative) are frozen for this step: ``self._ok`` masks them out of the update kernel; their gradient (and, in
+        negative), or whose sensitivity sweeps report an interval accepted above `aux_rtol` (the `stats` output of
+        lfsd_aux_solve: refinement stopped gaining next to a conjugate point) are frozen for this step: ``self._ok`` masks them out of the update kernel; their gradient (and, in
         shared mode, their loss, which enters a sum) is zeroed."""
         ok = ((status == 1) | (status == 2)) & torch.isfinite(loss) & torch.isfinite(grad).all(dim=1)
+        st = self._aux.get("stats") if self._aux is not None else None
+        if st is not None:      # ... or whose auxiliary sweeps accepted an interval above their tolerance (next to a conjugate point)
+            ok = ok & ((st[:, 1] + st[:, 3]) == 0)
         self._ok = ok
         grad = torch.where(ok.unsqueeze(1), grad, torch.zeros_like(grad))
         if self.mode == "shared":

@@ -497,14 +497,15 @@ def test_robotarm_12_vanilla_steps_every_gradient_applied():
         if k <= 1:
             assert adm.all(), k
         # ... and the exclusion is not a convenience of this test: the solves that do NOT converge are exactly those whose
-        # cost has run far below anything a well-posed seed reaches (admissible seeds end at J >= -40, asserted > -60; the diverged ones, asserted < -60,
-        # were measured at -230 ... -2200 after 300 iterations, profiles/r03_b_arm_j0.txt) or whose parameters have
+        # cost is running away below anything a well-posed seed reaches (admissible seeds end at J >= -40 from J_0 = +980,
+        # asserted > -50; the diverged ones, asserted < -50, were measured at -59 ... -1440 when the iteration limit of 120
+        # stops them and at -230 ... -2200 after 300 iterations, profiles/r03_b_arm_j0.txt) or whose parameters have
         # blown up: the reference's IPOPT would be iterating on an NLP without a minimiser as well
         J = L._sol["cost"].double().cpu().numpy()
         bad = ~np.isin(st, (1, 2))                     # every solve that did not converge (all of them excluded above) ...
         blown = ~np.isfinite(th).all(1) | (np.abs(th) >= 1e3).any(1)
-        assert (blown[bad] | ~np.isfinite(J[bad]) | (J[bad] < -60.0)).all(), (k, J[bad], st[bad])      # ... is a cost running away
-        assert J[adm].min() > -60.0, (k, J[adm].min())
+        assert (blown[bad] | ~np.isfinite(J[bad]) | (J[bad] < -50.0)).all(), (k, J[bad], st[bad])      # ... is a cost running away
+        assert J[adm].min() > -50.0, (k, J[adm].min())
 
 
 
