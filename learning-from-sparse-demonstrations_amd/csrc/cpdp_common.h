@@ -175,10 +175,26 @@
 
 // LFSD_SCHED_FENCE: stop the instruction scheduler from hoisting loads across this point (bounds live ranges in
 // the fully unrolled contractions); no-op in the emulator build
-#if defined(LFSD_EMU) || !defined(LFSD_USE_SCHED_FENCE)
+#ifndef LFSD_FENCE64
+#define LFSD_FENCE64 3
+#endif
+#if defined(LFSD_EMU)
 #define LFSD_SCHED_FENCE()
+#define LFSD_SCHED_FENCE64(T)
 #else
+#if defined(LFSD_USE_SCHED_FENCE)
 #define LFSD_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+#else
+#define LFSD_SCHED_FENCE()
+#endif
+// ... in the fp64 instantiations only (LFSD_FENCE64, default on).  The fp64 kernels have half the registers per value: with
+// the max-ILP scheduler free to hoist, the backward sweep issued every LDS read of a stage's dense products up front
+// (34 ds_read_b128 = 136 registers of operands in flight), spilled the rest of its state to scratch and waited on the
+// reloads -- 95 000 cycles per stage, 66 % of oc_solve<double> (tools/oc_clock64.py, profiles/r03_o_fp64_sched_fence.txt)
+#ifndef LFSD_FENCE64
+#define LFSD_FENCE64 3
+#endif
+#define LFSD_SCHED_FENCE64(T) do { if constexpr (((LFSD_FENCE64) & 2) != 0 && sizeof(T) == 8) __builtin_amdgcn_sched_barrier(0); } while (0)
 #endif
 
 // LFSD_WAVE_SYNC: LDS hand-over between lanes of ONE wavefront (kernels whose workgroup is a single wavefront: the
@@ -330,6 +346,13 @@ template <typename T> LFSD_DEV void pin(T&) {}
 #else
 template <typename T> LFSD_DEV void pin(T& x) { asm volatile("" : "+v"(x)); }
 #endif
+
+// pin64(x): pin() in the fp64 instantiations only.  There a dense product whose result is first used beyond a branch had
+// its FMAs sunk to that use by the compiler while its LDS reads stayed put (they cannot cross the barrier in between): all
+// 221 operands of Q = [A B]^T Y of the backward sweep were read, spilled to scratch and reloaded one by one -- 157 scratch
+// round trips per stage that miss the L2 (116 KB of scratch per wavefront), 95 000 cycles of a stage that computes for
+// about 5 000 (tools/oc_clock64.py, profiles/r03_o_fp64_backward.txt).  A pinned result keeps the FMAs with their reads.
+template <typename T> LFSD_DEV void pin64(T& x) { if constexpr (sizeof(T) == 8 && ((LFSD_FENCE64) & 1) != 0) pin(x); }
 
 template <typename T> struct Eps;
 template <> struct Eps<float> { static LFSD_DEV float v() { return 1.1920929e-07f; } };

@@ -154,7 +154,7 @@ template <class M, typename T, int G, bool EXACT, bool BND = false> struct OcSol
     }
 #pragma unroll
     for (int i = 0; i < NX; ++i) { ax[i] = f[i]; xs[i] = x[i] + hh * f[i]; if (SENS) { am[i] = d[i]; ms[i] = m[i] + hh * d[i]; } }
-    LFSD_SCHED_FENCE();
+    LFSD_SCHED_FENCE(); LFSD_SCHED_FENCE64(T);
     if (SENS) M::dyn_cost_jvp(t, xs, u, e, c, ms, du, f, cq, d, dq); else M::dyn_cost(t, xs, u, e, c, f, cq);
     aq += T(2) * cq; if (SENS) adq += T(2) * dq;
     if (NZ) {
@@ -164,7 +164,7 @@ template <class M, typename T, int G, bool EXACT, bool BND = false> struct OcSol
     }
 #pragma unroll
     for (int i = 0; i < NX; ++i) { ax[i] += T(2) * f[i]; xs[i] = x[i] + hh * f[i]; if (SENS) { am[i] += T(2) * d[i]; ms[i] = m[i] + hh * d[i]; } }
-    LFSD_SCHED_FENCE();
+    LFSD_SCHED_FENCE(); LFSD_SCHED_FENCE64(T);
     if (SENS) M::dyn_cost_jvp(t, xs, u, e, c, ms, du, f, cq, d, dq); else M::dyn_cost(t, xs, u, e, c, f, cq);
     aq += T(2) * cq; if (SENS) adq += T(2) * dq;
     if (NZ) {
@@ -174,7 +174,7 @@ template <class M, typename T, int G, bool EXACT, bool BND = false> struct OcSol
     }
 #pragma unroll
     for (int i = 0; i < NX; ++i) { ax[i] += T(2) * f[i]; xs[i] = x[i] + DT * f[i]; if (SENS) { am[i] += T(2) * d[i]; ms[i] = m[i] + DT * d[i]; } }
-    LFSD_SCHED_FENCE();
+    LFSD_SCHED_FENCE(); LFSD_SCHED_FENCE64(T);
     if (SENS) M::dyn_cost_jvp(t, xs, u, e, c, ms, du, f, cq, d, dq); else M::dyn_cost(t, xs, u, e, c, f, cq);
     aq += cq; if (SENS) adq += dq;
     const T h6 = DT / T(6);
@@ -448,16 +448,18 @@ template <class M, typename T, int G, bool EXACT, bool BND = false> struct OcSol
         T s = T(0);
 #pragma unroll
         for (int kk = 0; kk < NX; ++kk) s += ldsV[i * NX + kk] * m[kk];
+        pin64(s);
         Y[i] = s;
-        LFSD_SCHED_FENCE();
+        LFSD_SCHED_FENCE(); LFSD_SCHED_FENCE64(T);
       }
 #pragma unroll
       for (int r = 0; r < NXU; ++r) {
         T s = T(0);
 #pragma unroll
         for (int i = 0; i < NX; ++i) s += ldsM[r * NX + i] * Y[i];
+        pin64(s);
         Qcol[r] = s;
-        LFSD_SCHED_FENCE();
+        LFSD_SCHED_FENCE(); LFSD_SCHED_FENCE64(T);
       }
       if (EXACT && mode == 2) {
         // column `lane` of the exact stage Hessian depends on the nominal and its costates only, not on the shift: a

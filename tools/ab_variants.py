@@ -35,6 +35,9 @@ VARIANTS = {
     "cs1e4": (("-DLFSD_COARSE_SWITCH=0.0001",), None, False),
     "cs0": (("-DLFSD_COARSE_SWITCH=0.0",), None, False),
     "bwclock": (("-DLFSD_BW_CLOCK=1",), None, False),
+    "occlock": (("-DLFSD_OC_CLOCK=3",), None, False),
+    "nofence64": (("-DLFSD_FENCE64=0",), None, False),
+    "pin64only": (("-DLFSD_FENCE64=1",), None, False),
     "pflate": (("-DLFSD_BW_PREFETCH=2",), None, False),
     "pflateclock": (("-DLFSD_BW_PREFETCH=2", "-DLFSD_BW_CLOCK=1"), None, False),
 }
