@@ -338,7 +338,9 @@ def main(argv=None):
         # (perf_model.py), times the solver iterations the batch actually ran
         flops, mflops = perf_model.kernel_flops(oc.model_spec(), dom, args.n_grid, 4, max(1, args.substeps) if args.aux_rtol > 0 else (args.substeps or 4),
                                                 mean_iters=float(it.mean()), units_per_interval=units.get(dom), split=True,
-                                                midpoint=(args.dtype == "f32"), coarse_rollouts=(5 if args.dtype == "f32" else 0))
+                                                midpoint=(args.dtype == "f32"), coarse_rollouts=5)
+        if args.dtype == "f64":      # no matrix cores in the fp64 kernels: the dense products are vector FMAs there
+            flops, mflops = flops + mflops, 0.0
         useful_tflops = flops * B / (ktime[dom] * 1e-3) / 1e12
         executed = issue.get("valu_flops_executed_per_launch")
         out = {

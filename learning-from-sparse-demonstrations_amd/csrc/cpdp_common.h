@@ -175,6 +175,14 @@
 
 // LFSD_SCHED_FENCE: stop the instruction scheduler from hoisting loads across this point (bounds live ranges in
 // the fully unrolled contractions); no-op in the emulator build
+// fp64 lean OC kernel of the 32-lane models on 16-lane groups (four trajectories per wavefront); 0: 32-lane groups (round 2)
+#ifndef LFSD_FP64_LIVE
+#define LFSD_FP64_LIVE 1
+#endif
+// ... with the between-stage values of its tangent RK4 step parked in LDS (OcSolver::rk4_step_parked)
+#ifndef LFSD_FP64_PARK
+#define LFSD_FP64_PARK 1
+#endif
 #ifndef LFSD_FENCE64
 #define LFSD_FENCE64 3
 #endif

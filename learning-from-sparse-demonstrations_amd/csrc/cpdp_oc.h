@@ -131,6 +131,7 @@ template <class M, typename T, int G, bool EXACT, bool BND = false> struct OcSol
   LFSD_DEV T* xbp(int i) const { return i ? xb[1] : xb[0]; }
   LFSD_DEV T* ubp(int i) const { return i ? ub[1] : ub[0]; }
   LFSD_DEV T* Mwp(int i) const { return i ? Mws[1] : Mws[0]; }
+  T *pkx = nullptr, *pkm = nullptr;      // rk4_step_parked: LDS homes of (x, sum of k) of the group and of this lane's (m, sum of dk)
   bool reuse_hess = false;   // exact stage Hessians in Hws belong to the nominal being swept (a retry with another shift)
   T* lam_out;   // costate grid of this trajectory (or scratch when invalid)
 
@@ -186,6 +187,69 @@ template <class M, typename T, int G, bool EXACT, bool BND = false> struct OcSol
 #pragma unroll
     for (int i = 0; i < NX; ++i) { x[i] += h6 * (ax[i] + f[i]); if (SENS) m[i] += h6 * (am[i] + d[i]); }
     q += h6 * aq; if (SENS) mq += h6 * adq;
+  }
+
+  // The tangent step of the fp64 live-column roll-out (rollout_sens_live).  Same arithmetic as rk4_step<true, T, NZ>, but the
+  // values that are only needed BETWEEN the stages -- x_n and the running sum of the k_i (group-uniform: one LDS copy per
+  // group, written by its lane 0), this lane's m_n and its running sum -- live in LDS while a stage is evaluated: 52 doubles
+  // = 104 registers of a kernel that runs at 256 + 256 and spilled its roll-out loop to scratch (56 reloads per step that
+  // miss the L2: 4 wavefronts x 39 KB per CU).  pkm is indexed [i * 64] (one word per lane: conflict-free).
+  template <int NZ>
+  LFSD_DEV void rk4_step_parked(T t, T* x, T& q, const T* u, T* m, T& mq, const T* du, T* qz) const {
+    T xs[NX], f[NX], ms[NX], d[NX], cq, aq, dq, adq;
+    T cz[NZ ? NZ : 1], az[NZ ? NZ : 1];
+    const T hh = DT * T(0.5);
+    const bool l0 = lane == 0;
+    M::dyn_cost_jvp(t, x, u, e, c, m, du, f, cq, d, dq);
+    aq = cq; adq = dq;
+    if (NZ) {
+      M::cost_grad_zc(t, x, u, e, c, cz);
+#pragma unroll
+      for (int i = 0; i < NZ; ++i) az[i] = cz[i];
+    }
+    LFSD_WAVE_SYNC();                    // (the previous step's readers of pkx are done)
+    if (l0) {
+#pragma unroll
+      for (int i = 0; i < NX; ++i) { pkx[i] = x[i]; pkx[NX + i] = f[i]; }
+    }
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+      pkm[i * 64] = m[i]; pkm[(NX + i) * 64] = d[i];
+      xs[i] = x[i] + hh * f[i]; ms[i] = m[i] + hh * d[i];
+    }
+    LFSD_WAVE_SYNC();
+#pragma unroll
+    for (int stage = 1; stage < 3; ++stage) {
+      const T hs = (stage == 1) ? hh : DT;
+      M::dyn_cost_jvp(t, xs, u, e, c, ms, du, f, cq, d, dq);
+      aq += T(2) * cq; adq += T(2) * dq;
+      if (NZ) {
+        M::cost_grad_zc(t, xs, u, e, c, cz);
+#pragma unroll
+        for (int i = 0; i < NZ; ++i) az[i] += T(2) * cz[i];
+      }
+      if (l0) {
+#pragma unroll
+        for (int i = 0; i < NX; ++i) pkx[NX + i] += T(2) * f[i];
+      }
+#pragma unroll
+      for (int i = 0; i < NX; ++i) {
+        pkm[(NX + i) * 64] += T(2) * d[i];
+        xs[i] = pkx[i] + hs * f[i]; ms[i] = pkm[i * 64] + hs * d[i];
+      }
+      LFSD_WAVE_SYNC();
+    }
+    M::dyn_cost_jvp(t, xs, u, e, c, ms, du, f, cq, d, dq);
+    aq += cq; adq += dq;
+    const T h6 = DT / T(6);
+    if (NZ) {
+      M::cost_grad_zc(t, xs, u, e, c, cz);
+#pragma unroll
+      for (int i = 0; i < NZ; ++i) qz[i] += h6 * (az[i] + cz[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < NX; ++i) { x[i] = pkx[i] + h6 * (pkx[NX + i] + f[i]); m[i] = pkm[i * 64] + h6 * (pkm[(NX + i) * 64] + d[i]); }
+    q += h6 * aq; mq += h6 * adq;
   }
 
   // closed-loop control  u = ubar + alpha*kff + K (x - xbar)   (all operands group-uniform loads)
@@ -279,6 +343,64 @@ template <class M, typename T, int G, bool EXACT, bool BND = false> struct OcSol
 #pragma unroll
         for (int i = 0; i < NX; ++i) Mk[i * (Lay::NXUP / 2)] = m[i];
         Mk[NX * (Lay::NXUP / 2)] = mq;
+      }
+    }
+    if (lane == 0) {
+#pragma unroll
+      for (int i = 0; i < NX; ++i) xbp(nxt)[N * NX + i] = x[i];
+    }
+    J += M::final_cost(tk(N), x, e, c);
+    return J;
+  }
+
+  // The same sweep of the fp64 lean kernel (round 3): ONE column per lane on 16-lane groups, four trajectories per wavefront
+  // like the packed fp32 roll-out (fp64 has no packed math; two columns per lane would double the tangent registers of a
+  // kernel that already runs at 256 + 256).  Only the LIVE = NXU - ZC columns the dynamics act on are propagated -- lane l
+  // carries column ZC + l; the quadrotor's 14 and the rocket's 13 fit the 16 lanes -- and the structurally constant ones
+  // (unit vectors through every RK4 stage, see rollout_sens_sc) are written as such, with the quadrature of dc/dx_z along the
+  // stages (rk4_step's NZ) as their cost-row entry.  The stored [A B; q] has the layout of rollout_sens: the backward sweep
+  // keeps its 32-lane mapping (two passes per wavefront through the mailbox, as for the packed kernel without MFMA).
+  LFSD_DEV T rollout_sens_live(int cur, int nxt, T alpha, bool gains) {
+    constexpr int ZC_ = Lay::ZC, LIVE_ = Lay::LIVE;
+    static_assert(LIVE_ <= G || G != 16, "live columns: one per lane of the group");
+    T x[NX], u[NU], J = T(0);
+#pragma unroll
+    for (int i = 0; i < NX; ++i) x[i] = x0[i];
+    const int col = ZC_ + lane;          // lanes >= LIVE: col >= NXU, a zero tangent that is never stored
+    for (int k = 0; k < N; ++k) {
+      control(cur, k, x, alpha, gains, u);
+      if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < NX; ++i) xbp(nxt)[k * NX + i] = x[i];
+#pragma unroll
+        for (int a = 0; a < NU; ++a) ubp(nxt)[k * NU + a] = u[a];
+      }
+      T m[NX], du[NU], mq = T(0), q = T(0), qz[ZC_ ? ZC_ : 1];
+#pragma unroll
+      for (int i = 0; i < (ZC_ ? ZC_ : 1); ++i) qz[i] = T(0);
+#pragma unroll
+      for (int i = 0; i < NX; ++i) m[i] = (col == i) ? T(1) : T(0);
+#pragma unroll
+      for (int a = 0; a < NU; ++a) du[a] = (col == NX + a) ? T(1) : T(0);
+      const T t = tk(k);
+      for (int s = 0; s < S; ++s) {
+        if (LFSD_FP64_PARK) rk4_step_parked<ZC_>(t, x, q, u, m, mq, du, qz);
+        else rk4_step<true, T, ZC_>(t, x, q, u, m, mq, du, qz);
+      }
+      J += q;
+      T* Mk = Mwp(nxt) + (long long)k * Lay::M_ELEMS;
+      if (lane < LIVE_) {
+#pragma unroll
+        for (int i = 0; i < NX; ++i) Mk[i * Lay::NXUP + col] = m[i];
+        Mk[NX * Lay::NXUP + col] = mq;
+      }
+      if constexpr (ZC_ > 0) {
+        if (lane < ZC_) {
+#pragma unroll
+          for (int i = 0; i < NX; ++i) Mk[i * Lay::NXUP + lane] = (i == lane) ? T(1) : T(0);
+#pragma unroll
+          for (int z = 0; z < ZC_; ++z) { if (lane == z) Mk[NX * Lay::NXUP + z] = qz[z]; }
+        }
       }
     }
     if (lane == 0) {
@@ -1569,9 +1691,12 @@ __global__ void __launch_bounds__(64, LFSD_WAVES_OC) oc_solve_kernel(OcArgs<T> a
   constexpr int RS = EXACT ? Lay::template lds_elems<G>() : ((Lay::template lds_ex<G>() + 3) / 4) * 4;
   constexpr int MB = 12;                          // mailbox floats per trajectory
   static_assert(64 % G == 0 && G >= NX + NU, "lane group must hold one column of [A B] per lane");
-  static_assert(!PK || (!EXACT && G == 32 && 2 * GR >= NX + NU), "packed roll-out: lean kernel of a 32-lane model");
+  // PK in fp64: no packed math -- one LIVE column per lane of the 16-lane group instead (OcSolver::rollout_sens_live)
+  constexpr bool LV = PK && sizeof(T) == 8;
+  static_assert(!PK || (!EXACT && G == 32 && (LV ? Lay::LIVE <= GR : 2 * GR >= NX + NU)), "packed / live-column roll-out: lean kernel of a 32-lane model");
   __shared__ T lds_all[GPB * RS];
   __shared__ T mbox[PK ? GPB * MB : 1];
+  __shared__ T park[(LV && LFSD_FP64_PARK) ? 2 * NX * 64 + GPB * 2 * NX : 1];      // rk4_step_parked: [2 NX][64 lanes], then [GPB][2 NX]
   __shared__ int vote[3];
   poison_lds(lds_all, GPB * RS);
   Sol s;
@@ -1592,6 +1717,7 @@ __global__ void __launch_bounds__(64, LFSD_WAVES_OC) oc_solve_kernel(OcArgs<T> a
     __syncthreads();
   }
   oc_bind<M, T, G>(s, a, lds_all + gib * RS, slot, valid, traj);
+  if constexpr (LV && LFSD_FP64_PARK) { s.pkm = park + threadIdx.x; s.pkx = park + 2 * NX * 64 + gib * 2 * NX; }
   {
     T* le = s.lds + Lay::template lds_e<G>();
     T* lc = s.lds + Lay::template lds_c<G>();
@@ -1658,6 +1784,7 @@ __global__ void __launch_bounds__(64, LFSD_WAVES_OC) oc_solve_kernel(OcArgs<T> a
   };
   auto do_rollout = [&](int cur_, int nxt_, T alpha_, bool gains_) LFSD_LAMBDA_RO -> T {
     if constexpr (SC) return s.rollout_sens_sc(cur_, nxt_, alpha_, gains_);
+    else if constexpr (LV) return s.rollout_sens_live(cur_, nxt_, alpha_, gains_);
     else if constexpr (PK) return s.rollout_sens_pk(cur_, nxt_, alpha_, gains_);
     else return s.rollout_sens(cur_, nxt_, alpha_, gains_);
   };

@@ -143,9 +143,11 @@ def test_quadrotor_against_reference_golden_run(emu):
 
 def test_quadrotor_fp32_packed_rollout_matches_fp64(emu, monkeypatch):
     """The fp32 lean OC kernel of the 32-lane models rolls out on 16-lane groups with two tangent columns per lane
-    (oc_solve_kernel<..., PK=true>, four trajectories per workgroup, backward sweep on the (emulated) matrix cores); fp64 keeps the
-    one-column-per-lane mapping.  Same inputs, ragged batch of 5 (one full workgroup + one partial), stated fp32
-    tolerances: loss 5e-4, gradient 2e-2, grids 5e-3."""
+    (oc_solve_kernel<..., PK=true>, four trajectories per workgroup, backward sweep on the (emulated) matrix cores); the fp64
+    lean kernel rolls out on 16-lane groups too, one LIVE column per lane with the between-stage values of the tangent step
+    parked in LDS (rollout_sens_live, rk4_step_parked).  Same inputs, ragged batch of 5 (one full workgroup + one partial),
+    stated fp32 tolerances: loss 5e-4, gradient 2e-2, grids 5e-3; the fp64 lock-step kernel against the fp64 wide kernel
+    (another mapping, the plain rk4_step, all 17 columns propagated): 1e-6, both stop on the same gradient test."""
     monkeypatch.setattr(CPDP.COCSys, "mapping_override", "lockstep")          # this test is about the lock-step kernels
     oc, env, d = models.quadrotor(n_grid=int(G["n_grid"]))
     emu(oc)
@@ -160,6 +162,13 @@ def test_quadrotor_fp32_packed_rollout_matches_fp64(emu, monkeypatch):
         out[dt] = (sol, aux)
     s64, a64 = out[torch.float64]
     s32, a32 = out[torch.float32]
+    monkeypatch.setattr(CPDP.COCSys, "mapping_override", "wide")
+    oc.setDevice(dtype=torch.float64)
+    w64 = oc.cocSolverBatch(np.tile(G["ini_state"], (len(idx), 1)), float(G["horizon"]), G["lookahead_theta"][idx],
+                            consts=consts.to(torch.float64))
+    assert np.isin(s64["status"].numpy(), (1, 2)).all() and np.isin(w64["status"].numpy(), (1, 2)).all()
+    assert rel(s64["state_grid"], w64["state_grid"]) < 1e-6 and rel(s64["control_grid"], w64["control_grid"]) < 1e-6
+    assert rel(s64["costate_grid"], w64["costate_grid"]) < 1e-6
     assert (s32["status"] != 4).all() and (s32["status"] != 3).all(), s32["status"]      # neither failed nor at the limit
     assert rel(s32["state_grid"], s64["state_grid"]) < 5e-3
     assert rel(s32["costate_grid"], s64["costate_grid"]) < 5e-3
