@@ -129,6 +129,15 @@
 // prefetch to its first use (LFSD_ISSUE_FENCE below); with the loads really issued ahead (r03_g_ab_prefetch_pin.txt)
 // oc_solve takes 2.65 ms against 2.59 ms without the prefetch: the 23 registers it holds through the stage cost more
 // accumulator-register traffic than the loads' latency does beside 7000 cycles of stage work.
+// the same look-ahead in the GENERIC backward sweep (OcSolver::backward: wide kernel, lock-step kernels without MFMA, fp64):
+// 1 = fp32 instantiations, 3 = fp64 too
+#ifndef LFSD_BW_PREFETCH_GEN
+#define LFSD_BW_PREFETCH_GEN 1
+#endif
+// stages of look-ahead of the wide kernel's costate sweep (0: load where used)
+#ifndef LFSD_CS_AHEAD
+#define LFSD_CS_AHEAD 3
+#endif
 #ifndef LFSD_BW_PREFETCH
 #define LFSD_BW_PREFETCH 0
 #endif
@@ -184,7 +193,16 @@
 #define LFSD_FP64_PARK 1
 #endif
 #ifndef LFSD_FENCE64
-#define LFSD_FENCE64 3
+#define LFSD_FENCE64 7
+#endif
+// double-buffered rows of the dense products in the generic backward sweep, fp32 instantiations (fp64: LFSD_FENCE64 & 4)
+#ifndef LFSD_BW_ROWBUF32
+#define LFSD_BW_ROWBUF32 1
+#endif
+#if defined(LFSD_EMU)
+#define LFSD_ROW_FENCE()
+#else
+#define LFSD_ROW_FENCE() __builtin_amdgcn_sched_barrier(0)
 #endif
 #if defined(LFSD_EMU)
 #define LFSD_SCHED_FENCE()
@@ -200,7 +218,7 @@
 // (34 ds_read_b128 = 136 registers of operands in flight), spilled the rest of its state to scratch and waited on the
 // reloads -- 95 000 cycles per stage, 66 % of oc_solve<double> (tools/oc_clock64.py, profiles/r03_o_fp64_sched_fence.txt)
 #ifndef LFSD_FENCE64
-#define LFSD_FENCE64 3
+#define LFSD_FENCE64 7
 #endif
 #define LFSD_SCHED_FENCE64(T) do { if constexpr (((LFSD_FENCE64) & 2) != 0 && sizeof(T) == 8) __builtin_amdgcn_sched_barrier(0); } while (0)
 #endif

@@ -550,8 +550,18 @@ template <class M, typename T, int G, bool EXACT, bool BND = false> struct OcSol
 #pragma unroll
       for (int a = 0; a < NU; ++a) uk_[a] = up[a];
     };
+    // (the wide kernel and the lock-step kernels without a partner wavefront on their SIMD: one stage of look-ahead on the
+    //  global loads of a stage -- rocket, wide fp32, n_grid 100: 128.8 -> 126.0 ms together with the costate sweep's,
+    //  profiles/r03_t_generic_backward.txt; fp64 lean quadrotor: 9.4 -> 11.9 ms, the registers are not there: off)
+    constexpr bool PFG = (LFSD_BW_PREFETCH_GEN) != 0 && (sizeof(T) == 4 || ((LFSD_BW_PREFETCH_GEN) & 2) != 0);
     T m[NX], mq = T(0), mN[NX], mqN = T(0), xkN[NX], ukN[NU];
+    T hC[(EXACT && PFG) ? NXU : 1], hN[(EXACT && PFG) ? NXU : 1];
     load_stage(N - 1, m, mq, xk, uk);
+    if (EXACT && PFG && mode == 2 && reuse_hess) {
+      const T* hn = Hws + (long long)(N - 1) * Lay::H_ELEMS + (lane < NXU ? lane : 0);
+#pragma unroll
+      for (int i = 0; i < NXU; ++i) hC[i] = hn[i * Lay::NXUP];
+    }
     for (int k = N - 1; k >= 0; --k) {
       if (lane < NX) {
 #pragma unroll
@@ -562,9 +572,46 @@ template <class M, typename T, int G, bool EXACT, bool BND = false> struct OcSol
         for (int i = 0; i < NX; ++i) ldsM[lane * NX + i] = m[i];
       }
       __syncthreads();
-      if (LFSD_BW_PREFETCH && k > 0) { load_stage(k - 1, mN, mqN, xkN, ukN); LFSD_ISSUE_FENCE(); }
+      if (PFG && k > 0) {
+        load_stage(k - 1, mN, mqN, xkN, ukN);
+        if (EXACT && mode == 2 && reuse_hess) {      // ... and its column of the cached stage Hessian
+          const T* hn = Hws + (long long)(k - 1) * Lay::H_ELEMS + (lane < NXU ? lane : 0);
+#pragma unroll
+          for (int i = 0; i < NXU; ++i) hN[i] = hn[i * Lay::NXUP];
+        }
+        LFSD_ISSUE_FENCE();
+      }
       // Y = Vxx' m_j ;  Qcol = [A B]^T Y
       T Y[NX], Qcol[NXU];
+      if constexpr (sizeof(T) == 8 ? ((LFSD_FENCE64) & 4) != 0 : ((LFSD_BW_ROWBUF32) != 0 && NX >= 8)) {
+        // a row's reads are issued while the previous row is multiplied (two row buffers, constant indices after the
+        // unrolling).  fp64: with one buffer every row waited a full LDS round trip between the scheduling barriers; fp32
+        // (wide kernel, lock-step kernels without MFMA): left to itself the compiler issued the 104 ds_read_b128 of a stage one
+        // at a time, each followed by its wait, on a SIMD with nothing else to run (rocket, wide, n_grid 100, 1024 seeds: 126.0 ->
+        // 113.7 ms).  Not for the small models: the robot arm's rows of 4 lose more to the barriers than they gain (17.8 -> 23.5 ms)
+        T rowb[2][NX];
+#pragma unroll
+        for (int kk = 0; kk < NX; ++kk) rowb[0][kk] = ldsV[kk];
+#pragma unroll
+        for (int r = 0; r < NX + NXU; ++r) {
+          const T* nxt = (r + 1 < NX) ? ldsV + (r + 1) * NX : ldsM + (r + 1 - NX) * NX;
+          if (r + 1 < NX + NXU) {
+#pragma unroll
+            for (int kk = 0; kk < NX; ++kk) rowb[(r + 1) & 1][kk] = nxt[kk];
+          }
+          T s = T(0);
+          if (r < NX) {
+#pragma unroll
+            for (int kk = 0; kk < NX; ++kk) s += rowb[r & 1][kk] * m[kk];
+          } else {
+#pragma unroll
+            for (int kk = 0; kk < NX; ++kk) s += rowb[r & 1][kk] * Y[kk];
+          }
+          pin(s);
+          if (r < NX) Y[r] = s; else Qcol[r - NX] = s;
+          LFSD_ROW_FENCE();
+        }
+      } else {
 #pragma unroll
       for (int i = 0; i < NX; ++i) {
         T s = T(0);
@@ -583,12 +630,18 @@ template <class M, typename T, int G, bool EXACT, bool BND = false> struct OcSol
         Qcol[r] = s;
         LFSD_SCHED_FENCE(); LFSD_SCHED_FENCE64(T);
       }
+      }
       if (EXACT && mode == 2) {
         // column `lane` of the exact stage Hessian depends on the nominal and its costates only, not on the shift: a
         // retry of the sweep with a larger shift reads it back instead of repeating the second-order adjoint
         T hx[NX], hu[NU];
         T* hcol = Hws + (long long)k * Lay::H_ELEMS + (lane < NXU ? lane : 0);      // [row][column], column = lane
-        if (reuse_hess) {
+        if (reuse_hess && PFG) {
+#pragma unroll
+          for (int i = 0; i < NX; ++i) hx[i] = hC[i];
+#pragma unroll
+          for (int a = 0; a < NU; ++a) hu[a] = hC[NX + a];
+        } else if (reuse_hess) {
 #pragma unroll
           for (int i = 0; i < NX; ++i) hx[i] = hcol[i * Lay::NXUP];
 #pragma unroll
@@ -744,12 +797,16 @@ template <class M, typename T, int G, bool EXACT, bool BND = false> struct OcSol
       }
       __syncthreads();
       if (k > 0) {
-        if (LFSD_BW_PREFETCH) {
+        if (PFG) {
 #pragma unroll
           for (int i = 0; i < NX; ++i) { m[i] = mN[i]; xk[i] = xkN[i]; }
 #pragma unroll
           for (int a = 0; a < NU; ++a) uk[a] = ukN[a];
           mq = mqN;
+          if (EXACT) {
+#pragma unroll
+            for (int i = 0; i < NXU; ++i) hC[i] = hN[i];
+          }
         } else {
           load_stage(k - 1, m, mq, xk, uk);
         }
@@ -1568,13 +1625,39 @@ template <class M, typename T, bool EXACT, bool BND = false> struct OcWide : OcS
       for (int i = 0; i < NX; ++i) lam_out[N * NX + i] = lam[i];
     }
     T gl_max = T(0);
+    // this lane's column of [A_k B_k; q_k], loaded LFSD_CS_AHEAD stages ahead of its use: the recursion itself is NX FMAs and
+    // an LDS exchange per stage, a global load is ~1 500 clocks and nothing else runs on the SIMD
+    constexpr int AH = LFSD_CS_AHEAD;
+    T mc[AH > 0 ? AH : 1][NX + 1];
+    auto load_col = [&](int k_, T* dst) LFSD_LAMBDA_INLINE {
+      const T* Mk = Mwp(cur) + (long long)(k_ < 0 ? 0 : k_) * Lay::M_ELEMS + (lane < NXU ? lane : 0);
+#pragma unroll
+      for (int i = 0; i <= NX; ++i) dst[i] = Mk[i * Lay::NXUP];
+    };
+    if (AH > 0) {
+#pragma unroll
+      for (int j = 0; j < AH; ++j) load_col(N - 1 - j, mc[j]);
+    }
     for (int k = N - 1; k >= 0; --k) {
       T gl = T(0);
-      if (lane < NXU) {
-        const T* Mk = Mwp(cur) + (long long)k * Lay::M_ELEMS + lane;
-        gl = Mk[NX * Lay::NXUP];
+      T col[NX + 1];
+      if (AH > 0) {
 #pragma unroll
-        for (int i = 0; i < NX; ++i) gl += Mk[i * Lay::NXUP] * lam[i];
+        for (int i = 0; i <= NX; ++i) col[i] = mc[0][i];
+#pragma unroll
+        for (int j = 0; j + 1 < AH; ++j) {
+#pragma unroll
+          for (int i = 0; i <= NX; ++i) mc[j][i] = mc[j + 1][i];
+        }
+        load_col(k - AH, mc[AH - 1]);
+        LFSD_ISSUE_FENCE();
+      } else {
+        load_col(k, col);
+      }
+      if (lane < NXU) {
+        gl = col[NX];
+#pragma unroll
+        for (int i = 0; i < NX; ++i) gl += col[i] * lam[i];
         if (BND && this->xm != nullptr && k > 0 && lane < NX) {      // + the state-bound term of node k
           T xi = T(0), lbi = T(0), ubi = T(0), g_, h_;
 #pragma unroll
@@ -2123,6 +2206,13 @@ __global__ void __launch_bounds__(64, 1) oc_solve_wide_kernel(OcArgs<T> a) {
   bool coarse = CSW && a.steps_per_grid > 1 && a.u_init == nullptr && a.max_iter > 8 && a.n_grid >= LFSD_COARSE_MIN_GRID;
   bool relin = false;
   if (coarse) { s.S = 1; s.DT = s.dgrid; }
+#if defined(LFSD_OC_CLOCK)      // diagnostic build (tools/wide_clock.py): shader clocks of the phases of the slowest solves
+  long long wck[5] = {0, 0, 0, 0, 0};
+  const long long wck_t0 = clock64();
+#define LFSD_WCK(i, stmt) { const long long c0_ = clock64(); stmt; wck[i] += clock64() - c0_; }
+#else
+#define LFSD_WCK(i, stmt) { stmt; }
+#endif
   T J = s.rollout_alphas(1, false, alpha_l);             // (every lane rolls the same controls out; lane 0's copy is adopted)
   ldsRed[s.lane] = J;
   __syncthreads();
@@ -2166,13 +2256,14 @@ __global__ void __launch_bounds__(64, 1) oc_solve_wide_kernel(OcArgs<T> a) {
     }
     if (EXACT && a.exact_after >= 0 && mode < 2 && (it >= a.exact_after || gn_crawl)) mode = 2;
     if (EXACT && mode == 2 && !hess_ok) {
-      s.costate_sweep(cur);
-      s.hessians_parallel(cur);
+      LFSD_WCK(2, s.costate_sweep(cur));
+      LFSD_WCK(3, s.hessians_parallel(cur));
       hess_ok = true;
     }
     s.reuse_hess = EXACT && mode == 2;
     T dmin = T(0);
-    const bool bw_ok = s.backward(cur, mode, mu, gnorm, dV1, dV2, dmin);
+    bool bw_ok;
+    LFSD_WCK(4, bw_ok = s.backward(cur, mode, mu, gnorm, dV1, dV2, dmin));
     costates_ok = true;
     if (!bw_ok) {
       if (mode == 1 && !LFSD_HAM_SHIFT) { mode = 0; ham_ok = false; }
@@ -2190,7 +2281,8 @@ __global__ void __launch_bounds__(64, 1) oc_solve_wide_kernel(OcArgs<T> a) {
       status = ST_STALLED; ++it; break;      // (this iteration's sweep counts)
     }
     // all step lengths at once; the largest one that passes the Armijo test is taken
-    const T Ja = s.rollout_alphas(cur, true, alpha_l);
+    T Ja;
+    LFSD_WCK(0, Ja = s.rollout_alphas(cur, true, alpha_l));
     ldsRed[s.lane] = Ja;
     __syncthreads();
     int ia = -1;
@@ -2226,7 +2318,7 @@ __global__ void __launch_bounds__(64, 1) oc_solve_wide_kernel(OcArgs<T> a) {
 #endif
     if (accept) {
       s.adopt_alpha(ia, cur ^ 1);
-      s.linearise_parallel(cur ^ 1);
+      LFSD_WCK(1, s.linearise_parallel(cur ^ 1));
       cur ^= 1;
       g_last = gnorm; dec_last = (mode >= 1 && mu == T(0)) ? -(dV1 + dV2) : T(1e30);
       hess_ok = false; costates_ok = false;
@@ -2246,6 +2338,12 @@ __global__ void __launch_bounds__(64, 1) oc_solve_wide_kernel(OcArgs<T> a) {
     }
   }
   if (status == ST_RUNNING) status = ST_MAXITER;
+#if defined(LFSD_OC_CLOCK)
+  if (threadIdx.x == 0 && (it >= LFSD_OC_CLOCK || blockIdx.x == 0))
+    printf("wide clock traj %d: iterations %d total %lld rollout_alphas %lld linearise %lld costates %lld hessians %lld backward %lld\n",
+           (int)blockIdx.x, it, clock64() - wck_t0, wck[0], wck[1], wck[2], wck[3], wck[4]);
+#endif
+#undef LFSD_WCK
   if (!costates_ok) s.costate_sweep(cur);                 // costates of the final nominal
   __syncthreads();
   {

@@ -38,6 +38,7 @@ VARIANTS = {
     "occlock": (("-DLFSD_OC_CLOCK=3",), None, False),
     "nofence64": (("-DLFSD_FENCE64=0",), None, False),
     "pin64only": (("-DLFSD_FENCE64=1",), None, False),
+    "fence3": (("-DLFSD_FENCE64=3",), None, False),
     "nolive64": (("-DLFSD_FP64_LIVE=0",), None, False),
     "nopark64": (("-DLFSD_FP64_PARK=0",), None, False),
     "pflate": (("-DLFSD_BW_PREFETCH=2",), None, False),
