@@ -195,6 +195,11 @@
 #ifndef LFSD_FENCE64
 #define LFSD_FENCE64 7
 #endif
+// wide kernel, models with at most 16 columns of [A B] and NX >= 8 (rocket): rows of the backward sweep's dense products
+// split over the four 16-lane quarters of the wavefront (OcSolver::backward, QS)
+#ifndef LFSD_BW_QSPLIT
+#define LFSD_BW_QSPLIT 1
+#endif
 // double-buffered rows of the dense products in the generic backward sweep, fp32 instantiations (fp64: LFSD_FENCE64 & 4)
 #ifndef LFSD_BW_ROWBUF32
 #define LFSD_BW_ROWBUF32 1
@@ -345,6 +350,36 @@ LFSD_DEV void tile_transpose(f32x16& acc) {
       acc[8 * R1 + 4 + r] = __builtin_bit_cast(float, v1);
     }
   }
+}
+#endif
+
+// quarter_sum(v): sum of v over the four lanes l, l^16, l^32, l^48 of the wavefront, in every one of them (the wide kernel's
+// backward sweep splits the rows of its dense products over the four 16-lane quarters).  Must be reached by all 64 lanes.
+#if defined(LFSD_EMU)
+template <typename T> inline T quarter_sum(T v) {
+  static T sq[64];
+  const int l = threadIdx.x;
+  sq[l] = v;
+  __syncthreads();
+  const T r = (sq[l & 15] + sq[(l & 15) + 16]) + (sq[(l & 15) + 32] + sq[(l & 15) + 48]);
+  __syncthreads();
+  return r;
+}
+#else
+LFSD_DEV float quarter_sum(float v) {
+  // v_permlane32_swap(a, b): a' = [a.lo32, b.lo32], b' = [a.hi32, b.hi32]; with a = b = v their sum is v.lo + v.hi everywhere
+  const unsigned u = __builtin_bit_cast(unsigned, v);
+  const auto p = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+  const unsigned p0 = p[0], p1 = p[1];
+  const float w = __builtin_bit_cast(float, p0) + __builtin_bit_cast(float, p1);
+  const unsigned uw = __builtin_bit_cast(unsigned, w);
+  const auto q = __builtin_amdgcn_permlane16_swap(uw, uw, false, false);
+  const unsigned q0 = q[0], q1 = q[1];
+  return __builtin_bit_cast(float, q0) + __builtin_bit_cast(float, q1);
+}
+LFSD_DEV double quarter_sum(double v) {
+  const double w = v + __shfl_xor(v, 32);
+  return w + __shfl_xor(w, 16);
 }
 #endif
 

@@ -533,9 +533,15 @@ template <class M, typename T, int G, bool EXACT, bool BND = false> struct OcSol
     }
     // this lane's column of [A B; q] and the nominal (x_k, u_k) of one interval.  The loads of interval k-1 are issued
     // while interval k is being processed (one wave per SIMD: nothing else would hide their latency)
+    // QS (wide kernel, at most 16 columns): the backward sweep is one column per lane on 16 of the wavefront's 64 lanes.  Its
+    // dense products  Y = V_xx m_j,  Q = [A B]^T Y  -- half of a stage's instructions -- are split four ways instead: every
+    // 16-lane quarter holds the columns, quarter p computes rows p, p+4, p+8, (p+12) of Y and its share of the sum over
+    // those rows in Q, and two cross-quarter exchanges per entry of Q add the shares up (quarter_sum).
+    constexpr bool QS = (G == 64) && (LFSD_BW_QSPLIT != 0) && NX >= 8 && NXU <= 16 && !BND;
+    const int jcol = QS ? (lane & 15) : lane;
     auto load_stage = [&](int k_, T* m_, T& mq_, T* xk_, T* uk_) LFSD_LAMBDA_INLINE {
-      if (lane < NXU) {
-        const T* Mk = Mwp(cur) + (long long)k_ * Lay::M_ELEMS + lane;
+      if (jcol < NXU) {
+        const T* Mk = Mwp(cur) + (long long)k_ * Lay::M_ELEMS + jcol;
 #pragma unroll
         for (int i = 0; i < NX; ++i) m_[i] = Mk[i * Lay::NXUP];
         mq_ = Mk[NX * Lay::NXUP];
@@ -569,7 +575,7 @@ template <class M, typename T, int G, bool EXACT, bool BND = false> struct OcSol
       }
       if (lane < NXU) {
 #pragma unroll
-        for (int i = 0; i < NX; ++i) ldsM[lane * NX + i] = m[i];
+        for (int i = 0; i < NX; ++i) { if (QS) ldsM[i * NXU + lane] = m[i]; else ldsM[lane * NX + i] = m[i]; }      // QS: transposed, row i = entries (i, all columns)
       }
       __syncthreads();
       if (PFG && k > 0) {
@@ -583,7 +589,54 @@ template <class M, typename T, int G, bool EXACT, bool BND = false> struct OcSol
       }
       // Y = Vxx' m_j ;  Qcol = [A B]^T Y
       T Y[NX], Qcol[NXU];
-      if constexpr (sizeof(T) == 8 ? ((LFSD_FENCE64) & 4) != 0 : ((LFSD_BW_ROWBUF32) != 0 && NX >= 8)) {
+      if constexpr (QS) {
+        constexpr int RP = (NX + 3) / 4;
+        const int part = lane >> 4;
+        T Yp[RP], Qp[NXU];
+#pragma unroll
+        for (int r = 0; r < NXU; ++r) Qp[r] = T(0);
+        // (row addresses depend on the lane: the reads of all of a quarter's rows are issued back to back, then used)
+        T vrow[RP][NX], mrow[RP][NXU];
+#pragma unroll
+        for (int q = 0; q < RP; ++q) {
+          const int i = part + 4 * q;
+          const T* vr = ldsV + ((i < NX) ? i : 0) * NX;
+#pragma unroll
+          for (int kk = 0; kk < NX; ++kk) vrow[q][kk] = vr[kk];
+        }
+#pragma unroll
+        for (int q = 0; q < RP; ++q) {
+#pragma unroll
+          for (int kk = 0; kk < NX; ++kk) pin(vrow[q][kk]);
+        }
+#pragma unroll
+        for (int q = 0; q < RP; ++q) {
+          const int i = part + 4 * q;
+          const T* mr = ldsM + ((i < NX) ? i : 0) * NXU;
+#pragma unroll
+          for (int r = 0; r < NXU; ++r) mrow[q][r] = mr[r];
+        }
+#pragma unroll
+        for (int q = 0; q < RP; ++q) {
+          T s = T(0);
+#pragma unroll
+          for (int kk = 0; kk < NX; ++kk) s += vrow[q][kk] * m[kk];
+          Yp[q] = (part + 4 * q < NX) ? s : T(0);
+        }
+#pragma unroll
+        for (int q = 0; q < RP; ++q) {
+#pragma unroll
+          for (int r = 0; r < NXU; ++r) pin(mrow[q][r]);
+        }
+#pragma unroll
+        for (int q = 0; q < RP; ++q) {
+#pragma unroll
+          for (int r = 0; r < NXU; ++r) Qp[r] += mrow[q][r] * Yp[q];
+        }
+#pragma unroll
+        for (int r = 0; r < NXU; ++r) Qcol[r] = quarter_sum(Qp[r]);
+        (void)Y;
+      } else if constexpr (sizeof(T) == 8 ? ((LFSD_FENCE64) & 4) != 0 : ((LFSD_BW_ROWBUF32) != 0 && NX >= 8)) {
         // a row's reads are issued while the previous row is multiplied (two row buffers, constant indices after the
         // unrolling).  fp64: with one buffer every row waited a full LDS round trip between the scheduling barriers; fp32
         // (wide kernel, lock-step kernels without MFMA): left to itself the compiler issued the 104 ds_read_b128 of a stage one
