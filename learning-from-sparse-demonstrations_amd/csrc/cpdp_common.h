@@ -182,8 +182,7 @@
 #define LFSD_HAM_SHIFT 0
 #endif
 
-// LFSD_SCHED_FENCE: stop the instruction scheduler from hoisting loads across this point (bounds live ranges in
-// the fully unrolled contractions); no-op in the emulator build
+// ---- fp64 OC kernels (round 3; profiles/r03_o_fp64_backward.txt, r03_q_fp64_live_park.txt) --------------------------------
 // fp64 lean OC kernel of the 32-lane models on 16-lane groups (four trajectories per wavefront); 0: 32-lane groups (round 2)
 #ifndef LFSD_FP64_LIVE
 #define LFSD_FP64_LIVE 1
@@ -192,38 +191,37 @@
 #ifndef LFSD_FP64_PARK
 #define LFSD_FP64_PARK 1
 #endif
+// LFSD_FENCE64, bits: 1 = pin64 (row sums of the backward sweep's dense products are materialised where they are computed),
+// 2 = LFSD_SCHED_FENCE64 (a scheduling barrier per row), 4 = two row buffers (a row's LDS reads are issued while the previous
+// row is multiplied).  The pathology they remove: Q = [A B]^T Y is first used behind a branch; the compiler sank its FMAs
+// there, left the 221 LDS reads of their operands where they were, spilled every operand to scratch and reloaded it one at a
+// time -- 95 000 clocks for a stage that computes for 5 000, 66 % of oc_solve<double> (tools/oc_clock64.py).
 #ifndef LFSD_FENCE64
 #define LFSD_FENCE64 7
 #endif
+// ---- the generic backward sweep in fp32 (wide kernel, lock-step kernels without MFMA; profiles/r03_t_generic_backward.txt) --
 // wide kernel, models with at most 16 columns of [A B] and NX >= 8 (rocket): rows of the backward sweep's dense products
 // split over the four 16-lane quarters of the wavefront (OcSolver::backward, QS)
 #ifndef LFSD_BW_QSPLIT
 #define LFSD_BW_QSPLIT 1
 #endif
-// double-buffered rows of the dense products in the generic backward sweep, fp32 instantiations (fp64: LFSD_FENCE64 & 4)
+// two row buffers for the dense products, fp32 instantiations with NX >= 8 (fp64: LFSD_FENCE64 & 4)
 #ifndef LFSD_BW_ROWBUF32
 #define LFSD_BW_ROWBUF32 1
 #endif
+// LFSD_ROW_FENCE / LFSD_SCHED_FENCE64(T): the instruction scheduler moves nothing across this point (bounds the live ranges of
+// the fully unrolled contractions); LFSD_SCHED_FENCE: the same between the RK4 stages, off unless LFSD_USE_SCHED_FENCE is
+// defined.  No-ops in the emulator build.
 #if defined(LFSD_EMU)
 #define LFSD_ROW_FENCE()
-#else
-#define LFSD_ROW_FENCE() __builtin_amdgcn_sched_barrier(0)
-#endif
-#if defined(LFSD_EMU)
 #define LFSD_SCHED_FENCE()
 #define LFSD_SCHED_FENCE64(T)
 #else
+#define LFSD_ROW_FENCE() __builtin_amdgcn_sched_barrier(0)
 #if defined(LFSD_USE_SCHED_FENCE)
 #define LFSD_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 #else
 #define LFSD_SCHED_FENCE()
-#endif
-// ... in the fp64 instantiations only (LFSD_FENCE64, default on).  The fp64 kernels have half the registers per value: with
-// the max-ILP scheduler free to hoist, the backward sweep issued every LDS read of a stage's dense products up front
-// (34 ds_read_b128 = 136 registers of operands in flight), spilled the rest of its state to scratch and waited on the
-// reloads -- 95 000 cycles per stage, 66 % of oc_solve<double> (tools/oc_clock64.py, profiles/r03_o_fp64_sched_fence.txt)
-#ifndef LFSD_FENCE64
-#define LFSD_FENCE64 7
 #endif
 #define LFSD_SCHED_FENCE64(T) do { if constexpr (((LFSD_FENCE64) & 2) != 0 && sizeof(T) == 8) __builtin_amdgcn_sched_barrier(0); } while (0)
 #endif
