@@ -191,6 +191,11 @@
 #ifndef LFSD_FP64_PARK
 #define LFSD_FP64_PARK 1
 #endif
+// ... and with the one-pass backward sweep of the structural-column layout (backward_sc, LDS-fed products) instead of two
+// passes of the generic sweep on 32-lane groups
+#ifndef LFSD_FP64_SC
+#define LFSD_FP64_SC 1
+#endif
 // LFSD_FENCE64, bits: 1 = pin64 (row sums of the backward sweep's dense products are materialised where they are computed),
 // 2 = LFSD_SCHED_FENCE64 (a scheduling barrier per row), 4 = two row buffers (a row's LDS reads are issued while the previous
 // row is multiplied).  The pathology they remove: Q = [A B]^T Y is first used behind a branch; the compiler sank its FMAs

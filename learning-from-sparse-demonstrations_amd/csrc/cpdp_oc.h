@@ -132,6 +132,7 @@ template <class M, typename T, int G, bool EXACT, bool BND = false> struct OcSol
   LFSD_DEV T* ubp(int i) const { return i ? ub[1] : ub[0]; }
   LFSD_DEV T* Mwp(int i) const { return i ? Mws[1] : Mws[0]; }
   T *pkx = nullptr, *pkm = nullptr;      // rk4_step_parked: LDS homes of (x, sum of k) of the group and of this lane's (m, sum of dk)
+  T* yz64 = nullptr;                     // backward_sc without matrix cores: [16][ZC] exchange rows (the LDS_M region holds the live columns there)
   bool reuse_hess = false;   // exact stage Hessians in Hws belong to the nominal being swept (a retry with another shift)
   T* lam_out;   // costate grid of this trajectory (or scratch when invalid)
 
@@ -360,6 +361,9 @@ template <class M, typename T, int G, bool EXACT, bool BND = false> struct OcSol
   // (unit vectors through every RK4 stage, see rollout_sens_sc) are written as such, with the quadrature of dc/dx_z along the
   // stages (rk4_step's NZ) as their cost-row entry.  The stored [A B; q] has the layout of rollout_sens: the backward sweep
   // keeps its 32-lane mapping (two passes per wavefront through the mailbox, as for the packed kernel without MFMA).
+  // SCL: store [A B; q] in the structural layout of rollout_sens_sc (live columns only + the cost-row entries of the constant
+  // states) for the one-pass sweep backward_sc; else in the full layout of rollout_sens for the two-pass generic sweep.
+  template <bool SCL = false>
   LFSD_DEV T rollout_sens_live(int cur, int nxt, T alpha, bool gains) {
     constexpr int ZC_ = Lay::ZC, LIVE_ = Lay::LIVE;
     static_assert(LIVE_ <= G || G != 16, "live columns: one per lane of the group");
@@ -388,6 +392,19 @@ template <class M, typename T, int G, bool EXACT, bool BND = false> struct OcSol
         else rk4_step<true, T, ZC_>(t, x, q, u, m, mq, du, qz);
       }
       J += q;
+      if constexpr (SCL) {
+        T* Ms = Mwp(nxt) + (long long)k * Lay::MS_ELEMS;
+        if (lane < LIVE_) {
+#pragma unroll
+          for (int i = 0; i < NX; ++i) Ms[i * Lay::LIVEP + lane] = m[i];
+          Ms[NX * Lay::LIVEP + lane] = mq;
+        }
+        if (lane == 0) {
+#pragma unroll
+          for (int z = 0; z < ZC_; ++z) Ms[(NX + 1) * Lay::LIVEP + z] = qz[z];
+        }
+        continue;
+      }
       T* Mk = Mwp(nxt) + (long long)k * Lay::M_ELEMS;
       if (lane < LIVE_) {
 #pragma unroll
@@ -1263,7 +1280,12 @@ template <class M, typename T, int G, bool EXACT, bool BND = false> struct OcSol
     T* ldsV = lds + Lay::LDS_V;  T* ldsK = lds + Lay::LDS_K;
     T* ldsQux = lds + Lay::LDS_QUX;  T* ldsQuu = lds + Lay::LDS_QUU;  T* ldsQu = lds + Lay::LDS_QU;
     T* ldsVx = lds + Lay::LDS_VX;  T* ldsLam = lds + Lay::LDS_LAM;  T* ldsRed = lds + Lay::LDS_RED;
-    T* ldsYZ = lds + Lay::LDS_M;              // [16 lanes][ZC] rows Y(Z, column of the lane)   (LDS_M region: NXU*NX words)
+    // MM: the two dense products on the matrix cores (fp32).  Otherwise (fp64, round 3) they are LDS-fed FMAs in the same lane
+    // roles: V_xx (symmetric, natural row order) and this stage's live columns are published in LDS, every lane reads the rows
+    // it needs two row buffers ahead -- ONE pass for the wavefront's four trajectories where the generic sweep took two.
+    constexpr bool MM = sizeof(T) == 4;
+    T* ldsMl = lds + Lay::LDS_M;              // !MM: [LIVE][NX] live column r of [A B] as row r   (LDS_M region: NXU*NX words)
+    T* ldsYZ = MM ? lds + Lay::LDS_M : yz64;  // [16 lanes][ZC] rows Y(Z, column of the lane)
     const bool has_v = lane < NX;                       // V-role: lanes < LX live state ZC + lane, lanes LX.. constant state lane - LX
     const bool st_zc = lane >= LX && lane < NX;
     const int sv = has_v ? (lane < LX ? ZC + lane : lane - LX) : 0;       // natural state index of the V-role
@@ -1292,6 +1314,10 @@ template <class M, typename T, int G, bool EXACT, bool BND = false> struct OcSol
           for (int i = 0; i < NX; ++i) lam_out[N * NX + i] = lam[i];
         }
       }
+      if (!MM && has_v) {
+#pragma unroll
+        for (int i = 0; i < NX; ++i) ldsV[sv * NX + i] = vcol[i];
+      }
     }
     __syncthreads();
     T m[NX], mq = T(0), qzl = T(0), mN[NX], mqN = T(0), qzN = T(0), xkN[NX], ukN[NU];
@@ -1302,40 +1328,83 @@ template <class M, typename T, int G, bool EXACT, bool BND = false> struct OcSol
     for (int k = N - 1; k >= 0; --k) {
       if (LFSD_BW_PREFETCH == 1) { if (k > 0) { sc_load_stage(cur, k - 1, mN, mqN, qzN, xkN, ukN); LFSD_ISSUE_FENCE(); } }
       // Y(V-lane r, live column of this lane) = sum_kk V[kk][state of lane r] M[kk][column]
-      f32x16 acc;
+      typename std::conditional<MM, f32x16, T[16]>::type acc;
+      T yn[NX];                                    // Y(:, column of this lane) in NATURAL row order
+      if constexpr (!MM) {
+        if (lane < LIVE) {
+#pragma unroll
+          for (int i = 0; i < NX; ++i) ldsMl[lane * NX + i] = m[i];
+        }
+        __syncthreads();                           // V_xx (published at the end of the previous stage) and the columns are visible
+        T rowb[2][NX];
+#pragma unroll
+        for (int kk = 0; kk < NX; ++kk) rowb[0][kk] = ldsV[kk];
+#pragma unroll
+        for (int r = 0; r < NX + LIVE; ++r) {
+          const T* nxt = (r + 1 < NX) ? ldsV + (r + 1) * NX : ldsMl + (r + 1 - NX) * NX;
+          if (r + 1 < NX + LIVE) {
+#pragma unroll
+            for (int kk = 0; kk < NX; ++kk) rowb[(r + 1) & 1][kk] = nxt[kk];
+          }
+          T sacc = T(0);
+          if (r < NX) {
+#pragma unroll
+            for (int kk = 0; kk < NX; ++kk) sacc += rowb[r & 1][kk] * m[kk];
+          } else {
+#pragma unroll
+            for (int kk = 0; kk < NX; ++kk) sacc += rowb[r & 1][kk] * yn[kk];
+          }
+          pin(sacc);
+          if (r < NX) yn[r] = sacc; else acc[r - NX] = sacc;
+          LFSD_ROW_FENCE();
+        }
+      }
+      if constexpr (MM) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 #pragma unroll
       for (int kk = 0; kk < NX; ++kk) mfma4b(vcol[kk], m[kk], acc);
+      }
       // stage-Hessian column(s) of this lane on the vector pipe, beside the products in flight on the matrix pipe
       T hx[NX], hu[NU];
       {
         T ox[NX], ou[NU], ls[NX];          // one-hots of BOTH roles: the V-role's state and the M-role's control
         const T HL = (mode == 1) ? T(1) : T(0);
 #pragma unroll
-        for (int i = 0; i < NX; ++i) { ox[i] = (has_v && sv == i) ? T(1) : T(0); ls[i] = HL * lam[i]; }
+        for (int i = 0; i < NX; ++i) { ox[i] = (has_v && sv == i) ? T(1) : T(0); ls[i] = HL * (MM ? lam[i] : ldsLam[i]); }
 #pragma unroll
         for (int a = 0; a < NU; ++a) ou[a] = (lane == LX + a) ? T(1) : T(0);
         M::ham_hess_mul(tk(k), xk, uk, ls, e, c, ox, ou, hx, hu);
       }
-      tile_transpose(acc);
-      LFSD_BWC(0)                                  // loads issued, MFMA #1, stage Hessian column, transpose
-      T yn[NX];                                    // Y(:, column of this lane) in NATURAL row order
+      if constexpr (MM) {
+        tile_transpose(acc);
+        LFSD_BWC(0)                                // loads issued, MFMA #1, stage Hessian column, transpose
 #pragma unroll
-      for (int s_ = 0; s_ < NX; ++s_) yn[s_] = acc[s_ < ZC ? LX + s_ : s_ - ZC];
+        for (int s_ = 0; s_ < NX; ++s_) yn[s_] = acc[s_ < ZC ? LX + s_ : s_ - ZC];
+      }
       if (lane < LIVE) {
 #pragma unroll
         for (int z = 0; z < ZC; ++z) ldsYZ[lane * ZC + z] = yn[z];
       }
       // Q(live, live) = M_live^T Y
+      if constexpr (MM) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 #pragma unroll
-      for (int kk = 0; kk < NX; ++kk) mfma4b(m[kk], yn[kk], acc);
+        for (int kk = 0; kk < NX; ++kk) mfma4b(m[kk], yn[kk], acc);
+      }
       T Qg = mq, gl = mq;
+      if constexpr (MM) {
 #pragma unroll
-      for (int i = 0; i < NX; ++i) { Qg += m[i] * Vx[i]; gl += m[i] * lam[i]; }
-      tile_transpose(acc);
+        for (int i = 0; i < NX; ++i) { Qg += m[i] * Vx[i]; gl += m[i] * lam[i]; }
+      } else {                                     // fp64: V_x and the costate stay in LDS (52 registers less through the stage)
+        T vxl[NX], lml[NX];
+#pragma unroll
+        for (int i = 0; i < NX; ++i) { vxl[i] = ldsVx[i]; lml[i] = ldsLam[i]; }
+#pragma unroll
+        for (int i = 0; i < NX; ++i) { Qg += m[i] * vxl[i]; gl += m[i] * lml[i]; }
+      }
+      if constexpr (MM) tile_transpose(acc);
       __syncthreads();                             // ldsYZ visible
       if (LFSD_BW_PREFETCH == 2) { if (k > 0) { sc_load_stage(cur, k - 1, mN, mqN, qzN, xkN, ukN); LFSD_ISSUE_FENCE(); } }      // (experiment: behind the MFMA chains)
       LFSD_BWC(1)                                  // MFMA #2, gradient dot products, transpose
@@ -1427,12 +1496,11 @@ template <class M, typename T, int G, bool EXACT, bool BND = false> struct OcSol
 #pragma unroll
         for (int a = 0; a < NU; ++a) { sacc += ldsK[i * NU + a] * t1[a]; sacc += ldsQux[i * NU + a] * Kj[a]; }      // (two FMAs; one statement compiles to mul + fma + add)
         vcol[i] = sacc;
-        Vx[i] = ldsVx[i];
-        lam[i] = ldsLam[i];
+        if (MM) { Vx[i] = ldsVx[i]; lam[i] = ldsLam[i]; }
       }
       if (lane == 0 && live) {
 #pragma unroll
-        for (int i = 0; i < NX; ++i) lam_out[k * NX + i] = lam[i];
+        for (int i = 0; i < NX; ++i) lam_out[k * NX + i] = MM ? lam[i] : ldsLam[i];
       }
       LFSD_BWC(4)                                  // gains to LDS / HBM, V_xx update
       // symmetrise V_xx through LDS (the rank-1 feeds rely on row i == column i)
@@ -1451,6 +1519,10 @@ template <class M, typename T, int G, bool EXACT, bool BND = false> struct OcSol
         for (int i = 0; i < NX; ++i) vcol[i] = has_v ? T(0.5) * (vcol[i] + vt[i]) : T(0);
       }
       __syncthreads();
+      if (!MM && has_v) {                          // publish the symmetric V_xx for the next stage's products
+#pragma unroll
+        for (int i = 0; i < NX; ++i) ldsV[sv * NX + i] = vcol[i];
+      }
       LFSD_BWC(5)                                  // symmetrisation
       if (k > 0) {
         if (LFSD_BW_PREFETCH) {
@@ -1833,6 +1905,9 @@ __global__ void __launch_bounds__(64, LFSD_WAVES_OC) oc_solve_kernel(OcArgs<T> a
   __shared__ T lds_all[GPB * RS];
   __shared__ T mbox[PK ? GPB * MB : 1];
   __shared__ T park[(LV && LFSD_FP64_PARK) ? 2 * NX * 64 + GPB * 2 * NX : 1];      // rk4_step_parked: [2 NX][64 lanes], then [GPB][2 NX]
+  // ... and the ONE-pass backward sweep of the structural layout (backward_sc with LDS-fed products) where the model has it
+  constexpr bool SC64 = LV && (LFSD_FP64_SC != 0) && Lay::sc_ok;
+  __shared__ T yzx[SC64 ? GPB * 16 * (Lay::ZC ? Lay::ZC : 1) : 1];
   __shared__ int vote[3];
   poison_lds(lds_all, GPB * RS);
   Sol s;
@@ -1854,6 +1929,7 @@ __global__ void __launch_bounds__(64, LFSD_WAVES_OC) oc_solve_kernel(OcArgs<T> a
   }
   oc_bind<M, T, G>(s, a, lds_all + gib * RS, slot, valid, traj);
   if constexpr (LV && LFSD_FP64_PARK) { s.pkm = park + threadIdx.x; s.pkx = park + 2 * NX * 64 + gib * 2 * NX; }
+  if constexpr (SC64) s.yz64 = yzx + gib * 16 * Lay::ZC;
   {
     T* le = s.lds + Lay::template lds_e<G>();
     T* lc = s.lds + Lay::template lds_c<G>();
@@ -1869,7 +1945,7 @@ __global__ void __launch_bounds__(64, LFSD_WAVES_OC) oc_solve_kernel(OcArgs<T> a
   // backward sweep of this lane's trajectory; `force`: also when the trajectory is no longer running (final refresh
   // of the costates).  Returns whether the sweep ran (PK skips a pass none of whose trajectories wants it).
   auto do_backward = [&](int cur_, int mode_, T mu_, bool want_, T& gnorm_, T& dV1_, T& dV2_, T& dmin_, bool& ok_) LFSD_LAMBDA_BW -> bool {
-    if constexpr (MF) {
+    if constexpr (MF || SC64) {
       // all four trajectories of the wavefront sweep together on the matrix cores; a group that does not want the sweep
       // rides along without writing anything (the MFMAs need every lane)
       if (threadIdx.x == 0) vote[2] = 0;
@@ -1881,7 +1957,7 @@ __global__ void __launch_bounds__(64, LFSD_WAVES_OC) oc_solve_kernel(OcArgs<T> a
       if (!any) return false;
       T g_, d1_, d2_, dm_;
       bool okb;
-      if constexpr (SC) okb = s.backward_sc(cur_, mode_, mu_, want_, g_, d1_, d2_, dm_);
+      if constexpr (SC || SC64) okb = s.backward_sc(cur_, mode_, mu_, want_, g_, d1_, d2_, dm_);
       else okb = s.backward_mf(cur_, mode_, mu_, want_, g_, d1_, d2_, dm_);
       if (want_) { ok_ = okb; gnorm_ = g_; dV1_ = d1_; dV2_ = d2_; dmin_ = dm_; }
       return want_;
@@ -1920,7 +1996,7 @@ __global__ void __launch_bounds__(64, LFSD_WAVES_OC) oc_solve_kernel(OcArgs<T> a
   };
   auto do_rollout = [&](int cur_, int nxt_, T alpha_, bool gains_) LFSD_LAMBDA_RO -> T {
     if constexpr (SC) return s.rollout_sens_sc(cur_, nxt_, alpha_, gains_);
-    else if constexpr (LV) return s.rollout_sens_live(cur_, nxt_, alpha_, gains_);
+    else if constexpr (LV) return s.template rollout_sens_live<SC64>(cur_, nxt_, alpha_, gains_);
     else if constexpr (PK) return s.rollout_sens_pk(cur_, nxt_, alpha_, gains_);
     else return s.rollout_sens(cur_, nxt_, alpha_, gains_);
   };

@@ -13,7 +13,7 @@ from ab_variants import variant_path
 args = bench.parse_args(["--no-cpu-baseline"])
 oc, env, d = models.quadrotor(n_grid=args.n_grid)
 oc.use_library(variant_path(oc.model_spec(), sys.argv[1] if len(sys.argv) > 1 else "bwclock"))
-oc.setDevice("cuda:0", torch.float32)
+oc.setDevice("cuda:0", torch.float64 if (len(sys.argv) > 2 and sys.argv[2] == "f64") else torch.float32)
 L, theta0, x0 = bench.build_learner(args, oc, d, oc.compile(), 0, 1, "independent")
 for rep in range(2):
     print("=== solve %d" % rep, flush=True)
