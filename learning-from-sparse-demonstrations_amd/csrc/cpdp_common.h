@@ -182,6 +182,12 @@
 #define LFSD_HAM_SHIFT 0
 #endif
 
+// structural backward sweep, fp32: V_x and the costate read from their LDS images where used (1) or carried in registers (0).
+// In fp64 the LDS form is what made the one-pass sweep pay (11.1 -> 9.2 ms); in fp32 it frees 21 accumulator registers and
+// costs 2 % (oc_solve 2.58 -> 2.63 ms, profiles/r03_aa_ab_vx_lds.txt): the registers are there.
+#ifndef LFSD_SC_VX_LDS
+#define LFSD_SC_VX_LDS 0
+#endif
 // ---- fp64 OC kernels (round 3; profiles/r03_o_fp64_backward.txt, r03_q_fp64_live_park.txt) --------------------------------
 // fp64 lean OC kernel of the 32-lane models on 16-lane groups (four trajectories per wavefront); 0: 32-lane groups (round 2)
 #ifndef LFSD_FP64_LIVE

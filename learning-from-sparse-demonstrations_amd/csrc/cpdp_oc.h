@@ -1284,6 +1284,7 @@ template <class M, typename T, int G, bool EXACT, bool BND = false> struct OcSol
     // roles: V_xx (symmetric, natural row order) and this stage's live columns are published in LDS, every lane reads the rows
     // it needs two row buffers ahead -- ONE pass for the wavefront's four trajectories where the generic sweep took two.
     constexpr bool MM = sizeof(T) == 4;
+    constexpr bool VXR = MM && (LFSD_SC_VX_LDS == 0);      // V_x and the costate carried in registers through the stage (else: read from their LDS images)
     T* ldsMl = lds + Lay::LDS_M;              // !MM: [LIVE][NX] live column r of [A B] as row r   (LDS_M region: NXU*NX words)
     T* ldsYZ = MM ? lds + Lay::LDS_M : yz64;  // [16 lanes][ZC] rows Y(Z, column of the lane)
     const bool has_v = lane < NX;                       // V-role: lanes < LX live state ZC + lane, lanes LX.. constant state lane - LX
@@ -1371,7 +1372,7 @@ template <class M, typename T, int G, bool EXACT, bool BND = false> struct OcSol
         T ox[NX], ou[NU], ls[NX];          // one-hots of BOTH roles: the V-role's state and the M-role's control
         const T HL = (mode == 1) ? T(1) : T(0);
 #pragma unroll
-        for (int i = 0; i < NX; ++i) { ox[i] = (has_v && sv == i) ? T(1) : T(0); ls[i] = HL * (MM ? lam[i] : ldsLam[i]); }
+        for (int i = 0; i < NX; ++i) { ox[i] = (has_v && sv == i) ? T(1) : T(0); ls[i] = HL * (VXR ? lam[i] : ldsLam[i]); }
 #pragma unroll
         for (int a = 0; a < NU; ++a) ou[a] = (lane == LX + a) ? T(1) : T(0);
         M::ham_hess_mul(tk(k), xk, uk, ls, e, c, ox, ou, hx, hu);
@@ -1394,7 +1395,7 @@ template <class M, typename T, int G, bool EXACT, bool BND = false> struct OcSol
         for (int kk = 0; kk < NX; ++kk) mfma4b(m[kk], yn[kk], acc);
       }
       T Qg = mq, gl = mq;
-      if constexpr (MM) {
+      if constexpr (VXR) {
 #pragma unroll
         for (int i = 0; i < NX; ++i) { Qg += m[i] * Vx[i]; gl += m[i] * lam[i]; }
       } else {                                     // fp64: V_x and the costate stay in LDS (52 registers less through the stage)
@@ -1496,11 +1497,11 @@ template <class M, typename T, int G, bool EXACT, bool BND = false> struct OcSol
 #pragma unroll
         for (int a = 0; a < NU; ++a) { sacc += ldsK[i * NU + a] * t1[a]; sacc += ldsQux[i * NU + a] * Kj[a]; }      // (two FMAs; one statement compiles to mul + fma + add)
         vcol[i] = sacc;
-        if (MM) { Vx[i] = ldsVx[i]; lam[i] = ldsLam[i]; }
+        if (VXR) { Vx[i] = ldsVx[i]; lam[i] = ldsLam[i]; }
       }
       if (lane == 0 && live) {
 #pragma unroll
-        for (int i = 0; i < NX; ++i) lam_out[k * NX + i] = MM ? lam[i] : ldsLam[i];
+        for (int i = 0; i < NX; ++i) lam_out[k * NX + i] = VXR ? lam[i] : ldsLam[i];
       }
       LFSD_BWC(4)                                  // gains to LDS / HBM, V_xx update
       // symmetrise V_xx through LDS (the rank-1 feeds rely on row i == column i)

@@ -42,6 +42,7 @@ VARIANTS = {
     "nolive64": (("-DLFSD_FP64_LIVE=0",), None, False),
     "nopark64": (("-DLFSD_FP64_PARK=0",), None, False),
     "nosc64": (("-DLFSD_FP64_SC=0",), None, False),
+    "vxlds": (("-DLFSD_SC_VX_LDS=1",), None, False),
     "pflate": (("-DLFSD_BW_PREFETCH=2",), None, False),
     "pflateclock": (("-DLFSD_BW_PREFETCH=2", "-DLFSD_BW_CLOCK=1"), None, False),
 }
