@@ -371,8 +371,15 @@ template <class M, typename T, int G, bool EXACT, bool BND = false> struct OcSol
 #pragma unroll
     for (int i = 0; i < NX; ++i) x[i] = x0[i];
     const int col = ZC_ + lane;          // lanes >= LIVE: col >= NXU, a zero tangent that is never stored
+#if defined(LFSD_OC_CLOCK) && !defined(LFSD_EMU)      // diagnostic build (tools/oc_clock64.py): clocks of control law | RK4 steps | stores, per roll-out
+    long long rck[3] = {0, 0, 0}, rck_t = clock64();
+#define LFSD_RCK(i) { const long long t_ = clock64(); rck[i] += t_ - rck_t; rck_t = t_; }
+#else
+#define LFSD_RCK(i)
+#endif
     for (int k = 0; k < N; ++k) {
       control(cur, k, x, alpha, gains, u);
+      LFSD_RCK(0)
       if (lane == 0) {
 #pragma unroll
         for (int i = 0; i < NX; ++i) xbp(nxt)[k * NX + i] = x[i];
@@ -391,6 +398,7 @@ template <class M, typename T, int G, bool EXACT, bool BND = false> struct OcSol
         if (LFSD_FP64_PARK) rk4_step_parked<ZC_>(t, x, q, u, m, mq, du, qz);
         else rk4_step<true, T, ZC_>(t, x, q, u, m, mq, du, qz);
       }
+      LFSD_RCK(1)
       J += q;
       if constexpr (SCL) {
         T* Ms = Mwp(nxt) + (long long)k * Lay::MS_ELEMS;
@@ -403,6 +411,7 @@ template <class M, typename T, int G, bool EXACT, bool BND = false> struct OcSol
 #pragma unroll
           for (int z = 0; z < ZC_; ++z) Ms[(NX + 1) * Lay::LIVEP + z] = qz[z];
         }
+        LFSD_RCK(2)
         continue;
       }
       T* Mk = Mwp(nxt) + (long long)k * Lay::M_ELEMS;
@@ -425,6 +434,10 @@ template <class M, typename T, int G, bool EXACT, bool BND = false> struct OcSol
       for (int i = 0; i < NX; ++i) xbp(nxt)[N * NX + i] = x[i];
     }
     J += M::final_cost(tk(N), x, e, c);
+#if defined(LFSD_OC_CLOCK) && !defined(LFSD_EMU)
+    if (threadIdx.x == 0 && blockIdx.x == 0) printf("rollout clock (wave 0): S %d intervals %d control %lld steps %lld stores %lld\n", S, N, rck[0], rck[1], rck[2]);
+#endif
+#undef LFSD_RCK
     return J;
   }
 
