@@ -331,6 +331,29 @@ def test_quadalgorithm_driver_replays_reference_run_start(emu):
         S.load_optimization_function({"learning_rate": 0.01, "iter_num": 3, "method": "RMSprop"})
 
 
+def test_rocket_lean_kernels_fp64_vs_fp32_same_iterates(emu, monkeypatch):
+    """The lean lock-step kernels on the rocket's dimensions (13 live columns of 16, 3 constant states, 3 controls -- the
+    quadrotor has 14 / 3 / 4; the rocket's default solve is Newton from the first iteration on the wide kernel and never
+    gets here): the same six Gauss-Newton / Hamiltonian iterations from a cold start, no exact-Hessian phase, in fp64
+    (live-column roll-out, parked RK4 step, one-pass structural sweep with LDS-fed products) and in fp32 (packed roll-out,
+    structural sweep on the emulated matrix cores).  Same step control, same path: after six iterations -- far from
+    converged, cost 1.1e4 and 3.8e2 -- the iterates agree to the fp32 class (measured: cost 1.7e-6, states 1e-5)."""
+    monkeypatch.setattr(CPDP.COCSys, "mapping_override", "lockstep")
+    oc, env, d = models.rocket(n_grid=15)
+    emu(oc)
+    oc.setSolverOptions(max_iter=6, exact_after=-1)
+    th = np.array([d["true_theta"], d["theta0"]], dtype=float)
+    x0 = np.tile(d["ini_state"], (2, 1))
+    out = {}
+    for dt in (torch.float64, torch.float32):
+        oc.setDevice(dtype=dt)
+        out[dt] = oc.cocSolverBatch(x0, d["horizon"], th)
+        assert (out[dt]["iters"] == 6).all() and (out[dt]["status"] == 3).all(), (dt, out[dt]["iters"], out[dt]["status"])
+    l64, l32 = out[torch.float64], out[torch.float32]
+    assert rel(l32["cost"].double(), l64["cost"]) < 2e-5
+    assert rel(l32["state_grid"].double(), l64["state_grid"]) < 2e-4 and rel(l32["control_grid"].double(), l64["control_grid"]) < 2e-3
+
+
 def test_rocket_newton_mode_vs_oracle(emu):
     """Examples/rocket_groundtruth.py (6-DoF powered landing, T=3): needs the exact stage Hessians (second-order
     adjoint through the RK4 stages) from the first iteration.  The problem has several local minima and which one a

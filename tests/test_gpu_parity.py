@@ -337,6 +337,33 @@ def test_rocket_newton_mode_vs_oracle(oc_mapping):
     assert rel(sol2["state_grid"][0], r0[2]) < 1e-6 and rel(sol2["costate_grid"][0], r0[4]) < 1e-5
 
 
+def test_rocket_lean_kernels_fp64_vs_fp32_same_iterates(monkeypatch):
+    """The lean lock-step kernels on the rocket's dimensions (13 live columns, 3 constant states, 3 controls; the rocket's
+    default solve never gets here): six Gauss-Newton / Hamiltonian iterations from a cold start in fp64 (live-column roll-out,
+    parked RK4 step, one-pass structural sweep with LDS-fed products) and in fp32 (packed roll-out, structural sweep on the
+    matrix cores) walk the same path -- ragged batch of 6 (one full wavefront of four + a partial one)."""
+    monkeypatch.setattr(CPDP.COCSys, "mapping_override", "lockstep")
+    oc, env, d = models.rocket(n_grid=15)
+    oc.setSolverOptions(max_iter=6, exact_after=-1)
+    rng = np.random.default_rng(3)
+    th = np.array([d["true_theta"], d["theta0"]] * 3, dtype=float) * (1 + 0.03 * rng.standard_normal((6, len(d["theta0"]))))
+    x0 = np.tile(d["ini_state"], (6, 1))
+    out = {}
+    for dt in (torch.float64, torch.float32):
+        gpu_prepare(oc, dt)
+        out[dt] = oc.cocSolverBatch(x0, d["horizon"], th)
+        assert (out[dt]["iters"] == 6).all() and (out[dt]["status"] == 3).all(), (dt, out[dt]["iters"], out[dt]["status"])
+    l64, l32 = out[torch.float64], out[torch.float32]
+    what = "rocket lean kernels, fp32 vs fp64 after 6 iterations"
+    # (measured on MI355X and, identically, in the CPU emulator: cost 3.1e-4, states 2.5e-4 -- one of the six trajectories,
+    #  at cost 1.4e4 after iteration 4, takes a marginally different step in fp32; the other five agree to 6e-6)
+    parity_record(what, "cost", rel(l32["cost"].double(), l64["cost"].cpu().numpy()), 3e-3)
+    parity_record(what, "state grid", rel(l32["state_grid"].double(), l64["state_grid"].cpu().numpy()), 3e-3)
+    parity_record(what, "control grid", rel(l32["control_grid"].double(), l64["control_grid"].cpu().numpy()), 3e-2)
+    c64, c32 = l64["cost"].cpu().numpy(), l32["cost"].double().cpu().numpy()
+    assert np.median(np.abs(c32 - c64) / np.abs(c64)) < 2e-5
+
+
 def test_rocket_fp32_solve_fp64_aux_vs_oracle(oc_mapping):
     """The mixed-precision path of BASELINE configs[4] (setDevice(aux_dtype=float64), CPDP.py:247-250 of this package)."""
     pc.rocket_mixed_precision(gpu_prepare)
