@@ -64,3 +64,55 @@ def test_kkt_certificate_other_robots():
         assert oc.last_info["converged"], kind
         defect, gmax, lmax = oc.kkt_certificate(x0, T, th, X, U, L)
         assert defect < 1e-10 and gmax < 1e-6 and lmax < 1e-7, (kind, defect, gmax, lmax)
+
+
+# ---- the robot models against the reference's own source text (tests/golden/jinenv_points.npz) --------------------------
+def _jinenv_cases():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_jinenv_golden", os.path.join(os.path.dirname(__file__), "golden",
+                                                                                      "make_jinenv_golden.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)             # (defines CASES / GOAL / evaluate; its main() is not run and nothing reads /root/reference)
+    return mod
+
+
+_JG = _jinenv_cases()
+_JP = np.load(os.path.join(os.path.dirname(__file__), "golden", "jinenv_points.npz"))
+
+
+@pytest.mark.parametrize("case", _JG.CASES, ids=[c[0] for c in _JG.CASES])
+@pytest.mark.parametrize("which", ["oracle", "product"])
+def test_jinenv_models_equal_the_reference_text(case, which):
+    """f, path_cost and final_cost of every initDyn / initCost* variant of the five robots, at 16 random points each, equal
+    what the reference's JinEnv.py (JinEnv/JinEnv.py:40-1575, evaluated through a sympy stand-in for casadi by
+    tests/golden/make_jinenv_golden.py) gives -- for the oracle's restatement (oracle/jinenv_sym.py) and for the product's
+    (learning-from-sparse-demonstrations_amd/JinEnv.py), which were written separately.  Same ordering of the learnable
+    parameters included: the points carry the parameter vector in the reference's order."""
+    name, cls, dyn_kw, cost_fn, cost_kw, wants_goal = case
+    subs = None
+    if which == "oracle":
+        from oracle import jinenv_sym as J
+        env = getattr(J, cls)()
+        env.initDyn(**dyn_kw)
+        if wants_goal:
+            g = _JG.GOAL
+            getattr(env, cost_fn)(g["position"], g["velocity"], g["attitude_quaternion"], g["angular_velocity"], **cost_kw)
+        else:
+            getattr(env, cost_fn)(**cost_kw)
+    else:
+        import lfsd_amd  # noqa: F401
+        from lfsd_amd import JinEnv as J, symbolic
+        env = getattr(J, cls)()
+        env.initDyn(**dyn_kw)
+        if wants_goal:
+            getattr(env, cost_fn)(J.QuadStates(**_JG.GOAL), **cost_kw)
+        else:
+            getattr(env, cost_fn)(**cost_kw)
+        free = set().union(*[e.free_symbols for e in list(env.f) + [env.path_cost, env.final_cost]])
+        subs = {s: symbolic.const_default(s) for s in free if symbolic.is_const(s)}      # run-time constants at their values
+    pts = {k: _JP["%s/%s" % (name, k)] for k in ("X", "U", "D", "E")}
+    f, pc, fc = _JG.evaluate(env, pts, subs=subs)
+    for got, key in ((f, "f"), (pc, "path_cost"), (fc, "final_cost")):
+        ref = _JP["%s/%s" % (name, key)]
+        err = np.abs(got - ref).max() / max(1.0, np.abs(ref).max())
+        assert err < 1e-12, "%s %s %s: %.3e" % (which, name, key, err)
