@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define LFSD_ABI_VERSION 7
+#define LFSD_ABI_VERSION 8
 #define LFSD_F32 0
 #define LFSD_F64 1
 #define LFSD_EINVAL (-1)   /* bad argument (null pointer, non-positive size, unknown enum) */
@@ -124,7 +124,14 @@ int lfsd_coc_solve(int dtype, int batch, int n_grid, int steps_per_grid,
  *   stats   [B][4] int32 or NULL: per trajectory, {split units executed by the Riccati sweep (rejected attempts included),
  *           intervals of it that were accepted ABOVE rtol because refinement stopped gaining (next to a conjugate point) or hit
  *           its cap, the same two numbers of the forward sweep}.  A non-zero second or fourth entry marks a loss / gradient
- *           whose error estimate exceeds the tolerance asked for.                                */
+ *           whose error estimate exceeds the tolerance asked for.
+ *   oc_status [B] int32 or NULL, skip_status_mask (ABI 8): the status[] lfsd_coc_solve wrote for these trajectories and a
+ *           bit mask over its values (bit s set = skip rows with status s, e.g. 1 << LFSD_ST_FAILED).  A skipped row costs
+ *           nothing: neither sweep runs for it, its loss and gradient are NaN, its stats 0, its Z_grid / auxX / auxU rows
+ *           are left untouched.  Without it a solve that FAILED (non-finite grids) or ran out of iterations on a problem
+ *           without a minimiser still goes through the error-controlled sweeps, refines to the cap and holds its launch
+ *           many times longer than the well-posed batch needs.  NULL (or mask 0): every row is differentiated, as the
+ *           reference does.                                                                   */
 int lfsd_aux_solve(int dtype, int batch, int n_grid,
                    const void* horizon, const void* auxvar, const void* consts, int const_per_traj,
                    const void* state_grid, const void* control_grid, const void* costate_grid,
@@ -132,7 +139,8 @@ int lfsd_aux_solve(int dtype, int batch, int n_grid,
                    int n_waypoints, int n_iface, const int* iface_idx,
                    const void* taus, const void* waypoints,
                    void* loss, void* grad, void* auxX_grid, void* auxU_grid,
-                   int substeps, double rtol, int* stats, void* stream);
+                   int substeps, double rtol, int* stats,
+                   const int* oc_status, int skip_status_mask, void* stream);
 
 /* The two phases of lfsd_aux_solve as separate launches (same arguments; lfsd_aux_solve == riccati then forward):
  *   lfsd_aux_riccati  CPDP/CPDP.py:316-338  backward Riccati sweep, fills Z_grid
@@ -140,7 +148,8 @@ int lfsd_aux_solve(int dtype, int batch, int n_grid,
 int lfsd_aux_riccati(int dtype, int batch, int n_grid,
                      const void* horizon, const void* auxvar, const void* consts, int const_per_traj,
                      const void* state_grid, const void* control_grid, const void* costate_grid,
-                     void* Z_grid, int substeps, double rtol, int* stats, void* stream);
+                     void* Z_grid, int substeps, double rtol, int* stats,
+                     const int* oc_status, int skip_status_mask, void* stream);
 int lfsd_aux_forward(int dtype, int batch, int n_grid,
                      const void* horizon, const void* auxvar, const void* consts, int const_per_traj,
                      const void* state_grid, const void* control_grid, const void* costate_grid,
@@ -148,7 +157,8 @@ int lfsd_aux_forward(int dtype, int batch, int n_grid,
                      int n_waypoints, int n_iface, const int* iface_idx,
                      const void* taus, const void* waypoints,
                      void* loss, void* grad, void* auxX_grid, void* auxU_grid,
-                     int substeps, double rtol, int* stats, void* stream);
+                     int substeps, double rtol, int* stats,
+                     const int* oc_status, int skip_status_mask, void* stream);
 
 /* theta <- update(theta, grad) for every trajectory; m/v/vhat are optimizer state [B][n_param]
  * (m: Nesterov velocity or first moment; v: second moment; vhat: AMSGrad max; unused ones may be NULL).

@@ -282,8 +282,20 @@ class COCSys:
         lu <- max(0, lu + rho (x - ub)), ll <- max(0, ll + rho (lb - x)); rho grows when the worst violation of the batch
         shrinks by less than 4x.  Done when every node of every trajectory is feasible to `state_tol` and the multipliers
         have stopped moving: the last subproblem's stationarity is then the KKT condition of the bounded NLP, with
-        lu - ll the bound multipliers (IPOPT's lam_x) and the returned costates the dynamics multipliers (lam_g)."""
+        lu - ll the bound multipliers (IPOPT's lam_x) and the returned costates the dynamics multipliers (lam_g).
+
+        Failure is reported per trajectory, as IPOPT would (infeasible problem / iteration limit): when the loop ends
+        without meeting that test, every row that is still infeasible beyond `state_tol`, or whose last subproblem did not
+        end CONVERGED / STALLED, gets status 3 (MAXITER) -- `mask_unconverged`, `cocSolver` and the tests decide on
+        `status` alone.  The reference puts the bounds on X_0 as well (CPDP.py:126-134), so an `ini_state` outside a
+        finite box makes its NLP infeasible: that raises here.  The returned `cost` is the AUGMENTED value of the last
+        subproblem -- objective + multiplier terms, which at a node that violates its bound by g estimates the optimal value
+        to O(g^2) where the plain objective of the (slightly infeasible) iterate is off by lambda g (measured against the
+        independent SLSQP solve: 6e-12 against 1.5e-8); `cost_objective` is the plain objective of the returned grids."""
         B, n, N = x0.shape[0], lib.n_state, self.n_grid
+        if bool(((x0 < slb) | (x0 > sub)).any()):
+            raise LfsdError("ini_state violates the state bounds: the reference's NLP bounds X_0 too (CPDP.py:126-134) "
+                            "and is infeasible")
         if clb is None:                     # the bounded kernel reads both boxes
             clb, cub = self._t(lib.n_control * [-1e20]), self._t(lib.n_control * [1e20])
         mult = torch.zeros((B, N, 2, n), dtype=x0.dtype, device=x0.device)
@@ -292,6 +304,7 @@ class COCSys:
         scale = 1.0 + float(finite.abs().max())
         tol = self.state_tol if self.state_tol is not None else (1e-7 if x0.dtype == torch.float64 else 1e-4)
         viol_prev, iters_total, sol = None, None, None
+        met, viol_b = False, None
         for outer in range(int(self.state_max_outer)):
             sol = lib.coc_solve(x0, hz, th, consts, self.n_grid, self.steps_per_grid, u_init=u_init, workspace=workspace,
                                 out=out, control_lb=clb, control_ub=cub, state_lb=slb, state_ub=sub, state_mult=mult,
@@ -304,17 +317,27 @@ class COCSys:
             new_u = torch.clamp(mult[:, :, 0] + rho * gu, min=0.0)
             new_l = torch.clamp(mult[:, :, 1] + rho * gl, min=0.0)
             moved = max(float((new_u - mult[:, :, 0]).abs().max()), float((new_l - mult[:, :, 1]).abs().max()))
+            # the plain objective: the node terms the kernel added, at the multipliers and penalty it was called with
+            pen = ((torch.clamp(mult[:, :, 0] + rho * gu, min=0.0) ** 2 - mult[:, :, 0] ** 2
+                    + torch.clamp(mult[:, :, 1] + rho * gl, min=0.0) ** 2 - mult[:, :, 1] ** 2) / (2.0 * rho)).sum(dim=(1, 2))
             mult = torch.stack((new_u, new_l), dim=2).contiguous()
-            viol = float(torch.clamp(torch.maximum(gu, gl), min=0.0).max())
+            viol_b = torch.clamp(torch.maximum(gu, gl), min=0.0).amax(dim=(1, 2))       # per trajectory
+            viol = float(viol_b.max())
             solved = bool(((sol["status"] == 1) | (sol["status"] == 2)).all())
             if solved and viol <= tol * scale and moved <= tol * scale * rho:
+                met = True
                 break
             if viol_prev is not None and viol > 0.25 * viol_prev and rho < 1e8:
                 rho *= float(self.state_rho_growth)
             viol_prev = viol
             u_init = sol["control_grid"][:, :-1].contiguous()
         sol["iters"] = iters_total
+        sol["cost_objective"] = sol["cost"] - pen.to(sol["cost"].dtype)
+        if not met:         # outer-iteration limit or penalty cap: infeasible / non-KKT rows must not pass for solved
+            bad = (viol_b > tol * scale) | ~((sol["status"] == 1) | (sol["status"] == 2))
+            sol["status"] = torch.where(bad & (sol["status"] != 4), torch.full_like(sol["status"], 3), sol["status"])
         sol["state_mult"], sol["state_rho"], sol["al_outer"], sol["state_violation"] = mult, rho, outer + 1, viol
+        sol["state_violation_rows"] = viol_b
         return sol
 
     def check_waypoints(self, taus, horizon, interface_idx):
@@ -332,8 +355,12 @@ class COCSys:
             raise ValueError("A value in taus is outside the interpolation range [0, horizon].")
 
     def auxSysSolverBatch(self, sol, taus=None, waypoints=None, interface_idx=None, auxvar=None, want_grids=False,
-                          Z_grid=None, out=None, phase_hook=None, validate=True):
-        """Differentiate the PMP along ``sol`` and (optionally) evaluate the sparse-waypoint loss + gradient."""
+                          Z_grid=None, out=None, phase_hook=None, validate=True, skip_status=None):
+        """Differentiate the PMP along ``sol`` and (optionally) evaluate the sparse-waypoint loss + gradient.
+        ``skip_status``: OC-solve statuses whose rows are NOT differentiated (NaN loss / gradient, no sweep).  Default:
+        FAILED (4) only -- a solve that ended with non-finite grids has nothing to differentiate and would otherwise hold
+        the launch at the refinement cap; a solve at the iteration limit (3) is differentiated as the reference does,
+        unless the caller (SparseDemoLearner with skip_unconverged) says otherwise."""
         lib = self.compile()
         B = sol["state_grid"].shape[0]
         th = sol["auxvar"] if auxvar is None else self._t(auxvar, (B, lib.n_auxvar))
@@ -353,8 +380,14 @@ class COCSys:
         if ad is not None and ad != X.dtype:          # mixed precision: promote the solved grids for the aux pass
             cv = lambda t: None if t is None else t.to(ad).contiguous()
             hz, th, cs, X, U, Lm, tt, wp = (cv(t) for t in (hz, th, cs, X, U, Lm, tt, wp))
+        status = sol.get("status")
+        if skip_status is None:
+            skip_status = (4,)
+        if status is None:
+            skip_status = ()
         return lib.aux_solve(hz, th, cs, X, U, Lm, tt, wp, ii, substeps=self.aux_substeps, want_grids=want_grids,
-                             Z_grid=Z_grid, out=out, phase_hook=phase_hook, rtol=self.aux_rtol)
+                             Z_grid=Z_grid, out=out, phase_hook=phase_hook, rtol=self.aux_rtol, oc_status=status,
+                             skip_status=skip_status)
 
     # ---- the reference's one-trajectory calls --------------------------------------------------------
     def cocSolver(self, ini_state, horizon, auxvar_value=1, interplation_level=1, print_level=0):
@@ -499,8 +532,11 @@ class SparseDemoLearner:
                                            workspace=self._ws, out=self._sol_out())
         self._ws = self._sol["workspace"]
         phase = None if hook is None else (lambda nm: hook("aux_" + nm) if nm != "end" else None)
+        # a learner that freezes unconverged rows anyway does not pay for differentiating them (they are masked by their
+        # status below): the diverged seeds of a fixed learning rate otherwise hold the Riccati launch 20x longer
         self._aux = self.oc.auxSysSolverBatch(self._sol, self.taus, self.wps, self.iface, Z_grid=self._Z,
-                                              out=self._aux_out(), phase_hook=phase, validate=False)
+                                              out=self._aux_out(), phase_hook=phase, validate=False,
+                                              skip_status=(3, 4) if self.skip_unconverged else None)
         self._Z = self._aux["Z_grid"]
         loss, grad = self._aux["loss"].to(self.theta.dtype), self._aux["grad"].to(self.theta.dtype)
         if self.skip_unconverged:

@@ -26,7 +26,7 @@ import hashlib
 import sympy as sp
 from sympy.printing.c import C99CodePrinter
 
-CODEGEN_VERSION = 11
+CODEGEN_VERSION = 12
 
 
 class ModelSpec:
@@ -202,26 +202,32 @@ def _nz(e):
 
 
 class _Sparse:
-    """Structurally sparse matrix packed into the coefficient array, start aligned to 16 bytes.  Two packing orders
-    over the same slots: layout 0 (Riccati sweep) and layout 1 (forward sweep) each store the matrix in the order
-    ('r'ow- or 'c'olumn-major) in which that kernel's hot operator walks it, so the reads are contiguous LDS words."""
+    """Structurally sparse matrix packed into the coefficient array, start aligned to 16 bytes.  Two packings: layout 0
+    (Riccati sweep) and layout 1 (forward sweep) each store the matrix in the order ('r'ow- or 'c'olumn-major) in which
+    that kernel's hot operator walks it, so the reads are contiguous LDS words -- and each at its own offset: a layout
+    only holds the matrices its kernel applies ('-' in `orders`: not staged; the forward sweep never touches Hxx / Hxe)."""
 
-    def __init__(self, name, mat, off, orders):
+    def __init__(self, name, mat, offs, orders):
         self.name, self.mat = name, mat
-        off = (off + 3) // 4 * 4
-        self.off = off
         rc = [(r, c) for r in range(mat.shape[0]) for c in range(mat.shape[1]) if _nz(mat[r, c])]
-        self.lay = []
-        for o in orders:
+        self.nnz = len(rc)
+        self.lay, self.off, self.end = [], [], []
+        for off, o in zip(offs, orders):
+            if o == '-':
+                self.lay.append(None); self.off.append(None); self.end.append(off)
+                continue
+            off = (off + 3) // 4 * 4
             seq = rc if o == 'r' else sorted(rc, key=lambda t: (t[1], t[0]))
             self.lay.append([(r, c, off + i, mat[r, c]) for i, (r, c) in enumerate(seq)])
-        self.entries = self.lay[0]
-        self.end = off + len(rc)
+            self.off.append(off)
+            self.end.append(off + len(rc))
 
     def stores(self, lay):
-        return [('L[%d]' % o, ex) for (_, _, o, ex) in self.lay[lay]]
+        return [('L[%d]' % o, ex) for (_, _, o, ex) in (self.lay[lay] or [])]
 
     def _lines(self, lay, transposed):
+        if self.lay[lay] is None:
+            return '      static_assert(LAY != %d, "%s is not staged in this layout");' % (lay, self.name)
         nr, ncol = self.mat.shape
         rows = {}
         for (r, cc, o, _) in sorted(self.lay[lay], key=lambda t: t[2]):
@@ -245,13 +251,13 @@ class _Sparse:
             out.append('  // y[%d] (+)= %s%s * v[%d]   (%d non-zeros; LAY picks the packing the calling kernel staged)\n'
                        '  template<bool ACC, int LAY, class T> static LFSD_DEV void %s_%s(const T* L, const T* v, T* y) {\n'
                        '    if constexpr (LAY == 0) {\n%s\n    } else {\n%s\n    }\n  }'
-                       % (nout, self.name, "^T" if transposed else "", nr if transposed else ncol, len(self.entries),
+                       % (nout, self.name, "^T" if transposed else "", nr if transposed else ncol, self.nnz,
                           self.name, suffix, self._lines(0, transposed), self._lines(1, transposed)))
         return '\n'.join(out)
 
 
 # packing order per matrix: (layout 0 = Riccati sweep, layout 1 = forward sweep)
-_ORDERS = {'fx': 'cr', 'fu': 'cr', 'fe': 'cr', 'Hxx': 'rr', 'Hxu': 'rc', 'Hxe': 'rr', 'Hue': 'cr'}
+_ORDERS = {'fx': 'cr', 'fu': 'cr', 'fe': 'cr', 'Hxx': 'r-', 'Hxu': 'rc', 'Hxe': 'r-', 'Hue': 'cr'}
 
 
 def emit_header(spec):
@@ -383,37 +389,58 @@ def emit_header(spec):
     S.append('  template<class T> static LFSD_DEV void ham_huu(%s, T* Huu_out) {' % sig_xul)
     S.append(_body(_loads(spec, with_l=True), [('Huu_out[%d]' % (a * m + b), Huu[a, b]) for a in range(m) for b in range(m)]))
     S.append('  }')
-    # 5. packed PMP coefficients
+    # 5. packed PMP coefficients, one packing per layout (0: Riccati sweep, every matrix; 1: forward sweep, without Hxx / Hxe)
     mats = []
-    off = 0
+    offs = [0, 0]
     for nm, mat in (('fx', fx), ('fu', fu), ('fe', fe), ('Hxx', Hxx), ('Hxu', Hxu), ('Hxe', Hxe), ('Hue', Hue)):
-        sm = _Sparse(nm, mat, off, _ORDERS[nm])
+        sm = _Sparse(nm, mat, offs, _ORDERS[nm])
         mats.append(sm)
-        off = sm.end
-    off_huu = (off + 3) // 4 * 4
-    off_ihuu = (off_huu + m * m + 3) // 4 * 4
-    off_zero = off_ihuu + m * m                 # one word that always holds 0 (gather target of structural zeros)
-    ncoef = ((off_zero + 1 + 3) // 4) * 4
-    S.append('  static constexpr int OFF_HUU = %d, OFF_IHUU = %d, OFF_ZERO = %d, NCOEF = %d;' % (off_huu, off_ihuu, off_zero, ncoef))
-    S.append('  // packed (16-byte aligned starts): ' + ', '.join('%s[%d..%d)' % (sm.name, sm.off, sm.end) for sm in mats) +
-             ', Huu dense, Huu^-1 dense (filled by the kernel)')
+        offs = list(sm.end)
+    off_huu = [(o + 3) // 4 * 4 for o in offs]
+    off_ihuu = [(o + m * m + 3) // 4 * 4 for o in off_huu]
+    off_zero = [o + m * m for o in off_ihuu]    # one word that always holds 0 (gather target of structural zeros)
+    ncoef = [((o + 1 + 3) // 4) * 4 for o in off_zero]
+    # A diagonal Huu (control cost separable in the controls, dynamics affine in them: every model of the zoo) is inverted
+    # in closed form by the staging lane's own pmp_coeffs; a general Huu is inverted by the kernel (mat_inverse)
+    ihuu_closed = all(not _nz(Huu[a, b]) for a in range(m) for b in range(m) if a != b)
+    pair = lambda v: '{%d, %d}' % (v[0], v[1])
+    S.append('  static constexpr int OFF_HUU_L[2] = %s, OFF_IHUU_L[2] = %s, OFF_ZERO_L[2] = %s, NCOEF_L[2] = %s;'
+             % (pair(off_huu), pair(off_ihuu), pair(off_zero), pair(ncoef)))
+    S.append('  static constexpr int OFF_HUU = %d, OFF_IHUU = %d, OFF_ZERO = %d, NCOEF = %d;      // layout 0'
+             % (off_huu[0], off_ihuu[0], off_zero[0], ncoef[0]))
+    S.append('  static constexpr bool IHUU_CLOSED = %s;      // Huu diagonal: pmp_coeffs stores Huu^-1 as well' % ('true' if ihuu_closed else 'false'))
+    for lay in (0, 1):
+        S.append('  // layout %d, packed (16-byte aligned starts): ' % lay +
+                 ', '.join('%s[%d..%d)' % (sm.name, sm.off[lay], sm.end[lay]) for sm in mats if sm.lay[lay] is not None) +
+                 ', Huu dense @%d, Huu^-1 dense @%d' % (off_huu[lay], off_ihuu[lay]))
     S.append('  template<int LAY, class T> static LFSD_DEV void pmp_coeffs(%s, T* L) {' % sig_xul)
     for lay in (0, 1):
         outs = []
         for sm in mats:
             outs += sm.stores(lay)
-        outs += [('L[%d]' % (off_huu + a * m + b), Huu[a, b]) for a in range(m) for b in range(m)]
-        outs += [('L[%d]' % off_zero, sp.Integer(0))]
+        outs += [('L[%d]' % (off_huu[lay] + a * m + b), Huu[a, b]) for a in range(m) for b in range(m)]
+        if ihuu_closed:
+            outs += [('L[%d]' % (off_ihuu[lay] + a * m + b), (1 / Huu[a, a]) if a == b else sp.Integer(0))
+                     for a in range(m) for b in range(m)]
+        outs += [('L[%d]' % off_zero[lay], sp.Integer(0))]
         S.append('    %s (LAY == %d) {' % ('if constexpr' if lay == 0 else '} else', lay) if lay == 0 else '    } else {')
         S.append(_body(_loads(spec, with_l=True), outs, indent='      '))
     S.append('    }')
+    S.append('  }')
+    # y = Huu^-1 v from the staged inverse: m products when Huu is diagonal, a dense m x m product otherwise
+    S.append('  template<int LAY, class T> static LFSD_DEV void ihuu_mul(const T* L, const T* v, T* y) {')
+    S.append('    const T* iH = L + OFF_IHUU_L[LAY];')
+    if ihuu_closed:
+        S.append('\n'.join('    y[%d] = iH[%d]*v[%d];' % (a, a * m + a, a) for a in range(m)))
+    else:
+        S.append('\n'.join('    y[%d] = %s;' % (a, ' + '.join('iH[%d]*v[%d]' % (a * m + b, b) for b in range(m))) for a in range(m)))
     S.append('  }')
     for sm in mats:
         S.append(sm.emit_ops())
     # packed offset of fx[r][c] per layout, OFF_ZERO for a structural zero: lets a lane gather ITS column of fx as a dense
     # vector -- the operand layout of the matrix-core experiment in the Riccati sweep (cpdp_aux.h, LFSD_RIC_MFMA)
     for lay in (0, 1):
-        tab = [off_zero] * (n * n)
+        tab = [off_zero[lay]] * (n * n)
         for (r, cc, o, _) in mats[0].lay[lay]:
             tab[r * n + cc] = o
         S.append('  static LFSD_DEV int fx_off%d(int r, int c) { constexpr short tab[%d] = {%s}; return tab[r * %d + c]; }'

@@ -40,18 +40,24 @@ template <typename T> struct AuxArgs {
   T* auxX_grid;                   // [B][N+1][NP][NX] or nullptr  (dx/dtheta, column-major)
   T* auxU_grid;                   // [B][N+1][NP][NU] or nullptr
   int* stats;                     // [B][4] or nullptr: split units executed and intervals accepted ABOVE rtol, Riccati | forward sweep
+  const int* oc_status;           // [B] or nullptr: status of the OC solve; rows whose status bit is set in skip_mask are not
+  int skip_mask;                  // differentiated (no sweep, NaN loss / gradient): include/lfsd_cpdp.h, ABI 8
+  LFSD_DEV bool skipped(long long traj) const { return oc_status != nullptr && ((skip_mask >> (oc_status[traj] & 31)) & 1) != 0; }
 };
 
-template <class M> struct AuxLayout {
+// LAY: which packing of the staged coefficients the kernel uses (codegen: 0 Riccati sweep, every matrix; 1 forward sweep,
+// without Hxx / Hxe) -- the node stride NCOEF and every offset behind it follow
+template <class M, int LAY = 0> struct AuxLayout {
   static constexpr int NX = M::NX, NU = M::NU, NP = M::NP, NZ = NX + NP, NNODE = 5;
+  static constexpr int NCOEF = M::NCOEF_L[LAY];
   static constexpr int LDS_L = 0;
-  static constexpr int LDS_S = LDS_L + NNODE * M::NCOEF;
+  static constexpr int LDS_S = LDS_L + NNODE * NCOEF;
   static constexpr int LDS_T = LDS_S + NX * NU;
   // LDS_T (transposed exchange of the Riccati right-hand side) and LDS_KN/LDS_PSI (forward sweep) share one region:
   // each kernel uses only its own
   static constexpr int LDS_KN = LDS_T;                        // 3 stiff nodes x (NX x NU) feedback rows K^T
   static constexpr int LDS_PSI = LDS_KN + 3 * NX * NU;        // 3 stiff nodes x {phi1(h/4 K fu), phi1(h/2 K fu)}
-  static constexpr int LDS_TSZ0 = (NX * NZ > 3 * NX * NU + 6 * NU * NU ? NX * NZ : 3 * NX * NU + 6 * NU * NU);
+  static constexpr int LDS_TSZ0 = (LAY == 0) ? NX * NZ : 3 * NX * NU + 6 * NU * NU;
   static constexpr int LDS_TSZ = LDS_TSZ0 > 128 ? LDS_TSZ0 : 128;      // (>= 2 x 64: the error reduction of the step control)
   static constexpr int LDS_E = LDS_T + LDS_TSZ;
                                                               // cold per-trajectory state: auxvar, consts,
@@ -60,12 +66,18 @@ template <class M> struct AuxLayout {
   static constexpr int LDS_GB = LDS_GA + 2 * NX + NU;         // [x_k+1 u_k+1 l_k+1]
   static constexpr int LDS_END = LDS_GB + 2 * NX + NU;
   static constexpr int lds_elems() { return ((LDS_END + 3) / 4) * 4; }
-  // forward kernel only: parking slot for X(t_k) (row i of column j at [i*NP + j])
-  // ... plus, per node and column, the X-independent part of the right-hand side (fe - fu Huu^-1 (fu^T W + Hue)) e_j
-  // ... plus the P columns at both ends of the interval ([end][column][row], and one zero row that lanes without a P
-  // column point at): they are needed three times per unit only, too cold for 2*NX registers per lane
-  static constexpr int FWD_P = NX * NP + NNODE * NX * NP;                 // offset of that block behind LDS_END
-  template <int G> static constexpr int lds_elems_fwd() { return ((LDS_END + FWD_P + 2 * NX * NX + NX + 3) / 4) * 4; }
+  // forward kernel only, behind LDS_END:
+  static constexpr int FWD_XPREV = LDS_END;                   // parking slot for X(t_k) (row i of column j at [i*NP + j])
+  // ... per node and column, the X-independent part of the right-hand side (fe - fu Huu^-1 (fu^T W + Hue)) e_j
+  static constexpr int FWD_BC = FWD_XPREV + NX * NP;
+  // ... the P columns at both ends of the interval ([end][column][row], and one zero row that lanes without a P column
+  // point at): they are needed three times per unit only, too cold for 2*NX registers per lane
+  static constexpr int FWD_P = FWD_BC + NNODE * NX * NP;
+  // ... the hand-over of the two Richardson chains, which run on different lanes ([chain][row][column])
+  static constexpr int FWD_XCH = FWD_P + 2 * NX * NX + NX;
+  // ... and the reductions of the step control (one word per lane, twice)
+  static constexpr int FWD_RED = FWD_XCH + 2 * NX * NP;
+  static constexpr int lds_elems_fwd() { return ((FWD_RED + 128 + 3) / 4) * 4; }
   // Riccati kernel only: per node and lane, this lane's column of [Hxx Hxe] and of Huu^-1 [Hux Hue]
   static constexpr int RIC_ROWS = LFSD_RIC_CACHE == 1 ? NX + NU : (LFSD_RIC_CACHE == 2 ? NU : 0);
   // ... plus one parking slot per lane for a column of Z (row i of lane l at [i*G + l]): of the unit's start value and
@@ -75,23 +87,27 @@ template <class M> struct AuxLayout {
 };
 
 // Lanes per trajectory of the forward sweep.  Only the NP columns of X = dx/dtheta advance there; the NX columns of P are
-// merely interpolated.  One lane carries P column `lane` (lane < NX) AND X / W column `lane` (lane < NP), so
-// max(NX, NP) lanes are enough (quadrotor: 16 instead of the 32 the Riccati sweep needs for its NX+NP columns).
+// merely interpolated.  The two chains of a Richardson pair run side by side on the two halves of the lane group -- lanes
+// j < NP carry column j through the two fine Strang steps, lanes G/2 + j carry the same column through the coarse one --
+// and lanes < NX double as the owners of P column `lane` where the feedback gains are formed, so max(NX, 2 NP) lanes are
+// needed (quadrotor: 16, four trajectories per wavefront; the Riccati sweep needs 32 for its NX+NP columns).  The m x m
+// matrix functions of the three stiff nodes run row per lane on sub-groups of sub_lanes<NU>() lanes.
 template <class M> constexpr int fwd_lanes() {
-  int need = M::NX > M::NP ? M::NX : M::NP;
-  if (need < AuxLayout<M>::NNODE) need = AuxLayout<M>::NNODE;
+  int need = M::NX > 2 * M::NP ? M::NX : 2 * M::NP;
+  if (need < 5) need = 5;                                      // AuxLayout::NNODE staging lanes
+  if (need < 3 * sub_lanes<M::NU>()) need = 3 * sub_lanes<M::NU>();
   int g = 8;
   while (g < need) g *= 2;
   return g;
 }
 
-// LAY: packing order of the staged coefficients (0: Riccati sweep, transposed operators contiguous; 1: forward sweep)
 template <class M, typename T, int G, int LAY> struct AuxCtx {
   static constexpr int NX = M::NX, NU = M::NU, NP = M::NP, NC = M::NC, NZ = NX + NP;
-  using Lay = AuxLayout<M>;
+  using Lay = AuxLayout<M, LAY>;
+  static constexpr int H = G / 2;      // forward sweep: first lane of the coarse Richardson chain
   int lane;
-  int xcol;                  // forward sweep: column of X = dx/dtheta (and of W) this lane carries (lanes < NP), else 0
-  bool xlane;
+  int xcol;                  // forward sweep: column of X = dx/dtheta (and of W) this lane carries (fine chain: lanes < NP,
+  bool xlane, coarse;        // coarse chain: lanes H .. H+NP-1), else 0
   const T *e, *c;            // [NP], [NC] in LDS
   const T *xa_, *ua_, *la_, *xb_, *ub_, *lb_;   // grid values at both ends of the interval, in LDS
   T t_a, dgrid;
@@ -122,26 +138,27 @@ template <class M, typename T, int G, int LAY> struct AuxCtx {
       for (int i = 0; i < NX; ++i) { x[i] = xa_[i] + s * (xb_[i] - xa_[i]); l[i] = la_[i] + s * (lb_[i] - la_[i]); }
 #pragma unroll
       for (int i = 0; i < NU; ++i) u[i] = ua_[i] + s * (ub_[i] - ua_[i]);
-      T* L = lds + Lay::LDS_L + lane * M::NCOEF;
+      T* L = lds + Lay::LDS_L + lane * Lay::NCOEF;
       M::template pmp_coeffs<LAY>(t_a + s * dgrid, x, u, l, e, c, L);
-      T Huu[NU * NU], iH[NU * NU];
+      if constexpr (!M::IHUU_CLOSED) {      // (a diagonal Huu is inverted in closed form by pmp_coeffs itself)
+        T Huu[NU * NU], iH[NU * NU];
 #pragma unroll
-      for (int i = 0; i < NU * NU; ++i) Huu[i] = L[M::OFF_HUU + i];
-      mat_inverse<NU>(Huu, iH);       // casadi.pinv(ddHuu) of a nonsingular Huu (CPDP.py:262)
+        for (int i = 0; i < NU * NU; ++i) Huu[i] = L[M::OFF_HUU_L[LAY] + i];
+        mat_inverse<NU>(Huu, iH);       // casadi.pinv(ddHuu) of a nonsingular Huu (CPDP.py:262)
 #pragma unroll
-      for (int i = 0; i < NU * NU; ++i) L[M::OFF_IHUU + i] = iH[i];
+        for (int i = 0; i < NU * NU; ++i) L[M::OFF_IHUU_L[LAY] + i] = iH[i];
+      }
     }
     LFSD_WAVE_SYNC();
   }
-  LFSD_DEV const T* node(int i) const { return lds + Lay::LDS_L + i * M::NCOEF; }
+  LFSD_DEV const T* node(int i) const { return lds + Lay::LDS_L + i * Lay::NCOEF; }
 
   // |Huu^-1 fu^T P fu|_inf : rate of the stiff closed-loop modes at one node (P = first NX lanes' columns)
   LFSD_DEV T stiff_rate(const T* zt, const T* L) {
     T* ldsS = lds + Lay::LDS_S;
-    const T* iH = L + M::OFF_IHUU;
     T s[NU], kj[NU];
     M::template fu_mulT<false, LAY>(L, zt, s);
-    matvec<NU>(iH, s, kj);
+    M::template ihuu_mul<LAY>(L, s, kj);
     if (lane < NX) {
 #pragma unroll
       for (int a = 0; a < NU; ++a) ldsS[lane * NU + a] = kj[a];
@@ -182,7 +199,7 @@ template <class M, typename T, int G, int LAY> struct AuxCtx {
     T Gm[NU * NU];
     const T idt = T(1) / dt;
 #pragma unroll
-    for (int i = 0; i < NU * NU; ++i) Gm[i] = L[M::OFF_HUU + i] * idt;
+    for (int i = 0; i < NU * NU; ++i) Gm[i] = L[M::OFF_HUU_L[LAY] + i] * idt;
     M::template fu_gram<true, LAY>(L, ldsS, Gm);
     lu_factor<NU>(Gm);
     lu_solve<NU>(Gm, s);
@@ -214,7 +231,7 @@ template <class M, typename T, int G, int LAY> struct AuxCtx {
       }
       M::template Hxu_mulT<false, LAY>(L, ox, hu);
       M::template Hue_mul<true, LAY>(L, oe, hu);
-      matvec<NU>(L + M::OFF_IHUU, hu, wq);
+      M::template ihuu_mul<LAY>(L, hu, wq);
 #pragma unroll
       for (int a = 0; a < NU; ++a) hc[(nd * R + HX + a) * G + lane] = wq[a];
     }
@@ -225,19 +242,18 @@ template <class M, typename T, int G, int LAY> struct AuxCtx {
     T* ldsT = lds + Lay::LDS_T;
     const T* L = node(nd);
     const T* hc = lds + Lay::LDS_END + nd * R * G;
-    const T* iH = L + M::OFF_IHUU;
     T s[NU], v[NU], w[NU], nv[NU], r[NP], wq[NU];
     if (R == 0) {
       T hu[NU];
       M::template Hxu_mulT<false, LAY>(L, ox, hu);
       M::template Hue_mul<true, LAY>(L, oe, hu);
-      matvec<NU>(iH, hu, wq);
+      M::template ihuu_mul<LAY>(L, hu, wq);
     } else {
 #pragma unroll
       for (int a = 0; a < NU; ++a) wq[a] = hc[(HX + a) * G + lane];
     }
     M::template fu_mulT<false, LAY>(L, z, s);
-    matvec<NU>(iH, s, v);
+    M::template ihuu_mul<LAY>(L, s, v);
 #pragma unroll
     for (int a = 0; a < NU; ++a) { nv[a] = -v[a]; w[a] = -(wq[a] + v[a]); }
 #if LFSD_RIC_MFMA && !defined(LFSD_EMU)
@@ -334,12 +350,16 @@ template <class M, typename T, int G, int LAY> struct AuxCtx {
   }
 
   // ---- forward auxiliary state -----------------------------------------------------------------
-  // lanes < NX carry P columns (interpolated); lanes < NP also carry one X = dx/dtheta column and its W column.
+  // Lane roles.  Lanes < NX own P column `lane` (both interval ends in LDS) wherever feedback gains are formed.  Lanes
+  // j < NP carry X / W column j through the FINE chain of a Richardson pair (two Strang steps), lanes H + j carry the same
+  // column through the COARSE one (one Strang step): the pair costs the instructions of the fine chain alone, and a lane
+  // holds one chain's state, not two.
   // stiff sub-flow  X' = -fu K X,  K = Huu^-1 fu^T P (frozen over the sub-step), solved exactly:
   //   X(dt) = X - dt fu phi1(dt K fu) K X,   phi1(M) = M^-1 (I - e^-M)   (m x m matrix function).
   // (An A-stable rational step is not enough here: with a cheap control cost dt*|K fu| reaches O(10^2).)
-  // fwd_prep: for the three stiff nodes (0, 2, 4) of a unit the P lanes gather K(t_node); then lanes 0..2
-  // each evaluate phi1 for ONE node (quarter and half step), so the matrix function costs one evaluation per unit.
+  // fwd_prep: for the three stiff nodes (0, 2, 4) of a unit the P lanes gather K(t_node); then the matrix function of
+  // each node (quarter and half step) is evaluated once per unit, ROW PER LANE on a sub-group of Q lanes per node
+  // (phi1_neg_rows: the m x m products cost m FMAs + m DPP moves per lane instead of m^3 FMAs on one lane of the group).
   LFSD_DEV void fwd_prep(const T* zA, const T* zB, T s0, T ds, T hq) {
     T* ldsK = lds + Lay::LDS_KN;
     T* ldsP = lds + Lay::LDS_PSI;
@@ -351,28 +371,63 @@ template <class M, typename T, int G, int LAY> struct AuxCtx {
 #pragma unroll
       for (int i = 0; i < NX; ++i) zt[i] = zA[i] + sr * (zB[i] - zA[i]);
       M::template fu_mulT<false, LAY>(L, zt, sv);
-      matvec<NU>(L + M::OFF_IHUU, sv, kj);
+      M::template ihuu_mul<LAY>(L, sv, kj);
       if (lane < NX) {
 #pragma unroll
         for (int a = 0; a < NU; ++a) ldsK[(r * NX + lane) * NU + a] = kj[a];
       }
     }
     LFSD_WAVE_SYNC();
-    if (lane < 3) {
-      T Mx[NU * NU], Pq[NU * NU], Ph[NU * NU];
-      M::template fu_gram<false, LAY>(node(2 * lane), ldsK + lane * NX * NU, Mx);       // K fu
+    if constexpr (NU <= 4) {
+      constexpr int Q = sub_lanes<NU>();
+      // every lane of the group runs the same instructions (sub_bcast needs its sources active): sub-groups beyond the
+      // third repeat node 4 and drop the result
+      const int sg = lane / Q, a = lane % Q;
+      const int r = sg < 2 ? sg : 2;
+      const bool row = a < NU;
+      const bool mine = sg < 3 && row;
+      const int ar = row ? a : 0;
+      T sa[NX], Mrow[NU], Pq[NU], Ph[NU];
 #pragma unroll
-      for (int i = 0; i < NU * NU; ++i) Mx[i] *= hq;
-      phi1_neg<NU>(Mx, Pq, Ph);
+      for (int i = 0; i < NX; ++i) sa[i] = ldsK[(r * NX + i) * NU + ar];
+      M::template fu_mulT<false, LAY>(node(2 * r), sa, Mrow);                  // row a of K fu = fu^T (row a of K)
+      T rs = T(0);
 #pragma unroll
-      for (int i = 0; i < NU * NU; ++i) { ldsP[lane * 2 * NU * NU + i] = Pq[i]; ldsP[(lane * 2 + 1) * NU * NU + i] = Ph[i]; }
+      for (int j = 0; j < NU; ++j) { Mrow[j] = row ? Mrow[j] * hq : T(0); rs += t_abs(Mrow[j]); }
+      // one scaling for the three nodes (|.|_inf over all rows of the group): uniform trip count of the squaring loop
+      T* red = lds + Lay::FWD_RED;
+      red[lane] = mine ? rs : T(0);
+      LFSD_WAVE_SYNC();
+      T nrm = T(0);
+#pragma unroll
+      for (int l = 0; l < 3 * Q; ++l) nrm = t_max(nrm, red[l]);
+      LFSD_WAVE_SYNC();
+      int sq = 0;
+      T sc = T(1);
+      while (nrm * sc > T(0.25) && sq < 60) { sc *= T(0.5); ++sq; }
+      phi1_neg_rows<NU, Q>(Mrow, a, sq, sc, Pq, Ph);
+      if (mine) {
+#pragma unroll
+        for (int j = 0; j < NU; ++j) { ldsP[(r * 2) * NU * NU + a * NU + j] = Pq[j]; ldsP[(r * 2 + 1) * NU * NU + a * NU + j] = Ph[j]; }
+      }
+    } else {
+      if (lane < 3) {
+        T Mx[NU * NU], Pq[NU * NU], Ph[NU * NU];
+        M::template fu_gram<false, LAY>(node(2 * lane), ldsK + lane * NX * NU, Mx);       // K fu
+#pragma unroll
+        for (int i = 0; i < NU * NU; ++i) Mx[i] *= hq;
+        phi1_neg<NU>(Mx, Pq, Ph);
+#pragma unroll
+        for (int i = 0; i < NU * NU; ++i) { ldsP[lane * 2 * NU * NU + i] = Pq[i]; ldsP[(lane * 2 + 1) * NU * NU + i] = Ph[i]; }
+      }
     }
     LFSD_WAVE_SYNC();
   }
-  // apply the prepared exact stiff step of node r (0..2); half = false: dt = hq, true: dt = 2 hq
-  LFSD_DEV void fwd_stiff(T* xa, int r, bool half, T hq) {
+  // apply the prepared exact stiff step of stiff node r (0..2) over dt = hq (half == 0) or 2 hq (half == 1); r and half
+  // may differ between the lanes (the two chains sit at different nodes)
+  LFSD_DEV void fwd_stiff(T* xa, int r, int half, T dt) {
     const T* Kn = lds + Lay::LDS_KN + r * NX * NU;
-    const T* Psi = lds + Lay::LDS_PSI + (r * 2 + (half ? 1 : 0)) * NU * NU;
+    const T* Psi = lds + Lay::LDS_PSI + (r * 2 + half) * NU * NU;
     T kx[NU], y[NU];
 #pragma unroll
     for (int a = 0; a < NU; ++a) kx[a] = T(0);
@@ -382,19 +437,20 @@ template <class M, typename T, int G, int LAY> struct AuxCtx {
       for (int a = 0; a < NU; ++a) kx[a] += Kn[i * NU + a] * xa[i];
     }
     matvec<NU>(Psi, kx, y);
-    const T dt = half ? T(2) * hq : hq;
 #pragma unroll
     for (int a = 0; a < NU; ++a) y[a] *= -dt;
     M::template fu_mul<true, LAY>(node(2 * r), y, xa);
   }
   // non-stiff part  X' = fx X + fe - fu Huu^-1 (Hux X + Hue + fu^T W).  Its X-independent part
   //   b_j(t) = (fe - fu Huu^-1 (fu^T W(t) + Hue)) e_j
-  // is evaluated once per staged node (fwd_cols) and parked per lane; the 12 right-hand sides of a unit then cost
+  // is evaluated once per staged node (fwd_cols) and parked per column; the right-hand sides of a unit then cost
   //   y = fx x - fu Huu^-1 Hux x + b_j.
+  // Three rounds for the five nodes: the fine lanes of a column take nodes 0, 1, 2, its coarse lanes nodes 3, 4 (and 4 again).
   LFSD_DEV void fwd_cols(const T* zA, const T* zB, T s0, T ds) {
-    T* bc = lds + Lay::LDS_END + NX * NP;
+    T* bc = lds + Lay::FWD_BC;
     LFSD_FWD_NODE_LOOP
-    for (int nd = 0; nd < Lay::NNODE; ++nd) {
+    for (int rd = 0; rd < 3; ++rd) {
+      const int nd = coarse ? (rd < 2 ? 3 + rd : 4) : rd;
       const T* L = node(nd);
       const T sr = s0 + T(nd) * ds;
       T wt[NX], sv[NU], v[NU], b[NX];
@@ -402,7 +458,7 @@ template <class M, typename T, int G, int LAY> struct AuxCtx {
       for (int i = 0; i < NX; ++i) wt[i] = zA[i] + sr * (zB[i] - zA[i]);
       M::template fu_mulT<false, LAY>(L, wt, sv);
       M::template Hue_mul<true, LAY>(L, oe, sv);
-      matvec<NU>(L + M::OFF_IHUU, sv, v);
+      M::template ihuu_mul<LAY>(L, sv, v);
 #pragma unroll
       for (int a = 0; a < NU; ++a) v[a] = -v[a];
       M::template fe_mul<false, LAY>(L, oe, b);
@@ -415,10 +471,10 @@ template <class M, typename T, int G, int LAY> struct AuxCtx {
   }
   LFSD_DEV void fwd_rhs(const T* xa, int nd, T* y) {
     const T* L = node(nd);
-    const T* bc = lds + Lay::LDS_END + NX * NP + nd * NX * NP;     // lanes without an X column read column 0; their result is dropped
+    const T* bc = lds + Lay::FWD_BC + nd * NX * NP;     // lanes without an X column read column 0; their result is dropped
     T s[NU], v[NU];
     M::template Hxu_mulT<false, LAY>(L, xa, s);
-    matvec<NU>(L + M::OFF_IHUU, s, v);
+    M::template ihuu_mul<LAY>(L, s, v);
 #pragma unroll
     for (int a = 0; a < NU; ++a) v[a] = -v[a];
     M::template fx_mul<false, LAY>(L, xa, y);
@@ -426,7 +482,7 @@ template <class M, typename T, int G, int LAY> struct AuxCtx {
 #pragma unroll
     for (int i = 0; i < NX; ++i) y[i] += bc[i * NP + xcol];
   }
-  // non-stiff RK4 step of length h over nodes (n0, n1, n2)
+  // non-stiff RK4 step of length h over nodes (n0, n1, n2) -- per-lane values
   LFSD_DEV void fwd_rk4(T* xa, int n0, int n1, int n2, T h) {
     T k[NX], acc[NX], xs[NX];
     if constexpr (aux_rk<T>() == 2) {
@@ -452,10 +508,25 @@ template <class M, typename T, int G, int LAY> struct AuxCtx {
 #pragma unroll
     for (int i = 0; i < NX; ++i) xa[i] += h / T(6) * (acc[i] + k[i]);
   }
+  // One split unit of length hc for this lane's chain:
+  //   fine    stiff(node 0, hq)   RK(nodes 0 1 2, hc/2)  stiff(node 2, 2 hq)  RK(nodes 2 3 4, hc/2)  stiff(node 4, hq)
+  //   coarse  stiff(node 0, 2 hq) RK(nodes 0 2 4, hc)    stiff(node 4, 2 hq)
+  // (hq = hc/4; the two adjacent fine stiff quarter-steps at the middle node compose exactly into one half-step.)  The
+  // first three operations are the same instructions with per-lane nodes and step lengths; the coarse lanes sit out the
+  // last two.
+  LFSD_DEV void fwd_chain(T* x, T hc, T hq) {
+    const int c = coarse ? 1 : 0;
+    fwd_stiff(x, 0, c, coarse ? T(2) * hq : hq);
+    fwd_rk4(x, 0, 1 + c, 2 + 2 * c, coarse ? hc : hc * T(0.5));
+    fwd_stiff(x, 1 + c, 1, T(2) * hq);
+    if (!coarse) {
+      fwd_rk4(x, 2, 3, 4, hc * T(0.5));
+      fwd_stiff(x, 2, 0, hq);
+    }
+  }
   // auxiliary control at a grid point (CPDP.py:295):  U = -Huu^-1((Hux + fu^T P) X + fu^T W + Hue)
   LFSD_DEV void aux_control(const T* xa, const T* pt, const T* wt, const T* L, T* uo) {
     T* ldsS = lds + Lay::LDS_S;
-    const T* iH = L + M::OFF_IHUU;
     T s[NU];
     M::template fu_mulT<false, LAY>(L, pt, s);          // P role: row `lane` of (fu^T P)^T
     if (lane < NX) {
@@ -471,7 +542,7 @@ template <class M, typename T, int G, int LAY> struct AuxCtx {
 #pragma unroll
       for (int a = 0; a < NU; ++a) s[a] += ldsS[i * NU + a] * xa[i];
     }
-    matvec<NU>(iH, s, uo);
+    M::template ihuu_mul<LAY>(L, s, uo);
 #pragma unroll
     for (int a = 0; a < NU; ++a) uo[a] = -uo[a];
     LFSD_WAVE_SYNC();
@@ -479,13 +550,15 @@ template <class M, typename T, int G, int LAY> struct AuxCtx {
 };
 
 template <class M, typename T, int G, int LAY> LFSD_DEV void aux_setup(AuxCtx<M, T, G, LAY>& s, const AuxArgs<T>& a, long long traj,
-                                                            T* lds_all, int lds_stride = AuxLayout<M>::lds_elems()) {
+                                                            T* lds_all, int lds_stride) {
   constexpr int NX = M::NX, NP = M::NP, NC = M::NC;
-  using Lay = AuxLayout<M>;
+  using Lay = AuxLayout<M, LAY>;
   const int gib = threadIdx.x / G;
   s.lane = threadIdx.x % G;
-  s.xlane = (LAY == 1) && (s.lane < NP);
-  s.xcol = s.xlane ? s.lane : 0;
+  s.coarse = (LAY == 1) && (s.lane >= G / 2);
+  const int xl = s.coarse ? s.lane - G / 2 : s.lane;
+  s.xlane = (LAY == 1) && (xl < NP);
+  s.xcol = s.xlane ? xl : 0;
   s.lds = lds_all + gib * lds_stride;
   {
     T* le = s.lds + Lay::LDS_E;
@@ -500,7 +573,7 @@ template <class M, typename T, int G, int LAY> LFSD_DEV void aux_setup(AuxCtx<M,
 #pragma unroll
   for (int i = 0; i < NX; ++i) s.ox[i] = (s.lane == i) ? T(1) : T(0);
 #pragma unroll
-  for (int i = 0; i < NP; ++i) s.oe[i] = (LAY == 1 ? (s.xlane && s.lane == i) : (s.lane == NX + i)) ? T(1) : T(0);
+  for (int i = 0; i < NP; ++i) s.oe[i] = (LAY == 1 ? (s.xlane && s.xcol == i) : (s.lane == NX + i)) ? T(1) : T(0);
 }
 
 // Synchronisation in the two auxiliary sweeps: the number of split units per interval (`units`) follows each trajectory's
@@ -524,6 +597,10 @@ __global__ void __launch_bounds__(64, (sizeof(T) == 4 ? LFSD_WAVES_RIC : 1)) aux
   const long long slot = (long long)blockIdx.x * GPB + threadIdx.x / G;
   const bool valid = slot < a.batch;
   const long long traj = valid ? slot : (long long)a.batch - 1;
+  if (a.skipped(traj)) {                          // a solve the caller does not want differentiated: this lane group is done
+    if (valid && a.stats && threadIdx.x % G == 0) { a.stats[traj * 4 + 0] = 0; a.stats[traj * 4 + 1] = 0; }
+    return;                                       // (its lanes leave together; the other groups of the wavefront share nothing with it)
+  }
   Ctx s;
   aux_setup<M, T, G, 0>(s, a, traj, lds_all, Lay::template lds_elems_ric<G>());
   const int N = a.n_grid, Sa = a.substeps;
@@ -652,36 +729,50 @@ template <class M, typename T, int G>
 __global__ void __launch_bounds__(64, (sizeof(T) == 4 ? LFSD_WAVES_FWD : 1)) aux_forward_kernel(AuxArgs<T> a) {
   if (blockDim.x != 64) return;                   // one wavefront per workgroup: see the note above aux_riccati_kernel
   using Ctx = AuxCtx<M, T, G, 1>;
-  using Lay = AuxLayout<M>;
+  using Lay = AuxLayout<M, 1>;
   constexpr int NX = M::NX, NU = M::NU, NP = M::NP, NZ = NX + NP;
   constexpr int GPB = 64 / G;
-  static_assert(64 % G == 0 && G >= NX && G >= NP && G >= Lay::NNODE, "forward lane group: one P column and one X column per lane");
-  __shared__ T lds_all[GPB * Lay::template lds_elems_fwd<G>() + LFSD_AUX_LDS_PAD];
-  poison_lds(lds_all, GPB * Lay::template lds_elems_fwd<G>());
+  static_assert(64 % G == 0 && G >= NX && G >= 2 * NP && G >= Lay::NNODE && G >= 3 * sub_lanes<NU <= 4 ? NU : 1>(),
+                "forward lane group: one P column per lane, and one X column per lane in each half (fine / coarse chain)");
+  __shared__ T lds_all[GPB * Lay::lds_elems_fwd() + LFSD_AUX_LDS_PAD];
+  poison_lds(lds_all, GPB * Lay::lds_elems_fwd());
   const long long slot = (long long)blockIdx.x * GPB + threadIdx.x / G;
   const bool valid = slot < a.batch;
   const long long traj = valid ? slot : (long long)a.batch - 1;
+  if (a.skipped(traj)) {                          // not differentiated: NaN loss / gradient, nothing else touched
+    const int l = threadIdx.x % G;
+    const T nan = T(0) / T(0);
+    if (valid) {
+      if (l == 0) { a.loss[traj] = nan; if (a.stats) { a.stats[traj * 4 + 2] = 0; a.stats[traj * 4 + 3] = 0; } }
+      if (l < NP) a.grad[traj * NP + l] = nan;
+    }
+    return;
+  }
   Ctx s;
-  aux_setup<M, T, G, 1>(s, a, traj, lds_all, Lay::template lds_elems_fwd<G>());
+  aux_setup<M, T, G, 1>(s, a, traj, lds_all, Lay::lds_elems_fwd());
   const int N = a.n_grid, Sa = a.substeps;
   const int lane = s.lane;
-  const bool xlane = s.xlane;
+  const bool xlane = s.xlane, coarse = s.coarse;
+  const bool fine_x = xlane && !coarse;           // the lanes that own the results of a column
   const T* Zt = a.Z_grid + traj * (long long)(N + 1) * NZ * NX;
   T xa[NX], wA[NX], wB[NX];     // X column; W column at both ends of the interval (the P columns live in LDS)
 #pragma unroll
   for (int i = 0; i < NX; ++i) { xa[i] = T(0); wA[i] = T(0); wB[i] = T(0); }     // X(0) = 0, CPDP.py:355
-  T* ldsPA = s.lds + Lay::LDS_END + Lay::FWD_P;
+  T* ldsPA = s.lds + Lay::FWD_P;
   T* ldsPB = ldsPA + NX * NX;
   T* ldsP0 = ldsPB + NX * NX;                                  // zero row
   for (int i = lane; i < NX; i += G) ldsP0[i] = T(0);
   const T* pA = (lane < NX) ? ldsPA + lane * NX : ldsP0;
   const T* pB = (lane < NX) ? ldsPB + lane * NX : ldsP0;
+  T* xprev = s.lds + Lay::FWD_XPREV;                 // X(t_k), parked in LDS: start value of a redone interval, and the loss needs it
+  T* xch = s.lds + Lay::FWD_XCH;
+  T* ldsR = s.lds + Lay::FWD_RED;
   T loss = T(0), gacc = T(0);
   int units_hint = Sa;
   int n_units = 0, n_unmet = 0;
   T* Xo = a.auxX_grid ? a.auxX_grid + traj * (long long)(N + 1) * NP * NX : nullptr;
   T* Uo = a.auxU_grid ? a.auxU_grid + traj * (long long)(N + 1) * NP * NU : nullptr;
-  if (valid && Xo && xlane) {
+  if (valid && Xo && fine_x) {
 #pragma unroll
     for (int i = 0; i < NX; ++i) Xo[(long long)s.xcol * NX + i] = T(0);
   }
@@ -693,10 +784,9 @@ __global__ void __launch_bounds__(64, (sizeof(T) == 4 ? LFSD_WAVES_FWD : 1)) aux
     }
     if (xlane) {
 #pragma unroll
-      for (int i = 0; i < NX; ++i) { wA[i] = Zt[((long long)k * NZ + NX + lane) * NX + i]; wB[i] = Zt[((long long)(k + 1) * NZ + NX + lane) * NX + i]; }
+      for (int i = 0; i < NX; ++i) { wA[i] = Zt[((long long)k * NZ + NX + s.xcol) * NX + i]; wB[i] = Zt[((long long)(k + 1) * NZ + NX + s.xcol) * NX + i]; }
     }
-    T* xprev = s.lds + Lay::LDS_END;                 // this lane's X(t_k), parked in LDS until the loss needs it
-    if (xlane) {
+    if (fine_x) {
 #pragma unroll
       for (int i = 0; i < NX; ++i) xprev[i * NP + s.xcol] = xa[i];
     }
@@ -718,40 +808,35 @@ __global__ void __launch_bounds__(64, (sizeof(T) == 4 ? LFSD_WAVES_FWD : 1)) aux
         if (Uo && unit == 0) {
           T uo[NU];
           s.aux_control(xa, pA, wA, s.node(0), uo);
-          if (valid && xlane) {
+          if (valid && fine_x) {
 #pragma unroll
             for (int b = 0; b < NU; ++b) Uo[((long long)k * NP + s.xcol) * NU + b] = uo[b];
           }
         }
-        T xc[NX], xf[NX];
-#pragma unroll
-        for (int i = 0; i < NX; ++i) { xc[i] = xa[i]; xf[i] = xa[i]; }
         const T hq = hc * T(0.25);
         s.fwd_prep(pA, pB, s_lo, ds, hq);
         s.fwd_cols(wA, wB, s_lo, ds);
-        // coarse Strang step (stiff h/2, RK4 h, stiff h/2) and two fine ones; the two adjacent fine stiff
-        // quarter-steps at the middle node compose exactly into one half-step.  (Unlike the Riccati sweep, which runs its
-        // two chains in place with the other value parked in LDS, this one-wave-per-SIMD kernel is 20 % faster with both
-        // chains as independent instruction streams the compiler can interleave.)
-        s.fwd_stiff(xc, 0, true, hq);
-        s.fwd_rk4(xc, 0, 2, 4, hc);
-        s.fwd_stiff(xc, 2, true, hq);
-        s.fwd_stiff(xf, 0, false, hq);
-        s.fwd_rk4(xf, 0, 1, 2, hc * T(0.5));
-        s.fwd_stiff(xf, 1, true, hq);
-        s.fwd_rk4(xf, 2, 3, 4, hc * T(0.5));
-        s.fwd_stiff(xf, 2, false, hq);
-        LFSD_WAVE_SYNC();      // all reads of this unit's staged coefficients are done before the next staging
+        LFSD_WAVE_SYNC();      // the parked columns b_j of every node are in place
+        // the Richardson pair: coarse Strang step on the upper half of the lane group, two fine ones on the lower half,
+        // both in place from the same start value
+        s.fwd_chain(xa, hc, hq);
+        if (xlane) {
+#pragma unroll
+          for (int i = 0; i < NX; ++i) xch[((coarse ? NX : 0) + i) * NP + s.xcol] = xa[i];
+        }
+        LFSD_WAVE_SYNC();      // (also: all reads of this unit's staged coefficients are done before the next staging)
 #pragma unroll
         for (int i = 0; i < NX; ++i) {
-          if (xlane) err_l = t_max(err_l, t_abs(xf[i] - xc[i]));
-          xa[i] = xlane ? (T(4) * xf[i] - xc[i]) * (T(1) / T(3)) : T(0);
+          const T xo = xlane ? xch[((coarse ? 0 : NX) + i) * NP + s.xcol] : T(0);      // the other chain's result
+          const T xf = coarse ? xo : xa[i], xc = coarse ? xa[i] : xo;
+          err_l = t_max(err_l, t_abs(xf - xc));
+          xa[i] = xlane ? (T(4) * xf - xc) * (T(1) / T(3)) : T(0);      // both halves continue from the extrapolated value
           scl_l = t_max(scl_l, t_abs(xa[i]));
         }
         if (Uo && k == N - 1 && unit == units - 1) {
           T uo[NU];
           s.aux_control(xa, pB, wB, s.node(4), uo);
-          if (valid && xlane) {
+          if (valid && fine_x) {
 #pragma unroll
             for (int b = 0; b < NU; ++b) Uo[((long long)N * NP + s.xcol) * NU + b] = uo[b];
           }
@@ -759,7 +844,7 @@ __global__ void __launch_bounds__(64, (sizeof(T) == 4 ? LFSD_WAVES_FWD : 1)) aux
       }
       n_units += units;
       if (!(a.rtol > T(0))) break;
-      T* ldsR = s.lds + Lay::LDS_T;           // (the feedback / phi1 images of the last unit are dead by now)
+      LFSD_WAVE_SYNC();
       ldsR[lane] = err_l; ldsR[G + lane] = scl_l;
       LFSD_WAVE_SYNC();
       T eX = T(0), sX = T(0);
@@ -781,7 +866,7 @@ __global__ void __launch_bounds__(64, (sizeof(T) == 4 ? LFSD_WAVES_FWD : 1)) aux
 #pragma unroll
       for (int i = 0; i < NX; ++i) xa[i] = xlane ? xprev[i * NP + s.xcol] : T(0);
     }
-    if (valid && Xo && xlane) {
+    if (valid && Xo && fine_x) {
 #pragma unroll
       for (int i = 0; i < NX; ++i) Xo[((long long)(k + 1) * NP + s.xcol) * NX + i] = xa[i];
     }
@@ -815,7 +900,7 @@ __global__ void __launch_bounds__(64, (sizeof(T) == 4 ? LFSD_WAVES_FWD : 1)) aux
   }
   if (valid) {
     if (lane == 0) a.loss[traj] = loss;
-    if (xlane) a.grad[traj * NP + s.xcol] = gacc;
+    if (fine_x) a.grad[traj * NP + s.xcol] = gacc;
     if (a.stats && lane == 0) { a.stats[traj * 4 + 2] = n_units; a.stats[traj * 4 + 3] = n_unmet; }
   }
 }

@@ -657,6 +657,84 @@ template <int n, typename T> LFSD_DEV void phi1_neg(const T* M, T* P, T* P2) {
 #pragma unroll
   for (int i = 0; i < n * n; ++i) P2[i] = T(0.5) * (P[i] + W[i]);
 }
+// ---- a small matrix spread ROW PER LANE over a sub-group of Q = 1 / 2 / 4 adjacent lanes (Q | 4, sub-group aligned) ------
+// sub_bcast<Q>(v, k): v of lane k of the caller's sub-group, in every lane of it.  On the GPU a DPP move (quad_perm), i.e. a
+// register-to-register instruction without LDS; k must be a constant after unrolling.  Every lane that could be a SOURCE
+// has to be active: the callers run whole lane groups through the same control flow.  The CPU emulator restates it with an
+// exchange buffer (all lanes of the sub-group must call it together).
+template <int Q> constexpr bool sub_ok() { return Q == 1 || Q == 2 || Q == 4; }
+#if defined(LFSD_EMU)
+template <int Q, typename T> inline T sub_bcast(T v, int k) {
+  static_assert(sub_ok<Q>(), "sub-group of 1, 2 or 4 lanes");
+  if (Q == 1) return v;
+  static T sb[64];
+  const int l = threadIdx.x;
+  sb[l] = v;
+  __syncthreads();
+  const T r = sb[(l & ~(Q - 1)) | k];
+  __syncthreads();
+  return r;
+}
+#else
+template <int CTRL> LFSD_DEV float dpp_mov(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+template <int CTRL> LFSD_DEV double dpp_mov(double v) {
+  const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+  const int lo = __builtin_amdgcn_mov_dpp((int)(unsigned)u, CTRL, 0xf, 0xf, true);
+  const int hi = __builtin_amdgcn_mov_dpp((int)(unsigned)(u >> 32), CTRL, 0xf, 0xf, true);
+  return __builtin_bit_cast(double, ((unsigned long long)(unsigned)hi << 32) | (unsigned long long)(unsigned)lo);
+}
+template <int Q, typename T> LFSD_DEV T sub_bcast(T v, int k) {
+  static_assert(sub_ok<Q>(), "sub-group of 1, 2 or 4 lanes");
+  if constexpr (Q == 1) return v;
+  else if constexpr (Q == 2) return k == 0 ? dpp_mov<0xA0>(v) : dpp_mov<0xF5>(v);            // quad_perm [0,0,2,2] / [1,1,3,3]
+  else return k == 0 ? dpp_mov<0x00>(v) : (k == 1 ? dpp_mov<0x55>(v) : (k == 2 ? dpp_mov<0xAA>(v) : dpp_mov<0xFF>(v)));
+}
+#endif
+// smallest sub-group that holds one row per lane of an n x n matrix (n <= 4)
+template <int n> constexpr int sub_lanes() { return n <= 1 ? 1 : (n == 2 ? 2 : 4); }
+// W = A B, row a of each matrix in lane a of the sub-group (lanes a >= n carry zeros); same summation order as matmul<n>
+template <int n, int Q, typename T> LFSD_DEV void matmul_rows(const T* Arow, const T* Brow, T* Wrow) {
+#pragma unroll
+  for (int j = 0; j < n; ++j) Wrow[j] = T(0);
+#pragma unroll
+  for (int k = 0; k < n; ++k) {
+#pragma unroll
+    for (int j = 0; j < n; ++j) Wrow[j] += Arow[k] * sub_bcast<Q>(Brow[j], k);
+  }
+}
+// phi1_neg with the matrix spread row per lane: lane a of the sub-group holds row a of M and receives row a of
+// P = phi1(M) and P2 = phi1(2M).  The scaling (sc = 2^-sq with |M| sc <= 1/4) comes from the caller, who makes it uniform
+// over everything that runs through here together (over-scaling is harmless: more squarings of a smaller argument).
+template <int n, int Q, typename T> LFSD_DEV void phi1_neg_rows(const T* Mrow, int a, int sq, T sc, T* P, T* P2) {
+  T A[n], E[n], W[n];
+  const T ck[10] = {T(1), T(1) / T(2), T(1) / T(6), T(1) / T(24), T(1) / T(120), T(1) / T(720), T(1) / T(5040),
+                    T(1) / T(40320), T(1) / T(362880), T(1) / T(3628800)};
+  constexpr int DEG = PhiDeg<T>::v;
+#pragma unroll
+  for (int j = 0; j < n; ++j) { A[j] = Mrow[j] * sc; P[j] = (j == a) ? ck[DEG] : T(0); }
+#pragma unroll
+  for (int k = DEG - 1; k >= 0; --k) {
+    matmul_rows<n, Q>(A, P, W);
+#pragma unroll
+    for (int j = 0; j < n; ++j) P[j] = ((j == a) ? ck[k] : T(0)) - W[j];
+  }
+  matmul_rows<n, Q>(A, P, W);
+#pragma unroll
+  for (int j = 0; j < n; ++j) E[j] = ((j == a) ? T(1) : T(0)) - W[j];
+  for (int it = 0; it < sq; ++it) {
+    matmul_rows<n, Q>(E, P, W);
+#pragma unroll
+    for (int j = 0; j < n; ++j) P[j] = T(0.5) * (P[j] + W[j]);
+    matmul_rows<n, Q>(E, E, W);
+#pragma unroll
+    for (int j = 0; j < n; ++j) E[j] = W[j];
+  }
+  matmul_rows<n, Q>(E, P, W);
+#pragma unroll
+  for (int j = 0; j < n; ++j) P2[j] = T(0.5) * (P[j] + W[j]);
+}
 template <int n, typename T> LFSD_DEV void matvec(const T* A, const T* v, T* y) {
 #pragma unroll
   for (int i = 0; i < n; ++i) {

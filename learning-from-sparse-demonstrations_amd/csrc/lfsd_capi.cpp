@@ -159,7 +159,7 @@ static int aux_phase_t(int phases, int batch, int n_grid, const void* horizon, c
                        int const_per_traj, const void* state_grid, const void* control_grid, const void* costate_grid,
                        void* Z_grid, int n_waypoints, int n_iface, const int* iface_idx, const void* taus,
                        const void* waypoints, void* loss, void* grad, void* auxX_grid, void* auxU_grid, int substeps,
-                       double rtol, int* stats, void* stream) {
+                       double rtol, int* stats, const int* oc_status, int skip_mask, void* stream) {
   lfsd::AuxArgs<T> a;
   // rtol > 0: error-controlled sub-stepping from `substeps` (default 1) units per interval upwards;
   // rtol = 0: a fixed minimum of `substeps` (default 4) units, refined for stiffness only (the round-1 behaviour)
@@ -175,6 +175,7 @@ static int aux_phase_t(int phases, int batch, int n_grid, const void* horizon, c
   a.taus = (const T*)taus; a.waypoints = (const T*)waypoints;
   a.loss = (T*)loss; a.grad = (T*)grad; a.auxX_grid = (T*)auxX_grid; a.auxU_grid = (T*)auxU_grid;
   a.stats = stats;
+  a.oc_status = skip_mask ? oc_status : nullptr; a.skip_mask = skip_mask;
   const unsigned grid = (unsigned)(((long long)batch + GPB - 1) / GPB);
   if (phases & 1) {
     int rc;
@@ -197,20 +198,22 @@ static int aux_dispatch(int phases, int dtype, int batch, int n_grid, const void
                         const void* consts, int const_per_traj, const void* state_grid, const void* control_grid,
                         const void* costate_grid, void* Z_grid, int n_waypoints, int n_iface, const int* iface_idx,
                         const void* taus, const void* waypoints, void* loss, void* grad, void* auxX_grid,
-                        void* auxU_grid, int substeps, double rtol, int* stats, void* stream) {
+                        void* auxU_grid, int substeps, double rtol, int* stats, const int* oc_status, int skip_mask,
+                        void* stream) {
   if (batch <= 0 || n_grid <= 0 || n_waypoints < 0 || n_iface < 0 || substeps < 0 || !(rtol >= 0)) return LFSD_EINVAL;
   if (!horizon || !auxvar || !state_grid || !control_grid || !costate_grid || !Z_grid) return LFSD_EINVAL;
   if ((phases & 2) && (!loss || !grad)) return LFSD_EINVAL;
   if ((phases & 2) && n_waypoints > 0 && (n_iface <= 0 || !iface_idx || !taus || !waypoints)) return LFSD_EINVAL;
   if (Model::NC_REAL > 0 && !consts) return LFSD_EINVAL;
+  if (skip_mask < 0 || (skip_mask != 0 && !oc_status)) return LFSD_EINVAL;
   if (dtype == LFSD_F32)
     return aux_phase_t<float>(phases, batch, n_grid, horizon, auxvar, consts, const_per_traj, state_grid, control_grid,
                               costate_grid, Z_grid, n_waypoints, n_iface, iface_idx, taus, waypoints, loss, grad,
-                              auxX_grid, auxU_grid, substeps, rtol, stats, stream);
+                              auxX_grid, auxU_grid, substeps, rtol, stats, oc_status, skip_mask, stream);
   if (dtype == LFSD_F64)
     return aux_phase_t<double>(phases, batch, n_grid, horizon, auxvar, consts, const_per_traj, state_grid,
                                control_grid, costate_grid, Z_grid, n_waypoints, n_iface, iface_idx, taus, waypoints,
-                               loss, grad, auxX_grid, auxU_grid, substeps, rtol, stats, stream);
+                               loss, grad, auxX_grid, auxU_grid, substeps, rtol, stats, oc_status, skip_mask, stream);
   return LFSD_EINVAL;
 }
 
@@ -218,19 +221,20 @@ LFSD_API int lfsd_aux_solve(int dtype, int batch, int n_grid, const void* horizo
                             const void* consts, int const_per_traj, const void* state_grid, const void* control_grid,
                             const void* costate_grid, void* Z_grid, int n_waypoints, int n_iface,
                             const int* iface_idx, const void* taus, const void* waypoints, void* loss, void* grad,
-                            void* auxX_grid, void* auxU_grid, int substeps, double rtol, int* stats, void* stream) {
+                            void* auxX_grid, void* auxU_grid, int substeps, double rtol, int* stats,
+                            const int* oc_status, int skip_status_mask, void* stream) {
   return aux_dispatch(3, dtype, batch, n_grid, horizon, auxvar, consts, const_per_traj, state_grid, control_grid,
                       costate_grid, Z_grid, n_waypoints, n_iface, iface_idx, taus, waypoints, loss, grad, auxX_grid,
-                      auxU_grid, substeps, rtol, stats, stream);
+                      auxU_grid, substeps, rtol, stats, oc_status, skip_status_mask, stream);
 }
 
 LFSD_API int lfsd_aux_riccati(int dtype, int batch, int n_grid, const void* horizon, const void* auxvar,
                               const void* consts, int const_per_traj, const void* state_grid,
                               const void* control_grid, const void* costate_grid, void* Z_grid, int substeps,
-                              double rtol, int* stats, void* stream) {
+                              double rtol, int* stats, const int* oc_status, int skip_status_mask, void* stream) {
   return aux_dispatch(1, dtype, batch, n_grid, horizon, auxvar, consts, const_per_traj, state_grid, control_grid,
                       costate_grid, Z_grid, 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
-                      substeps, rtol, stats, stream);
+                      substeps, rtol, stats, oc_status, skip_status_mask, stream);
 }
 
 LFSD_API int lfsd_aux_forward(int dtype, int batch, int n_grid, const void* horizon, const void* auxvar,
@@ -238,10 +242,10 @@ LFSD_API int lfsd_aux_forward(int dtype, int batch, int n_grid, const void* hori
                               const void* control_grid, const void* costate_grid, const void* Z_grid, int n_waypoints,
                               int n_iface, const int* iface_idx, const void* taus, const void* waypoints, void* loss,
                               void* grad, void* auxX_grid, void* auxU_grid, int substeps, double rtol, int* stats,
-                              void* stream) {
+                              const int* oc_status, int skip_status_mask, void* stream) {
   return aux_dispatch(2, dtype, batch, n_grid, horizon, auxvar, consts, const_per_traj, state_grid, control_grid,
                       costate_grid, const_cast<void*>(Z_grid), n_waypoints, n_iface, iface_idx, taus, waypoints, loss,
-                      grad, auxX_grid, auxU_grid, substeps, rtol, stats, stream);
+                      grad, auxX_grid, auxU_grid, substeps, rtol, stats, oc_status, skip_status_mask, stream);
 }
 
 template <typename T>

@@ -168,15 +168,15 @@ class ModelLibrary:
         L.lfsd_coc_solve.argtypes = [ci, ci, ci, ci, vp, vp, vp, vp, ci, vp, vp, vp, vp, vp, vp, cd, vp, vp, vp, vp, vp, vp, ci, cd, ci,
                                      ci, vp, ctypes.c_size_t, vp]
         L.lfsd_aux_solve.argtypes = [ci, ci, ci, vp, vp, vp, ci, vp, vp, vp, vp, ci, ci, vp, vp, vp, vp, vp, vp, vp,
-                                     ci, cd, vp, vp]
-        L.lfsd_aux_riccati.argtypes = [ci, ci, ci, vp, vp, vp, ci, vp, vp, vp, vp, ci, cd, vp, vp]
+                                     ci, cd, vp, vp, ci, vp]
+        L.lfsd_aux_riccati.argtypes = [ci, ci, ci, vp, vp, vp, ci, vp, vp, vp, vp, ci, cd, vp, vp, ci, vp]
         L.lfsd_aux_forward.argtypes = [ci, ci, ci, vp, vp, vp, ci, vp, vp, vp, vp, ci, ci, vp, vp, vp, vp, vp, vp, vp,
-                                       ci, cd, vp, vp]
+                                       ci, cd, vp, vp, ci, vp]
         L.lfsd_optimizer_step.argtypes = [ci, ci, ci, ci, ci, cd, cd, cd, cd, cd, vp, vp, vp, vp, vp, vp, vp, vp]
         L.lfsd_lookahead.argtypes = [ci, ctypes.c_longlong, cd, vp, vp, vp, vp]
         info = _ModelInfo()
         rc = L.lfsd_get_model_info(ctypes.byref(info))
-        if rc != 0 or info.abi_version != 7:
+        if rc != 0 or info.abi_version != 8:
             raise LfsdError("ABI mismatch in %s" % path)
         self.n_state, self.n_control, self.n_auxvar, self.n_const = (info.n_state, info.n_control, info.n_auxvar,
                                                                       info.n_const)
@@ -291,9 +291,12 @@ class ModelLibrary:
         return out
 
     def aux_solve(self, horizon, auxvar, consts, state_grid, control_grid, costate_grid, taus, waypoints, iface_idx,
-                  substeps=0, want_grids=False, Z_grid=None, out=None, phase_hook=None, rtol=1e-3):
+                  substeps=0, want_grids=False, Z_grid=None, out=None, phase_hook=None, rtol=1e-3, oc_status=None,
+                  skip_status=()):
         """``phase_hook(name)``, if given, is called before/after each of the two launches
-        ("riccati", "forward") so a caller can bracket them with HIP events (bench.py)."""
+        ("riccati", "forward") so a caller can bracket them with HIP events (bench.py).
+        ``oc_status`` [B] int32 (the status the OC solve wrote) + ``skip_status`` (status values, e.g. (3, 4)): rows with
+        one of these statuses are not differentiated -- NaN loss / gradient, no sweep (include/lfsd_cpdp.h, ABI 8)."""
         dt = state_grid.dtype
         B, N1, n = state_grid.shape
         N = N1 - 1
@@ -329,6 +332,15 @@ class ModelLibrary:
             # [B][4]: split units executed / intervals accepted above rtol, Riccati sweep | forward sweep (include/lfsd_cpdp.h)
             out["stats"] = torch.zeros((B, 4), dtype=torch.int32, device=dev)
         self._check(out["stats"], (B, 4), torch.int32, "stats")
+        skip_mask = 0
+        for st in skip_status:
+            if not 0 <= int(st) < 31:
+                raise LfsdError("skip_status values must be OC-solve statuses (0..30)")
+            skip_mask |= 1 << int(st)
+        if skip_mask:
+            self._check(oc_status, (B,), torch.int32, "oc_status")
+        else:
+            oc_status = None
         auxX = auxU = None
         if want_grids:
             auxX = torch.empty((B, N + 1, p, n), dtype=dt, device=dev)
@@ -337,14 +349,14 @@ class ModelLibrary:
                   self._p(state_grid), self._p(control_grid), self._p(costate_grid), self._p(Z_grid))
         tail = (nw, ni, self._p(iface_idx), self._p(taus), self._p(waypoints), self._p(out["loss"]),
                 self._p(out["grad"]), self._p(auxX), self._p(auxU), int(substeps), float(rtol), self._p(out["stats"]),
-                self._stream(state_grid))
+                self._p(oc_status), skip_mask, self._stream(state_grid))
         with self._on(state_grid):
             if phase_hook is None:
                 self._rc(self.lib.lfsd_aux_solve(*common, *tail), "lfsd_aux_solve")
             else:
                 phase_hook("riccati")
                 self._rc(self.lib.lfsd_aux_riccati(*common, int(substeps), float(rtol), self._p(out["stats"]),
-                                                   self._stream(state_grid)), "lfsd_aux_riccati")
+                                                   self._p(oc_status), skip_mask, self._stream(state_grid)), "lfsd_aux_riccati")
                 phase_hook("forward")
                 self._rc(self.lib.lfsd_aux_forward(*common, *tail), "lfsd_aux_forward")
                 phase_hook("end")

@@ -26,7 +26,8 @@ int main() {
                             cost.data(), it.data(), st.data(), 40, dtype ? 1e-9 : 1e-6, 3, mapping, ws.data(), wsb, nullptr);
     printf("dtype %d coc rc %d status %d iters %d\n", dtype, rc, st[0], it[0]);
     rc = lfsd_aux_solve(dtype, B, N, hz.data(), th.data(), nc ? cs.data() : nullptr, 0, X.data(), U.data(), L.data(), Z.data(), nw, ni, iface.data(),
-                        taus.data(), wps.data(), loss.data(), grad.data(), aX.data(), aU.data(), (pass & 2) ? 1 : 4, (pass & 2) ? 1e-3 : 0.0, stats.data(), nullptr);
+                        taus.data(), wps.data(), loss.data(), grad.data(), aX.data(), aU.data(), (pass & 2) ? 1 : 4, (pass & 2) ? 1e-3 : 0.0, stats.data(),
+                        st.data(), (1 << LFSD_ST_FAILED) | ((pass & 1) ? (1 << st[1]) : 0), nullptr);      // (odd passes: row 1 is skipped whatever its status)
     printf("dtype %d aux units %d / %d unmet %d / %d\n", dtype, stats[0], stats[2], stats[1], stats[3]);
     printf("dtype %d aux rc %d\n", dtype, rc);
     for (int meth = 0; meth < 5; ++meth)

@@ -242,11 +242,12 @@ def state_bounds(prepare, dtype=torch.float64):
         oc.setDyn(beta * env.f); oc.setPathCost(beta * env.path_cost); oc.setFinalCost(env.final_cost)
         oc.setIntegrator(10)
         return oc
-    th, x0 = [2.0, 1.0, 1.0], [0.0, 0.0]
-    cases = [([-1e20, -1e20], [2.6, 2.0], [], []),
-             ([-1e20, 0.3], [1e20, 2.2], [-1e20], [9.0])]
+    th = [2.0, 1.0, 1.0]
+    # (the reference bounds X_0 as well, CPDP.py:136-140: the initial state has to lie inside the box)
+    cases = [([0.0, 0.0], [-1e20, -1e20], [2.6, 2.0], [], []),
+             ([0.0, 0.5], [-1e20, 0.3], [1e20, 2.2], [-1e20], [9.0])]
     o = make_oracle("pendulum", 10)
-    for xlb, xub, ulb, uub in cases:
+    for x0, xlb, xub, ulb, uub in cases:
         oc = bounded(xlb, xub, ulb, uub)
         prepare(oc, dtype)
         sol = oc.cocSolverBatch([x0] * 3, 1.0, [th] * 3)                 # ragged batch of 3
@@ -267,6 +268,22 @@ def state_bounds(prepare, dtype=torch.float64):
         assert (mult >= 0).all()
         inside = (X[1:] < np.array(xub) - 1e-3) & (X[1:] > np.array(xlb) + 1e-3)
         assert np.abs(mult[:, 0][inside]).max() < 1e-6 and np.abs(mult[:, 1][inside]).max() < 1e-6
+    # an initial state outside the box: the reference's NLP (bounds on X_0 + the constraint X_0 = ini_state) is infeasible
+    oc = bounded([-1e20, 0.3], [1e20, 2.2], [], [])
+    prepare(oc, dtype)
+    try:
+        oc.cocSolverBatch([[0.0, 0.0]], 1.0, [th])
+        raise AssertionError("an initial state outside the state bounds must be refused")
+    except Exception as exc:
+        assert "ini_state violates the state bounds" in str(exc), exc
+    # a box no trajectory can stay in (the angle must rise from 0.2 to ~pi but is capped at 0.25 with the velocity forced
+    # >= 0.5): the multiplier loop ends at its limits and must SAY so -- status 3, as IPOPT's "infeasible" / iteration limit
+    oc = bounded([-1e20, 0.5], [0.25, 1e20], [], [])
+    prepare(oc, dtype)
+    oc.state_max_outer = 6
+    sol = oc.cocSolverBatch([[0.2, 0.6]] * 2, 1.0, [th] * 2)
+    assert set(sol["status"].tolist()) <= {3, 4}, sol["status"]
+    assert float(sol["state_violation_rows"].min()) > 1e-3
     # bounds of the wrong length are ignored, as in the reference (CPDP.py:23-31)
     oc = bounded([-1.0], [1.0], [], [])
     assert oc.state_lb == [-1e20, -1e20] and oc.state_ub == [1e20, 1e20]

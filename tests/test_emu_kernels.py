@@ -598,3 +598,35 @@ def test_state_bounds_vs_independent_bounded_solve(emu):
     assert oc._lib is None and oc.state_lb == [-1e20, -1e20]
     with pytest.raises(ValueError):
         oc.setStateVariable(env.X, [1.0, 0.0], [0.0, 1.0])
+
+
+def test_aux_pass_skips_rows_by_oc_status(emu):
+    """ABI 8: rows whose OC-solve status is in `skip_status` are not differentiated -- NaN loss / gradient, zero stats, their
+    Z_grid rows untouched -- and every other row is bit-identical to the unskipped call (Examples/robotarm_random.py:60-73
+    applies every gradient; a learner that freezes unconverged rows does not pay for their sweeps)."""
+    oc, env, d = models.pendulum(n_grid=10)
+    emu(oc)
+    oc.setDevice(dtype=torch.float64)
+    th = np.array([[1.0, 0.5, 1.5], [2.0, 1.0, 1.0], [0.7, 1.3, 0.6], [1.5, 0.8, 1.2], [1.2, 0.9, 0.7]])
+    taus, wps = [0.1, 0.3, 0.6], [[0.4], [1.2], [2.1]]
+    sol = oc.cocSolverBatch(np.tile(d["ini_state"], (5, 1)), d["horizon"], th)
+    ref = oc.auxSysSolverBatch(sol, taus, wps, d["interface"], skip_status=())
+    ref_l, ref_g, ref_Z = ref["loss"].clone(), ref["grad"].clone(), ref["Z_grid"].clone()
+    sol2 = dict(sol)
+    st = sol["status"].clone()
+    st[1], st[3] = 4, 3                            # pretend: row 1 failed, row 3 ran out of iterations
+    sol2["status"] = st
+    Z = torch.full_like(ref_Z, 7.0)
+    a4 = oc.auxSysSolverBatch(sol2, taus, wps, d["interface"], Z_grid=Z)             # default: FAILED rows only
+    assert torch.isnan(a4["loss"][1]) and torch.isnan(a4["grad"][1]).all() and bool((a4["Z_grid"][1] == 7.0).all())
+    assert a4["stats"][1].tolist() == [0, 0, 0, 0]
+    keep = [0, 2, 3, 4]
+    assert torch.equal(a4["loss"][keep], ref_l[keep]) and torch.equal(a4["grad"][keep], ref_g[keep])
+    assert torch.equal(a4["Z_grid"][keep], ref_Z[keep])
+    a34 = oc.auxSysSolverBatch(sol2, taus, wps, d["interface"], skip_status=(3, 4))
+    assert torch.isnan(a34["loss"][[1, 3]]).all() and torch.isnan(a34["grad"][[1, 3]]).all()
+    assert torch.equal(a34["loss"][[0, 2, 4]], ref_l[[0, 2, 4]]) and torch.equal(a34["grad"][[0, 2, 4]], ref_g[[0, 2, 4]])
+    # a mask without the status array is an argument error, not a silent no-op
+    with pytest.raises(runtime.LfsdError):
+        oc.compile().aux_solve(sol["horizon"], sol["auxvar"], sol["consts"], sol["state_grid"], sol["control_grid"],
+                               sol["costate_grid"], None, None, None, skip_status=(4,))

@@ -1,0 +1,33 @@
+#!/bin/bash
+# GPU sessions of a round as ONE parameterised script (the 27 one-off tools/gpu_r03_*.sh of round 3 are in the history).
+# usage (on the GPU box, via gpurun):  bash tools/gpu_session.sh <session> [tag]     -> gpurun_out/<tag>/
+#   quick    bench lines fp32 + fp64 (no CPU leg) and the parity tests that pin the auxiliary sweeps
+#   tier     smoke() + the whole -m gpu tier with the parity-floor report
+#   profile  tools/gpu_profile.sh <tag> (rocprofv3 kernel stats + PMC passes of bench.py)
+#   configs  bench.py --config robotarm / rocket lines (+ their rocprofv3 kernel stats)
+#   ab       tools/ab_variants.py run <names...>   (variants built beforehand with `ab_variants.py build`)
+S=${1:-quick}; TAG=${2:-r04_$S}; OUT=gpurun_out/$TAG
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
+line() { python3 -c "
+import json,sys
+o=json.load(open(sys.argv[1])); r=o.get('roofline',{})
+print(sys.argv[1].split('/')[-1], round(o['value']), o['ms_per_step'], o['config'].get('kernel_ms'), o['config'].get('oc_status_hist'), o['config'].get('aux_units_per_interval'), r.get('valu_frac'))" $1; }
+case $S in
+quick)
+  python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline > $OUT/bench_f32.json 2> $OUT/bench_f32.err; line $OUT/bench_f32.json
+  python3 bench.py --steps 10 --warmup 2 --dtype f64 --no-cpu-baseline > $OUT/bench_f64.json 2> $OUT/bench_f64.err; line $OUT/bench_f64.json
+  rm -f $OUT/parity_floors.jsonl
+  LFSD_PARITY_REPORT=$PWD/$OUT/parity_floors.jsonl timeout 1500 python3 -m pytest tests -m gpu -q -x -k "${K:-every_output_grid or bench_seeds or outer_iteration_12 or reference_shaped or time_varying or fp64_aux}" > $OUT/pytest_gpu.txt 2>&1
+  tail -5 $OUT/pytest_gpu.txt ;;
+tier)
+  python3 -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.txt 2>&1; tail -2 $OUT/smoke.txt
+  rm -f $OUT/parity_floors.jsonl
+  LFSD_PARITY_REPORT=$PWD/$OUT/parity_floors.jsonl timeout 2700 python3 -m pytest tests -m gpu -q > $OUT/pytest_gpu.txt 2>&1
+  tail -5 $OUT/pytest_gpu.txt ;;
+profile)
+  bash tools/gpu_profile.sh $TAG ;;
+ab)
+  shift; shift; python3 tools/ab_variants.py run "$@" > $OUT/ab.txt 2>&1; cat $OUT/ab.txt ;;
+*) echo "unknown session $S"; exit 2 ;;
+esac
