@@ -16,6 +16,13 @@ Workloads (Quadrotor CPDP with time-warping, n_grid "horizon" 50, 4 RK4 steps pe
 `value` = trajectories * K / wall seconds over all ranks (trajectory outer-iterations per second, whole job).
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--dtype f32|f64] [--mode independent|shared]
+                    [--config quadrotor|robotarm|rocket]
+
+`--config` selects another BASELINE configuration with the same JSON schema (WORKLOADS below): `robotarm` = configs[1]
+(Examples/robotarm_random.py:14-73: n_grid 50, 1024 random seeds, fp32, plain gradient steps at lr 0.1), `rocket` =
+configs[4] at one GPU's shard (Examples/rocket_groundtruth.py:14-111: n_grid 100, 8192 / 8 = 1024 seeds, fp32 solve +
+fp64 auxiliary pass, ground-truth waypoints, lr 1e-3).  The default line (quadrotor, fp32, N = 1) also carries an
+`"f64"` object: the same workload run for 5 steps at the reference's own precision after the timed region.
 
 `--gpus N` with N > 1 and no torch.distributed.run environment: this process touches no GPU, starts
 `python -m torch.distributed.run --nproc-per-node N bench.py ...` as a child, relays rank 0's JSON line and exits
@@ -33,7 +40,21 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
 VALU_PEAK_TFLOPS = {"f32": 157.3, "f64": 78.6}
-PROFILE_TAG = "r03"            # profiles/<tag>_hbm_traffic.json, <tag>_issue_counters.json feed the roofline object
+PROFILE_TAG = "r04"            # profiles/<tag>_hbm_traffic.json, <tag>_issue_counters.json feed the roofline object
+
+# The workloads of BASELINE.json's configs that bench.py can emit a line for.  `batch` is per GPU.
+WORKLOADS = {
+    "quadrotor": dict(kind="quadrotor", n_grid=50, batch=4096, dtype="f32", aux_dtype=None, method="Nesterov", lr=1e-2,
+                      spread=None, baseline="configs[2]", cpu_seeds=64, cpu_workers=64,
+                      what="Quadrotor (JinEnv, initCost_Polynomial, beta time-warp) CPDP"),
+    "robotarm": dict(kind="robotarm", n_grid=50, batch=1024, dtype="f32", aux_dtype=None, method="Vanilla", lr=1e-1,
+                     spread=0.05, baseline="configs[1]", cpu_seeds=64, cpu_workers=64,
+                     what="RobotArm 2-link (JinEnv, initCost_Polynomial, beta time-warp) CPDP, Examples/robotarm_random.py:14-73"),
+    "rocket": dict(kind="rocket", n_grid=100, batch=1024, dtype="f32", aux_dtype="f64", method="Vanilla", lr=1e-3,
+                   spread=0.05, baseline="configs[4] (one GPU's shard of 8192 / 8)", cpu_seeds=16, cpu_workers=16,
+                   what="Rocket 6-DoF (JinEnv, initCost2, beta time-warp) CPDP, Examples/rocket_groundtruth.py:14-111, "
+                        "fp32 OC solve + fp64 auxiliary (Riccati / sensitivity) pass, waypoints from the true parameters"),
+}
 
 
 def parse_args(argv=None):
@@ -41,9 +62,12 @@ def parse_args(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=4096)
-    ap.add_argument("--n-grid", type=int, default=50)
-    ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
+    ap.add_argument("--config", default="quadrotor", choices=sorted(WORKLOADS),
+                    help="BASELINE configuration: quadrotor = configs[2] / [3] (headline), robotarm = configs[1], rocket = configs[4]")
+    ap.add_argument("--batch", type=int, default=None, help="trajectories per GPU (default: the configuration's)")
+    ap.add_argument("--n-grid", type=int, default=None)
+    ap.add_argument("--dtype", default=None, choices=["f32", "f64"], help="arithmetic of the OC solve (default: the configuration's)")
+    ap.add_argument("--no-f64-leg", action="store_true", help="skip the 5 fp64 steps appended to the default fp32 headline line")
     ap.add_argument("--substeps", type=int, default=0,
                     help="minimum split units per grid interval of the auxiliary sweeps (0: library default = 1 with error control)")
     ap.add_argument("--aux-rtol", type=float, default=1e-3,
@@ -57,7 +81,12 @@ def parse_args(argv=None):
     ap.add_argument("--warm-start", action="store_true",
                     help="NOT the headline: start each OC solve from the previous iteration's controls")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl == RCCL on ROCm)")
-    return ap.parse_args(argv)
+    args = ap.parse_args(argv)
+    w = WORKLOADS[args.config]
+    args.batch = args.batch or w["batch"]
+    args.n_grid = args.n_grid or w["n_grid"]
+    args.dtype = args.dtype or w["dtype"]
+    return args
 
 
 def spawn_ranks(args, argv):
@@ -87,12 +116,12 @@ def algorithmic_bytes(kernel, n, m, p, nc, N, nw, ni, es):
 
 
 # ---- CPU baseline: the oracle (port of the reference pipeline) on ALL host cores -----------------------------------
-def cpu_worker(n_grid):
-    """`bench.py --cpu-worker N_GRID`: build the oracle, say READY, read one JSON line of jobs, answer one JSON line."""
+def cpu_worker(kind, n_grid):
+    """`bench.py --cpu-worker KIND N_GRID`: build the oracle, say READY, read one JSON line of jobs, answer one JSON line."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from conftest import make_oracle
     from oracle.cpdp_oracle import getloss_corrections
-    o = make_oracle("quadrotor", n_grid)
+    o = make_oracle(kind, n_grid)
     o.diffPMP()
     print("READY", flush=True)
     jobs = json.loads(sys.stdin.readline())
@@ -105,7 +134,7 @@ def cpu_worker(n_grid):
     print(json.dumps(out), flush=True)
 
 
-def cpu_baseline(d, n_grid, thetas, n_sample, timeout=240.0):
+def cpu_baseline(kind, d, n_grid, thetas, n_sample, max_workers=64, timeout=240.0):
     """The oracle (fp64 numpy/scipy port of the reference pipeline; CasADi/IPOPT cannot be installed here) on a
     bounded sample of the benchmark's own seeds, one worker PROCESS per host core (plain child processes of this
     script: nothing is forked from the process that holds the GPU context).  Every worker has imported and lambdified
@@ -118,12 +147,12 @@ def cpu_baseline(d, n_grid, thetas, n_sample, timeout=240.0):
     # 64 seeds on at most 64 workers: one seed costs 2.5-6 s of one core, so the leg stays inside ~10-30 s on any host
     # (on the 256-core GPU box 256 workers x 2 seeds took 154 s: the processes fight over memory bandwidth)
     n_sample = min(len(thetas), n_sample if n_sample > 0 else 64)
-    workers = min(cores, n_sample, 64)
+    workers = min(cores, n_sample, max_workers)
     jobs = [(list(map(float, d["ini_state"])), float(d["horizon"]), list(map(float, d["taus"])),
              [list(map(float, w)) for w in d["waypoints"]], list(map(int, d["interface"])),
              [float(x) for x in thetas[b]]) for b in range(n_sample)]
     env = dict(os.environ, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1")   # the processes are the parallelism
-    procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", str(n_grid)], env=env,
+    procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", kind, str(n_grid)], env=env,
                               stdin=subprocess.PIPE, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
              for _ in range(workers)]
     ready, go = [threading.Event() for _ in procs], threading.Event()
@@ -169,15 +198,21 @@ def cpu_baseline(d, n_grid, thetas, n_sample, timeout=240.0):
                        "and cannot be (no network)" % (n_sample, len(thetas), workers, cores, dt)), results
 
 
-def demo_set(args, d, rank, mode):
+def demo_set(args, d, rank, mode, w=None, p=None):
     """The problem set rank `rank` draws (weak scaling: every rank its own `--batch` trajectories, seeded by the rank)."""
     import numpy as np
+    w = w or WORKLOADS[args.config]
+    p = p or len(d["theta0"])
     B = args.batch
     rng = np.random.default_rng(1234 + rank)
     x0 = np.tile(d["ini_state"], (B, 1))
     if mode == "independent":
-        theta0 = np.array(d["theta0"])[None, :] + 0.05 * rng.standard_normal((B, len(d["theta0"])))
-        theta0[:, 0] = np.abs(theta0[:, 0]) + 0.5
+        if w["spread"] is None:       # quadrotor (configs[2]): additive spread around the example's initial guess
+            theta0 = np.array(d["theta0"])[None, :] + 0.05 * rng.standard_normal((B, len(d["theta0"])))
+            theta0[:, 0] = np.abs(theta0[:, 0]) + 0.5
+        else:                         # robot arm / rocket: random seeds = the example's initial guess, 5 % relative spread
+            theta0 = np.array(d["theta0"])[None, :] * (1 + w["spread"] * rng.standard_normal((B, p)))
+            theta0[:, 0] = np.abs(theta0[:, 0]) + 0.1
         return dict(x0=x0, theta0=theta0)
     # shared theta, random demonstrations: start position, goal and waypoints perturbed per trajectory
     x0[:, 0:3] += 0.2 * rng.standard_normal((B, 3))
@@ -200,23 +235,85 @@ def shared_learner(oc, d, demos, n_total, pg=None, warm_start=False):
                                   mode="shared", process_group=pg, warm_start=warm_start)
 
 
-def build_learner(args, oc, d, lib, rank, world, mode, pg=None):
+def demonstration(oc, d, n_grid):
+    """(taus, waypoints) of the workload.  Examples with fixed waypoints carry them; the ground-truth examples
+    (rocket_groundtruth.py:77-86) take them from the optimal trajectory at the true parameters, at the same fractions of
+    the horizon as the example's grid indices [1, 3, 6, 10, 13] of 15."""
+    import numpy as np
+    if "taus" in d:
+        return list(d["taus"]), [list(w) for w in d["waypoints"]]
+    sol = oc.cocSolverBatch([d["ini_state"]], d["horizon"], [d["true_theta"]])
+    assert int(sol["status"][0]) in (1, 2), "the ground-truth solve of the demonstration did not converge"
+    tg = np.linspace(0, d["horizon"], n_grid + 1)
+    idx = sorted(set(int(round(f * n_grid)) for f in (1 / 15, 3 / 15, 6 / 15, 10 / 15, 13 / 15)))
+    wps = sol["state_grid"][0, idx][:, list(d["interface"])].double().cpu().numpy()
+    return tg[idx].tolist(), wps.tolist()
+
+
+def build_learner(args, oc, d, lib, rank, world, mode, w=None, pg=None):
     """The benchmark's learner for rank `rank`."""
     from lfsd_amd import CPDP
-    demos = demo_set(args, d, rank, mode)
+    w = w or WORKLOADS[args.config]
+    demos = demo_set(args, d, rank, mode, w, lib.n_auxvar)
     if mode == "independent":
         L = CPDP.SparseDemoLearner(oc, demos["x0"], d["horizon"], d["taus"], d["waypoints"], d["interface"], demos["theta0"],
-                                   method="Nesterov", learning_rate=1e-2, mu=0.9, warm_start=args.warm_start)
+                                   method=w["method"], learning_rate=w["lr"], mu=0.9, warm_start=args.warm_start)
         return L, demos["theta0"], demos["x0"]
     L = shared_learner(oc, d, demos, args.batch * world, pg=pg, warm_start=args.warm_start)
     return L, demos["theta0"][None, :], demos["x0"]
 
 
+def timed_steps(L, steps, warmup, sync, torch):
+    """`warmup` untimed steps, then exactly `steps` steps between two synchronisations, every kernel of a step bracketed
+    by HIP events on the stream it is launched on (torch's current stream).  -> (seconds, {kernel: ms per step}, last loss)"""
+    import numpy as np
+    names = ("oc_solve", "aux_riccati", "aux_forward", "update")
+    ev = {k: [] for k in names}
+    cur = {}
+
+    def hook(name):
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        if cur.get("prev"):
+            ev[cur["prev"][0]].append((cur["prev"][1], e))
+        cur["prev"] = None if name == "end" else (name, e)
+    for _ in range(warmup):
+        L.step()
+    sync()
+    L.event_hook = hook
+    t0 = time.perf_counter()
+    loss = None
+    for _ in range(steps):
+        loss, _g = L.step()
+    sync()
+    elapsed = time.perf_counter() - t0
+    L.event_hook = None
+    ktime = {k: float(np.mean([a.elapsed_time(b) for a, b in v])) for k, v in ev.items()}    # ms per step
+    return elapsed, ktime, loss
+
+
+def kernel_model(perf_model, spec, args, dtype_name, aux_dtype_name, kernel, ktime, it_mean, units, B, warm):
+    """(useful vector TFLOP/s, useful matrix-core TFLOP/s, useful flops per launch) of `kernel` by the operation-count model."""
+    sub = max(1, args.substeps) if args.aux_rtol > 0 else (args.substeps or 4)
+    kd = dtype_name if kernel == "oc_solve" else (aux_dtype_name or dtype_name)
+    # mesh continuation: 5 of the roll-outs of a cold lean fp32 / fp64 solve run on the coarse grid (DESIGN.md 3.1); none when
+    # the solve is warm-started or the model has no coarse phase
+    coarse = 0 if (warm or kernel != "oc_solve" or args.config != "quadrotor") else 5
+    flops, mflops = perf_model.kernel_flops(spec, kernel, args.n_grid, 4, sub, mean_iters=it_mean,
+                                            units_per_interval=units.get(kernel), split=True, midpoint=(kd == "f32"),
+                                            coarse_rollouts=coarse)
+    if kd == "f64" or args.config != "quadrotor":      # matrix cores only in the lean fp32 kernel of the 13-state models' lock-step mapping
+        flops, mflops = flops + mflops, 0.0
+    t = ktime[kernel] * 1e-3
+    return flops * B / t / 1e12, mflops * B / t / 1e12, flops * B, kd
+
+
 def main(argv=None):
     argv = sys.argv[1:] if argv is None else argv
-    if len(argv) == 2 and argv[0] == "--cpu-worker":
-        return cpu_worker(int(argv[1]))
+    if len(argv) == 3 and argv[0] == "--cpu-worker":
+        return cpu_worker(argv[1], int(argv[2]))
     args = parse_args(argv)
+    w = WORKLOADS[args.config]
     in_launcher = "RANK" in os.environ and "MASTER_PORT" in os.environ      # started by torch.distributed.run
     if args.gpus > 1 and not in_launcher:
         spawn_ranks(args, argv)
@@ -240,12 +337,17 @@ def main(argv=None):
 
     import lfsd_amd  # noqa: F401
     from lfsd_amd import models, perf_model
-    dtype = torch.float32 if args.dtype == "f32" else torch.float64
+    TD = {"f32": torch.float32, "f64": torch.float64}
+    dtype = TD[args.dtype]
+    aux_name = w["aux_dtype"] if args.dtype == w["dtype"] else None      # (an explicit --dtype f64 runs everything in fp64)
     mode = args.mode or ("shared" if world > 1 else "independent")
-    oc, env, d = models.quadrotor(n_grid=args.n_grid)
+    if mode == "shared" and args.config != "quadrotor":
+        print("bench.py: --mode shared is the quadrotor's configs[3] workload", file=sys.stderr)
+        sys.exit(2)
+    oc, env, d = models.ZOO[w["kind"]](n_grid=args.n_grid)
     if args.library:
         oc.use_library(args.library)
-    oc.setDevice(dev, dtype)
+    oc.setDevice(dev, dtype, aux_dtype=TD[aux_name] if aux_name else None)
     oc.setSolverOptions(aux_substeps=args.substeps, aux_rtol=args.aux_rtol)
     if use_dist and rank != 0:
         dist.barrier()                                 # rank 0 makes sure the model library exists (it is normally prebuilt)
@@ -254,7 +356,9 @@ def main(argv=None):
         dist.barrier()
     assert not lib.is_emulator
     B = args.batch
-    L, theta0, x0 = build_learner(args, oc, d, lib, rank, world, mode)
+    d = dict(d)
+    d["taus"], d["waypoints"] = demonstration(oc, d, args.n_grid)
+    L, theta0, x0 = build_learner(args, oc, d, lib, rank, world, mode, w)
     L.count_unconverged = False                       # no device->host read inside the timed loop
 
     # HIP results of the first seeds at theta_0, kept for the cross-check against the CPU baseline's oracle results
@@ -265,84 +369,58 @@ def main(argv=None):
         aux_c = oc.auxSysSolverBatch(sol_c, d["taus"], d["waypoints"], d["interface"])
         chk_loss, chk_grad = aux_c["loss"].double().cpu().numpy(), aux_c["grad"].double().cpu().numpy()
 
-    # per-kernel HIP events on the stream the kernels are launched on (torch's current stream)
-    names = ("oc_solve", "aux_riccati", "aux_forward", "update")
-    ev = {k: [] for k in names}
-    cur = {}
-
-    def hook(name):
-        e = torch.cuda.Event(enable_timing=True)
-        e.record()
-        if cur.get("prev"):
-            ev[cur["prev"][0]].append((cur["prev"][1], e))
-        cur["prev"] = None if name == "end" else (name, e)
-
     def sync():
         if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        L.step()
-    sync()
-    L.event_hook = hook
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss, _g = L.step()
-    sync()
-    elapsed = time.perf_counter() - t0
-    L.event_hook = None
+    elapsed, ktime, loss = timed_steps(L, args.steps, args.warmup, sync, torch)
     if use_dist:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
-    ktime = {k: float(np.mean([a.elapsed_time(b) for a, b in v])) for k, v in ev.items()}    # ms per step
     st = L._sol["status"].cpu().numpy()
     it = L._sol["iters"].cpu().numpy()
     if rank == 0:
         n, m, p, nc = lib.n_state, lib.n_control, lib.n_auxvar, lib.n_const
-        es = 4 if args.dtype == "f32" else 8
         dom = max(("oc_solve", "aux_riccati", "aux_forward"), key=lambda k: ktime[k])
         nw, ni = L.taus.shape[1], len(d["interface"])
+        stats = L._aux["stats"].double().cpu().numpy()
+        units = {"aux_riccati": float(stats[:, 0].mean()) / args.n_grid, "aux_forward": float(stats[:, 2].mean()) / args.n_grid}
+        useful_tflops, mfma_tflops, useful_flops, dom_dtype = kernel_model(perf_model, oc.model_spec(), args, args.dtype, aux_name, dom,
+                                                                           ktime, float(it.mean()), units, B, args.warm_start)
+        es = 4 if dom_dtype == "f32" else 8
         abytes = B * algorithmic_bytes(dom, n, m, p, nc, args.n_grid, nw, ni, es)
         achieved = abytes / (ktime[dom] * 1e-3) / 1e9
         # PMC passes are separate rocprofv3 runs (tools/hbm_traffic.py, tools/issue_counters.py); the figures only apply
-        # to the workload they were collected on, so they are attached to the headline configuration and null otherwise
-        headline = (B == 4096 and args.n_grid == 50 and args.dtype == "f32" and args.substeps == 0 and args.aux_rtol == 1e-3
-                    and mode == "independent" and not args.warm_start and not args.library)
-
+        # to the workload they were collected on, so they are attached to the configuration's default command and null otherwise
+        default_cmd = (B == w["batch"] and args.n_grid == w["n_grid"] and args.dtype == w["dtype"] and args.substeps == 0
+                       and args.aux_rtol == 1e-3 and mode == "independent" and not args.warm_start and not args.library)
+        tag = PROFILE_TAG if args.config == "quadrotor" else "%s_%s" % (PROFILE_TAG, args.config)
         sources = {}
 
         def profile(name):
             """Counter figures that THIS run does not measure: read from a committed fold of separate rocprofv3 --pmc passes
-            of the same command, and named as such in the line (file + git blob hash of the file read)."""
+            of the same command, and named as such in the line (file + git blob hash of the file read, and the commit the
+            fold was collected at when the fold records it)."""
             import hashlib
-            rel = "profiles/%s_%s.json" % (PROFILE_TAG, name)
+            rel = "profiles/%s_%s.json" % (tag, name)
             path = os.path.join(ROOT, rel)
-            if not (headline and os.path.exists(path)):
+            if not (default_cmd and os.path.exists(path)):
                 return {}
             try:
                 raw = open(path, "rb").read()
-                sources[name] = {"file": rel, "git_blob": hashlib.sha1(b"blob %d\0" % len(raw) + raw).hexdigest()}
-                return json.loads(raw).get(dom, {})
+                js = json.loads(raw)
+                sources[name] = {"file": rel, "git_blob": hashlib.sha1(b"blob %d\0" % len(raw) + raw).hexdigest(),
+                                 "collected_at_commit": js.get("collected_at_commit")}
+                return js.get(dom, {})
             except Exception:
                 return {}
         traffic = profile("hbm_traffic").get("hbm_bytes_per_launch")
         issue = profile("issue_counters")
-        # split units the error control of the auxiliary sweeps actually spent (per-trajectory statistics output of the
-        # kernels, read once after the timed loop) -- also what the flop model of those kernels is evaluated at
-        stats = L._aux["stats"].double().cpu().numpy()
-        units = {"aux_riccati": float(stats[:, 0].mean()) / args.n_grid, "aux_forward": float(stats[:, 2].mean()) / args.n_grid}
-        # useful flops of the dominant kernel: operation counts of the generated model code x calls x active columns
-        # (perf_model.py), times the solver iterations the batch actually ran
-        flops, mflops = perf_model.kernel_flops(oc.model_spec(), dom, args.n_grid, 4, max(1, args.substeps) if args.aux_rtol > 0 else (args.substeps or 4),
-                                                mean_iters=float(it.mean()), units_per_interval=units.get(dom), split=True,
-                                                midpoint=(args.dtype == "f32"), coarse_rollouts=5)
-        if args.dtype == "f64":      # no matrix cores in the fp64 kernels: the dense products are vector FMAs there
-            flops, mflops = flops + mflops, 0.0
-        useful_tflops = flops * B / (ktime[dom] * 1e-3) / 1e12
         executed = issue.get("valu_flops_executed_per_launch")
+        peak = VALU_PEAK_TFLOPS[dom_dtype]
         out = {
             "metric": "CPDP outer iterations/sec (batch trajectories)",
             "value": B * world * args.steps / elapsed,
@@ -350,24 +428,24 @@ def main(argv=None):
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": ("Quadrotor (JinEnv, initCost_Polynomial, beta time-warp) CPDP, n_grid(horizon) %d x 4 RK4 "
-                                    "steps, batch %d per GPU, Nesterov mu 0.9, %s OC solve every iteration; " %
-                                    (args.n_grid, B, "WARM-started (not the headline configuration)" if args.warm_start
-                                     else "cold-start")) +
-                                   ("BASELINE configs[2]: random initial-guess seeds on the quad_example waypoints, one theta "
-                                    "and optimizer state per seed, lr 0.01" if mode == "independent" else
+            "dtype": args.dtype if not aux_name else "%s (OC solve) + %s (auxiliary pass)" % (args.dtype, aux_name), "data": "synthetic",
+            "config": {"workload": ("%s, n_grid(horizon) %d x 4 RK4 steps, batch %d per GPU, %s%s, %s OC solve every iteration; " %
+                                    (w["what"], args.n_grid, B, w["method"] if mode == "independent" else "Nesterov",
+                                     " mu 0.9" if (mode == "shared" or w["method"] == "Nesterov") else "",
+                                     "WARM-started (not the headline configuration)" if args.warm_start else "cold-start")) +
+                                   ("BASELINE %s: random initial-guess seeds, one theta and optimizer state per seed, lr %g" %
+                                    (w["baseline"], w["lr"]) if mode == "independent" else
                                     "BASELINE configs[3] at 4096 per GPU: random demonstrations (start, goal, waypoints), ONE "
                                     "shared theta, summed d(theta)+loss all-reduced over the ranks every iteration and "
                                     "driving the update (SparseDemoLearner mode='shared')"),
-                       "mode": mode, "batch_per_gpu": B, "n_grid": args.n_grid, "steps_per_grid": 4,
+                       "name": args.config, "mode": mode, "batch_per_gpu": B, "n_grid": args.n_grid, "steps_per_grid": 4,
                        "aux_substeps": args.substeps, "aux_rtol": args.aux_rtol,
                        "aux_integration": ("error-controlled split-step + Richardson sweeps, rtol %g on the un-extrapolated "
                                            "estimate (the reference integrates the same ODEs with solve_ivp at rtol 1e-3), from %d unit(s) per interval" %
                                            (args.aux_rtol, max(1, args.substeps))) if args.aux_rtol > 0 else
                                           ("fixed %d units per interval" % (args.substeps or 4)),
                        "oc_status_hist": np.bincount(st, minlength=5).tolist(), "oc_iters_mean": float(it.mean()),
-                       "oc_iters_max": int(it.max()), "loss_mean": float(loss.mean().item()) / (1 if mode == "independent" else B * world),
+                       "oc_iters_max": int(it.max()), "loss_mean": float(torch.nanmean(loss.double()).item()) / (1 if mode == "independent" else B * world),
                        "kernel_ms": {k: round(v, 3) for k, v in ktime.items()},
                        "aux_units_per_interval": {k: round(v, 3) for k, v in units.items()},
                        "aux_intervals_accepted_above_rtol": int(stats[:, 1].sum() + stats[:, 3].sum()),
@@ -378,30 +456,55 @@ def main(argv=None):
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": abytes, "avg_launch_ms": ktime[dom],
-                         # the fraction that actually bounds this path: fp32 vector issue, not HBM
+                         # the fraction that actually bounds this path: vector issue, not HBM
                          "valu_useful_tflops": useful_tflops,
-                         "valu_frac": useful_tflops / VALU_PEAK_TFLOPS[args.dtype],
+                         "valu_frac": useful_tflops / peak, "valu_peak_tflops": peak, "kernel_dtype": dom_dtype,
                          # what the vector pipe EXECUTED per launch by the counters (every enabled lane, redundant group-uniform
                          # work included) at this run's launch time, and the modelled useful share of it
                          "valu_executed_tflops": None if executed is None else executed / (ktime[dom] * 1e-3) / 1e12,
-                         "valu_useful_over_executed": None if executed is None else flops * B / executed,
-                         "mfma_useful_tflops": mflops * B / (ktime[dom] * 1e-3) / 1e12,
+                         "valu_useful_over_executed": None if executed is None else useful_flops / executed,
+                         "mfma_useful_tflops": mfma_tflops,
                          "valu_issue_util": issue.get("valu_issue_util"),
                          "valu_lane_util": issue.get("valu_lane_util"),
                          "mfma_busy": issue.get("mfma_busy"),
                          "source": sources or None,
                          "note": "the per-trajectory recursions are latency/VALU-issue bound, not HBM bound: "
                                  "algorithmic bytes are O(10 KB) per trajectory against O(10^7) FLOP of sequential "
-                                 "fp32 vector work per solve; valu_frac = useful VECTOR flops (perf_model.py, corrected in round 3 against the "
-                                 "counters) / 157.3 TFLOP/s, "
+                                 "vector work per solve; valu_frac = useful VECTOR flops (perf_model.py, checked against the "
+                                 "counters in round 3) / the vector peak of the kernel's arithmetic (157.3 fp32, 78.6 fp64 TFLOP/s); "
                                  "traffic, valu_issue_util, valu_lane_util (EXEC-enabled lanes per vector instruction) and "
                                  "mfma_busy are NOT measured by this run: they come from the committed fold of separate rocprofv3 "
-                                 "--pmc passes of this command named in `source` (null when the run is not the headline "
-                                 "configuration); see DESIGN.md section 4"},
+                                 "--pmc passes of this command named in `source` (null when the run is not the configuration's "
+                                 "default command or no fold is committed for it); see DESIGN.md section 4"},
         }
+        # the reference computes in fp64 throughout (CPDP.py:183, :329): the same workload at that precision, 5 steps after the
+        # timed region of the default fp32 headline line -- a reported figure beside `value`, which stays the fp32 rate
+        if (args.config == "quadrotor" and default_cmd and world == 1 and not args.no_f64_leg):
+            try:
+                oc.setDevice(dev, torch.float64)
+                L64, _, _ = build_learner(args, oc, d, lib, rank, world, mode, w)
+                L64.count_unconverged = False
+                e64, k64, _ = timed_steps(L64, 5, 1, sync, torch)
+                st64 = L64._aux["stats"].double().cpu().numpy()
+                u64 = {"aux_riccati": float(st64[:, 0].mean()) / args.n_grid, "aux_forward": float(st64[:, 2].mean()) / args.n_grid}
+                d64 = max(("oc_solve", "aux_riccati", "aux_forward"), key=lambda k: k64[k])
+                it64 = float(L64._sol["iters"].double().mean().item())
+                a64 = argparse.Namespace(**dict(vars(args), dtype="f64"))
+                uf64, _, _, _ = kernel_model(perf_model, oc.model_spec(), a64, "f64", None, d64, k64, it64, u64, B, False)
+                out["f64"] = {"value": B * 5 / e64, "unit": "trajectory outer-iterations/s", "steps": 5, "warmup": 1,
+                              "ms_per_step": e64 / 5 * 1e3, "kernel_ms": {k: round(v, 3) for k, v in k64.items()},
+                              "aux_units_per_interval": {k: round(v, 3) for k, v in u64.items()},
+                              "oc_status_hist": np.bincount(L64._sol["status"].cpu().numpy(), minlength=5).tolist(),
+                              "kernel": d64, "valu_useful_tflops": uf64, "valu_frac": uf64 / VALU_PEAK_TFLOPS["f64"],
+                              "note": "same seeds, every kernel in fp64 (the reference's precision); model-only utilisation"}
+                del L64
+            except Exception as exc:
+                out["f64"] = {"value": None, "note": "failed: %r" % (exc,)}
+            oc.setDevice(dev, dtype)
         if world == 1 and mode == "independent" and not args.no_cpu_baseline:
             try:
-                out["cpu_baseline"], ores = cpu_baseline(d, args.n_grid, theta0, args.cpu_seeds)
+                out["cpu_baseline"], ores = cpu_baseline(w["kind"], d, args.n_grid, theta0, args.cpu_seeds or w["cpu_seeds"],
+                                                         max_workers=w["cpu_workers"])
             except Exception as exc:          # the GPU measurement must not be lost to a host-side problem
                 out["cpu_baseline"], ores = dict(value=None, unit="trajectory outer-iterations/s", cores=0, kind="port",
                                                  sample="failed: %r" % (exc,)), []

@@ -26,7 +26,7 @@ import hashlib
 import sympy as sp
 from sympy.printing.c import C99CodePrinter
 
-CODEGEN_VERSION = 12
+CODEGEN_VERSION = 14
 
 
 class ModelSpec:
@@ -213,10 +213,10 @@ class _Sparse:
         self.nnz = len(rc)
         self.lay, self.off, self.end = [], [], []
         for off, o in zip(offs, orders):
-            if o == '-':
-                self.lay.append(None); self.off.append(None); self.end.append(off)
+            if o == '-' or off is None:
+                self.lay.append(None); self.off.append(None); self.end.append(None)
                 continue
-            off = (off + 3) // 4 * 4
+            assert off % 4 == 0
             seq = rc if o == 'r' else sorted(rc, key=lambda t: (t[1], t[0]))
             self.lay.append([(r, c, off + i, mat[r, c]) for i, (r, c) in enumerate(seq)])
             self.off.append(off)
@@ -389,17 +389,35 @@ def emit_header(spec):
     S.append('  template<class T> static LFSD_DEV void ham_huu(%s, T* Huu_out) {' % sig_xul)
     S.append(_body(_loads(spec, with_l=True), [('Huu_out[%d]' % (a * m + b), Huu[a, b]) for a in range(m) for b in range(m)]))
     S.append('  }')
-    # 5. packed PMP coefficients, one packing per layout (0: Riccati sweep, every matrix; 1: forward sweep, without Hxx / Hxe)
+    # 5. packed PMP coefficients, one packing per layout (0: Riccati sweep, every matrix; 1: forward sweep, without Hxx / Hxe
+    #    and ordered so that what its inner loops read is a PREFIX of the node: fu (stiff step), then fx, Hxu, Huu^-1 (right-hand
+    #    side) -- the kernel fetches that prefix into registers with back-to-back LDS reads, FU_N / RHS_N words)
+    named = dict(fx=fx, fu=fu, fe=fe, Hxx=Hxx, Hxu=Hxu, Hxe=Hxe, Hue=Hue)
+    seqs = [['fx', 'fu', 'fe', 'Hxx', 'Hxu', 'Hxe', 'Hue', 'HUU', 'IHUU'], ['fu', 'fx', 'Hxu', 'IHUU', 'fe', 'Hue', 'HUU']]
+    place = [dict(), dict()]                       # name -> (offset, end) per layout
+    off_huu, off_ihuu, off_zero, ncoef, fu_n, rhs_n = [0, 0], [0, 0], [0, 0], [0, 0], [0, 0], [0, 0]
+    for lay, seq in enumerate(seqs):
+        off = 0
+        for nm in seq:
+            off = (off + 3) // 4 * 4
+            if nm == 'HUU':
+                off_huu[lay] = off; off += m * m
+            elif nm == 'IHUU':
+                off_ihuu[lay] = off; off += m * m
+            else:
+                cnt = sum(1 for e in named[nm] if _nz(e))
+                place[lay][nm] = off
+                off += cnt
+            if nm == 'fu':
+                fu_n[lay] = (off + 3) // 4 * 4
+            if nm == 'IHUU' and lay == 1:
+                rhs_n[lay] = (off + 3) // 4 * 4
+        off_zero[lay] = off                        # one word that always holds 0 (gather target of structural zeros)
+        ncoef[lay] = ((off + 1 + 3) // 4) * 4
+    rhs_n[0] = ncoef[0]
     mats = []
-    offs = [0, 0]
-    for nm, mat in (('fx', fx), ('fu', fu), ('fe', fe), ('Hxx', Hxx), ('Hxu', Hxu), ('Hxe', Hxe), ('Hue', Hue)):
-        sm = _Sparse(nm, mat, offs, _ORDERS[nm])
-        mats.append(sm)
-        offs = list(sm.end)
-    off_huu = [(o + 3) // 4 * 4 for o in offs]
-    off_ihuu = [(o + m * m + 3) // 4 * 4 for o in off_huu]
-    off_zero = [o + m * m for o in off_ihuu]    # one word that always holds 0 (gather target of structural zeros)
-    ncoef = [((o + 1 + 3) // 4) * 4 for o in off_zero]
+    for nm in ('fx', 'fu', 'fe', 'Hxx', 'Hxu', 'Hxe', 'Hue'):
+        mats.append(_Sparse(nm, named[nm], [place[0].get(nm), place[1].get(nm)], _ORDERS[nm]))
     # A diagonal Huu (control cost separable in the controls, dynamics affine in them: every model of the zoo) is inverted
     # in closed form by the staging lane's own pmp_coeffs; a general Huu is inverted by the kernel (mat_inverse)
     ihuu_closed = all(not _nz(Huu[a, b]) for a in range(m) for b in range(m) if a != b)
@@ -408,6 +426,8 @@ def emit_header(spec):
              % (pair(off_huu), pair(off_ihuu), pair(off_zero), pair(ncoef)))
     S.append('  static constexpr int OFF_HUU = %d, OFF_IHUU = %d, OFF_ZERO = %d, NCOEF = %d;      // layout 0'
              % (off_huu[0], off_ihuu[0], off_zero[0], ncoef[0]))
+    S.append('  // leading words of a node that hold fu | fu, fx, Hxu, Huu^-1 (layout 1; layout 0: the whole node)')
+    S.append('  static constexpr int FU_N_L[2] = %s, RHS_N_L[2] = %s;' % (pair(fu_n), pair(rhs_n)))
     S.append('  static constexpr bool IHUU_CLOSED = %s;      // Huu diagonal: pmp_coeffs stores Huu^-1 as well' % ('true' if ihuu_closed else 'false'))
     for lay in (0, 1):
         S.append('  // layout %d, packed (16-byte aligned starts): ' % lay +
@@ -445,6 +465,42 @@ def emit_header(spec):
             tab[r * n + cc] = o
         S.append('  static LFSD_DEV int fx_off%d(int r, int c) { constexpr short tab[%d] = {%s}; return tab[r * %d + c]; }'
                  % (lay, n * n, ', '.join(map(str, tab)), n))
+    # Column gathers.  The auxiliary sweeps carry one column per lane and add "their" column of a staged matrix to a
+    # vector: y += Hxx e_j, hu = Hux e_j ...  As products with a one-hot vector those cost one FMA per non-zero of the whole
+    # matrix; as gathers they cost one LDS read per ROW through a per-lane offset (OFF_ZERO where the entry is structurally
+    # zero).  hcol_off(c, i): packed offset of [Hxx Hxe][i][c]; ucol_off(c, a): of [Hux Hue][a][c]; ecol_off(c, i): of fe[i][c]
+    # (c over the NX + NP columns of Z = [P W], resp. the NP parameters).
+    by = {sm.name: sm for sm in mats}
+
+    def _tab(lay, rows, cols, entry):
+        t = []
+        for c in range(cols):
+            for i in range(rows):
+                t.append(entry(lay, i, c))
+        return t
+
+    def _or(v, dflt):
+        return dflt if v is None else v
+
+    def _find(sm, lay, r, c):
+        if sm.lay[lay] is None:
+            return None
+        for (rr, cc, o, _) in sm.lay[lay]:
+            if rr == r and cc == c:
+                return o
+        return None
+    for lay in (0, 1):
+        z = off_zero[lay]
+        if by['Hxx'].lay[lay] is not None:
+            t = _tab(lay, n, n + p, lambda l, i, c: _or(_find(by['Hxx'], l, i, c) if c < n else _find(by['Hxe'], l, i, c - n), z))
+            S.append('  static LFSD_DEV int hcol_off%d(int c, int i) { constexpr short tab[%d] = {%s}; return tab[c * %d + i]; }'
+                     % (lay, len(t), ', '.join(map(str, t)), n))
+        t = _tab(lay, m, n + p, lambda l, a, c: _or(_find(by['Hxu'], l, c, a) if c < n else _find(by['Hue'], l, a, c - n), z))
+        S.append('  static LFSD_DEV int ucol_off%d(int c, int a) { constexpr short tab[%d] = {%s}; return tab[c * %d + a]; }'
+                 % (lay, len(t), ', '.join(map(str, t)), m))
+        t = _tab(lay, n, p, lambda l, i, c: _or(_find(by['fe'], l, i, c), z))
+        S.append('  static LFSD_DEV int ecol_off%d(int c, int i) { constexpr short tab[%d] = {%s}; return tab[c * %d + i]; }'
+                 % (lay, len(t), ', '.join(map(str, t)), n))
     # G[a*NU+b] (+)= sum_i S[i*NU+a] * fu[i][b]    (S = rows of B^T P gathered in LDS)
     fu_sm = mats[1]
     S.append('  // G = S^T fu  with S an NX x NU row-major matrix (e.g. S = P fu  ->  G = fu^T P fu)')

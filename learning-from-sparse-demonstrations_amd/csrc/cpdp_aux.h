@@ -113,6 +113,10 @@ template <class M, typename T, int G, int LAY> struct AuxCtx {
   T t_a, dgrid;
   T* lds;
   T ox[NX], oe[NP];    // one-hot selectors of this lane's column
+  // Riccati sweep: where this lane's column of [Hxx Hxe] (NX rows) and of [Hux Hue] (NU rows) sits in node 0 (structural
+  // zeros point at the node's zero word): `y += H e_lane` is a gather of NX words, not a product with a one-hot vector
+  const T* hcol[LAY == 0 ? NX : 1];
+  const T* ucol[LAY == 0 ? NU : 1];
   int fxo[(LFSD_RIC_MFMA != 0) ? NX : 1];      // experiment: offsets of column (lane % 16) of fx in the packed coefficients
 
   LFSD_DEV void load_interval(const AuxArgs<T>& a, long long traj, int k, int N) {
@@ -245,8 +249,8 @@ template <class M, typename T, int G, int LAY> struct AuxCtx {
     T s[NU], v[NU], w[NU], nv[NU], r[NP], wq[NU];
     if (R == 0) {
       T hu[NU];
-      M::template Hxu_mulT<false, LAY>(L, ox, hu);
-      M::template Hue_mul<true, LAY>(L, oe, hu);
+#pragma unroll
+      for (int a = 0; a < NU; ++a) hu[a] = ucol[a][nd * Lay::NCOEF];      // (Hux | Hue) e_lane
       M::template ihuu_mul<LAY>(L, hu, wq);
     } else {
 #pragma unroll
@@ -294,8 +298,8 @@ template <class M, typename T, int G, int LAY> struct AuxCtx {
 #pragma unroll
       for (int i = 0; i < NX; ++i) y[i] += hc[i * G + lane];
     } else {
-      M::template Hxx_mul<true, LAY>(L, ox, y);
-      M::template Hxe_mul<true, LAY>(L, oe, y);
+#pragma unroll
+      for (int i = 0; i < NX; ++i) y[i] += hcol[i][nd * Lay::NCOEF];      // [Hxx Hxe] e_lane
     }
     M::template Hxu_mul<true, LAY>(L, w, y);
     LFSD_WAVE_SYNC();
@@ -425,9 +429,31 @@ template <class M, typename T, int G, int LAY> struct AuxCtx {
   }
   // apply the prepared exact stiff step of stiff node r (0..2) over dt = hq (half == 0) or 2 hq (half == 1); r and half
   // may differ between the lanes (the two chains sit at different nodes)
+  static constexpr bool FETCH = ((LFSD_FWD_FETCH) & (sizeof(T) == 4 ? 1 : 2)) != 0;
   LFSD_DEV void fwd_stiff(T* xa, int r, int half, T dt) {
-    const T* Kn = lds + Lay::LDS_KN + r * NX * NU;
-    const T* Psi = lds + Lay::LDS_PSI + (r * 2 + half) * NU * NU;
+    if constexpr (!FETCH) {
+      const T* Kn = lds + Lay::LDS_KN + r * NX * NU;
+      const T* Psi = lds + Lay::LDS_PSI + (r * 2 + half) * NU * NU;
+      T kx[NU], y[NU];
+#pragma unroll
+      for (int a = 0; a < NU; ++a) kx[a] = T(0);
+#pragma unroll
+      for (int i = 0; i < NX; ++i) {
+#pragma unroll
+        for (int a = 0; a < NU; ++a) kx[a] += Kn[i * NU + a] * xa[i];
+      }
+      matvec<NU>(Psi, kx, y);
+#pragma unroll
+      for (int a = 0; a < NU; ++a) y[a] *= -dt;
+      M::template fu_mul<true, LAY>(node(2 * r), y, xa);
+      return;
+    }
+    // gain rows, matrix function and fu of the node: fetched into registers with back-to-back reads, one wait (lds_fetch)
+    T Kn[NX * NU], Psi[NU * NU], Lf[M::FU_N_L[LAY]];
+    lds_issue<NX * NU>(lds + Lay::LDS_KN + r * NX * NU, Kn);
+    lds_issue<NU * NU>(lds + Lay::LDS_PSI + (r * 2 + half) * NU * NU, Psi);
+    lds_issue<M::FU_N_L[LAY]>(node(2 * r), Lf);
+    lds_land<NX * NU>(Kn); lds_land<NU * NU>(Psi); lds_land<M::FU_N_L[LAY]>(Lf);
     T kx[NU], y[NU];
 #pragma unroll
     for (int a = 0; a < NU; ++a) kx[a] = T(0);
@@ -439,7 +465,7 @@ template <class M, typename T, int G, int LAY> struct AuxCtx {
     matvec<NU>(Psi, kx, y);
 #pragma unroll
     for (int a = 0; a < NU; ++a) y[a] *= -dt;
-    M::template fu_mul<true, LAY>(node(2 * r), y, xa);
+    M::template fu_mul<true, LAY>(Lf, y, xa);
   }
   // non-stiff part  X' = fx X + fe - fu Huu^-1 (Hux X + Hue + fu^T W).  Its X-independent part
   //   b_j(t) = (fe - fu Huu^-1 (fu^T W(t) + Hue)) e_j
@@ -470,8 +496,25 @@ template <class M, typename T, int G, int LAY> struct AuxCtx {
     }
   }
   LFSD_DEV void fwd_rhs(const T* xa, int nd, T* y) {
-    const T* L = node(nd);
-    const T* bc = lds + Lay::FWD_BC + nd * NX * NP;     // lanes without an X column read column 0; their result is dropped
+    if constexpr (!FETCH) {
+      const T* L = node(nd);
+      const T* bc = lds + Lay::FWD_BC + nd * NX * NP;     // lanes without an X column read column 0; their result is dropped
+      T s[NU], v[NU];
+      M::template Hxu_mulT<false, LAY>(L, xa, s);
+      M::template ihuu_mul<LAY>(L, s, v);
+#pragma unroll
+      for (int a = 0; a < NU; ++a) v[a] = -v[a];
+      M::template fx_mul<false, LAY>(L, xa, y);
+      M::template fu_mul<true, LAY>(L, v, y);
+#pragma unroll
+      for (int i = 0; i < NX; ++i) y[i] += bc[i * NP + xcol];
+      return;
+    }
+    // the node's fu, fx, Hxu, Huu^-1 (a prefix of the forward packing) and this column's b_j: registers first (lds_fetch)
+    T L[M::RHS_N_L[LAY]], b[NX];
+    lds_issue<M::RHS_N_L[LAY]>(node(nd), L);
+    lds_issue_strided<NX>(lds + Lay::FWD_BC + nd * NX * NP + xcol, NP, b);     // lanes without an X column read column 0; their result is dropped
+    lds_land<M::RHS_N_L[LAY]>(L); lds_land<NX>(b);
     T s[NU], v[NU];
     M::template Hxu_mulT<false, LAY>(L, xa, s);
     M::template ihuu_mul<LAY>(L, s, v);
@@ -480,7 +523,7 @@ template <class M, typename T, int G, int LAY> struct AuxCtx {
     M::template fx_mul<false, LAY>(L, xa, y);
     M::template fu_mul<true, LAY>(L, v, y);
 #pragma unroll
-    for (int i = 0; i < NX; ++i) y[i] += bc[i * NP + xcol];
+    for (int i = 0; i < NX; ++i) y[i] += b[i];
   }
   // non-stiff RK4 step of length h over nodes (n0, n1, n2) -- per-lane values
   LFSD_DEV void fwd_rk4(T* xa, int n0, int n1, int n2, T h) {
@@ -609,6 +652,14 @@ __global__ void __launch_bounds__(64, (sizeof(T) == 4 ? LFSD_WAVES_RIC : 1)) aux
 #pragma unroll
   for (int kk = 0; kk < NX; ++kk) s.fxo[kk] = ((lane & 15) < NX) ? M::fx_off0(kk, lane & 15) : M::OFF_ZERO;
 #endif
+  {
+    const int col = lane < NZ ? lane : 0;
+    const T* n0 = s.lds + Lay::LDS_L;
+#pragma unroll
+    for (int i = 0; i < NX; ++i) s.hcol[i] = n0 + (lane < NZ ? M::hcol_off0(col, i) : M::OFF_ZERO);
+#pragma unroll
+    for (int a2 = 0; a2 < M::NU; ++a2) s.ucol[a2] = n0 + (lane < NZ ? M::ucol_off0(col, a2) : M::OFF_ZERO);
+  }
   T* Zt = a.Z_grid + traj * (long long)(N + 1) * NZ * NX;
   T z[NX];
   {

@@ -88,6 +88,14 @@
 #ifndef LFSD_FWD_NODE_LOOP
 #define LFSD_FWD_NODE_LOOP _Pragma("unroll 1")
 #endif
+// forward auxiliary sweep: operands of the stiff step / right-hand side fetched into registers with back-to-back LDS reads
+// (lds_fetch) before the sparse operators run -- bit 0: fp32 instantiation, bit 1: fp64.  Measured on MI355X (profiles/
+// r04_b): fp32 0.849 -> 0.625 ms (185 exposed LDS round trips per split unit become 7 batches); fp64 1.99 -> 2.30 ms (the
+// 96 + 13 doubles of a right-hand side do not fit beside the chain's state: scratch 144 -> 212 B/lane), so fp64 keeps
+// reading its operands where it uses them.
+#ifndef LFSD_FWD_FETCH
+#define LFSD_FWD_FETCH 1
+#endif
 #ifndef LFSD_WAVES_RIC
 #define LFSD_WAVES_RIC 2
 #endif
@@ -416,6 +424,26 @@ template <typename T> LFSD_DEV void pin(T&) {}
 #else
 template <typename T> LFSD_DEV void pin(T& x) { asm volatile("" : "+v"(x)); }
 #endif
+
+// lds_fetch<N>(src, dst): N consecutive LDS words into registers, ALL reads issued back to back, the values materialised
+// here.  Where a phase applies staged coefficients through the generated sparse operators the compiler, left to itself,
+// emits read - wait - four FMAs - read - wait ...: one exposed LDS round trip per 16 bytes (185 of them per split unit of
+// the forward auxiliary sweep, ~100 cycles each on a wavefront that is alone on its SIMD: two thirds of the kernel's time).
+// Fetched first, the operators run on registers and the phase waits once.
+// lds_issue / lds_land: the two halves, for several arrays fetched together (issue all, then land all).
+template <int N, typename T> LFSD_DEV void lds_issue(const T* src, T* dst) {
+#pragma unroll
+  for (int i = 0; i < N; ++i) dst[i] = src[i];
+}
+template <int N, typename T> LFSD_DEV void lds_issue_strided(const T* src, int stride, T* dst) {      // N words `stride` apart
+#pragma unroll
+  for (int i = 0; i < N; ++i) dst[i] = src[i * stride];
+}
+template <int N, typename T> LFSD_DEV void lds_land(T* dst) {
+#pragma unroll
+  for (int i = 0; i < N; ++i) pin(dst[i]);
+}
+template <int N, typename T> LFSD_DEV void lds_fetch(const T* src, T* dst) { lds_issue<N>(src, dst); lds_land<N>(dst); }
 
 // pin64(x): pin() in the fp64 instantiations only.  There a dense product whose result is first used beyond a branch had
 // its FMAs sunk to that use by the compiler while its LDS reads stayed put (they cannot cross the barrier in between): all

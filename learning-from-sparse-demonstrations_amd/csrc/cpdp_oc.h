@@ -2059,6 +2059,23 @@ __global__ void __launch_bounds__(64, LFSD_WAVES_OC) oc_solve_kernel(OcArgs<T> a
   if (coarse) { s.S = 1; s.DT = s.dgrid; }
   T J = do_rollout(1, 0, T(0), false);
   __syncthreads();
+  if constexpr (CS) {
+    // A coarse roll-out (ONE RK4 step per interval) that overflows says nothing about the reference's discretisation: before
+    // a trajectory is declared FAILED the initial guess is rolled out on the reference grid, as the wide kernel does.  The
+    // roll-out is a block-wide phase, so the decision goes through the vote; the partners of such a trajectory simply
+    // start on the reference grid as well.
+    if (threadIdx.x == 0) vote[0] = 0;
+    __syncthreads();
+    if (coarse && !t_finite(J)) vote[0] = 1;
+    __syncthreads();
+    const bool redo = vote[0] != 0;
+    __syncthreads();
+    if (redo) {
+      coarse = false; s.S = a.steps_per_grid; s.DT = s.dgrid / T(s.S);
+      J = do_rollout(1, 0, T(0), false);
+      __syncthreads();
+    }
+  }
   T mu = T(0);
   int mode = 0;             // stage Hessian model: 0 Gauss-Newton, 1 Hamiltonian (cheap Newton-like), 2 exact
   bool ham_ok = true;       // the cheap Newton-like model has not failed on this trajectory yet
@@ -2324,14 +2341,25 @@ __global__ void __launch_bounds__(64, 1) oc_solve_wide_kernel(OcArgs<T> a) {
   }
   // initial guess into buffer 1 (the reference's w0: zero, or the midpoint of finite control bounds, CPDP.py:153), rolled out
   // without gains into buffer 0, linearised
+  // (`warm`: the caller's initial guess of THIS trajectory is not all zero.  An all-zero row of u_init is the cold start -- a
+  //  learner that only continues the solves that ran out of iterations hands zeros for every other row -- and keeps the
+  //  mesh continuation below, exactly as in oc_solve_kernel)
+  T umax = T(0);
   for (int i = s.lane; i < N * NU; i += 64) {
     T u0 = a.u_init ? a.u_init[traj * N * NU + i] : T(0);
+    umax = t_max(umax, t_abs(u0));
     if constexpr (BND) {
       const T lb = a.u_lb[i % NU], ub_ = a.u_ub[i % NU];
       if (!a.u_init && t_abs(lb) < T(1e19) && t_abs(ub_) < T(1e19)) u0 = T(0.5) * (lb + ub_);
       u0 = t_min(t_max(u0, lb), ub_);
     }
     s.ub[1][i] = u0;
+  }
+  bool warm = false;
+  if (a.u_init != nullptr) {
+    ldsRed[s.lane] = umax;
+    __syncthreads();
+    for (int l = 0; l < 64; ++l) warm = warm || !(ldsRed[l] == T(0));
   }
   __syncthreads();
   int cur = 0;
@@ -2346,7 +2374,7 @@ __global__ void __launch_bounds__(64, 1) oc_solve_wide_kernel(OcArgs<T> a) {
   // 10-15 x 4): at n_grid 15 the rocket's coarse path ends in ANOTHER stationary point than the fine one (one with a
   // conjugate point inside the horizon, where the Riccati sweep of the auxiliary pass has a finite escape; emulator tier,
   // test_rocket_newton_mode_vs_oracle) -- a step of 0.2 s is too long for its attitude dynamics under aggressive controls.
-  bool coarse = CSW && a.steps_per_grid > 1 && a.u_init == nullptr && a.max_iter > 8 && a.n_grid >= LFSD_COARSE_MIN_GRID;
+  bool coarse = CSW && a.steps_per_grid > 1 && !warm && a.max_iter > 8 && a.n_grid >= LFSD_COARSE_MIN_GRID;
   bool relin = false;
   if (coarse) { s.S = 1; s.DT = s.dgrid; }
 #if defined(LFSD_OC_CLOCK)      // diagnostic build (tools/wide_clock.py): shader clocks of the phases of the slowest solves
