@@ -414,7 +414,7 @@ def main(argv=None):
                 js = json.loads(raw)
                 sources[name] = {"file": rel, "git_blob": hashlib.sha1(b"blob %d\0" % len(raw) + raw).hexdigest(),
                                  "collected_at_commit": js.get("collected_at_commit")}
-                return js.get(dom, {})
+                return js.get(dom) or (js.get("oc_solve_wide", {}) if dom == "oc_solve" else {})      # (models solved on the wide mapping)
             except Exception:
                 return {}
         traffic = profile("hbm_traffic").get("hbm_bytes_per_launch")

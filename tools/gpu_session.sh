@@ -3,8 +3,9 @@
 # usage (on the GPU box, via gpurun):  bash tools/gpu_session.sh <session> [tag]     -> gpurun_out/<tag>/
 #   quick    bench lines fp32 + fp64 (no CPU leg) and the parity tests that pin the auxiliary sweeps
 #   tier     smoke() + the whole -m gpu tier with the parity-floor report
-#   profile  tools/gpu_profile.sh <tag> (rocprofv3 kernel stats + PMC passes of bench.py)
-#   configs  bench.py --config robotarm / rocket lines (+ their rocprofv3 kernel stats)
+#   profile  tools/gpu_profile.sh <tag> $CFG (rocprofv3 kernel stats + PMC passes of one bench.py command)
+#   configs  bench.py --config robotarm / rocket: lines with CPU legs + their evidence sets
+#   f64      the same for bench.py --dtype f64
 #   ab       tools/ab_variants.py run <names...>   (variants built beforehand with `ab_variants.py build`)
 S=${1:-quick}; TAG=${2:-r04_$S}; OUT=gpurun_out/$TAG
 mkdir -p $OUT
@@ -25,8 +26,15 @@ tier)
   rm -f $OUT/parity_floors.jsonl
   LFSD_PARITY_REPORT=$PWD/$OUT/parity_floors.jsonl timeout 2700 python3 -m pytest tests -m gpu -q > $OUT/pytest_gpu.txt 2>&1
   tail -5 $OUT/pytest_gpu.txt ;;
-profile)
-  bash tools/gpu_profile.sh $TAG ;;
+profile)      # [CFG="--config rocket"] gpu_session.sh profile <tag>: evidence set of one bench.py command (default: the headline)
+  bash tools/gpu_profile.sh $TAG $CFG ;;
+configs)      # bench lines of the other BASELINE configurations with their CPU legs, and their evidence sets
+  for c in robotarm rocket; do
+    STEPS=5 WARM=1 bash tools/gpu_profile.sh ${TAG}_$c --config $c > $OUT/profile_$c.log 2>&1
+    line gpurun_out/${TAG}_$c/bench.json
+  done ;;
+f64)          # evidence set of the headline at the reference's precision
+  STEPS=10 WARM=2 F64_FLOPS=1 bash tools/gpu_profile.sh $TAG --dtype f64 ;;
 ab)
   shift; shift; python3 tools/ab_variants.py run "$@" > $OUT/ab.txt 2>&1; cat $OUT/ab.txt ;;
 *) echo "unknown session $S"; exit 2 ;;

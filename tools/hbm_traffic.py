@@ -80,8 +80,11 @@ def main(argv):
     res["_note"] = ("raw rocprofv3 FETCH_SIZE / WRITE_SIZE (KB) of separate --pmc passes, per full-batch dispatch; "
                     "FETCH_SIZE is uncalibrated (a lower bound) for 4-8-byte-per-lane accesses and both include "
                     "Infinity-Cache hits (MI355X_MICROARCH.md, HBM)")
+    import os
+    res["collected_at_commit"] = os.environ.get("LFSD_COMMIT")
     with open(out, "w") as f:
         json.dump(res, f, indent=1)
+    res.pop("collected_at_commit")
     print(json.dumps({k: {"launches": v["full_batch_launches"], "MB_per_launch": round(v["hbm_bytes_per_launch"] / 1e6, 1),
                           "each_MB": [round(p["bytes"] / 1e6, 1) for p in v["dispatches"]]}
                       for k, v in res.items() if not k.startswith("_")}))

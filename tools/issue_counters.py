@@ -23,7 +23,25 @@ from collections import defaultdict
 from hbm_traffic import classify
 # resident waves per SIMD of the fp32 kernels (tools/kernel_resources.py: 256+80 / 246 / 256+256 registers per lane; the
 # VGPR_Count column of the rocprofv3 CSV does not include the accumulator half reliably)
-WAVES_PER_SIMD = {"oc_solve": 1, "aux_riccati": 2, "aux_forward": 1}
+WAVES_PER_SIMD = {"oc_solve": 1, "oc_solve_wide": 1, "oc_solve_resume": 1, "aux_riccati": 2, "aux_forward": 1}
+
+
+def code_object_registers(kernel_name):
+    """"VGPRs+AGPRs" of a kernel as the COMPILER reports them (tools/kernel_resources.py <model> --json FILE, run at build time;
+    LFSD_KERNEL_RESOURCES names the file).  The rocprofv3 CSV's VGPR_Count / Accum_VGPR_Count columns are allocation
+    granules, not the kernel's footprint (round 3 reported 200 for a kernel the compiler builds with 256 + 137)."""
+    import os
+    import re
+    path = os.environ.get("LFSD_KERNEL_RESOURCES")
+    if not path or not os.path.exists(path):
+        return None
+    norm = lambda n: re.sub(r"^void", "", re.sub(r"\s+", "", re.sub(r"lfsd_gen_\w+::Model", "M", n)).split("(")[0])
+    want = norm(kernel_name)
+    for e in json.load(open(path)):
+        if norm(e["name"]) == want:
+            return {"vgprs": e.get("VGPRs"), "agprs": e.get("AGPRs"), "scratch_bytes_per_lane": e.get("ScratchSize"),
+                    "lds_bytes_per_workgroup": e.get("LDS"), "occupancy_waves_per_simd": e.get("Occupancy")}
+    return None
 
 
 def main(argv):
@@ -47,11 +65,11 @@ def main(argv):
                 continue
             tot[key][row["Counter_Name"]] += float(row["Counter_Value"])
             nd[key].add(row["Dispatch_Id"])
-            v = int(row["VGPR_Count"]) + int(row["Accum_VGPR_Count"])
-            regs[key] = max(regs.get(key, 0), v)
+            regs[key] = row["Kernel_Name"]
         for key, c in tot.items():
             wps = WAVES_PER_SIMD[key]
-            r = res.setdefault(key, {"registers_per_lane": regs.get(key), "waves_per_simd": wps, "counters": {}})
+            r = res.setdefault(key, {"code_object": code_object_registers(regs.get(key, "")), "kernel_name": regs.get(key),
+                                     "waves_per_simd": wps, "counters": {}})
             r["counters"].update({k: v / max(1, len(nd[key])) for k, v in c.items() if k not in r["counters"]})      # per launch
             r["full_batch_launches"] = len(nd[key])
             wc = c.get("SQ_WAVE_CYCLES")
@@ -75,8 +93,11 @@ def main(argv):
                     if c.get("SQ_THREAD_CYCLES_VALU") and c.get("SQ_INSTS_VALU"):
                         lu = c["SQ_THREAD_CYCLES_VALU"] / (64.0 * c["SQ_INSTS_VALU"])
                         r["valu_flops_executed_per_launch"] = c["SQ_INSTS_VALU_FLOPS_FP32"] / n * 64.0 * lu
+    import os
+    res["collected_at_commit"] = os.environ.get("LFSD_COMMIT")
     with open(out, "w") as f:
         json.dump(res, f, indent=1)
+    res.pop("collected_at_commit")
     print(json.dumps({k: {a: (round(b, 4) if isinstance(b, float) else b) for a, b in v.items() if a != "counters"}
                       for k, v in res.items()}))
 

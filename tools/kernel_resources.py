@@ -7,6 +7,12 @@ from lfsd_amd import models, runtime
 
 kind = sys.argv[1]
 extra = sys.argv[2:]
+json_out = None
+if "--json" in extra:            # kernel_resources.py <model> --json FILE: the same table as JSON (tools/issue_counters.py reads it)
+    i = extra.index("--json")
+    json_out = extra[i + 1]
+    del extra[i:i + 2]
+table = []
 oc, _, _ = models.ZOO[kind]()
 spec = oc.model_spec()
 runtime.write_header(spec)
@@ -27,6 +33,11 @@ for cmd in cmds[:2]:
                 vals[key.split(" ")[0].replace("\\", "")] = int(m2.group(1))
                 if key.startswith("LDS"):
                     print("%-112s %s" % (name, vals))
+                    table.append(dict(name=name, **vals))
 for o in objs:
     if os.path.exists(o):
         os.remove(o)
+if json_out:
+    import json
+    with open(json_out, "w") as f:
+        json.dump(table, f, indent=1)
