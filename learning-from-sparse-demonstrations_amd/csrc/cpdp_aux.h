@@ -894,6 +894,9 @@ __global__ void __launch_bounds__(64, (sizeof(T) == 4 ? LFSD_WAVES_FWD : 1)) aux
         }
       }
       n_units += units;
+#if defined(LFSD_AUX_TRACE)
+      if (lane == 0 && slot < LFSD_AUX_TRACE) printf("fwd traj %d k %d ran units %d hc %.6e xa %.9e %.9e %.9e\n", (int)slot, k, units, (double)hc, (double)xa[0], (double)xa[1], (double)xa[2]);
+#endif
       if (!(a.rtol > T(0))) break;
       LFSD_WAVE_SYNC();
       ldsR[lane] = err_l; ldsR[G + lane] = scl_l;

@@ -287,3 +287,45 @@ def state_bounds(prepare, dtype=torch.float64):
     # bounds of the wrong length are ignored, as in the reference (CPDP.py:23-31)
     oc = bounded([-1.0], [1.0], [], [])
     assert oc.state_lb == [-1e20, -1e20] and oc.state_ub == [1e20, 1e20]
+
+
+def dudtheta_refinement(prepare):
+    """du/dtheta of auxSysSolver (CPDP.py:370-381) is 1.2 % off the tight oracle on the robot arm at 16 minimum units, in
+    fp64 and fp32 alike (round 3).  Where and why: every error above 1e-6 sits in the LAST grid row.  dx/dtheta(T) carries
+    the discretisation error of the last interval -- dgrid * |Huu^-1 fu^T P fu| ~ 2000 there -- and du/dtheta(T) =
+    -Huu^-1 ((Hux + fu^T P) dx/dtheta(T) + ...) multiplies it by |Huu^-1 fu^T h_xx| ~ 3.6e3.  Asserted: (1) rows before T are
+    accurate to 2e-6; (2) the error at T falls with the order of the scheme when the minimum units double; (3) the error of
+    du/dtheta(T) is the SAME multiple of the error of dx/dtheta(T) at every refinement (one amplification factor, not a
+    second discrepancy); (4) it also falls when only rtol is tightened (the stiffness cap and the unit cap follow rtol).
+    Measurements: profiles/r04_d_dudtheta_refinement.txt."""
+    from conftest import make_oracle, oracle_loss_grad, parity_record
+    c = G_CASES["robotarm"]
+    oc, env, d = models.ZOO["robotarm"](n_grid=c["n_grid"])
+    prepare(oc, torch.float64)
+    o = make_oracle("robotarm", c["n_grid"])
+    th = np.asarray(c["thetas"][0], dtype=np.float64)
+    r = oracle_loss_grad(o, d["ini_state"], d["horizon"], th, c["taus"], c["wps"], d["interface"])
+    lib = oc.compile()
+    n, m, p = lib.n_state, lib.n_control, lib.n_auxvar
+    N1 = r["vU"].shape[0]
+    sol = oc.cocSolverBatch(np.asarray(d["ini_state"], dtype=np.float64)[None, :], d["horizon"], th[None, :])
+
+    def errors(sub, rtol):
+        oc.setSolverOptions(aux_substeps=sub, aux_rtol=rtol)
+        aux = oc.auxSysSolverBatch(sol, c["taus"], c["wps"], d["interface"], want_grids=True)
+        U = aux["auxU_grid"][0].permute(0, 2, 1).reshape(N1, m * p).double().cpu().numpy()
+        X = aux["auxX_grid"][0].permute(0, 2, 1).reshape(N1, n * p).double().cpu().numpy()
+        eU = np.abs(U - r["vU"]).max(axis=1) / np.abs(r["vU"]).max()
+        eX = np.abs(X - r["vX"]).max(axis=1) / np.abs(r["vX"]).max()
+        return eX, eU
+    eX16, eU16 = errors(16, 1e-3)
+    eX32, eU32 = errors(32, 1e-3)
+    parity_record("du/dtheta refinement", "du/dtheta before T at 16 units", eU16[:-1].max(), 2e-6)       # measured 6.1e-7
+    parity_record("du/dtheta refinement", "du/dtheta before T at 32 units", eU32[:-1].max(), 2e-7)       # measured 4.1e-8
+    assert eX16[-1] > 6.0 * eX32[-1] and eU16[-1] > 6.0 * eU32[-1], (eX16[-1], eX32[-1], eU16[-1], eU32[-1])      # measured 10.5x
+    amp16, amp32 = eU16[-1] / eX16[-1], eU32[-1] / eX32[-1]
+    assert abs(amp16 / amp32 - 1.0) < 0.1 and 1e3 < amp16 < 1e4, (amp16, amp32)                           # measured 3.65e3 both
+    eXa, eUa = errors(1, 1e-3)
+    eXb, eUb = errors(1, 1e-5)
+    assert eXb[-1] < eXa[-1] / 3.0 and eXb[:-1].max() < 1e-6, (eXa[-1], eXb[-1], eXb[:-1].max())          # measured 1.8e-4 -> 3.8e-5
+    oc.setSolverOptions(aux_substeps=0, aux_rtol=1e-3)

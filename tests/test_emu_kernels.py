@@ -630,3 +630,12 @@ def test_aux_pass_skips_rows_by_oc_status(emu):
     with pytest.raises(runtime.LfsdError):
         oc.compile().aux_solve(sol["horizon"], sol["auxvar"], sol["consts"], sol["state_grid"], sol["control_grid"],
                                sol["costate_grid"], None, None, None, skip_status=(4,))
+
+
+def test_dudtheta_error_is_the_last_interval_times_one_gain(emu):
+    from parity_cases import dudtheta_refinement
+
+    def prepare(oc, dtype):
+        emu(oc)
+        oc.setDevice(dtype=dtype)
+    dudtheta_refinement(prepare)

@@ -629,3 +629,9 @@ def test_state_bounds_vs_independent_bounded_solve(dtype):
     """Finite state bounds of setStateVariable (CPDP.py:20-31, 140-147) on the GPU: augmented-Lagrangian loop around
     lfsd_coc_solve vs the oracle's SLSQP solve of the same bounded NLP."""
     pc.state_bounds(gpu_prepare, dtype)
+
+
+def test_dudtheta_error_is_the_last_interval_times_one_gain():
+    """du/dtheta(T) of auxSysSolver (CPDP.py:370-381) against the tight oracle under refinement, on the GPU: the whole
+    discrepancy is the last interval's dx/dtheta error times one constant gain (parity_cases.dudtheta_refinement)."""
+    pc.dudtheta_refinement(gpu_prepare)
