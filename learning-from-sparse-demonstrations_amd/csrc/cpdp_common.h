@@ -116,6 +116,14 @@
 #ifndef LFSD_MU_DOWN
 #define LFSD_MU_DOWN 0.31623
 #endif
+// wide kernel: factor by which the shift falls after a full step that gained at least LFSD_MU_GAIN_RHO of its predicted
+// decrease (>= LFSD_MU_DOWN switches the rule off)
+#ifndef LFSD_MU_DOWN_GOOD
+#define LFSD_MU_DOWN_GOOD 1.0
+#endif
+#ifndef LFSD_MU_GAIN_RHO
+#define LFSD_MU_GAIN_RHO 0.8
+#endif
 #ifndef LFSD_MU_HOLD
 #define LFSD_MU_HOLD 1
 #endif

@@ -2494,8 +2494,14 @@ __global__ void __launch_bounds__(64, 1) oc_solve_wide_kernel(OcArgs<T> a) {
       g_last = gnorm; dec_last = (mode >= 1 && mu == T(0)) ? -(dV1 + dV2) : T(1e30);
       hess_ok = false; costates_ok = false;
       if (ia == 0) {
-        const T mu_next = (mu > T(1e-8)) ? mu * T(LFSD_MU_DOWN) : T(0);
-        if (mu > T(0) && mu_bad >= T(0) && mu_next <= mu_bad && mu_hold < mu_hold_need) ++mu_hold;
+        // gain ratio of the full step (actual / predicted decrease of the shifted model): a step that gains at least
+        // LFSD_MU_GAIN_RHO of its prediction says the shift is larger than the model needs -- it falls by LFSD_MU_DOWN_GOOD
+        // instead of LFSD_MU_DOWN and does not wait out the hold (the rocket's long solves are accepted full steps that gain
+        // 1.5-2x their prediction at shifts that decay one sqrt(10) rung per step)
+        const T pred = -(dV1 + dV2);
+        const bool good = (LFSD_MU_DOWN_GOOD < LFSD_MU_DOWN) && pred > T(0) && (J - Jn) >= T(LFSD_MU_GAIN_RHO) * pred;
+        const T mu_next = (mu > T(1e-8)) ? mu * (good ? T(LFSD_MU_DOWN_GOOD) : T(LFSD_MU_DOWN)) : T(0);
+        if (!good && mu > T(0) && mu_bad >= T(0) && mu_next <= mu_bad && mu_hold < mu_hold_need) ++mu_hold;
         else { mu = mu_next; mu_hold = 0; }
         if (mode == 0 && ham_ok && (J - Jn) < T(LFSD_HAM_SWITCH) * t_abs(Jn)) mode = 1;
         else if (LFSD_GN_CRAWL && mode == 0 && !ham_ok && (J - Jn) < T(1e-2) * t_abs(Jn)) gn_crawl = true;

@@ -222,7 +222,7 @@ def assert_grids_match(sol, aux, b, r, n, m, p, tol, what=""):
     if aux.get("auxX_grid") is not None:
         N1 = r["PW"].shape[0]
         Zo = np.concatenate([r["PW"][:, :n * n].reshape(N1, n, n), r["PW"][:, n * n:].reshape(N1, n, p)], axis=2)
-        parity_record(what, "Z_grid", rel(aux["Z_grid"][b].permute(0, 2, 1), Zo), tol["aux"])
+        parity_record(what, "Z_grid", rel(aux["Z_grid"][b].permute(0, 2, 1), Zo), tol.get("Z", tol["aux"]))
         parity_record(what, "auxX_grid", rel(aux["auxX_grid"][b].permute(0, 2, 1).reshape(N1, n * p), r["vX"]), tol["aux"])
         # du/dtheta(T) = -Huu^-1 (fu^T h_xx) dx/dtheta(T) + ...  amplifies the error of dx/dtheta by |Huu^-1 fu^T h_xx| (10^3 for
         # the arm's final-cost weight 100), hence its own tolerance

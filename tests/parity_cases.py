@@ -16,7 +16,24 @@ import lfsd_amd  # noqa: F401
 from lfsd_amd import models
 from conftest import oracle_parallel, assert_grids_match
 
-TOL64 = dict(grid=1e-6, costate=1e-5, aux=2e-3, auxU=2e-2, loss=1e-6, grad=1e-4)
+TOL64 = dict(grid=1e-6, costate=1e-5, aux=2e-3, auxU=2e-2, loss=1e-6, grad=1e-4)      # loosest fp64 class (API-shaped calls, edge cases)
+# fp64, per model: about 10x the largest error MEASURED on MI355X over both mappings and every seed of the case at 16 minimum
+# units (profiles/r03_ag_parity_floors.jsonl, r04_b_parity_floors.jsonl; measured maxima beside each row) -- round 3 asserted
+# the blanket class above, 40-1000x over what the kernels deliver: a 100-fold regression of the fp64 Riccati sweep passed.
+# `Z` = [P W], `aux` = dx/dtheta, `auxU` = du/dtheta (its last row carries dx/dtheta(T)'s error times |Huu^-1 fu^T h_xx|:
+# parity_cases.dudtheta_refinement).  Figures at rounding level are floored at 1e-8 (the CPU emulator tier shares the table
+# and rounds differently: no FMA contraction).
+TOL64_MODEL = {
+    # measured fp64 maxima:        state/control  costate   [P W]     dx/dth    du/dth    loss      gradient
+    #   pendulum                   8.9e-8         2.7e-9    4.2e-6    5.3e-5    1.1e-4    4.7e-9    8.2e-6
+    "pendulum": dict(grid=1e-6, costate=3e-8, Z=5e-5, aux=5e-4, auxU=1.2e-3, loss=5e-8, grad=1e-4),
+    #   robot arm                  6.8e-9         1.3e-9    2.0e-9    3.4e-6    1.2e-2    4.5e-9    3.1e-7
+    "robotarm": dict(grid=1e-7, costate=2e-8, Z=1e-7, aux=4e-5, auxU=2e-2, loss=5e-8, grad=4e-6),
+    #   cart-pole                  3.4e-8         3.5e-9    2.2e-8    1.5e-6    1.5e-5    7.9e-10   1.3e-8
+    "cartpole": dict(grid=4e-7, costate=4e-8, Z=3e-7, aux=2e-5, auxU=2e-4, loss=1e-8, grad=2e-7),
+    #   quadrotor (n_grid 10)      6.0e-8         2.3e-8    3.1e-8    2.2e-7    7.8e-6    2.6e-9    7.1e-9
+    "quadrotor": dict(grid=6e-7, costate=3e-7, Z=4e-7, aux=3e-6, auxU=1e-4, loss=3e-8, grad=1e-7),
+}
 TOL32 = {
     # measured fp32 maxima (r03):  state/control  costate   [P W]    dx/dth   du/dth   loss     gradient
     #   pendulum                   2.8e-4         3.4e-4    1.4e-3   1.0e-3   9.2e-4   1.6e-5   9.5e-4
@@ -31,7 +48,7 @@ TOL32 = {
 
 
 def tol_for(kind, dtype):
-    return TOL64 if dtype == torch.float64 else TOL32[kind]
+    return TOL64_MODEL[kind] if dtype == torch.float64 else TOL32[kind]
 
 
 TOL = {torch.float64: TOL64, torch.float32: dict(grid=5e-3, costate=2e-2, aux=2e-2, auxU=5e-2, loss=2e-3, grad=2e-2)}   # (loosest fp32 class; single_trajectory_api)

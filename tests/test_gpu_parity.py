@@ -51,7 +51,7 @@ def test_reference_shaped_single_trajectory_api(kind):
 
 
 @pytest.mark.parametrize("substeps", [0, 4])        # 0: the library default bench.py runs (error-controlled, rtol 1e-3); 4: fixed units
-@pytest.mark.parametrize("dtype,ltol,gtol,xtol", [(torch.float64, 1e-6, 1e-4, 2e-6), (torch.float32, 5e-5, 1e-3, 3e-4)])
+@pytest.mark.parametrize("dtype,ltol,gtol,xtol", [(torch.float64, 2e-7, 1e-5, 2e-6), (torch.float32, 5e-5, 1e-3, 3e-4)])
 def test_quadrotor_bench_seeds_vs_tight_oracle(dtype, ltol, gtol, xtol, substeps):
     """The headline configuration itself (n_grid 50, the first seeds bench.py draws; library defaults and fixed 4 units)
     against the TIGHT oracle (Radau, rtol 1e-10), so the floor of the shipped fp32 path is known apart from the reference
@@ -70,7 +70,9 @@ def test_quadrotor_bench_seeds_vs_tight_oracle(dtype, ltol, gtol, xtol, substeps
     assert set(sol["status"].tolist()) <= {1, 2}
     refs = oracle_parallel([dict(kind="quadrotor", n_grid=50, ini_state=d["ini_state"], horizon=d["horizon"], theta=list(t),
                                  taus=d["taus"], wps=d["waypoints"], iface=d["interface"]) for t in th])
-    tol = dict(grid=xtol, costate=10 * xtol, aux=3e-3, auxU=5e-2, loss=ltol, grad=gtol)
+    # fp64 (round 4): loss 1.6e-8 -> 2e-7, gradient 4.6e-7 -> 1e-5, costate 2.8e-7 -> 3e-6, [P W] 1.0e-5 -> 1e-4 (measured -> asserted)
+    f64 = dtype == torch.float64
+    tol = dict(grid=xtol, costate=(1.5 if f64 else 10) * xtol, Z=1e-4 if f64 else 3e-3, aux=3e-3, auxU=5e-2, loss=ltol, grad=gtol)
     for b in range(4):
         assert_grids_match(sol, aux, b, refs[b], 13, 4, 7, tol, what="bench seed %d %s" % (b, dtype))
 
@@ -190,7 +192,8 @@ def test_headline_defaults_vs_tight_oracle_at_outer_iteration_12():
     of the auxiliary sweeps (library defaults: rtol 1e-3 from one unit) -- they are compared with the TIGHT ORACLE, not
     with fp64 HIP: the benchmark's own learner runs 12 outer iterations, and at the parameters of the 12th (later
     iterations need more split units than theta_0) six trajectories that ended CONVERGED and six that ended at WORKING
-    PRECISION go through the fp64 oracle (IPOPT-equivalent solve, Radau rtol 1e-10 sweeps).
+    PRECISION go through the fp64 oracle (IPOPT-equivalent solve, Radau rtol 1e-10 sweeps) -- round 4: SIXTEEN of each, 32
+    trajectories on the oracle fan-out (conftest.oracle_parallel, one worker per host core).
     Measured floors (profiles/r03_a_parity_floors.jsonl): state 2e-5, loss 3e-6, gradient 3e-4; asserted with a margin of
     ~5x: state 2e-4, costate 5e-3, loss 5e-5, gradient 2e-3."""
     import sys
@@ -210,8 +213,8 @@ def test_headline_defaults_vs_tight_oracle_at_outer_iteration_12():
     pick = []
     for code in (1, 2):
         idx = np.where(st == code)[0]
-        assert len(idx) >= 6, (code, np.bincount(st, minlength=5))        # both exits are really taken on this workload
-        pick += list(rng.choice(idx, 6, replace=False))
+        assert len(idx) >= 16, (code, np.bincount(st, minlength=5))        # both exits are really taken on this workload
+        pick += list(rng.choice(idx, 16, replace=False))
     th64 = th.double().cpu().numpy()
     refs = oracle_parallel([dict(kind="quadrotor", n_grid=args.n_grid, ini_state=d["ini_state"], horizon=d["horizon"],
                                  theta=list(th64[b]), taus=d["taus"], wps=d["waypoints"], iface=d["interface"]) for b in pick])
@@ -606,15 +609,21 @@ def test_full_size_properties_rocket_n100_mixed_precision():
     Z = aux["Z_grid"]
     P = Z[:, :, :13, :]
     assert (P - P.transpose(2, 3)).abs().max() < 1e-6 * P.abs().max()
-    b = 5
-    X, U, Lm = (sol[k][b].double().cpu().numpy() for k in ("state_grid", "control_grid", "costate_grid"))
-    r = oracle_parallel([dict(kind="rocket", n_grid=100, ini_state=d["ini_state"], horizon=d["horizon"], theta=list(th[b]),
-                              taus=list(taus), wps=wps, iface=d["interface"], check=(X, U, Lm), tight=True)] * 1)[0]
-    J = float(sol["cost"][b])
-    assert r["defect"] < 1e-4 * np.abs(X).max() and r["gmax"] < 2e-4 * (1 + abs(J)) and r["lmax"] < 5e-3 * np.abs(Lm).max(), \
-        (r["defect"], r["gmax"], r["lmax"], J)
-    assert abs(aux["loss"][b].item() - r["loss"]) < 1e-5 * max(1.0, r["loss"])
-    assert rel(aux["grad"][b], r["grad"]) < 5e-3
+    # EIGHT trajectories (round 4; one in round 3) certified by the oracle, fanned out over the host cores: each is a KKT point
+    # of the reference's NLP at the fp32 floor, and the fp64 auxiliary pass along it is reproduced to fp64 tolerance
+    picks = [5, 17, 101, 233, 310, 404, 467, 511]
+    jobs = []
+    for b in picks:
+        X, U, Lm = (sol[k][b].double().cpu().numpy() for k in ("state_grid", "control_grid", "costate_grid"))
+        jobs.append(dict(kind="rocket", n_grid=100, ini_state=d["ini_state"], horizon=d["horizon"], theta=list(th[b]),
+                         taus=list(taus), wps=wps, iface=d["interface"], check=(X, U, Lm), tight=True))
+    for b, r in zip(picks, oracle_parallel(jobs)):
+        X, Lm = sol["state_grid"][b].double().cpu().numpy(), sol["costate_grid"][b].double().cpu().numpy()
+        J = float(sol["cost"][b])
+        assert r["defect"] < 1e-4 * np.abs(X).max() and r["gmax"] < 2e-4 * (1 + abs(J)) and r["lmax"] < 5e-3 * np.abs(Lm).max(), \
+            (b, r["defect"], r["gmax"], r["lmax"], J)
+        parity_record("rocket n_grid 100 mixed precision, trajectory %d" % b, "loss", abs(aux["loss"][b].item() - r["loss"]) / max(1.0, r["loss"]), 1e-5)
+        parity_record("rocket n_grid 100 mixed precision, trajectory %d" % b, "grad", rel(aux["grad"][b], r["grad"]), 5e-3)
 
 
 @pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
@@ -635,3 +644,48 @@ def test_dudtheta_error_is_the_last_interval_times_one_gain():
     """du/dtheta(T) of auxSysSolver (CPDP.py:370-381) against the tight oracle under refinement, on the GPU: the whole
     discrepancy is the last interval's dx/dtheta error times one constant gain (parity_cases.dudtheta_refinement)."""
     pc.dudtheta_refinement(gpu_prepare)
+
+
+@pytest.mark.parametrize("dtype,xtol,jtol", [(torch.float64, 2e-6, 1e-9), (torch.float32, 3e-3, 2e-5)])
+def test_mesh_continuation_ends_at_the_same_kkt_point(dtype, xtol, jtol):
+    """The lean OC kernels start a cold solve on a coarse mesh (one RK4 step per interval) and leave it WITH a step that is
+    accepted although the cost may rise by up to 1e-3 |J| (cpdp_oc.h, oc_solve_kernel: `fine_step`, the two discretisations
+    cannot be refereed by the Armijo test).  Direct check of that exit: the same 64 headline seeds solved by the product
+    library and by a build without the coarse phase (-DLFSD_COARSE_START=0, compiled here if the tree does not carry it)
+    reach the same KKT point of the NLP of CPDP.py:110-175 -- states, controls, costates and cost to the precision class of
+    the arithmetic -- and both report convergence on the reference's discretisation."""
+    import subprocess
+    oc, env, d = models.quadrotor(n_grid=50)
+    spec = oc.model_spec()
+    runtime.write_header(spec)
+    variant = os.path.join(runtime.BUILD_DIR, "ab_%s_nocoarse.so" % spec.hash())
+    if not os.path.exists(variant):
+        cmds, objs = runtime.hipcc_commands(spec, variant, ["-DLFSD_COARSE_START=0"])
+        try:
+            for c in cmds:
+                r = subprocess.run(c, cwd=runtime.CSRC_DIR, capture_output=True, text=True)
+                assert r.returncode == 0, r.stderr[-3000:]
+        finally:
+            for o in objs:
+                if os.path.exists(o):
+                    os.remove(o)
+    rng = np.random.default_rng(1234)
+    th = np.array(d["theta0"])[None, :] + 0.05 * rng.standard_normal((4096, 7))
+    th[:, 0] = np.abs(th[:, 0]) + 0.5
+    th = th[:64]
+    x0 = np.tile(d["ini_state"], (64, 1))
+    sols = []
+    for lib in (None, variant):
+        o2, _, _ = models.quadrotor(n_grid=50)
+        if lib:
+            o2.use_library(lib)
+        o2 = gpu_prepare(o2, dtype)
+        o2.setSolverOptions(mapping="lockstep")
+        sols.append(o2.cocSolverBatch(x0, d["horizon"], th))
+    a, b = sols
+    assert set(a["status"].tolist()) <= {1, 2} and set(b["status"].tolist()) <= {1, 2}
+    # the coarse phase is really taken by the product build: it changes the iteration path (not necessarily the count)
+    for k, t in (("state_grid", xtol), ("control_grid", 5 * xtol), ("costate_grid", 10 * xtol)):
+        parity_record("mesh continuation on/off %s" % dtype, k, rel(a[k], b[k].double().cpu().numpy()), t)
+    ja, jb = a["cost"].double().cpu().numpy(), b["cost"].double().cpu().numpy()
+    parity_record("mesh continuation on/off %s" % dtype, "cost", float(np.abs(ja - jb).max() / np.abs(jb).max()), jtol)
