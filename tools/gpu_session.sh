@@ -38,6 +38,8 @@ f64)          # evidence set of the headline at the reference's precision
 rocket)       # A/B of build variants on the rocket's cold OC solve (tools/model_ab.py build rocket <tag> ... beforehand): TAGS="product g10 ..."
   python3 tools/model_ab.py run rocket 100 1024 f32 ${TAGS:-product} > $OUT/rocket_ab.txt 2>&1; cat $OUT/rocket_ab.txt
   python3 tools/wide_clock.py run rocket 100 1024 f32 > $OUT/rocket_wide_clock.txt 2>&1; grep -c "wide clock" $OUT/rocket_wide_clock.txt; sort -t' ' -k6 -n -r $OUT/rocket_wide_clock.txt | head -4 ;;
+steps)        # CFGS="robotarm rocket": per-outer-iteration kernel times and unit / iteration distributions (tools/config_steps.py)
+  for c in ${CFGS:-robotarm}; do python3 tools/config_steps.py $c ${NSTEPS:-6} > $OUT/steps_$c.txt 2>&1; cat $OUT/steps_$c.txt; done ;;
 ab)
   shift; shift; python3 tools/ab_variants.py run "$@" > $OUT/ab.txt 2>&1; cat $OUT/ab.txt ;;
 *) echo "unknown session $S"; exit 2 ;;
