@@ -202,9 +202,26 @@ template <class M, typename T, int G, int LAY> struct AuxCtx {
     LFSD_WAVE_SYNC();
     T Gm[NU * NU];
     const T idt = T(1) / dt;
+    if constexpr (LFSD_RIC_GRAM_ROWS != 0) {
+      // Huu/dt + fu^T (P fu) is the same m x m matrix in every lane of the group: lane a < m computes ROW a (= fu^T applied to
+      // column a of P fu: m x nnz(fu)/m FMAs on m lanes instead of m x nnz(fu) on all) and hands it over through LDS
+      T* ldsG = lds + Lay::LDS_T;      // (the transposed exchange of the right-hand side is idle during a stiff step)
+      if (lane < NU) {
+        T col[NX], g[NU];
 #pragma unroll
-    for (int i = 0; i < NU * NU; ++i) Gm[i] = L[M::OFF_HUU_L[LAY] + i] * idt;
-    M::template fu_gram<true, LAY>(L, ldsS, Gm);
+        for (int i = 0; i < NX; ++i) col[i] = ldsS[i * NU + lane];
+        M::template fu_mulT<false, LAY>(L, col, g);
+#pragma unroll
+        for (int b = 0; b < NU; ++b) ldsG[lane * NU + b] = g[b] + L[M::OFF_HUU_L[LAY] + lane * NU + b] * idt;
+      }
+      LFSD_WAVE_SYNC();
+#pragma unroll
+      for (int i = 0; i < NU * NU; ++i) Gm[i] = ldsG[i];
+    } else {
+#pragma unroll
+      for (int i = 0; i < NU * NU; ++i) Gm[i] = L[M::OFF_HUU_L[LAY] + i] * idt;
+      M::template fu_gram<true, LAY>(L, ldsS, Gm);
+    }
     lu_factor<NU>(Gm);
     lu_solve<NU>(Gm, s);
 #pragma unroll

@@ -96,6 +96,11 @@
 #ifndef LFSD_FWD_FETCH
 #define LFSD_FWD_FETCH 1
 #endif
+// Riccati sweep, stiff update: the m x m matrix Huu/dt + fu^T P fu by m lanes, one row each, handed over through LDS (1) or
+// by every lane on its own (0)
+#ifndef LFSD_RIC_GRAM_ROWS
+#define LFSD_RIC_GRAM_ROWS 1
+#endif
 #ifndef LFSD_WAVES_RIC
 #define LFSD_WAVES_RIC 2
 #endif

@@ -83,6 +83,13 @@ def main(argv):
                 r["mfma_per_valu_inst"] = c["SQ_INSTS_MFMA"] / c["SQ_INSTS_VALU"]
             if c.get("SQ_INSTS_VALU") and "SQ_THREAD_CYCLES_VALU" in c:
                 r["valu_lane_util"] = c["SQ_THREAD_CYCLES_VALU"] / (64.0 * c["SQ_INSTS_VALU"])
+            if "SQ_INSTS_VALU_FMA_F64" in c:      # fp64 workloads (gpu_profile.sh F64_FLOPS=1): the same fold over the fp64 instruction classes
+                n = max(1, len(nd[key]))
+                r["valu_f64_insts_per_launch"] = {k2: c.get("SQ_INSTS_VALU_" + k2, 0.0) / n for k2 in ("FMA_F64", "ADD_F64", "MUL_F64", "TRANS_F64")}
+                if "SQ_INSTS_VALU_FLOPS_FP64" in c and c.get("SQ_THREAD_CYCLES_VALU") and c.get("SQ_INSTS_VALU"):
+                    lu = c["SQ_THREAD_CYCLES_VALU"] / (64.0 * c["SQ_INSTS_VALU"])
+                    r["SQ_INSTS_VALU_FLOPS_FP64_per_launch"] = c["SQ_INSTS_VALU_FLOPS_FP64"] / n
+                    r["valu_flops64_executed_per_launch"] = c["SQ_INSTS_VALU_FLOPS_FP64"] / n * 64.0 * lu
             if "SQ_INSTS_VALU_FMA_F32" in c:
                 n = max(1, len(nd[key]))
                 r["valu_f32_insts_per_launch"] = {k2: c.get("SQ_INSTS_VALU_" + k2, 0.0) / n for k2 in ("FMA_F32", "ADD_F32", "MUL_F32", "TRANS_F32")}
