@@ -97,9 +97,11 @@
 #define LFSD_FWD_FETCH 1
 #endif
 // Riccati sweep, stiff update: the m x m matrix Huu/dt + fu^T P fu by m lanes, one row each, handed over through LDS (1) or
-// by every lane on its own (0)
+// by every lane on its own (0).  Measured (profiles/r04_h_*): 338 fewer vector instructions in the kernel, and SLOWER --
+// fp32 1.474 -> 1.496 ms, fp64 4.61 -> 4.71 ms: the extra LDS hand-over of a stiff step (five per unit) costs more than the
+// 55 redundant FMAs it removes from a sweep that issues 37 % of its cycles.  Off.
 #ifndef LFSD_RIC_GRAM_ROWS
-#define LFSD_RIC_GRAM_ROWS 1
+#define LFSD_RIC_GRAM_ROWS 0
 #endif
 #ifndef LFSD_WAVES_RIC
 #define LFSD_WAVES_RIC 2
@@ -263,8 +265,24 @@
 // flight are not drained) around a wave_barrier, which emits nothing and only keeps the compiler from moving LDS accesses
 // across it.  Unlike __syncthreads() it is well defined under control flow that differs between the lanes of the wavefront.
 // The CPU emulator runs every lane as a fiber and needs a real rendez-vous there.
+// LFSD_SYNC_LIGHT (experiment, round 4): the hand-over as a COMPILER barrier only.  The release fence above costs an
+// `s_waitcnt lgkmcnt(0)` -- the wavefront parks until every LDS operation it has in flight is acknowledged -- although the
+// LDS pipeline executes the DS instructions of one wavefront in issue order: a ds_read issued after a ds_write of the same
+// wavefront sees the written data without any wait, whichever lanes wrote and read (the wait the READ's consumer needs
+// is inserted by the compiler as for any load).  With the knob the macro only keeps the compiler from moving LDS accesses
+// across the point.
+#ifndef LFSD_SYNC_LIGHT
+#define LFSD_SYNC_LIGHT 0
+#endif
 #if defined(LFSD_EMU)
 #define LFSD_WAVE_SYNC() __syncthreads()
+#elif LFSD_SYNC_LIGHT
+#define LFSD_WAVE_SYNC()                   \
+  do {                                     \
+    asm volatile("" ::: "memory");         \
+    __builtin_amdgcn_wave_barrier();       \
+    asm volatile("" ::: "memory");         \
+  } while (0)
 #else
 #define LFSD_WAVE_SYNC()                                            \
   do {                                                              \

@@ -49,3 +49,17 @@ def test_default_workload_per_world_size():
     # mode None -> independent seeds (configs[2]) at N = 1, shared theta + all-reduce (configs[3]) at N > 1: see bench.main
     src = open(os.path.join(ROOT, "bench.py")).read()
     assert 'args.mode or ("shared" if world > 1 else "independent")' in src
+
+
+def test_config_selects_the_baseline_workload():
+    """`--config` picks BASELINE configs[1] / configs[4] with their own batch, grid and arithmetic; explicit flags still win."""
+    import bench
+    a = bench.parse_args(["--config", "robotarm"])
+    assert (a.batch, a.n_grid, a.dtype) == (1024, 50, "f32") and bench.WORKLOADS["robotarm"]["method"] == "Vanilla"
+    r = bench.parse_args(["--config", "rocket"])
+    assert (r.batch, r.n_grid, r.dtype) == (1024, 100, "f32") and bench.WORKLOADS["rocket"]["aux_dtype"] == "f64"
+    assert bench.parse_args(["--config", "rocket", "--batch", "64", "--n-grid", "15"]).batch == 64
+    q = bench.parse_args([])
+    assert (q.config, q.batch, q.n_grid, q.dtype, q.no_f64_leg) == ("quadrotor", 4096, 50, "f32", False)
+    with pytest.raises(SystemExit):
+        bench.parse_args(["--config", "pendulum"])
