@@ -292,6 +292,26 @@
   } while (0)
 #endif
 
+// LFSD_STAGE_SYNC: the hand-overs INSIDE a stage of the lean kernels' backward sweep (one wavefront per workgroup; every one of
+// them goes through LDS).  __syncthreads() is a workgroup fence over ALL address spaces: on this hardware it compiles to
+// `s_waitcnt vmcnt(0) lgkmcnt(0)` (the s_barrier of a one-wave workgroup is elided), so the sync that follows the stage's
+// global stores of the gains parks the wavefront until those stores are acknowledged by the L2 -- once per stage, ~1 600 of a
+// stage's 7 200 cycles by the phase clocks (profiles/r03_g_ab_prefetch_pin.txt, "K+Vupdate"), and it drains whatever was
+// prefetched for the next stage with it.  The gains are read by the NEXT roll-out, behind the block-wide votes of the main
+// loop (real __syncthreads); nothing inside the sweep reads them back.  LFSD_OC_LDS_SYNC 1: LDS-scoped fence there instead,
+// and the stage's loads are waited for at its top (cpdp_oc.h, backward_sc).  MEASURED (profiles/r04_j_ab_stage_sync.txt): the
+// `s_waitcnt vmcnt(0)` behind the stores is gone from the stage's ISA and oc_solve takes exactly as long -- 2.587 ms against
+// 2.589 with the old syncs, 2.629 with the next stage's loads prefetched on top (LFSD_BW_PREFETCH 1): the stores are long
+// acknowledged when the wait is reached; the sweep is bound by issue, as round 3 concluded.  Kept: it is the narrower fence.
+#ifndef LFSD_OC_LDS_SYNC
+#define LFSD_OC_LDS_SYNC 1
+#endif
+#if defined(LFSD_EMU) || !LFSD_OC_LDS_SYNC
+#define LFSD_STAGE_SYNC() __syncthreads()
+#else
+#define LFSD_STAGE_SYNC() LFSD_WAVE_SYNC()
+#endif
+
 namespace lfsd {
 
 // debug aid for the emulator build: start every kernel with NaN-filled LDS so that a read of

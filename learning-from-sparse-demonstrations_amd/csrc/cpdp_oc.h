@@ -1341,6 +1341,16 @@ template <class M, typename T, int G, bool EXACT, bool BND = false> struct OcSol
 #endif
     for (int k = N - 1; k >= 0; --k) {
       if (LFSD_BW_PREFETCH == 1) { if (k > 0) { sc_load_stage(cur, k - 1, mN, mqN, qzN, xkN, ukN); LFSD_ISSUE_FENCE(); } }
+      if constexpr (LFSD_OC_LDS_SYNC != 0) {
+        // every global load of the stage lands HERE.  Loads and stores share one in-order counter on this hardware: the stage's
+        // nominal control, first used in the middle of the stage, was waited for behind the global stores of the gains -- i.e.
+        // the wavefront sat out the stores' round trip to the L2 once per stage (`s_waitcnt vmcnt(0)` in the ISA)
+#pragma unroll
+        for (int a = 0; a < NU; ++a) pin(uk[a]);
+#pragma unroll
+        for (int i = 0; i < NX; ++i) pin(xk[i]);
+        pin(mq); pin(qzl);
+      }
       // Y(V-lane r, live column of this lane) = sum_kk V[kk][state of lane r] M[kk][column]
       typename std::conditional<MM, f32x16, T[16]>::type acc;
       T yn[NX];                                    // Y(:, column of this lane) in NATURAL row order
@@ -1349,7 +1359,7 @@ template <class M, typename T, int G, bool EXACT, bool BND = false> struct OcSol
 #pragma unroll
           for (int i = 0; i < NX; ++i) ldsMl[lane * NX + i] = m[i];
         }
-        __syncthreads();                           // V_xx (published at the end of the previous stage) and the columns are visible
+        LFSD_STAGE_SYNC();                           // V_xx (published at the end of the previous stage) and the columns are visible
         T rowb[2][NX];
 #pragma unroll
         for (int kk = 0; kk < NX; ++kk) rowb[0][kk] = ldsV[kk];
@@ -1419,7 +1429,7 @@ template <class M, typename T, int G, bool EXACT, bool BND = false> struct OcSol
         for (int i = 0; i < NX; ++i) { Qg += m[i] * vxl[i]; gl += m[i] * lml[i]; }
       }
       if constexpr (MM) tile_transpose(acc);
-      __syncthreads();                             // ldsYZ visible
+      LFSD_STAGE_SYNC();                             // ldsYZ visible
       if (LFSD_BW_PREFETCH == 2) { if (k > 0) { sc_load_stage(cur, k - 1, mN, mqN, qzN, xkN, ukN); LFSD_ISSUE_FENCE(); } }      // (experiment: behind the MFMA chains)
       LFSD_BWC(1)                                  // MFMA #2, gradient dot products, transpose
       // column of Q (natural row order) of this lane's V-role, control rows of its M-role
@@ -1455,7 +1465,7 @@ template <class M, typename T, int G, bool EXACT, bool BND = false> struct OcSol
         ldsQu[b] = Qg;
         gl_max = t_max(gl_max, t_abs(gl));
       }
-      __syncthreads();
+      LFSD_STAGE_SYNC();
       LFSD_BWC(2)                                  // gather of the constant states' columns, Q columns, Q_ux / Q_uu to LDS
       T Quu0[NU * NU], Lc[NU * NU], Qu[NU], kff[NU], Kj[NU], t1[NU];
 #pragma unroll
@@ -1500,7 +1510,7 @@ template <class M, typename T, int G, bool EXACT, bool BND = false> struct OcSol
 #pragma unroll
         for (int a = 0; a < NU; ++a) kws[k * NU + a] = kff[a];
       }
-      __syncthreads();
+      LFSD_STAGE_SYNC();
       matvec<NU>(Quu0, Kj, t1);
 #pragma unroll
       for (int a = 0; a < NU; ++a) t1[a] += Quxj[a];
@@ -1522,7 +1532,7 @@ template <class M, typename T, int G, bool EXACT, bool BND = false> struct OcSol
 #pragma unroll
         for (int i = 0; i < NX; ++i) ldsV[sv * NX + i] = vcol[i];
       }
-      __syncthreads();
+      LFSD_STAGE_SYNC();
       {
         T vt[NX];                                  // row sv of V_xx: thirteen loads in flight together (pin), then the select
 #pragma unroll
@@ -1532,7 +1542,7 @@ template <class M, typename T, int G, bool EXACT, bool BND = false> struct OcSol
 #pragma unroll
         for (int i = 0; i < NX; ++i) vcol[i] = has_v ? T(0.5) * (vcol[i] + vt[i]) : T(0);
       }
-      __syncthreads();
+      LFSD_STAGE_SYNC();
       if (!MM && has_v) {                          // publish the symmetric V_xx for the next stage's products
 #pragma unroll
         for (int i = 0; i < NX; ++i) ldsV[sv * NX + i] = vcol[i];

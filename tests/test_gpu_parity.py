@@ -659,7 +659,8 @@ def test_mesh_continuation_ends_at_the_same_kkt_point(dtype, xtol, jtol):
     spec = oc.model_spec()
     runtime.write_header(spec)
     variant = os.path.join(runtime.BUILD_DIR, "ab_%s_nocoarse.so" % spec.hash())
-    if not os.path.exists(variant):
+    deps = [runtime.header_path(spec.hash())] + [os.path.join(runtime.CSRC_DIR, f) for f in runtime.KERNEL_SOURCES]
+    if not os.path.exists(variant) or any(os.path.getmtime(variant) < os.path.getmtime(p) for p in deps):
         cmds, objs = runtime.hipcc_commands(spec, variant, ["-DLFSD_COARSE_START=0"])
         try:
             for c in cmds:

@@ -18,6 +18,8 @@ sys.path.insert(0, ROOT)
 # name -> (extra flags for both units, capi-unit flags or None for the tuned default, drop -fno-slp-vectorize from the capi unit)
 VARIANTS = {
     "base": ((), None, False),
+    "noldssync": (("-DLFSD_OC_LDS_SYNC=0",), None, False),
+    "pf1": (("-DLFSD_BW_PREFETCH=1",), None, False),
     "synclight": (("-DLFSD_SYNC_LIGHT=1",), None, False),
     "gramrows": (("-DLFSD_RIC_GRAM_ROWS=1",), None, False),
     "synclight_gram": (("-DLFSD_SYNC_LIGHT=1", "-DLFSD_RIC_GRAM_ROWS=1"), None, False),
