@@ -638,4 +638,4 @@ def test_dudtheta_error_is_the_last_interval_times_one_gain(emu):
     def prepare(oc, dtype):
         emu(oc)
         oc.setDevice(dtype=dtype)
-    dudtheta_refinement(prepare)
+    dudtheta_refinement(prepare, with_rtol=False)      # (the rtol law is asserted in the GPU tier)
