@@ -311,6 +311,17 @@
 #else
 #define LFSD_STAGE_SYNC() LFSD_WAVE_SYNC()
 #endif
+// ... the same inside a stage of the GENERIC backward sweep (wide kernel, lock-step kernels without MFMA): there the next
+// stage's global loads ARE issued a stage ahead (LFSD_BW_PREFETCH_GEN), and every __syncthreads() of the stage drained them.
+// Measured (profiles/r04_k_ab_generic_stage_sync.txt): rocket 107.8 / 107.5 ms, robot arm 17.8 / 17.7 ms with / without: nothing.
+#ifndef LFSD_OC_LDS_SYNC_GEN
+#define LFSD_OC_LDS_SYNC_GEN 1
+#endif
+#if defined(LFSD_EMU) || !LFSD_OC_LDS_SYNC_GEN
+#define LFSD_STAGE_SYNC_GEN() __syncthreads()
+#else
+#define LFSD_STAGE_SYNC_GEN() LFSD_WAVE_SYNC()
+#endif
 
 namespace lfsd {
 

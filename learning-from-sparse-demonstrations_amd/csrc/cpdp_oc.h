@@ -607,7 +607,7 @@ template <class M, typename T, int G, bool EXACT, bool BND = false> struct OcSol
 #pragma unroll
         for (int i = 0; i < NX; ++i) { if (QS) ldsM[i * NXU + lane] = m[i]; else ldsM[lane * NX + i] = m[i]; }      // QS: transposed, row i = entries (i, all columns)
       }
-      __syncthreads();
+      LFSD_STAGE_SYNC_GEN();
       if (PFG && k > 0) {
         load_stage(k - 1, mN, mqN, xkN, ukN);
         if (EXACT && mode == 2 && reuse_hess) {      // ... and its column of the cached stage Hessian
@@ -788,7 +788,7 @@ template <class M, typename T, int G, bool EXACT, bool BND = false> struct OcSol
         }
         gl_max = t_max(gl_max, t_abs(glp));
       }
-      __syncthreads();
+      LFSD_STAGE_SYNC_GEN();
       T Quu0[NU * NU], Lc[NU * NU], Qu[NU], kff[NU], Kj[NU], t1[NU];
 #pragma unroll
       for (int a = 0; a < NU; ++a) {
@@ -842,7 +842,7 @@ template <class M, typename T, int G, bool EXACT, bool BND = false> struct OcSol
 #pragma unroll
         for (int a = 0; a < NU; ++a) kws[k * NU + a] = kff[a];
       }
-      __syncthreads();
+      LFSD_STAGE_SYNC_GEN();
       matvec<NU>(Quu0, Kj, t1);
 #pragma unroll
       for (int a = 0; a < NU; ++a) t1[a] += Quxj[a];
@@ -873,12 +873,12 @@ template <class M, typename T, int G, bool EXACT, bool BND = false> struct OcSol
 #pragma unroll
         for (int i = 0; i < NX; ++i) ldsV[lane * NX + i] = vcol[i];
       }
-      __syncthreads();
+      LFSD_STAGE_SYNC_GEN();
       if (lane < NX) {
 #pragma unroll
         for (int i = 0; i < NX; ++i) vcol[i] = T(0.5) * (vcol[i] + ldsV[i * NX + lane]);
       }
-      __syncthreads();
+      LFSD_STAGE_SYNC_GEN();
       if (k > 0) {
         if (PFG) {
 #pragma unroll
