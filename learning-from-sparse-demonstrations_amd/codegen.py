@@ -26,7 +26,7 @@ import hashlib
 import sympy as sp
 from sympy.printing.c import C99CodePrinter
 
-CODEGEN_VERSION = 14
+CODEGEN_VERSION = 15
 
 
 class ModelSpec:
@@ -89,6 +89,12 @@ class _HipPrinter(C99CodePrinter):
 
     def _print_Pi(self, e):
         return 'T(3.141592653589793)'
+
+    def _print_sin(self, e):
+        return 'lfsd::t_sin(%s)' % self._print(e.args[0])
+
+    def _print_cos(self, e):
+        return 'lfsd::t_cos(%s)' % self._print(e.args[0])
 
     def _print_Pow(self, e):
         b, ex = e.base, e.exp

@@ -538,6 +538,49 @@ LFSD_DEV float t_rsqrt(float a) { float r = __builtin_amdgcn_rsqf(a); return r *
 #endif
 LFSD_DEV double t_rcp(double a) { return 1.0 / a; }
 LFSD_DEV double t_rsqrt(double a) { return 1.0 / sqrt(a); }
+// sin / cos of the generated model code (codegen.py prints lfsd::t_sin / lfsd::t_cos).  The device library's sinf / cosf are
+// ~140-instruction routines each (150 for both through sincosf; tools/probes/trig_probe.hip), and the robot arm's dynamics
+// call four of them per evaluation -- 800 evaluations per iteration of its roll-outs, the largest phase of its solve
+// (profiles/r04_g_arm_wide_clock.txt).  fp32 on the GPU: one Cody-Waite reduction by multiples of pi/2 (three constants, exact
+// products for |x| <= 100) + the two degree-7 / degree-8 minimax polynomials of cephes' sinf / cosf on [-pi/4, pi/4]; t_sin(a)
+// and t_cos(a) of the same argument share the reduction after inlining.  Measured against fp64 on 2^24 arguments in
+// [-100, 100] (trig_probe): see profiles/r04_l_trig_probe.txt.  Beyond |x| = 100, in fp64 and in the CPU emulator: the library.
+#ifndef LFSD_FAST_TRIG
+#define LFSD_FAST_TRIG 1
+#endif
+LFSD_DEV double t_sin(double a) { return sin(a); }
+LFSD_DEV double t_cos(double a) { return cos(a); }
+#if defined(LFSD_EMU) || !LFSD_FAST_TRIG
+LFSD_DEV float t_sin(float a) { return sinf(a); }
+LFSD_DEV float t_cos(float a) { return cosf(a); }
+#else
+LFSD_DEV void sincos_pio4(float x, float& sr, float& cr, int& quad) {
+  const float q = __builtin_rintf(x * 0.63661977236758134f);          // nearest multiple of pi/2
+  float r = fmaf(q, -1.57073974609375f, x);                             // pi/2 = A + B + C, A and B with short mantissas
+  r = fmaf(q, -5.657970905303955078125e-05f, r);
+  r = fmaf(q, -9.920936294705029468e-10f, r);
+  const float z = r * r;
+  sr = fmaf(fmaf(fmaf(-1.9515295891e-4f, z, 8.3321608736e-3f), z, -1.6666654611e-1f) * z, r, r);
+  cr = fmaf(fmaf(fmaf(2.443315711809948e-5f, z, -1.388731625493765e-3f), z, 4.166664568298827e-2f) * z, z, fmaf(-0.5f, z, 1.0f));
+  quad = (int)q;
+}
+LFSD_DEV float t_sin(float x) {
+  float sr, cr; int n;
+  sincos_pio4(x, sr, cr, n);
+  float v = (n & 1) ? cr : sr;
+  v = (n & 2) ? -v : v;
+  if (!(__builtin_fabsf(x) <= 100.0f)) v = sinf(x);
+  return v;
+}
+LFSD_DEV float t_cos(float x) {
+  float sr, cr; int n;
+  sincos_pio4(x, sr, cr, n);
+  float v = (n & 1) ? sr : cr;
+  v = ((n + 1) & 2) ? -v : v;
+  if (!(__builtin_fabsf(x) <= 100.0f)) v = cosf(x);
+  return v;
+}
+#endif
 LFSD_DEV float t_floor(float a) { return floorf(a); }
 LFSD_DEV double t_floor(double a) { return floor(a); }
 LFSD_DEV float t_pow(float a, float b) { return powf(a, b); }
