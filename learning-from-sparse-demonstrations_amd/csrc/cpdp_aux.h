@@ -21,6 +21,9 @@ template <typename T> struct AuxArgs {
   int batch, n_grid, substeps;    // substeps = minimum coarse split-steps per grid interval (fine = 2x, Richardson)
   T rate_max;                     // refine an interval until  dt * |Huu^-1 fu^T P fu|_inf <= rate_max
   int max_refine;                 // cap on that refinement (factor over `substeps`)
+  int unit_budget;                // > 0: once a trajectory has spent this many split units in a sweep its remaining intervals run at
+                                  // `substeps` units without refinement (and count as accepted above rtol when they are): one row whose
+                                  // parameters have left the well-posed region must not hold its launch at the cap of EVERY interval
   T rtol;                         // > 0: error-controlled sub-stepping -- an interval is redone with twice the units while the
                                   // Richardson estimate |fine - coarse| / 3 of a column exceeds rtol * (its magnitude + floor)
   const T* horizon;               // [B]
@@ -705,11 +708,12 @@ __global__ void __launch_bounds__(64, (sizeof(T) == 4 ? LFSD_WAVES_RIC : 1)) aux
     // when the stiffness estimate confirms the count the first unit need not stage again
     const int units_guess = units_hint;
     s.stage_nodes(T(1), T(-1) / T(4 * units_guess));
-    int units = s.units_for(s.stiff_rate(z, s.node(0)), Sa, a.rate_max, a.max_refine);
+    const int refine_k = (a.unit_budget > 0 && n_units >= a.unit_budget) ? 1 : a.max_refine;      // budget spent: no refinement
+    int units = s.units_for(s.stiff_rate(z, s.node(0)), Sa, a.rate_max, refine_k);
     // error-driven refinement stops at max_refine x the minimum units -- and as soon as a doubling fails to halve the
     // estimate: next to a conjugate point (finite escape of the Riccati solution) no step size meets a relative tolerance,
     // and one such trajectory must not stall the batch
-    const long long units_cap = (long long)Sa * a.max_refine;
+    const long long units_cap = (long long)Sa * refine_k;
     if (units < units_hint) units = (int)t_min((long long)units_hint, units_cap);
     T ratio_prev = T(-1);
     bool staged = (units == units_guess);
@@ -860,8 +864,9 @@ __global__ void __launch_bounds__(64, (sizeof(T) == 4 ? LFSD_WAVES_FWD : 1)) aux
     }
     s.stage_nodes(T(0), T(0.25));          // nodes at 0, 1/4 .. 1 of the interval: the stiffness at both ends -- and exactly
     const T rate = t_max(s.stiff_rate(pA, s.node(0)), s.stiff_rate(pB, s.node(4)));      // the staging of a single unit
-    int units = s.units_for(rate, Sa, a.rate_max, a.max_refine);
-    const long long units_cap = (long long)Sa * a.max_refine;
+    const int refine_k = (a.unit_budget > 0 && n_units >= a.unit_budget) ? 1 : a.max_refine;      // budget spent: no refinement
+    int units = s.units_for(rate, Sa, a.rate_max, refine_k);
+    const long long units_cap = (long long)Sa * refine_k;
     if (units < units_hint) units = (int)t_min((long long)units_hint, units_cap);
     T ratio_prev = T(-1);
     bool staged = (units == 1);

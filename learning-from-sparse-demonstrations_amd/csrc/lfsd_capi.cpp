@@ -4,6 +4,7 @@
 // (tests/emu builds the same file with g++ -DLFSD_EMU for the CPU SIMT emulator.)
 #include "lfsd_internal.h"
 #include <cmath>
+#include <algorithm>
 #ifndef LFSD_WIDE_MAX_BATCH
 #define LFSD_WIDE_MAX_BATCH 1536
 #endif
@@ -178,6 +179,11 @@ static int aux_phase_t(int phases, int batch, int n_grid, const void* horizon, c
   a.rate_max = (T)(8.0 / a.substeps / tight);
   a.max_refine = 256;
   while (a.max_refine < 256 * tight && a.max_refine < 16384) a.max_refine *= 2;
+  // a per-trajectory budget of 64 units per interval on average, 6 - 30 x what the well-posed problems of the zoo spend
+  // (quadrotor 2, robot arm 11, rocket 1 per interval): rows a fixed learning rate has driven to parameters of 1e14 refined
+  // EVERY interval to the cap (8 864 units against 565: the robot arm's Riccati launch 35 ms against 2.1, profiles/
+  // r04_l_steps_robotarm_fast_trig.txt); what they return is flagged in `stats` (intervals accepted above rtol)
+  a.unit_budget = (int)std::min<long long>(64LL * n_grid * a.substeps * (long long)tight, 1LL << 30);
   a.horizon = (const T*)horizon; a.auxvar = (const T*)auxvar;
   a.consts = consts ? (const T*)consts : (const T*)horizon;
   a.const_stride = (consts && const_per_traj) ? Model::NC : 0;
