@@ -42,6 +42,15 @@ def test_hip_library_exports_all_symbols(name):
     assert lib.lfsd_coc_solve(7, 1, 10, 4, None, None, None, None, 0, None, None, None, None, None, None, ctypes.c_double(0.0),
                               None, None, None, None, None, None,
                               10, ctypes.c_double(1e-6), 10, 0, None, ctypes.c_size_t(0), None) == -1
+    # ABI 8: a skip mask without the status array (or a negative mask) is an argument error -- caught before any launch, so
+    # host dummies stand in for the device arrays here
+    vp, ci, cd = ctypes.c_void_p, ctypes.c_int, ctypes.c_double
+    lib.lfsd_aux_solve.argtypes = [ci, ci, ci, vp, vp, vp, ci, vp, vp, vp, vp, ci, ci, vp, vp, vp, vp, vp, vp, vp, ci, cd, vp, vp, ci, vp]
+    buf = (ctypes.c_double * 8)()
+    d = ctypes.cast(buf, vp)
+    for mask in (1 << 4, -1):
+        assert lib.lfsd_aux_solve(0, 1, 10, d, d, d, 0, d, d, d, d, 0, 0, None, None, None, d, d, None, None, 0, 1e-3, None,
+                                  None, mask, None) == -1
     lib.lfsd_coc_workspace_bytes.restype = ctypes.c_size_t
     assert lib.lfsd_coc_workspace_bytes(0, 4096, 50, 16, 0, 0) > 0
     assert lib.lfsd_coc_workspace_bytes(3, 4096, 50, 16, 0, 0) == 0
