@@ -120,8 +120,8 @@ int lfsd_coc_solve(int dtype, int batch, int n_grid, int steps_per_grid,
  *           |fine - coarse| / 3 of a block of columns exceeds rtol x that block's magnitude (the reference integrates the
  *           same ODEs with scipy's solve_ivp at its default rtol 1e-3, CPDP.py:335, 368, which is the host side's default here too:
  *           measured gradient error 1e-5..1e-4 of the exact ODE solution against the reference integrator's 2.6e-3).
- *           0: fixed `substeps`.  A trajectory that has spent 64 x n_grid x substeps split units in a sweep (6 - 30 x what a
- *           well-posed problem of the zoo needs) runs its remaining intervals without refinement; they are reported in `stats`.
+ *           0: fixed `substeps`.  With oc_status given, a row whose solve did NOT end converged / at working precision (its grids
+ *           are not a KKT point) stops refining once it has spent 64 x n_grid x substeps split units in a sweep; reported in `stats`.
  *   stats   [B][4] int32 or NULL: per trajectory, {split units executed by the Riccati sweep (rejected attempts included),
  *           intervals of it that were accepted ABOVE rtol because refinement stopped gaining (next to a conjugate point) or hit
  *           its cap, the same two numbers of the forward sweep}.  A non-zero second or fourth entry marks a loss / gradient

@@ -21,8 +21,10 @@ template <typename T> struct AuxArgs {
   int batch, n_grid, substeps;    // substeps = minimum coarse split-steps per grid interval (fine = 2x, Richardson)
   T rate_max;                     // refine an interval until  dt * |Huu^-1 fu^T P fu|_inf <= rate_max
   int max_refine;                 // cap on that refinement (factor over `substeps`)
-  int unit_budget;                // > 0: once a trajectory has spent this many split units in a sweep its remaining intervals run at
-                                  // `substeps` units without refinement (and count as accepted above rtol when they are): one row whose
+  int unit_budget;                // > 0, for rows whose OC solve did NOT end converged / at working precision (oc_status given and not
+                                  // 1 or 2): once such a trajectory has spent this many split units in a sweep its remaining intervals
+                                  // run at `substeps` units without refinement (and count as accepted above rtol when they are).  Its
+                                  // grids are not a KKT point, so its sensitivities are approximate whatever the sweeps do; and a row whose
                                   // parameters have left the well-posed region must not hold its launch at the cap of EVERY interval
   T rtol;                         // > 0: error-controlled sub-stepping -- an interval is redone with twice the units while the
                                   // Richardson estimate |fine - coarse| / 3 of a column exceeds rtol * (its magnitude + floor)
@@ -46,6 +48,11 @@ template <typename T> struct AuxArgs {
   const int* oc_status;           // [B] or nullptr: status of the OC solve; rows whose status bit is set in skip_mask are not
   int skip_mask;                  // differentiated (no sweep, NaN loss / gradient): include/lfsd_cpdp.h, ABI 8
   LFSD_DEV bool skipped(long long traj) const { return oc_status != nullptr && ((skip_mask >> (oc_status[traj] & 31)) & 1) != 0; }
+  LFSD_DEV int budget(long long traj) const {
+    if (oc_status == nullptr || unit_budget <= 0) return 0;
+    const int st = oc_status[traj];
+    return (st == ST_CONVERGED || st == ST_STALLED) ? 0 : unit_budget;
+  }
 };
 
 // LAY: which packing of the staged coefficients the kernel uses (codegen: 0 Riccati sweep, every matrix; 1 forward sweep,
@@ -701,6 +708,7 @@ __global__ void __launch_bounds__(64, (sizeof(T) == 4 ? LFSD_WAVES_RIC : 1)) aux
   T* ldsT = s.lds + Lay::LDS_T;
   int units_hint = Sa;
   int n_units = 0, n_unmet = 0;      // (group-uniform) units executed incl. rejected attempts; intervals accepted above tolerance
+  const int budget = a.budget(traj);
   for (int k = N - 1; k >= 0; --k) {
     s.load_interval(a, traj, k, N);
     // stiffness-aware sub-stepping: P is largest at the later end of the interval (terminal transient).  The coefficients
@@ -708,7 +716,7 @@ __global__ void __launch_bounds__(64, (sizeof(T) == 4 ? LFSD_WAVES_RIC : 1)) aux
     // when the stiffness estimate confirms the count the first unit need not stage again
     const int units_guess = units_hint;
     s.stage_nodes(T(1), T(-1) / T(4 * units_guess));
-    const int refine_k = (a.unit_budget > 0 && n_units >= a.unit_budget) ? 1 : a.max_refine;      // budget spent: no refinement
+    const int refine_k = (budget > 0 && n_units >= budget) ? 1 : a.max_refine;      // budget spent: no refinement
     int units = s.units_for(s.stiff_rate(z, s.node(0)), Sa, a.rate_max, refine_k);
     // error-driven refinement stops at max_refine x the minimum units -- and as soon as a doubling fails to halve the
     // estimate: next to a conjugate point (finite escape of the Riccati solution) no step size meets a relative tolerance,
@@ -842,6 +850,7 @@ __global__ void __launch_bounds__(64, (sizeof(T) == 4 ? LFSD_WAVES_FWD : 1)) aux
   T loss = T(0), gacc = T(0);
   int units_hint = Sa;
   int n_units = 0, n_unmet = 0;
+  const int budget = a.budget(traj);
   T* Xo = a.auxX_grid ? a.auxX_grid + traj * (long long)(N + 1) * NP * NX : nullptr;
   T* Uo = a.auxU_grid ? a.auxU_grid + traj * (long long)(N + 1) * NP * NU : nullptr;
   if (valid && Xo && fine_x) {
@@ -864,7 +873,7 @@ __global__ void __launch_bounds__(64, (sizeof(T) == 4 ? LFSD_WAVES_FWD : 1)) aux
     }
     s.stage_nodes(T(0), T(0.25));          // nodes at 0, 1/4 .. 1 of the interval: the stiffness at both ends -- and exactly
     const T rate = t_max(s.stiff_rate(pA, s.node(0)), s.stiff_rate(pB, s.node(4)));      // the staging of a single unit
-    const int refine_k = (a.unit_budget > 0 && n_units >= a.unit_budget) ? 1 : a.max_refine;      // budget spent: no refinement
+    const int refine_k = (budget > 0 && n_units >= budget) ? 1 : a.max_refine;      // budget spent: no refinement
     int units = s.units_for(rate, Sa, a.rate_max, refine_k);
     const long long units_cap = (long long)Sa * refine_k;
     if (units < units_hint) units = (int)t_min((long long)units_hint, units_cap);

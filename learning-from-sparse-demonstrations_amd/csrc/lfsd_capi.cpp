@@ -179,10 +179,10 @@ static int aux_phase_t(int phases, int batch, int n_grid, const void* horizon, c
   a.rate_max = (T)(8.0 / a.substeps / tight);
   a.max_refine = 256;
   while (a.max_refine < 256 * tight && a.max_refine < 16384) a.max_refine *= 2;
-  // a per-trajectory budget of 64 units per interval on average, 6 - 30 x what the well-posed problems of the zoo spend
-  // (quadrotor 2, robot arm 11, rocket 1 per interval): rows a fixed learning rate has driven to parameters of 1e14 refined
-  // EVERY interval to the cap (8 864 units against 565: the robot arm's Riccati launch 35 ms against 2.1, profiles/
-  // r04_l_steps_robotarm_fast_trig.txt); what they return is flagged in `stats` (intervals accepted above rtol)
+  // a budget of 64 units per interval on average for rows whose OC solve did not converge (status not 1 / 2; needs oc_status): rows
+  // a fixed learning rate has driven to parameters of 1e14 refined EVERY interval to the cap (8 864 units against the 565 of
+  // a well-posed robot-arm row: Riccati launch 35 ms against 2.1, profiles/r04_l_steps_robotarm_fast_trig.txt); what they
+  // return is flagged in `stats`.  Converged rows are never budgeted (a stiff last interval alone may need thousands of units).
   a.unit_budget = (int)std::min<long long>(64LL * n_grid * a.substeps * (long long)tight, 1LL << 30);
   a.horizon = (const T*)horizon; a.auxvar = (const T*)auxvar;
   a.consts = consts ? (const T*)consts : (const T*)horizon;
@@ -193,7 +193,7 @@ static int aux_phase_t(int phases, int batch, int n_grid, const void* horizon, c
   a.taus = (const T*)taus; a.waypoints = (const T*)waypoints;
   a.loss = (T*)loss; a.grad = (T*)grad; a.auxX_grid = (T*)auxX_grid; a.auxU_grid = (T*)auxU_grid;
   a.stats = stats;
-  a.oc_status = skip_mask ? oc_status : nullptr; a.skip_mask = skip_mask;
+  a.oc_status = oc_status; a.skip_mask = skip_mask;      // (the status also decides which rows the unit budget applies to)
   const unsigned grid = (unsigned)(((long long)batch + GPB - 1) / GPB);
   if (phases & 1) {
     int rc;

@@ -337,10 +337,8 @@ class ModelLibrary:
             if not 0 <= int(st) < 31:
                 raise LfsdError("skip_status values must be OC-solve statuses (0..30)")
             skip_mask |= 1 << int(st)
-        if skip_mask:
+        if skip_mask or oc_status is not None:      # (without a mask the status still tells the sweeps which rows to budget)
             self._check(oc_status, (B,), torch.int32, "oc_status")
-        else:
-            oc_status = None
         auxX = auxU = None
         if want_grids:
             auxX = torch.empty((B, N + 1, p, n), dtype=dt, device=dev)
