@@ -208,6 +208,12 @@
 // structural backward sweep, fp32: V_x and the costate read from their LDS images where used (1) or carried in registers (0).
 // In fp64 the LDS form is what made the one-pass sweep pay (11.1 -> 9.2 ms); in fp32 it frees 21 accumulator registers and
 // costs 2 % (oc_solve 2.58 -> 2.63 ms, profiles/r03_aa_ab_vx_lds.txt): the registers are there.
+// structural backward sweep, fp32: gain rows / Q_ux rows of the V_xx update fetched into registers first (1) or read where used (0).
+// Measured (profiles/r04_p_ab_vupdate_fetch.txt): oc_solve 2.589 -> 2.633 ms with the fetch -- the sweep runs at 256 + 142 registers and
+// the 52 extra live values turn into accumulator-register moves; what lds_fetch bought the forward auxiliary sweep it does not buy here.
+#ifndef LFSD_SC_VUP_FETCH
+#define LFSD_SC_VUP_FETCH 0
+#endif
 #ifndef LFSD_SC_VX_LDS
 #define LFSD_SC_VX_LDS 0
 #endif

@@ -1514,6 +1514,29 @@ template <class M, typename T, int G, bool EXACT, bool BND = false> struct OcSol
       matvec<NU>(Quu0, Kj, t1);
 #pragma unroll
       for (int a = 0; a < NU; ++a) t1[a] += Quxj[a];
+      if constexpr ((LFSD_SC_VUP_FETCH) != 0 && sizeof(T) == 4) {
+        // EXPERIMENT (round 4): the gain rows and Q_ux rows of the update fetched with back-to-back LDS reads first (lds_fetch),
+        // in two halves of the rows
+        constexpr int H1 = (NX + 1) / 2;
+        T kr[H1 * NU], qr[H1 * NU];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int i0 = h * H1;
+          lds_issue<H1 * NU>(ldsK + i0 * NU, kr); lds_issue<H1 * NU>(ldsQux + i0 * NU, qr);
+          lds_land<H1 * NU>(kr); lds_land<H1 * NU>(qr);
+#pragma unroll
+          for (int ii = 0; ii < H1; ++ii) {
+            const int i = i0 + ii;
+            if (i < NX) {
+              T sacc = Qcol[i];
+#pragma unroll
+              for (int a = 0; a < NU; ++a) { sacc += kr[ii * NU + a] * t1[a]; sacc += qr[ii * NU + a] * Kj[a]; }
+              vcol[i] = sacc;
+              if (VXR) { Vx[i] = ldsVx[i]; lam[i] = ldsLam[i]; }
+            }
+          }
+        }
+      } else {
 #pragma unroll
       for (int i = 0; i < NX; ++i) {
         T sacc = Qcol[i];
@@ -1521,6 +1544,7 @@ template <class M, typename T, int G, bool EXACT, bool BND = false> struct OcSol
         for (int a = 0; a < NU; ++a) { sacc += ldsK[i * NU + a] * t1[a]; sacc += ldsQux[i * NU + a] * Kj[a]; }      // (two FMAs; one statement compiles to mul + fma + add)
         vcol[i] = sacc;
         if (VXR) { Vx[i] = ldsVx[i]; lam[i] = ldsLam[i]; }
+      }
       }
       if (lane == 0 && live) {
 #pragma unroll

@@ -20,6 +20,7 @@ VARIANTS = {
     "base": ((), None, False),
     "noldssync": (("-DLFSD_OC_LDS_SYNC=0",), None, False),
     "pf1": (("-DLFSD_BW_PREFETCH=1",), None, False),
+    "vupfetch": (("-DLFSD_SC_VUP_FETCH=1",), None, False),
     "synclight": (("-DLFSD_SYNC_LIGHT=1",), None, False),
     "gramrows": (("-DLFSD_RIC_GRAM_ROWS=1",), None, False),
     "synclight_gram": (("-DLFSD_SYNC_LIGHT=1", "-DLFSD_RIC_GRAM_ROWS=1"), None, False),
