@@ -40,6 +40,15 @@ rocket)       # A/B of build variants on the rocket's cold OC solve (tools/model
   python3 tools/wide_clock.py run rocket 100 1024 f32 > $OUT/rocket_wide_clock.txt 2>&1; grep -c "wide clock" $OUT/rocket_wide_clock.txt; sort -t' ' -k6 -n -r $OUT/rocket_wide_clock.txt | head -4 ;;
 steps)        # CFGS="robotarm rocket": per-outer-iteration kernel times and unit / iteration distributions (tools/config_steps.py)
   for c in ${CFGS:-robotarm}; do python3 tools/config_steps.py $c ${NSTEPS:-6} > $OUT/steps_$c.txt 2>&1; cat $OUT/steps_$c.txt; done ;;
+final)        # the round's closing record: evidence sets (headline, fp64, the two configurations), default line, other batch / mode, tier
+  bash tools/gpu_session.sh profile r04 > $OUT/profile.log 2>&1
+  bash tools/gpu_session.sh f64 r04_f64 > $OUT/f64.log 2>&1
+  bash tools/gpu_session.sh configs r04_c
+  python3 bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err; line $OUT/bench_default.json
+  python3 bench.py --batch 32768 --steps 5 --warmup 1 --no-cpu-baseline --no-f64-leg > $OUT/bench_f32_32768.json 2> /dev/null; line $OUT/bench_f32_32768.json
+  python3 bench.py --batch 32768 --steps 3 --warmup 1 --dtype f64 --no-cpu-baseline > $OUT/bench_f64_32768.json 2> /dev/null; line $OUT/bench_f64_32768.json
+  python3 bench.py --mode shared --no-cpu-baseline > $OUT/bench_shared_one_gpu.json 2> /dev/null; line $OUT/bench_shared_one_gpu.json
+  bash tools/gpu_session.sh tier ${TAG}_tier ;;
 ab)
   shift; shift; python3 tools/ab_variants.py run "$@" > $OUT/ab.txt 2>&1; cat $OUT/ab.txt ;;
 *) echo "unknown session $S"; exit 2 ;;
