@@ -692,3 +692,29 @@ def test_mesh_continuation_ends_at_the_same_kkt_point(dtype, xtol, jtol):
         parity_record("mesh continuation on/off %s" % dtype, k, rel(a[k], b[k].double().cpu().numpy()), t)
     ja, jb = a["cost"].double().cpu().numpy(), b["cost"].double().cpu().numpy()
     parity_record("mesh continuation on/off %s" % dtype, "cost", float(np.abs(ja - jb).max() / np.abs(jb).max()), jtol)
+
+
+@pytest.mark.parametrize("cfg,words", [("robotarm", ("configs[1]", "RobotArm")), ("rocket", ("configs[4]", "Rocket"))])
+def test_bench_config_lines_have_the_full_schema(cfg, words):
+    """`bench.py --config robotarm|rocket` (BASELINE configs[1] / configs[4]) as a fresh child at a small batch: one JSON line
+    with the headline's schema -- metric, value, roofline (with the kernel it names and its arithmetic), config.workload naming
+    the configuration -- and a CPU leg from the oracle on the run's own seeds."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--config", cfg, "--batch", "64", "--steps", "2", "--warmup", "1",
+                        "--cpu-seeds", "4"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    o = json.loads(lines[0])
+    assert o["metric"].startswith("CPDP outer iterations/sec") and o["unit"] == "trajectory outer-iterations/s"
+    assert o["n_gpus"] == 1 and o["steps"] == 2 and o["value"] > 0 and o["higher_is_better"] is True and o["vs_baseline"] is None
+    assert all(wd in o["config"]["workload"] for wd in words) and o["config"]["name"] == cfg and o["config"]["batch_per_gpu"] == 64
+    rf = o["roofline"]
+    assert rf["bound"] == "hbm" and rf["kernel"] in ("oc_solve", "aux_riccati", "aux_forward") and rf["achieved"] > 0 and 0 < rf["frac"] < 1
+    assert rf["kernel_dtype"] in ("f32", "f64") and rf["valu_useful_tflops"] > 0
+    cb = o["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] and cb["value"] > 0, cb
+    assert (cfg == "rocket") == ("f64 (auxiliary pass)" in o["dtype"])
