@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define LFSD_ABI_VERSION 8
+#define LFSD_ABI_VERSION 9
 #define LFSD_F32 0
 #define LFSD_F64 1
 #define LFSD_EINVAL (-1)   /* bad argument (null pointer, non-positive size, unknown enum) */
@@ -61,6 +61,11 @@ typedef struct lfsd_model_info {
 } lfsd_model_info;
 
 int lfsd_get_model_info(lfsd_model_info* out);
+/* outputs of the interface function y = g(x) compiled into this library (ABI 9), 0 if the model was generated without one.  The
+ * reference's interface functions are arbitrary CasADi expressions of the state (lib/QuadAlgorithm.py:616-639, Examples/*.py:
+ * `Function('interface', [oc.state], [...])` and its `jacobian`); every example selects state components, which `iface_idx` covers
+ * without a recompilation; a model generated with `setInterface(expr)` carries g and (dg/dx)^T r as generated code. */
+int lfsd_interface_dim(void);
 /* default value of runtime constant i (the number the reference would have baked into the CasADi graph) */
 double lfsd_const_default(int i);
 
@@ -108,7 +113,8 @@ int lfsd_coc_solve(int dtype, int batch, int n_grid, int steps_per_grid,
  * sparse-demonstration loss and its gradient.
  *   Z_grid  [B][n_grid+1][n_state+n_auxvar][n_state]  out: Riccati pair [P W], column-major
  *           (P_k, W_k of CPDP.py:329-338)
- *   iface_idx [n_iface] int32: state components exposed by the interface function
+ *   iface_idx [n_iface] int32: state components exposed by the interface function; NULL (ABI 9): the interface function
+ *           compiled into the library, n_iface = lfsd_interface_dim() (waypoints [B][n_waypoints][n_iface] as before)
  *   taus [B][n_waypoints], waypoints [B][n_waypoints][n_iface]
  *   loss [B], grad [B][n_auxvar]:  loss = sum_k |y(tau_k)-wp_k|^2, grad = sum_k (y-wp)^T dy/dx dx/dtheta
  *           (no factor 2, exactly as lib/QuadAlgorithm.py:630-637)

@@ -123,6 +123,15 @@ class COCSys:
         self.final_cost = sp.sympify(final_cost)
         self._lib = None
 
+    def setInterface(self, interface=None):
+        """The interface function y = g(x) of the sparse-demonstration loss as a symbolic expression of the state -- what the
+        reference's examples build as ``Function('interface', [oc.state], [expr])`` together with its ``jacobian``
+        (lib/QuadAlgorithm.py:616-639, Examples/robotarm_random.py:35-36).  It is compiled into the model library (g and
+        (dg/dx)^T r as generated code); ``auxSysSolverBatch`` / ``SparseDemoLearner`` called with ``interface_idx=None`` use
+        it.  Interfaces that merely select state components need none of this: pass ``interface_idx``."""
+        self.interface = None if interface is None else symbolic._flat([interface])
+        self._lib = None
+
     def setIntegrator(self, n_grid=10, steps_per_grid=4):
         self.n_grid = n_grid
         self.steps_per_grid = steps_per_grid
@@ -168,7 +177,9 @@ class COCSys:
                                          "path_cost": "Define the running cost/reward function first!",
                                          "final_cost": "Define the final cost/reward function first!"}[attr]
         known = set(self.state) | set(self.control) | set(self.auxvar) | {self.time}
-        free = (self.dyn.free_symbols | self.path_cost.free_symbols | self.final_cost.free_symbols) - known
+        iface = getattr(self, "interface", None)
+        ifree = set().union(*[sp.sympify(g).free_symbols for g in iface]) if iface else set()
+        free = (self.dyn.free_symbols | self.path_cost.free_symbols | self.final_cost.free_symbols | ifree) - known
         bad = [s for s in free if not symbolic.is_const(s)]
         if bad:
             raise LfsdError("free symbols that are neither state, control, auxvar nor const(): %s" % bad)
@@ -178,7 +189,7 @@ class COCSys:
         return codegen.ModelSpec(self.state, self.control, self.auxvar, consts, self.time, self.dyn, self.path_cost,
                                  self.final_cost, time_varying=tv,
                                  const_defaults=[symbolic.const_default(s) for s in consts],
-                                 name=name or self.sys_name)
+                                 name=name or self.sys_name, interface=iface)
 
     def compile(self, force=False, verbose=False):
         if self._lib is not None and not force:
@@ -345,9 +356,13 @@ class COCSys:
         which raises ValueError for t outside [0, horizon]; its interface functions are arbitrary CasADi expressions,
         ours select state components only."""
         lib = self.compile()
-        idx = [int(i) for i in interface_idx]
-        if any(i < 0 or i >= lib.n_state for i in idx):
-            raise LfsdError("interface_idx %s outside [0, n_state=%d)" % (idx, lib.n_state))
+        if interface_idx is None:
+            if lib.n_interface == 0:
+                raise LfsdError("no interface_idx given and no interface function set (COCSys.setInterface)")
+        else:
+            idx = [int(i) for i in interface_idx]
+            if any(i < 0 or i >= lib.n_state for i in idx):
+                raise LfsdError("interface_idx %s outside [0, n_state=%d)" % (idx, lib.n_state))
         tt = torch.as_tensor(taus, dtype=torch.float64).cpu() if not isinstance(taus, torch.Tensor) else taus.double().cpu()
         hz = torch.as_tensor(horizon, dtype=torch.float64).cpu() if not isinstance(horizon, torch.Tensor) else horizon.double().cpu()
         hz = hz.reshape(-1, 1) if (hz.dim() >= 1 and tt.dim() == 2 and hz.numel() == tt.shape[0]) else hz.min()
@@ -372,7 +387,7 @@ class COCSys:
             wp = self._t(waypoints)
             if wp.dim() == 2:
                 wp = wp.unsqueeze(0).expand(B, -1, -1).contiguous()
-            ii = torch.as_tensor(list(interface_idx), dtype=torch.int32, device=self._dev())
+            ii = None if interface_idx is None else torch.as_tensor(list(interface_idx), dtype=torch.int32, device=self._dev())
             if validate:          # (a device->host read: callers that validated at setup switch it off)
                 self.check_waypoints(tt, sol["horizon"], interface_idx)
         hz, cs, X, U, Lm = sol["horizon"], sol["consts"], sol["state_grid"], sol["control_grid"], sol["costate_grid"]
@@ -481,7 +496,7 @@ class SparseDemoLearner:
         self.taus = tt.unsqueeze(0).expand(B, -1).contiguous() if tt.dim() == 1 else tt
         wp = oc._t(waypoints)
         self.wps = wp.unsqueeze(0).expand(B, -1, -1).contiguous() if wp.dim() == 2 else wp
-        self.iface = torch.as_tensor(list(interface_idx), dtype=torch.int32, device=self.x0.device)
+        self.iface = None if interface_idx is None else torch.as_tensor(list(interface_idx), dtype=torch.int32, device=self.x0.device)
         oc.check_waypoints(self.taus, self.hz, interface_idx)
         th = oc._t(theta0)
         th = th.unsqueeze(0) if th.dim() == 1 else th

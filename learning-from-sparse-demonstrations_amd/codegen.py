@@ -26,12 +26,12 @@ import hashlib
 import sympy as sp
 from sympy.printing.c import C99CodePrinter
 
-CODEGEN_VERSION = 15
+CODEGEN_VERSION = 16
 
 
 class ModelSpec:
     def __init__(self, state, control, auxvar, consts, time, dyn, path_cost, final_cost,
-                 time_varying=False, const_defaults=None, name="model"):
+                 time_varying=False, const_defaults=None, name="model", interface=None):
         self.state, self.control, self.auxvar, self.consts = list(state), list(control), list(auxvar), list(consts)
         self.time = time
         self.dyn = sp.Matrix(dyn)
@@ -40,6 +40,9 @@ class ModelSpec:
         self.time_varying = bool(time_varying)
         self.const_defaults = list(const_defaults or [0.0] * len(self.consts))
         self.name = name
+        # interface function y = g(x) of the sparse-demonstration loss (lib/QuadAlgorithm.py:616-639: an arbitrary CasADi
+        # expression of the state; None: the loss selects state components by index, which every example does)
+        self.interface = None if interface is None else sp.Matrix(list(interface))
         self._canon()
 
     def _canon(self):
@@ -58,6 +61,10 @@ class ModelSpec:
         self.f = self.dyn.xreplace(sub)
         self.c = self.path_cost.xreplace(sub)
         self.h = self.final_cost.xreplace(sub)
+        self.g = None if self.interface is None else self.interface.xreplace(sub)
+        if self.g is not None and (self.g.free_symbols - set(self.X + self.C)):
+            raise ValueError("the interface function may depend on the state (and constants) only: %s"
+                             % sorted(map(str, self.g.free_symbols - set(self.X + self.C))))
         allowed = set(self.X + self.U + self.E + self.C + [self.Tt])
         stray = (self.f.free_symbols | self.c.free_symbols | self.h.free_symbols) - allowed
         if stray:
@@ -74,6 +81,8 @@ class ModelSpec:
         # constant values to the kernels (COCSys.const_values / consts_tensor), never the library's defaults.
         key = "v%d|%d %d %d %d %d|%s|%s|%s" % (CODEGEN_VERSION, self.n, self.m, self.p, self.nc, self.time_varying,
                                                sp.srepr(self.f), sp.srepr(self.c), sp.srepr(self.h))
+        if self.g is not None:
+            key += "|g:" + sp.srepr(self.g)
         return hashlib.sha1(key.encode()).hexdigest()[:16]
 
 
@@ -380,6 +389,25 @@ def emit_header(spec):
     S.append('  // y = hxx*dx + hxe*oe')
     S.append('  template<class T> static LFSD_DEV void final_hess_mul(%s, const T* dx, const T* oe, T* y) {' % sig_x)
     S.append(_body(_loads(spec, with_u=False) + tang_e, [('y[%d]' % i, yfin[i]) for i in range(n)]))
+    S.append('  }')
+    # 3b. interface function of the waypoint loss (optional): y = g(x), and rx = (dg/dx)^T r
+    nif = 0 if spec.g is None else spec.g.shape[0]
+    S.append('  static constexpr int NIF = %d;      // outputs of the compiled interface function (0: none, the loss selects components)' % nif)
+    S.append('  template<class T> static LFSD_DEV void iface(const T* x, const T* c, T* y) {')
+    if nif:
+        S.append(_body(_loads(spec, with_u=False), [('y[%d]' % i, spec.g[i]) for i in range(nif)]))
+    else:
+        S.append('    (void)x; (void)c; (void)y;')
+    S.append('  }')
+    S.append('  template<class T> static LFSD_DEV void iface_vjp(const T* x, const T* c, const T* r, T* rx) {')
+    if nif:
+        R = sp.Matrix([sp.Symbol('ri%d' % i, real=True) for i in range(nif)])
+        gx = spec.g.jacobian(X)
+        rx = gx.T * R
+        S.append(_body(_loads(spec, with_u=False) + [(s_, 'r[%d]' % i) for i, s_ in enumerate(R)],
+                       [('rx[%d]' % i, rx[i]) for i in range(n)]))
+    else:
+        S.append('    (void)x; (void)c; (void)r; (void)rx;')
     S.append('  }')
     # 4. Hamiltonian Hessian applied to a vector
     sig_xul = 'T t, const T* x, const T* u, const T* l, const T* e, const T* c'

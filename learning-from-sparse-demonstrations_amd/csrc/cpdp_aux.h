@@ -37,7 +37,8 @@ template <typename T> struct AuxArgs {
   T* Z_grid;                      // [B][N+1][NX+NP][NX]   column-major Z = [P W]
   // forward sweep / loss
   int n_waypoints, n_iface;
-  const int* iface_idx;           // [n_iface] state components the interface exposes
+  const int* iface_idx;           // [n_iface] state components the interface exposes; nullptr: the interface function compiled into
+                                  // the model (Model::NIF outputs; n_iface must equal it)
   const T* taus;                  // [B][n_waypoints]
   const T* waypoints;             // [B][n_waypoints][n_iface]
   T* loss;                        // [B]
@@ -966,7 +967,26 @@ __global__ void __launch_bounds__(64, (sizeof(T) == 4 ? LFSD_WAVES_FWD : 1)) aux
       T rvec[NX];
 #pragma unroll
       for (int i = 0; i < NX; ++i) rvec[i] = T(0);
-      for (int q = 0; q < a.n_iface; ++q) {
+      bool compiled_iface = false;
+      if constexpr (M::NIF > 0) {
+        // the interface function compiled into the model (iface_idx == NULL): y = g(x(tau)) on the interpolated state, residual
+        // r = y - waypoint, and r^T dg/dx as the vector the sensitivity is contracted with (lib/QuadAlgorithm.py:625-637: an
+        // arbitrary CasADi expression of the state and its jacobian)
+        if (a.iface_idx == nullptr) {
+          compiled_iface = true;
+          T cur[NX], y[M::NIF], r[M::NIF];
+#pragma unroll
+          for (int i = 0; i < NX; ++i) cur[i] = s.xa_[i] + sw * (s.xb_[i] - s.xa_[i]);
+          M::iface(cur, s.c, y);
+#pragma unroll
+          for (int q = 0; q < M::NIF; ++q) {
+            r[q] = y[q] - a.waypoints[(traj * a.n_waypoints + w) * M::NIF + q];
+            loss += r[q] * r[q];
+          }
+          M::iface_vjp(cur, s.c, r, rvec);
+        }
+      }
+      for (int q = 0; q < (compiled_iface ? 0 : a.n_iface); ++q) {
         const int idx = a.iface_idx[q];
         const T target = a.waypoints[(traj * a.n_waypoints + w) * a.n_iface + q];
 #pragma unroll

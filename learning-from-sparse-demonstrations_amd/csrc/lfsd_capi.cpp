@@ -28,6 +28,8 @@ LFSD_API int lfsd_get_model_info(lfsd_model_info* out) {
   return 0;
 }
 
+LFSD_API int lfsd_interface_dim(void) { return Model::NIF; }
+
 LFSD_API double lfsd_const_default(int i) {
   if (i < 0 || i >= Model::NC_REAL) return 0.0;
   return Model::const_default(i);
@@ -221,7 +223,9 @@ static int aux_dispatch(int phases, int dtype, int batch, int n_grid, const void
   if (batch <= 0 || n_grid <= 0 || n_waypoints < 0 || n_iface < 0 || substeps < 0 || !(rtol >= 0)) return LFSD_EINVAL;
   if (!horizon || !auxvar || !state_grid || !control_grid || !costate_grid || !Z_grid) return LFSD_EINVAL;
   if ((phases & 2) && (!loss || !grad)) return LFSD_EINVAL;
-  if ((phases & 2) && n_waypoints > 0 && (n_iface <= 0 || !iface_idx || !taus || !waypoints)) return LFSD_EINVAL;
+  if ((phases & 2) && n_waypoints > 0 && (n_iface <= 0 || !taus || !waypoints)) return LFSD_EINVAL;
+  // iface_idx == NULL selects the interface function compiled into the library: it must exist and n_iface must be its size
+  if ((phases & 2) && n_waypoints > 0 && !iface_idx && (Model::NIF == 0 || n_iface != Model::NIF)) return LFSD_EINVAL;
   if (Model::NC_REAL > 0 && !consts) return LFSD_EINVAL;
   if (skip_mask < 0 || (skip_mask != 0 && !oc_status)) return LFSD_EINVAL;
   if (dtype == LFSD_F32)

@@ -146,7 +146,7 @@ _DT = {torch.float32: LFSD_F32, torch.float64: LFSD_F64}
 class ModelLibrary:
     """One loaded model library (all entry points of include/lfsd_cpdp.h)."""
 
-    EXPORTS = ("lfsd_get_model_info", "lfsd_const_default", "lfsd_coc_workspace_bytes", "lfsd_coc_solve",
+    EXPORTS = ("lfsd_get_model_info", "lfsd_interface_dim", "lfsd_const_default", "lfsd_coc_workspace_bytes", "lfsd_coc_solve",
                "lfsd_aux_solve", "lfsd_aux_riccati", "lfsd_aux_forward", "lfsd_optimizer_step", "lfsd_lookahead")
 
     def __init__(self, path):
@@ -176,7 +176,7 @@ class ModelLibrary:
         L.lfsd_lookahead.argtypes = [ci, ctypes.c_longlong, cd, vp, vp, vp, vp]
         info = _ModelInfo()
         rc = L.lfsd_get_model_info(ctypes.byref(info))
-        if rc != 0 or info.abi_version != 8:
+        if rc != 0 or info.abi_version != 9:
             raise LfsdError("ABI mismatch in %s" % path)
         self.n_state, self.n_control, self.n_auxvar, self.n_const = (info.n_state, info.n_control, info.n_auxvar,
                                                                       info.n_const)
@@ -186,6 +186,7 @@ class ModelLibrary:
         self.name = info.name.decode()
         self.hash = info.hash.decode()
         self.const_defaults = [L.lfsd_const_default(i) for i in range(self.n_const)]
+        self.n_interface = int(L.lfsd_interface_dim())      # outputs of the compiled interface function (0: none)
 
     # ---- argument plumbing ---------------------------------------------------------------
     def _check(self, t, shape, dtype, name, optional=False):
@@ -320,10 +321,14 @@ class ModelLibrary:
             consts = None
         nw = 0 if taus is None else taus.shape[1]
         ni = 0 if iface_idx is None else iface_idx.shape[0]
+        if nw and iface_idx is None:      # the interface function compiled into the library (COCSys.setInterface)
+            ni = self.n_interface
+            if ni == 0:
+                raise LfsdError("no interface_idx given and the model library carries no compiled interface function")
         if nw:
             self._check(taus, (B, nw), dt, "taus")
             self._check(waypoints, (B, nw, ni), dt, "waypoints")
-            self._check(iface_idx, (ni,), torch.int32, "iface_idx")
+            self._check(iface_idx, (ni,), torch.int32, "iface_idx", optional=True)
         if Z_grid is None:
             Z_grid = torch.empty((B, N + 1, n + p, n), dtype=dt, device=dev)
         if out is None:

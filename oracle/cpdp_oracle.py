@@ -83,6 +83,15 @@ class COCSys:
         self.n_grid = n_grid
         self.steps_per_grid = steps_per_grid
 
+    def setInterface(self, interface):
+        """The examples' interface function and its Jacobian (Examples/robotarm_random.py:35-36:
+        ``Function('interface', [oc.state], [expr])`` and ``Function('diff_interface', [oc.state], [jacobian(expr, oc.state)])``),
+        as lambdified sympy expressions of the state."""
+        g = sp.Matrix(list(interface))
+        X = sp.Matrix(self.state)
+        self.interface_fn = sp.lambdify([self.state], list(g), modules="numpy")
+        self.diff_interface_fn = sp.lambdify([self.state], g.jacobian(X), modules="numpy")
+
     # ---- CPDP.py:201-248 --------------------------------------------------
     def diffPMP(self):
         if hasattr(self, '_fn'):
@@ -611,13 +620,18 @@ def getloss_corrections(oc, time_grid, target_waypoints, opt_sol, auxsys_sol, in
     n, p = oc.n_state, oc.n_auxvar
     loss = 0.0
     diff_loss = np.zeros(p)
-    idx = list(interface_idx)
+    idx = None if interface_idx is None else list(interface_idx)      # None: the general interface function of oc.setInterface
     for k, t in enumerate(time_grid):
         target = np.asarray(target_waypoints[k], dtype=float).ravel()
-        cur = opt_sol(t)[0:n][idx]
+        x = opt_sol(t)[0:n]
+        if idx is None:
+            cur = np.asarray(oc.interface_fn(x), dtype=float).ravel()
+            dy_dx = np.asarray(oc.diff_interface_fn(x), dtype=float).reshape(len(cur), n)
+        else:
+            cur = x[idx]
+            dy_dx = np.eye(n)[idx]
         loss += np.linalg.norm(target - cur) ** 2
         dl_dy = cur - target
-        dy_dx = np.eye(n)[idx]
         dx_dp = auxsys_sol(t)[0:n * p].reshape(n, p)
         diff_loss += dl_dy @ dy_dx @ dx_dp
     return loss, diff_loss

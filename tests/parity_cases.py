@@ -349,3 +349,55 @@ def dudtheta_refinement(prepare, with_rtol=True):
     eXb, eUb = errors(1, 1e-4)
     assert eXb[-1] < eXa[-1] / 1.5 and eXb[:-1].max() < 1e-5, (eXa[-1], eXb[-1], eXb[:-1].max())          # measured 1.8e-4 -> 3.8e-5 at 1e-5
     oc.setSolverOptions(aux_substeps=0, aux_rtol=1e-3)
+
+
+def general_interface(prepare, dtype=torch.float64):
+    """The interface function of the sparse-demonstration loss as an arbitrary expression of the state (the reference:
+    ``Function('interface', [oc.state], [expr])`` + its ``jacobian``, lib/QuadAlgorithm.py:616-639, Examples/robotarm_random.py:
+    35-47), compiled into the model library by ``COCSys.setInterface``: the robot arm observed through its END-EFFECTOR position
+    (l1 cos q1 + l2 cos(q1+q2), l1 sin q1 + l2 sin(q1+q2)) and the pendulum through (sin q, q dq), loss and gradient against the
+    oracle's general-interface restatement; and a compiled interface that merely selects components equals the index path."""
+    import sympy as sp
+    from conftest import make_oracle, oracle_loss_grad, parity_record
+    from oracle.cpdp_oracle import getloss_corrections
+    tol = dict(loss=1e-6, grad=1e-4) if dtype == torch.float64 else dict(loss=5e-4, grad=2e-2)
+    cases = [("robotarm", 12, [5., 1, 1, 1, 1], [0.3, 0.8], [[0.6, 0.2], [-0.4, 1.1]],
+              lambda X: [sp.cos(X[0]) + sp.cos(X[0] + X[1]), sp.sin(X[0]) + sp.sin(X[0] + X[1])]),
+             ("pendulum", 10, [1.0, 0.5, 1.5], [0.1, 0.6, 0.9], [[0.3, 0.5], [0.8, 2.0], [0.2, 0.1]],
+              lambda X: [sp.sin(X[0]), X[0] * X[1]])]
+    for kind, n_grid, th, taus, wps, gfun in cases:
+        oc, env, d = models.ZOO[kind](n_grid=n_grid)
+        oc.setInterface(gfun(list(oc.state)))
+        prepare(oc, dtype)
+        oc.setSolverOptions(aux_substeps=16)
+        assert oc.compile().n_interface == 2
+        sol = oc.cocSolverBatch(np.asarray(d["ini_state"], dtype=np.float64)[None, :], d["horizon"], np.asarray(th)[None, :])
+        aux = oc.auxSysSolverBatch(sol, taus, wps, None)
+        o = make_oracle(kind, n_grid)
+        o.setInterface(gfun(list(o.state)))
+        tg, osol = o.cocSolver(d["ini_state"], d["horizon"], np.asarray(th, dtype=float))
+        oaux = o.auxSysSolver(tg, osol, np.asarray(th, dtype=float), riccati_method='Radau', ivp_kwargs=dict(rtol=1e-10, atol=1e-12))
+        l_o, g_o = getloss_corrections(o, taus, wps, osol, oaux, None)
+        parity_record("general interface %s %s" % (kind, dtype), "loss", abs(float(aux["loss"][0]) - l_o) / max(1.0, abs(l_o)), tol["loss"])
+        parity_record("general interface %s %s" % (kind, dtype), "grad",
+                      float(np.abs(aux["grad"][0].double().cpu().numpy() - g_o).max() / max(np.abs(g_o).max(), 1e-300)), tol["grad"])
+    # a compiled interface that selects components = the index path
+    oc, env, d = models.pendulum(n_grid=10)
+    oc.setInterface([oc.state[1], oc.state[0]])
+    prepare(oc, dtype)
+    th = np.array([[1.0, 0.5, 1.5], [2.0, 1.0, 1.0]])
+    sol = oc.cocSolverBatch(np.tile(d["ini_state"], (2, 1)), d["horizon"], th)
+    wps2 = [[0.5, 0.3], [1.0, 2.0]]
+    a1 = oc.auxSysSolverBatch(sol, [0.2, 0.7], wps2, None)
+    a2 = oc.auxSysSolverBatch(sol, [0.2, 0.7], wps2, [1, 0])
+    assert torch.allclose(a1["loss"], a2["loss"], rtol=1e-12 if dtype == torch.float64 else 1e-5)
+    assert torch.allclose(a1["grad"], a2["grad"], rtol=1e-9 if dtype == torch.float64 else 1e-4, atol=1e-12 if dtype == torch.float64 else 1e-6)
+    # no compiled interface and no indices: an error, not a silent default
+    oc2, _, d2 = models.pendulum(n_grid=10)
+    prepare(oc2, dtype)
+    sol2 = oc2.cocSolverBatch(np.asarray(d2["ini_state"], dtype=np.float64)[None, :], d2["horizon"], th[:1])
+    try:
+        oc2.auxSysSolverBatch(sol2, [0.2], [[0.5]], None)
+        raise AssertionError("missing interface must be refused")
+    except Exception as exc:
+        assert "interface" in str(exc), exc

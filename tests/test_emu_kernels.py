@@ -639,3 +639,12 @@ def test_dudtheta_error_is_the_last_interval_times_one_gain(emu):
         emu(oc)
         oc.setDevice(dtype=dtype)
     dudtheta_refinement(prepare, with_rtol=False)      # (the rtol law is asserted in the GPU tier)
+
+
+def test_general_interface_function_vs_oracle(emu):
+    from parity_cases import general_interface
+
+    def prepare(oc, dtype):
+        emu(oc)
+        oc.setDevice(dtype=dtype)
+    general_interface(prepare, torch.float64)

@@ -718,3 +718,10 @@ def test_bench_config_lines_have_the_full_schema(cfg, words):
     cb = o["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] and cb["value"] > 0, cb
     assert (cfg == "rocket") == ("f64 (auxiliary pass)" in o["dtype"])
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+def test_general_interface_function_vs_oracle(dtype):
+    """An interface function that is an arbitrary expression of the state (lib/QuadAlgorithm.py:616-639), compiled into the model
+    library: robot-arm end-effector position and a nonlinear pendulum observation against the oracle's general-interface loss."""
+    pc.general_interface(gpu_prepare, dtype)
