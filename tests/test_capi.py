@@ -76,3 +76,24 @@ def test_product_refuses_cpu_tensors():
 def test_missing_library_is_loud(tmp_path):
     with pytest.raises(runtime.LfsdError):
         runtime.ModelLibrary(str(tmp_path / "liblfsd_missing.so"))
+
+
+def test_binding_argument_counts_match_the_header():
+    """Every entry point's ctypes signature (runtime.ModelLibrary, and the stub INTEGRATION.md shows a reference maintainer) has
+    exactly as many arguments as include/lfsd_cpdp.h declares."""
+    hdr = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "lfsd_cpdp.h")).read(), flags=re.S)
+    declared = {}
+    for name in runtime.ModelLibrary.EXPORTS:
+        m = re.search(name + r"\s*\((.*?)\);", hdr, flags=re.S)
+        assert m, name
+        args = [a.strip() for a in m.group(1).split(",") if a.strip() and a.strip() != "void"]
+        declared[name] = len(args)
+    count = lambda body: len([a for a in body.replace("\n", " ").split(",") if a.strip()])
+    src = open(os.path.join(ROOT, "learning-from-sparse-demonstrations_amd", "runtime.py")).read()
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    seen = 0
+    for text in (src, doc):
+        for m in re.finditer(r"L\.(lfsd_\w+)\.argtypes = \[(.*?)\]", text, flags=re.S):
+            assert count(m.group(2)) == declared[m.group(1)], (m.group(1), count(m.group(2)), declared[m.group(1)])
+            seen += 1
+    assert seen >= 9
