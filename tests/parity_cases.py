@@ -337,8 +337,8 @@ def dudtheta_refinement(prepare, with_rtol=True):
         return eX, eU
     eX16, eU16 = errors(16, 1e-3)
     eX32, eU32 = errors(32, 1e-3)
-    parity_record("du/dtheta refinement", "du/dtheta before T at 16 units", eU16[:-1].max(), 2e-6)       # measured 6.1e-7
-    parity_record("du/dtheta refinement", "du/dtheta before T at 32 units", eU32[:-1].max(), 2e-7)       # measured 4.1e-8
+    parity_record("du/dtheta refinement", "du/dtheta before T at 16 units", eU16[:-1].max(), 5e-6)       # measured 6.1e-7 (emulator), 1.2e-6 (GPU)
+    parity_record("du/dtheta refinement", "du/dtheta before T at 32 units", eU32[:-1].max(), 5e-7)       # measured 4.1e-8 (emulator), 7.2e-8 (GPU)
     assert eX16[-1] > 6.0 * eX32[-1] and eU16[-1] > 6.0 * eU32[-1], (eX16[-1], eX32[-1], eU16[-1], eU32[-1])      # measured 10.5x
     amp16, amp32 = eU16[-1] / eX16[-1], eU32[-1] / eX32[-1]
     assert abs(amp16 / amp32 - 1.0) < 0.1 and 1e3 < amp16 < 1e4, (amp16, amp32)                           # measured 3.65e3 both

@@ -451,7 +451,9 @@ def test_robotarm_batch1024_random_seeds_configs1():
         if name == "theta0":
             parity_record("robot arm 1024 seeds fp32 vs fp64 HIP at theta0", "grad, worst seed", gerr.max(), 2e-2)      # measured 3.7e-3
         else:
-            parity_record("robot arm 1024 seeds fp32 vs fp64 HIP at theta1", "share of seeds with grad error > 2e-2", float((gerr >= 2e-2).mean()), 0.02)
+            # (the share depends on the fp32 rounding of the build: 1.46 % in round 3, 1.27 % in round 4 after sin / cos changed by an
+            #  ulp -- asserted with room for that, 3 %; the 95th percentile below holds the bulk)
+            parity_record("robot arm 1024 seeds fp32 vs fp64 HIP at theta1", "share of seeds with grad error > 2e-2", float((gerr >= 2e-2).mean()), 0.03)
             # theta_1: about 1 % of the seeds sit next to a conjugate point of the optimal-control problem (the tight oracle's
             # Riccati integration has a finite escape there, next test); the same KKT point is found (loss above), but its
             # sensitivity is ill-conditioned with respect to the trajectory itself: fp32 round-off of the SOLVE moves it by
