@@ -131,6 +131,13 @@
 #ifndef LFSD_MU_GAIN_RHO
 #define LFSD_MU_GAIN_RHO 0.8
 #endif
+// generic backward sweep of a solve that runs Newton from its first iteration (exact_after == 0, the rocket): fraction of the
+// Levenberg shift a stage keeps when its Q_uu factorises with it (0: one shift for all stages).  Measured on the rocket learner
+// step with the coarse time grid: 0 -> 207 ms, 0.01 -> 191, 0.003 -> 149, 0.001 -> 150, 1e-4 -> 214 (profiles/r04_s_*).  Solves
+// that start with Gauss-Newton sweeps keep one shift: the robot arm's step went 28.4 -> 42.9 ms with a per-stage fraction.
+#ifndef LFSD_MU_STAGE_FRAC_NEWTON
+#define LFSD_MU_STAGE_FRAC_NEWTON 0.001
+#endif
 #ifndef LFSD_MU_HOLD
 #define LFSD_MU_HOLD 1
 #endif
@@ -193,6 +200,21 @@
 // wide kernel (one trajectory per wavefront): smallest n_grid with a coarse phase
 #ifndef LFSD_COARSE_MIN_GRID
 #define LFSD_COARSE_MIN_GRID 40
+#endif
+// wide kernel: control intervals merged in the coarse phase (1: none, the coarse phase only takes one RK4 step per interval), and
+// the smallest coarse grid it may produce
+#ifndef LFSD_COARSE_TIME
+#define LFSD_COARSE_TIME 4
+#endif
+#ifndef LFSD_COARSE_TIME_MIN
+#define LFSD_COARSE_TIME_MIN 20
+#endif
+// wide kernel: when an accepted step that gains less than LFSD_COARSE_SWITCH of the cost ends the coarse phase (cpdp_oc.h)
+#ifndef LFSD_COARSE_EXIT_RULE
+#define LFSD_COARSE_EXIT_RULE 2
+#endif
+#ifndef LFSD_COARSE_EXIT_MU
+#define LFSD_COARSE_EXIT_MU 1e-2
 #endif
 // leaving the coarse grid: 1 = always by a roll-out + linearisation of the nominal without a step, 0 = with the next full step
 #ifndef LFSD_COARSE_RELIN

@@ -38,6 +38,7 @@ template <typename T> struct OcArgs {
   const T* x_ub;
   const T* x_mult;      // [B][N][2][NX] multipliers lu (upper), ll (lower) of node k = 1..N at index k-1
   T x_rho;
+  T mu_stage_frac;      // > 0: a stage whose Q_uu factorises with this fraction of the Levenberg shift keeps only that fraction (generic sweep)
 };
 
 template <class M> struct OcLayout {
@@ -124,6 +125,7 @@ template <class M, typename T, int G, bool EXACT, bool BND = false> struct OcSol
   int lane, N, S;
   const T *e, *c, *x0;      // [NP], [NC], [NX] in LDS
   T horizon, dgrid, DT;
+  T mu_stage_frac = T(0);      // OcArgs::mu_stage_frac
   T *xb[2], *ub[2], *Mws[2], *Kws, *kws, *lds, *exws, *Hws;
   T *xa = nullptr, *ua = nullptr, *exwu = nullptr;      // wide mapping only: per-step-length roll-outs, per-lane sub-step states
   // the double-buffered arrays are picked by a select, not by indexing the pointer arrays with a run-time value: that would
@@ -796,13 +798,29 @@ template <class M, typename T, int G, bool EXACT, bool BND = false> struct OcSol
 #pragma unroll
         for (int b = 0; b < NU; ++b) Quu0[a * NU + b] = T(0.5) * (ldsQuu[b * NU + a] + ldsQuu[a * NU + b]);
       }
+      // The Levenberg shift PER STAGE (round 4; solves that run on exact stage Hessians from the first iteration, lfsd_coc_solve):
+      // a stage whose Q_uu is positive definite with mu_stage_frac of the shift keeps only that fraction; the full shift goes
+      // where the factorisation needs it.  The rocket's slowest solves were accepted full steps gaining 1-2 % each at shifts
+      // 20x the size of Q_uu (profiles/r04_s_rocket_trace.txt): negative curvature sits in a few stages, one shift for all
+      // damps every stage.  Still the block LDL^T of (Lagrangian Hessian + diag(mu_k)): the value recursion stays consistent.
+      T mu_k = mu;
+      if constexpr (!BND) {
+        if (mu > T(0) && mu_stage_frac > T(0)) {
+          T Lt[NU * NU], dd = T(0);
+#pragma unroll
+          for (int i = 0; i < NU * NU; ++i) Lt[i] = Quu0[i];
+#pragma unroll
+          for (int a = 0; a < NU; ++a) Lt[a * NU + a] += mu * mu_stage_frac;
+          if (chol_factor<NU>(Lt, dd)) mu_k = mu * mu_stage_frac;
+        }
+      }
 #pragma unroll
       for (int i = 0; i < NU * NU; ++i) Lc[i] = Quu0[i];
 #pragma unroll
-      for (int a = 0; a < NU; ++a) Lc[a * NU + a] += mu;
+      for (int a = 0; a < NU; ++a) Lc[a * NU + a] += mu_k;
       if (LFSD_REG_CONSISTENT) {
 #pragma unroll
-        for (int a = 0; a < NU; ++a) Quu0[a * NU + a] += mu;
+        for (int a = 0; a < NU; ++a) Quu0[a * NU + a] += mu_k;
       }
       if (BND) {
         // control-limited step: box QP for the feed-forward part, zero feedback gain on the clamped components
@@ -1881,6 +1899,7 @@ LFSD_DEV void oc_bind(Sol& s, const OcArgs<T>& a, T* region, long long slot, boo
   using Lay = OcLayout<M>;
   constexpr int NX = M::NX, NU = M::NU;
   s.N = a.n_grid; s.S = a.steps_per_grid;
+  s.mu_stage_frac = a.mu_stage_frac;
   s.lds = region;
   s.e = region + Lay::template lds_e<GL>();
   s.c = region + Lay::template lds_c<GL>();
@@ -2410,9 +2429,24 @@ __global__ void __launch_bounds__(64, 1) oc_solve_wide_kernel(OcArgs<T> a) {
   // test_rocket_newton_mode_vs_oracle) -- a step of 0.2 s is too long for its attitude dynamics under aggressive controls.
   bool coarse = CSW && a.steps_per_grid > 1 && !warm && a.max_iter > 8 && a.n_grid >= LFSD_COARSE_MIN_GRID;
   bool relin = false;
-  if (coarse) { s.S = 1; s.DT = s.dgrid; }
+  // ... and on a coarser CONTROL grid as well (LFSD_COARSE_TIME, round 4): `tc` grid intervals share one control, i.e. the coarse
+  // phase solves the problem on n_grid / tc intervals of length tc * dgrid with tc RK4 steps each -- the same RK4 step as one step
+  // per original interval, but tc times fewer stages in the backward recursion and tc times fewer exact stage Hessians, the two
+  // phases that are 63 % of an iteration (profiles/r04_e_rocket_wide_clock.txt).  Leaving the coarse phase prolongates the
+  // controls (each held over its tc intervals) and goes through the same re-linearisation on the reference's discretisation.
+  const int N_full = s.N;
+  const T dgrid_full = s.dgrid;
+  int tc = 1;
+  if (coarse) {
+    for (int f = LFSD_COARSE_TIME; f > 1; f /= 2) {
+      if (f <= Lay::SMAX && N_full % f == 0 && N_full / f >= LFSD_COARSE_TIME_MIN) { tc = f; break; }
+    }
+    s.N = N_full / tc; s.dgrid = dgrid_full * T(tc);
+    s.S = tc; s.DT = s.dgrid / T(s.S);
+  }
 #if defined(LFSD_OC_CLOCK)      // diagnostic build (tools/wide_clock.py): shader clocks of the phases of the slowest solves
-  long long wck[5] = {0, 0, 0, 0, 0};
+  long long wck[5] = {0, 0, 0, 0, 0}, wck_exit = 0;
+  int wck_it_exit = -1;
   const long long wck_t0 = clock64();
 #define LFSD_WCK(i, stmt) { const long long c0_ = clock64(); stmt; wck[i] += clock64() - c0_; }
 #else
@@ -2424,7 +2458,8 @@ __global__ void __launch_bounds__(64, 1) oc_solve_wide_kernel(OcArgs<T> a) {
   J = ldsRed[0];
   __syncthreads();
   if (coarse && !t_finite(J)) {                          // the coarse grid cannot even integrate the initial guess: reference grid
-    coarse = false; s.S = a.steps_per_grid; s.DT = s.dgrid / T(s.S);
+    coarse = false; tc = 1; s.N = N_full; s.dgrid = dgrid_full;      // (the initial guess in buffer 1 is zero / the midpoint of the bounds on every interval)
+    s.S = a.steps_per_grid; s.DT = s.dgrid / T(s.S);
     J = s.rollout_alphas(1, false, alpha_l);
     ldsRed[s.lane] = J;
     __syncthreads();
@@ -2445,6 +2480,23 @@ __global__ void __launch_bounds__(64, 1) oc_solve_wide_kernel(OcArgs<T> a) {
       // leave the coarse grid: the same controls rolled out (open loop) and linearised on the reference's discretisation; an
       // iteration without a sweep.  Every convergence test below only ever passes on this grid.
       coarse = false; relin = false;
+#if defined(LFSD_OC_CLOCK)
+      wck_exit = clock64() - wck_t0; wck_it_exit = it;
+#endif
+      if (tc > 1) {
+        // prolongation: control k of the reference grid = control k / tc of the coarse one (in place: sources into registers first)
+        // (chunks of 64 from the back: the source of element i is at an index <= i, so no chunk overwrites a later chunk's source)
+        T* uc = s.ubp(cur);
+        const int tot = N_full * NU;
+        for (int c0 = ((tot - 1) / 64) * 64; c0 >= 0; c0 -= 64) {
+          const int i = c0 + s.lane;
+          const T keep = (i < tot) ? uc[((i / NU) / tc) * NU + (i % NU)] : T(0);
+          __syncthreads();
+          if (i < tot) uc[i] = keep;
+          __syncthreads();
+        }
+        s.N = N_full; s.dgrid = dgrid_full; tc = 1;
+      }
       s.S = a.steps_per_grid; s.DT = s.dgrid / T(s.S);
       const T Jr = s.rollout_alphas(cur, false, alpha_l);
       ldsRed[s.lane] = Jr;
@@ -2522,6 +2574,7 @@ __global__ void __launch_bounds__(64, 1) oc_solve_wide_kernel(OcArgs<T> a) {
     if (s.lane == 0 && traj == 0) printf("wide it %d st %d mode %d g %.6e J %.12e ia %d accept %d mu %g dV1 %.4e dV2 %.4e Jmin %.12e\n", it, status, mode, (double)gnorm, (double)J, ia, (int)accept, (double)mu, (double)dV1, (double)dV2, (double)Jmin);
 #endif
     if (accept) {
+      const T mu_taken = mu;
       s.adopt_alpha(ia, cur ^ 1);
       LFSD_WCK(1, s.linearise_parallel(cur ^ 1));
       cur ^= 1;
@@ -2540,7 +2593,13 @@ __global__ void __launch_bounds__(64, 1) oc_solve_wide_kernel(OcArgs<T> a) {
         if (mode == 0 && ham_ok && (J - Jn) < T(LFSD_HAM_SWITCH) * t_abs(Jn)) mode = 1;
         else if (LFSD_GN_CRAWL && mode == 0 && !ham_ok && (J - Jn) < T(1e-2) * t_abs(Jn)) gn_crawl = true;
       }
-      if (coarse && (J - Jn) < T(LFSD_COARSE_SWITCH) * t_abs(Jn)) relin = true;      // past the big drops: the reference's grid
+      // past the big drops: the reference's grid.  LFSD_COARSE_EXIT_RULE 0: any accepted step that gains less than the switch;
+      // 1: full steps only (a short step through a badly modelled patch gains little too, and is no sign of convergence);
+      // 2: full steps at a shift below LFSD_COARSE_EXIT_MU; 3: never by the gain (only the convergence tests above)
+      if (coarse && (J - Jn) < T(LFSD_COARSE_SWITCH) * t_abs(Jn)) {
+        if ((LFSD_COARSE_EXIT_RULE) == 0 || ((LFSD_COARSE_EXIT_RULE) == 1 && ia == 0) ||
+            ((LFSD_COARSE_EXIT_RULE) == 2 && ia == 0 && mu_taken <= T(LFSD_COARSE_EXIT_MU))) relin = true;
+      }
       J = Jn;
       if (++n_acc >= 4) {
         if (J_ref - J <= T(16) * Eps<T>::v() * t_abs(J)) { if (coarse) relin = true; else status = ST_STALLED; }
@@ -2551,8 +2610,8 @@ __global__ void __launch_bounds__(64, 1) oc_solve_wide_kernel(OcArgs<T> a) {
   if (status == ST_RUNNING) status = ST_MAXITER;
 #if defined(LFSD_OC_CLOCK)
   if (threadIdx.x == 0 && (it >= LFSD_OC_CLOCK || blockIdx.x == 0))
-    printf("wide clock traj %d: iterations %d total %lld rollout_alphas %lld linearise %lld costates %lld hessians %lld backward %lld\n",
-           (int)blockIdx.x, it, clock64() - wck_t0, wck[0], wck[1], wck[2], wck[3], wck[4]);
+    printf("wide clock traj %d: iterations %d total %lld rollout_alphas %lld linearise %lld costates %lld hessians %lld backward %lld | left the coarse grid at iteration %d, clock %lld\n",
+           (int)blockIdx.x, it, clock64() - wck_t0, wck[0], wck[1], wck[2], wck[3], wck[4], wck_it_exit, wck_exit);
 #endif
 #undef LFSD_WCK
   if (!costates_ok) s.costate_sweep(cur);                 // costates of the final nominal

@@ -91,6 +91,7 @@ static int coc_solve_t(int batch, int n_grid, int steps_per_grid, const void* in
   a.ws = (T*)workspace; a.ws_stride = lfsd::OcLayout<Model>::template ws_elems<G>(n_grid);
   a.tol = (T)tol;
   a.exact_after = exact_after;
+  a.mu_stage_frac = (exact_after == 0) ? (T)(LFSD_MU_STAGE_FRAC_NEWTON) : T(0);
   if (use_wide(sizeof(T) == 4 ? LFSD_F32 : LFSD_F64, batch, exact_after, mapping, control_lb != nullptr)) {       // bounded problems: the wide kernel at every batch size
     a.ws_stride = lfsd::OcLayout<Model>::ws_elems_wide(n_grid);
     if (workspace_bytes < (size_t)batch * (size_t)a.ws_stride * sizeof(T)) return LFSD_ENOSPC;
