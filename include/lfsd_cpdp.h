@@ -70,7 +70,8 @@ int lfsd_interface_dim(void);
 double lfsd_const_default(int i);
 
 /* bytes of device scratch lfsd_coc_solve needs for `batch` trajectories when called with the same exact_after / mapping
- * and with (bounded != 0) or without control bounds: the two mappings of the solve lay their scratch out differently */
+ * and with (bounded != 0) or without control bounds: the two mappings of the solve lay their scratch out differently, and an
+ * fp64 solve that is seeded by an fp32 one (see lfsd_coc_solve) stages the fp32 problem behind its own scratch */
 size_t lfsd_coc_workspace_bytes(int dtype, int batch, int n_grid, int exact_after, int mapping, int bounded);
 
 /* Solve `batch` independent optimal-control problems (the NLP of CPDP.py:110-175:
@@ -98,7 +99,12 @@ size_t lfsd_coc_workspace_bytes(int dtype, int batch, int n_grid, int exact_afte
  *   (lu <- max(0, lu + rho (x_k - ub)), ll likewise) and the penalty between calls until the nodes are feasible -- the outer
  *   loop is host code (COCSys.cocSolverBatch).  The returned costates include the bound multipliers, as IPOPT's lam_g
  *   do.  With state bounds the control-bound arrays must be given too (entries of +-1e20 where there is none).
- *   mapping: LFSD_MAP_AUTO, or force one of the two mappings of the same algorithm (same KKT points either way).   */
+ *   mapping: LFSD_MAP_AUTO, or force one of the two mappings of the same algorithm (same KKT points either way).
+ *   dtype LFSD_F64, lock-step mapping, 32-lane models (quadrotor class), u_init == NULL, no bounds, exact_after != 0: the cold
+ *   start is solved in fp32 first and the fp64 kernel starts from those controls (a trajectory the fp32 solve failed on starts
+ *   cold).  Every output and every convergence test is the fp64 kernel's; iters[] counts both solves (so it may exceed
+ *   max_iter, which bounds each of them); lfsd_coc_workspace_bytes includes the staging area.  LFSD_F64_SEED=0 in the
+ *   environment switches the seeding off.   */
 int lfsd_coc_solve(int dtype, int batch, int n_grid, int steps_per_grid,
                    const void* ini_state, const void* horizon, const void* auxvar,
                    const void* consts, int const_per_traj, const void* u_init,

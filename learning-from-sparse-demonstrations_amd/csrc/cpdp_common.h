@@ -209,6 +209,11 @@
 #ifndef LFSD_COARSE_TIME_MIN
 #define LFSD_COARSE_TIME_MIN 20
 #endif
+// lfsd_coc_solve in fp64, lock-step mapping, 32-lane models, cold start: solve in fp32 first and start the fp64 kernel from those
+// controls with the Hamiltonian model (lfsd_capi.cpp, coc_solve_seeded).  Quadrotor headline in fp64: 9.8 -> see DESIGN section 3.1
+#ifndef LFSD_F64_SEED
+#define LFSD_F64_SEED 1
+#endif
 // wide kernel: when an accepted step that gains less than LFSD_COARSE_SWITCH of the cost ends the coarse phase (cpdp_oc.h)
 #ifndef LFSD_COARSE_EXIT_RULE
 #define LFSD_COARSE_EXIT_RULE 2

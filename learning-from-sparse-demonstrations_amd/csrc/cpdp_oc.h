@@ -38,6 +38,7 @@ template <typename T> struct OcArgs {
   const T* x_ub;
   const T* x_mult;      // [B][N][2][NX] multipliers lu (upper), ll (lower) of node k = 1..N at index k-1
   T x_rho;
+  int start_mode;       // lean kernel: stage-Hessian model a trajectory WITH an initial guess starts from (0 Gauss-Newton, 1 Hamiltonian: a guess next to the answer)
   T mu_stage_frac;      // > 0: a stage whose Q_uu factorises with this fraction of the Levenberg shift keeps only that fraction (generic sweep)
 };
 
@@ -2130,7 +2131,7 @@ __global__ void __launch_bounds__(64, LFSD_WAVES_OC) oc_solve_kernel(OcArgs<T> a
     }
   }
   T mu = T(0);
-  int mode = 0;             // stage Hessian model: 0 Gauss-Newton, 1 Hamiltonian (cheap Newton-like), 2 exact
+  int mode = (warm && a.start_mode == 1) ? 1 : 0;      // stage Hessian model: 0 Gauss-Newton, 1 Hamiltonian (cheap Newton-like), 2 exact
   bool ham_ok = true;       // the cheap Newton-like model has not failed on this trajectory yet
   bool optimistic = true;   // try the full step directly (skips the parallel line search while alpha = 1 keeps working)
   const int it_off = (a.resume && in_batch) ? (a.iters[traj] - a.it_start) : 0;   // iterations already spent in phase 1
@@ -2623,6 +2624,36 @@ __global__ void __launch_bounds__(64, 1) oc_solve_wide_kernel(OcArgs<T> a) {
     for (int i = s.lane; i < (N + 1) * NU; i += 64) uo[i] = s.ubp(cur)[(i < N * NU) ? i : i - NU];
     if (s.lane == 0) { a.cost[traj] = J; a.iters[traj] = (status == ST_CONVERGED) ? it + 1 : it; a.status[traj] = status; }
   }
+}
+
+
+// =====================================================================================
+//  fp64 solve seeded by the fp32 solve of the same problem (lfsd_capi.cpp, coc_solve_seeded): conversions between the two
+// =====================================================================================
+struct CastArgs { const void* src; void* dst; long long n; int to_f32; };
+template <typename Tag> __global__ void cast_kernel(CastArgs a) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= a.n) return;
+  if (a.to_f32) ((float*)a.dst)[i] = (float)((const double*)a.src)[i];
+  else ((double*)a.dst)[i] = (double)((const float*)a.src)[i];
+}
+
+// controls of the fp32 solve [B][N+1][NU] -> initial guess of the fp64 solve [B][N][NU]; a trajectory the fp32 solve FAILED
+// on (or whose cost is not finite) gets the all-zero row, which the kernels read as "cold start" (mesh continuation and all)
+struct SeedArgs { const float* u32; const float* cost32; const int* status32; double* u0; int batch, n_grid, nu; };
+template <typename Tag> __global__ void seed_controls_kernel(SeedArgs a) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long row = (long long)a.n_grid * a.nu;
+  if (i >= (long long)a.batch * row) return;
+  const long long b = i / row, j = i % row;
+  const bool usable = a.status32[b] != ST_FAILED && t_finite(a.cost32[b]);
+  a.u0[i] = usable ? (double)a.u32[b * (row + a.nu) + j] : 0.0;
+}
+
+struct AddItersArgs { int* iters; const int* more; int batch; };
+template <typename Tag> __global__ void add_iters_kernel(AddItersArgs a) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < a.batch) a.iters[i] += a.more[i];
 }
 
 }  // namespace lfsd

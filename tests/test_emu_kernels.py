@@ -339,6 +339,7 @@ def test_rocket_lean_kernels_fp64_vs_fp32_same_iterates(emu, monkeypatch):
     structural sweep on the emulated matrix cores).  Same step control, same path: after six iterations -- far from
     converged, cost 1.1e4 and 3.8e2 -- the iterates agree to the fp32 class (measured: cost 1.7e-6, states 1e-5)."""
     monkeypatch.setattr(CPDP.COCSys, "mapping_override", "lockstep")
+    monkeypatch.setenv("LFSD_F64_SEED", "0")      # the fp64 kernel's own six iterations, not the fp32-seeded solve
     oc, env, d = models.rocket(n_grid=15)
     emu(oc)
     oc.setSolverOptions(max_iter=6, exact_after=-1)
@@ -648,3 +649,12 @@ def test_general_interface_function_vs_oracle(emu):
         emu(oc)
         oc.setDevice(dtype=dtype)
     general_interface(prepare, torch.float64)
+
+
+def test_fp64_solve_seeded_by_fp32_reaches_the_same_kkt_point(emu):
+    from parity_cases import seeded_f64_same_kkt_point
+
+    def prepare(oc, dtype):
+        emu(oc)
+        oc.setDevice(dtype=dtype)
+    seeded_f64_same_kkt_point(prepare, n_grid=8, batch=5)

@@ -348,6 +348,7 @@ def test_rocket_lean_kernels_fp64_vs_fp32_same_iterates(monkeypatch):
     parked RK4 step, one-pass structural sweep with LDS-fed products) and in fp32 (packed roll-out, structural sweep on the
     matrix cores) walk the same path -- ragged batch of 6 (one full wavefront of four + a partial one)."""
     monkeypatch.setattr(CPDP.COCSys, "mapping_override", "lockstep")
+    monkeypatch.setenv("LFSD_F64_SEED", "0")      # the fp64 kernel's own six iterations, not the fp32-seeded solve
     oc, env, d = models.rocket(n_grid=15)
     oc.setSolverOptions(max_iter=6, exact_after=-1)
     rng = np.random.default_rng(3)
@@ -739,3 +740,9 @@ def test_general_interface_function_vs_oracle(dtype):
     """An interface function that is an arbitrary expression of the state (lib/QuadAlgorithm.py:616-639), compiled into the model
     library: robot-arm end-effector position and a nonlinear pendulum observation against the oracle's general-interface loss."""
     pc.general_interface(gpu_prepare, dtype)
+
+
+def test_fp64_solve_seeded_by_fp32_reaches_the_same_kkt_point():
+    """lfsd_coc_solve in fp64 (lock-step mapping, quadrotor class) runs the fp32 lean kernel first and starts the fp64 kernel from
+    its controls: same KKT point as the fp64 kernel from the cold start, a row the fp32 solve overflows on is started cold."""
+    pc.seeded_f64_same_kkt_point(gpu_prepare, n_grid=50, batch=70)
