@@ -327,14 +327,18 @@ def kernel_model(perf_model, spec, args, dtype_name, aux_dtype_name, kernel, kti
     return flops * B / t / 1e12, mflops * B / t / 1e12, flops * B, kd, flops * B / t / 1e12 / VALU_PEAK_TFLOPS[kd]
 
 
-def seed_iterations(models, torch, w, args, L, x0, d, dev):
+def seed_iterations(models, torch, w, args, L, dev):
     """mean iterations of the fp32 solve that seeds a cold fp64 solve at the learner's current parameters (outside the timed
-    region; only feeds the operation-count model of the two-precision `oc_solve`)"""
-    oc32, _, _ = models.ZOO[w["kind"]](n_grid=args.n_grid)
-    oc32.setDevice(dev, torch.float32)
-    x = torch.as_tensor(x0, device=dev).float() if not hasattr(x0, "float") else x0.to(dev).float()
-    s = oc32.cocSolverBatch(x, d["horizon"], L.theta.detach().float())
-    return float(s["iters"].double().mean().item())
+    region; only feeds the operation-count model of the two-precision `oc_solve`); None if it cannot be had"""
+    try:
+        oc32, _, _ = models.ZOO[w["kind"]](n_grid=args.n_grid)
+        oc32.setDevice(dev, torch.float32)
+        th = L.theta.detach().float()
+        consts = None if L.consts is None else L.consts.float()
+        s = oc32.cocSolverBatch(L.x0.float(), L.hz, th, consts=consts)
+        return float(s["iters"].double().mean().item())
+    except Exception:
+        return None
 
 
 def main(argv=None):
@@ -417,7 +421,7 @@ def main(argv=None):
         nw, ni = L.taus.shape[1], len(d["interface"])
         stats = L._aux["stats"].double().cpu().numpy()
         units = {"aux_riccati": float(stats[:, 0].mean()) / args.n_grid, "aux_forward": float(stats[:, 2].mean()) / args.n_grid}
-        it_seed = seed_iterations(models, torch, w, args, L, x0, d, dev) if seeded_f64(args, args.dtype, dom, args.warm_start) else None
+        it_seed = seed_iterations(models, torch, w, args, L, dev) if seeded_f64(args, args.dtype, dom, args.warm_start) else None
         useful_tflops, mfma_tflops, useful_flops, dom_dtype, valu_frac = kernel_model(perf_model, oc.model_spec(), args, args.dtype, aux_name, dom,
                                                                                       ktime, float(it.mean()), units, B, args.warm_start, it_seed)
         es = 4 if dom_dtype == "f32" else 8

@@ -197,6 +197,27 @@
 #ifndef LFSD_COARSE_SWITCH
 #define LFSD_COARSE_SWITCH 1e-3
 #endif
+// lean matrix-core kernels: level 0 of the mesh continuation merges LFSD_LEAN_TC control intervals (1: off) with LFSD_LEAN_TC_S RK4
+// steps per merged interval for the first LFSD_LEAN_TC_ITERS iterations of a cold start; never below LFSD_LEAN_TC_MIN intervals.
+// Measured on the headline (oc_solve per launch, 20 steps; profiles/r04_z_ab_lean_time_coarsening.txt): off 2.57 ms; 2 intervals x 1
+// step for 2 / 3 / 4 iterations 2.34 / 2.38 / 2.61; 5 x 2 for 2 / 3 / 4 / 5 iterations 2.45 / 2.16 / 2.72 / 2.61; 5 x 3 x 3 2.21;
+// 5 x 1 x 2 2.46; 10 x 4 x 3 2.52; 10 x 2 x 3 2.46; 5 x 2 for 4 / 5 iterations and straight to the reference's grid 2.50 / 2.60.
+#ifndef LFSD_LEAN_TC
+#define LFSD_LEAN_TC 5
+#endif
+#ifndef LFSD_LEAN_TC_S
+#define LFSD_LEAN_TC_S 2
+#endif
+#ifndef LFSD_LEAN_TC_ITERS
+#define LFSD_LEAN_TC_ITERS 3
+#endif
+#ifndef LFSD_LEAN_TC_MIN
+#define LFSD_LEAN_TC_MIN 10
+#endif
+// 1: level 0 hands over to the reference's grid directly (no iterations on the one-step-per-interval level in between)
+#ifndef LFSD_LEAN_TC_TO_FINE
+#define LFSD_LEAN_TC_TO_FINE 0
+#endif
 // wide kernel (one trajectory per wavefront): smallest n_grid with a coarse phase
 #ifndef LFSD_COARSE_MIN_GRID
 #define LFSD_COARSE_MIN_GRID 40

@@ -2111,6 +2111,28 @@ __global__ void __launch_bounds__(64, LFSD_WAVES_OC) oc_solve_kernel(OcArgs<T> a
   bool relin = false;       // leave the coarse grid at the next iteration ...
   bool relin_hard = LFSD_COARSE_RELIN != 0;      // ... by a roll-out + linearisation of the nominal without a step (else: with the step)
   if (coarse) { s.S = 1; s.DT = s.dgrid; }
+  // Level 0 of the mesh continuation (round 4; the matrix-core kernels only): the first LFSD_LEAN_TC_ITERS iterations of a
+  // workgroup whose trajectories are ALL cold also merge LFSD_LEAN_TC control intervals into one (n_grid / tc stages in the
+  // backward sweep, n_grid / tc * LFSD_LEAN_TC_S RK4 steps per roll-out), then the controls are prolongated -- each held over its
+  // tc intervals -- and rolled out + linearised on the coarse level above (an iteration's roll-out without a step).  The
+  // schedule is a fixed iteration count, so what a trajectory does never depends on its partners in the wavefront; a
+  // trajectory that wants to leave the coarse phase earlier waits for it (the tests that set `relin` are deferred).
+  constexpr bool TCL = CS && (MF || SC64) && (LFSD_LEAN_TC > 1);
+  const int N_full = s.N;
+  const T dgrid_full = s.dgrid;
+  int tc = 1;
+  if constexpr (TCL) {
+    if (threadIdx.x == 0) vote[0] = 0;
+    __syncthreads();
+    if (!coarse) vote[0] = 1;
+    __syncthreads();
+    const bool all_cold = vote[0] == 0;
+    __syncthreads();
+    if (all_cold && N_full % (LFSD_LEAN_TC) == 0 && N_full / (LFSD_LEAN_TC) >= LFSD_LEAN_TC_MIN && a.max_iter > LFSD_LEAN_TC_ITERS + 6) {
+      tc = LFSD_LEAN_TC;
+      s.N = N_full / tc; s.dgrid = dgrid_full * T(tc); s.S = LFSD_LEAN_TC_S; s.DT = s.dgrid / T(s.S);
+    }
+  }
   T J = do_rollout(1, 0, T(0), false);
   __syncthreads();
   if constexpr (CS) {
@@ -2125,7 +2147,8 @@ __global__ void __launch_bounds__(64, LFSD_WAVES_OC) oc_solve_kernel(OcArgs<T> a
     const bool redo = vote[0] != 0;
     __syncthreads();
     if (redo) {
-      coarse = false; s.S = a.steps_per_grid; s.DT = s.dgrid / T(s.S);
+      coarse = false; tc = 1; s.N = N_full; s.dgrid = dgrid_full;
+      s.S = a.steps_per_grid; s.DT = s.dgrid / T(s.S);
       J = do_rollout(1, 0, T(0), false);
       __syncthreads();
     }
@@ -2155,14 +2178,43 @@ __global__ void __launch_bounds__(64, LFSD_WAVES_OC) oc_solve_kernel(OcArgs<T> a
     __syncthreads();
     if (!vote[0]) break;
     __syncthreads();
-    if (coarse && it + 3 >= a.max_iter) relin = true;      // never leave a launch on the coarse grid
+    if constexpr (TCL) {
+      if (tc > 1 && (it >= a.it_start + LFSD_LEAN_TC_ITERS || it + 5 >= a.max_iter)) {      // (uniform in the workgroup)
+        // prolongation in place: control k of the finer level = control k / tc (chunks from the back: the source of element i is at
+        // an index <= i, so no chunk overwrites the source of an earlier one)
+        T* uc = s.ubp(cur);
+        const int tot = N_full * NU;
+        for (int c0 = ((tot - 1) / GR) * GR; c0 >= 0; c0 -= GR) {
+          const int i = c0 + s.lane;
+          const T keep = (i < tot) ? uc[((i / NU) / tc) * NU + (i % NU)] : T(0);
+          __syncthreads();
+          if (i < tot) uc[i] = keep;
+          __syncthreads();
+        }
+        s.N = N_full; s.dgrid = dgrid_full; tc = 1;
+        // a trajectory that already asked for the reference's grid goes there directly
+        if ((relin || (LFSD_LEAN_TC_TO_FINE) != 0) && status == ST_RUNNING) { s.S = a.steps_per_grid; coarse = false; relin = false; } else { s.S = 1; }
+        s.DT = s.dgrid / T(s.S);
+        T Jt;
+        LFSD_CLK(clk_ro, Jt = do_rollout(cur, cur ^ 1, T(0), false));
+        __syncthreads();
+        cur ^= 1; J = Jt;
+        need_bw = true; hess_ok = false; optimistic = true;
+        g_last = T(-1); dec_last = T(1e30); g_flat = T(-1); J_ref = J; n_acc = 0;
+        if (!t_finite(J) && status == ST_RUNNING) {
+          if (coarse) { relin = true; relin_hard = true; }      // the reference's discretisation decides
+          else status = ST_FAILED;
+        }
+      }
+    }
+    if (coarse && tc == 1 && it + 3 >= a.max_iter) relin = true;      // never leave a launch on the coarse grid
     // Leaving the coarse grid.  Normally WITH this iteration's step (`fine_step`): the backward sweep still runs on the coarse
     // linearisation, its full step is rolled out and linearised on the reference's discretisation and taken unless the cost
     // rises beyond what the two discretisations can differ by (their costs differ by ~1e-5 relative, about the gain a
     // Newton-like step predicts at this point, so the Armijo test cannot referee this one step).  Otherwise -- the full step
     // was refused, or a line search is due -- WITHOUT a step (`relin_now`): the nominal is rolled out and linearised again.
-    const bool fine_step = CS && relin && !relin_hard && optimistic && status == ST_RUNNING;
-    const bool relin_now = CS && relin && !fine_step && status == ST_RUNNING;
+    const bool fine_step = CS && relin && tc == 1 && !relin_hard && optimistic && status == ST_RUNNING;
+    const bool relin_now = CS && relin && tc == 1 && !fine_step && status == ST_RUNNING;
     if constexpr (MF) {
       // A solve whose last Newton step already predicted a decrease below the resolution of the cost is about to pass its
       // convergence test: try the costate-only sweep (gradient norm + costates, a few per cent of a full sweep) first.

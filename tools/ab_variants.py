@@ -51,6 +51,21 @@ VARIANTS = {
     "vxlds": (("-DLFSD_SC_VX_LDS=1",), None, False),
     "pflate": (("-DLFSD_BW_PREFETCH=2",), None, False),
     "pflateclock": (("-DLFSD_BW_PREFETCH=2", "-DLFSD_BW_CLOCK=1"), None, False),
+    # level 0 of the lean kernel's mesh continuation: tc merged control intervals x RK4 steps per merged interval x iterations
+    "tc2k3": (("-DLFSD_LEAN_TC=2", "-DLFSD_LEAN_TC_ITERS=3"), None, False),
+    "tc2k2": (("-DLFSD_LEAN_TC=2", "-DLFSD_LEAN_TC_ITERS=2"), None, False),
+    "tc2k4": (("-DLFSD_LEAN_TC=2", "-DLFSD_LEAN_TC_ITERS=4"), None, False),
+    "tc5k3": (("-DLFSD_LEAN_TC=5", "-DLFSD_LEAN_TC_S=2", "-DLFSD_LEAN_TC_ITERS=3"), None, False),
+    "tc5s1k2": (("-DLFSD_LEAN_TC=5", "-DLFSD_LEAN_TC_S=1", "-DLFSD_LEAN_TC_ITERS=2"), None, False),
+    "tc2s2k3": (("-DLFSD_LEAN_TC=2", "-DLFSD_LEAN_TC_S=2", "-DLFSD_LEAN_TC_ITERS=3"), None, False),
+    "tc5k2": (("-DLFSD_LEAN_TC=5", "-DLFSD_LEAN_TC_S=2", "-DLFSD_LEAN_TC_ITERS=2"), None, False),
+    "tc5k4": (("-DLFSD_LEAN_TC=5", "-DLFSD_LEAN_TC_S=2", "-DLFSD_LEAN_TC_ITERS=4"), None, False),
+    "tc5k5": (("-DLFSD_LEAN_TC=5", "-DLFSD_LEAN_TC_S=2", "-DLFSD_LEAN_TC_ITERS=5"), None, False),
+    "tc5s3k3": (("-DLFSD_LEAN_TC=5", "-DLFSD_LEAN_TC_S=3", "-DLFSD_LEAN_TC_ITERS=3"), None, False),
+    "tc10s4k3": (("-DLFSD_LEAN_TC=10", "-DLFSD_LEAN_TC_S=4", "-DLFSD_LEAN_TC_ITERS=3", "-DLFSD_LEAN_TC_MIN=5"), None, False),
+    "tc10s2k3": (("-DLFSD_LEAN_TC=10", "-DLFSD_LEAN_TC_S=2", "-DLFSD_LEAN_TC_ITERS=3", "-DLFSD_LEAN_TC_MIN=5"), None, False),
+    "tc5k4fine": (("-DLFSD_LEAN_TC=5", "-DLFSD_LEAN_TC_S=2", "-DLFSD_LEAN_TC_ITERS=4", "-DLFSD_LEAN_TC_TO_FINE=1"), None, False),
+    "tc5k5fine": (("-DLFSD_LEAN_TC=5", "-DLFSD_LEAN_TC_S=2", "-DLFSD_LEAN_TC_ITERS=5", "-DLFSD_LEAN_TC_TO_FINE=1"), None, False),
 }
 
 
