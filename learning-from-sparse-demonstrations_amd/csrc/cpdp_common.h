@@ -227,6 +227,10 @@
 #ifndef LFSD_COARSE_TIME
 #define LFSD_COARSE_TIME 4
 #endif
+// RK4 steps per merged interval of that phase (0: as many as merged intervals, i.e. the step of one step per interval)
+#ifndef LFSD_COARSE_TIME_S
+#define LFSD_COARSE_TIME_S 2
+#endif
 #ifndef LFSD_COARSE_TIME_MIN
 #define LFSD_COARSE_TIME_MIN 20
 #endif

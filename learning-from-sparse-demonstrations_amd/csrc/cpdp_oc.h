@@ -2495,7 +2495,7 @@ __global__ void __launch_bounds__(64, 1) oc_solve_wide_kernel(OcArgs<T> a) {
       if (f <= Lay::SMAX && N_full % f == 0 && N_full / f >= LFSD_COARSE_TIME_MIN) { tc = f; break; }
     }
     s.N = N_full / tc; s.dgrid = dgrid_full * T(tc);
-    s.S = tc; s.DT = s.dgrid / T(s.S);
+    s.S = ((LFSD_COARSE_TIME_S) > 0 && (LFSD_COARSE_TIME_S) < tc) ? (LFSD_COARSE_TIME_S) : tc; s.DT = s.dgrid / T(s.S);
   }
 #if defined(LFSD_OC_CLOCK)      // diagnostic build (tools/wide_clock.py): shader clocks of the phases of the slowest solves
   long long wck[5] = {0, 0, 0, 0, 0}, wck_exit = 0;

@@ -66,6 +66,14 @@ VARIANTS = {
     "tc10s2k3": (("-DLFSD_LEAN_TC=10", "-DLFSD_LEAN_TC_S=2", "-DLFSD_LEAN_TC_ITERS=3", "-DLFSD_LEAN_TC_MIN=5"), None, False),
     "tc5k4fine": (("-DLFSD_LEAN_TC=5", "-DLFSD_LEAN_TC_S=2", "-DLFSD_LEAN_TC_ITERS=4", "-DLFSD_LEAN_TC_TO_FINE=1"), None, False),
     "tc5k5fine": (("-DLFSD_LEAN_TC=5", "-DLFSD_LEAN_TC_S=2", "-DLFSD_LEAN_TC_ITERS=5", "-DLFSD_LEAN_TC_TO_FINE=1"), None, False),
+    # on top of the shipped level 0 (5 x 2 x 3 iterations)
+    "tc5k3fine": (("-DLFSD_LEAN_TC_TO_FINE=1",), None, False),
+    "ham3": (("-DLFSD_HAM_SWITCH=3.0",), None, False),
+    "ham09": (("-DLFSD_HAM_SWITCH=0.9",), None, False),
+    "ham01": (("-DLFSD_HAM_SWITCH=0.1",), None, False),
+    "tc5s2k3min5": (("-DLFSD_LEAN_TC_MIN=5",), None, False),
+    "notc": (("-DLFSD_LEAN_TC=1",), None, False),
+    "k4ham01": (("-DLFSD_LEAN_TC_ITERS=4", "-DLFSD_HAM_SWITCH=0.05"), None, False),
 }
 
 
