@@ -218,6 +218,16 @@
 #ifndef LFSD_LEAN_TC_TO_FINE
 #define LFSD_LEAN_TC_TO_FINE 0
 #endif
+// wide kernel: 1 = the models below 32 lanes get a coarse phase too (one RK4 step per interval, no merged intervals), at n_grid >=
+// LFSD_COARSE_MIN_GRID as the others.  Measured on the robot arm and left OFF (profiles/r04_ah_robotarm_coarse_phase_ab.txt, r04_aj_*):
+// the OC solve of the benchmark's learner goes 21.2 -> 12.7 ms with the same minima on 1 023 of 1 024 seeds, but a seed with a
+// quadratic weight of 0.06 crawls on the coarse discretisation to a minimum the reference's does not have (J = -63 on one RK4 step
+// per interval, 390 for the same controls on four) and runs out of iterations -- a seed the plain solve converges on -- and the rows
+// it pushes out make the auxiliary sweeps slower than the solve gained; ending the phase at the hand-over to the exact Hessians
+// keeps that seed and loses the gain (24.3 ms).
+#ifndef LFSD_COARSE_SMALL_MODELS
+#define LFSD_COARSE_SMALL_MODELS 0
+#endif
 // wide kernel (one trajectory per wavefront): smallest n_grid with a coarse phase
 #ifndef LFSD_COARSE_MIN_GRID
 #define LFSD_COARSE_MIN_GRID 40

@@ -2475,7 +2475,7 @@ __global__ void __launch_bounds__(64, 1) oc_solve_wide_kernel(OcArgs<T> a) {
   // r03_f_rocket_trace_head.txt, and every one of them pays a second-order adjoint sweep through S x 4 RK4 stages per
   // interval); never with an initial guess from the caller or with bounds (warm-started subproblems start next to their
   // answer).  Smaller models keep the reference's grid: their parity cases follow the oracle's path into one of several minima.
-  constexpr bool CSW = !BND && (LFSD_COARSE_START != 0) && (NX + (NU > NP ? NU : NP) > 16);
+  constexpr bool CSW = !BND && (LFSD_COARSE_START != 0) && ((NX + (NU > NP ? NU : NP) > 16) || (LFSD_COARSE_SMALL_MODELS) != 0);
   // ... and only where the coarse grid still has as many RK4 steps as the reference's example grids have in all (n_grid
   // 10-15 x 4): at n_grid 15 the rocket's coarse path ends in ANOTHER stationary point than the fine one (one with a
   // conjugate point inside the horizon, where the Riccati sweep of the auxiliary pass has a finite escape; emulator tier,
@@ -2491,7 +2491,8 @@ __global__ void __launch_bounds__(64, 1) oc_solve_wide_kernel(OcArgs<T> a) {
   const T dgrid_full = s.dgrid;
   int tc = 1;
   if (coarse) {
-    for (int f = LFSD_COARSE_TIME; f > 1; f /= 2) {
+    constexpr int TC0 = (NX + (NU > NP ? NU : NP) > 16) ? (LFSD_COARSE_TIME) : 1;      // (the small models: one RK4 step per interval only, measured)
+    for (int f = TC0; f > 1; f /= 2) {
       if (f <= Lay::SMAX && N_full % f == 0 && N_full / f >= LFSD_COARSE_TIME_MIN) { tc = f; break; }
     }
     s.N = N_full / tc; s.dgrid = dgrid_full * T(tc);
