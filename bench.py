@@ -292,6 +292,13 @@ def timed_steps(L, steps, warmup, sync, torch):
     return elapsed, ktime, loss
 
 
+def lean_level0(args):
+    """(iterations, merged intervals, RK4 steps per merged interval) of level 0 of the lean kernels' mesh continuation (csrc/
+    cpdp_common.h LFSD_LEAN_TC_ITERS / LFSD_LEAN_TC / LFSD_LEAN_TC_S and the rule of cpdp_oc.h), None where it does not apply.
+    With it the solve's roll-outs are: 1 + 3 on level 0, the transfer + ~1 on the one-step-per-interval level, the rest fine."""
+    return (3, 5, 2) if (args.n_grid % 5 == 0 and args.n_grid // 5 >= 10) else None
+
+
 def seeded_f64(args, dtype_name, kernel, warm):
     """lfsd_coc_solve in fp64 on the lock-step mapping of the quadrotor class solves a cold start in fp32 first and starts the
     fp64 kernel from those controls (csrc/lfsd_capi.cpp, coc_solve_seeded): `oc_solve` is then two kernels in two precisions."""
@@ -309,7 +316,7 @@ def kernel_model(perf_model, spec, args, dtype_name, aux_dtype_name, kernel, kti
     t = ktime[kernel] * 1e-3
     if seeded_f64(args, kd, kernel, warm) and it_seed:
         f32, m32 = perf_model.kernel_flops(spec, kernel, args.n_grid, 4, sub, mean_iters=it_seed, split=True, midpoint=True,
-                                           coarse_rollouts=5)
+                                           coarse_rollouts=2 if lean_level0(args) else 5, level0=lean_level0(args))
         f64, m64 = perf_model.kernel_flops(spec, kernel, args.n_grid, 4, sub, mean_iters=max(it_mean - it_seed, 0.0), split=True,
                                            midpoint=False, coarse_rollouts=0)
         f64 += m64
@@ -318,10 +325,12 @@ def kernel_model(perf_model, spec, args, dtype_name, aux_dtype_name, kernel, kti
         return flops * B / t / 1e12, 0.0, flops * B, kd, frac
     # mesh continuation: 5 of the roll-outs of a cold lean fp32 / fp64 solve run on the coarse grid; none when
     # the solve is warm-started or the model has no coarse phase
-    coarse = 0 if (warm or kernel != "oc_solve" or args.config != "quadrotor") else 5
+    cold_lean = not (warm or kernel != "oc_solve" or args.config != "quadrotor")
+    lvl0 = lean_level0(args) if cold_lean else None
+    coarse = 0 if not cold_lean else (2 if lvl0 else 5)
     flops, mflops = perf_model.kernel_flops(spec, kernel, args.n_grid, 4, sub, mean_iters=it_mean,
                                             units_per_interval=units.get(kernel), split=True, midpoint=(kd == "f32"),
-                                            coarse_rollouts=coarse)
+                                            coarse_rollouts=coarse, level0=lvl0)
     if kd == "f64" or args.config != "quadrotor":      # matrix cores only in the lean fp32 kernel of the 13-state models' lock-step mapping
         flops, mflops = flops + mflops, 0.0
     return flops * B / t / 1e12, mflops * B / t / 1e12, flops * B, kd, flops * B / t / 1e12 / VALU_PEAK_TFLOPS[kd]

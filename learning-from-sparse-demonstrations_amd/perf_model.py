@@ -88,7 +88,7 @@ def model_counts(spec):
 
 
 def kernel_flops(spec, kernel, n_grid, steps_per_grid, substeps, mean_iters=1.0, units_per_interval=None, midpoint=False,
-                 coarse_rollouts=0, split=False):
+                 coarse_rollouts=0, split=False, level0=None):
     """Useful flops of ONE trajectory in one launch of `kernel` ("oc_solve" | "aux_riccati" | "aux_forward").
 
     Round 3: the figures are checked against the counters (SQ_INSTS_VALU_FLOPS_FP32 x 64 lanes x EXEC share,
@@ -102,7 +102,10 @@ def kernel_flops(spec, kernel, n_grid, steps_per_grid, substeps, mean_iters=1.0,
     evaluation + the LIVE tangent columns: structurally constant columns are not computed, codegen NZC) + backward sweep
     (dense products V_xx [A B], [A B]^T Y -- on the matrix cores in the lean fp32 kernel, reported apart with split=True --
     stage Hessian column, gains, V_xx update) -- plus the initial roll-out.  `coarse_rollouts` of the 1 + mean_iters
-    roll-outs run with ONE RK4 step per interval (mesh continuation; 5 on the benchmark).
+    roll-outs run with ONE RK4 step per interval (mesh continuation; 5 on the benchmark).  `level0` = (iterations, merged
+    intervals, RK4 steps per merged interval) of the lean kernels' level 0 (round 4: 3, 5, 2): the initial roll-out and those
+    iterations' roll-outs and sweeps run on n_grid / merged stages, and ONE of the counted iterations is the transfer to the
+    next level -- a roll-out (counted in `coarse_rollouts`) without a backward sweep.
     aux kernels: per interval `units_per_interval` split units (default `substeps`; bench.py passes the measured mean of the
     error-controlled sweeps), each 12 right-hand sides (coarse RK4 + two fine RK4 steps; 6 with the explicit midpoint rule of
     the fp32 kernels, `midpoint`) per column + 5 coefficient nodes."""
@@ -121,6 +124,16 @@ def kernel_flops(spec, kernel, n_grid, steps_per_grid, substeps, mean_iters=1.0,
                         + 4 * n * nxu + m * m * m // 3 + 4 * m * m * nxu      # Q_u / lambda, Cholesky, gains K, k
                         + n * (4 * m * n + 2 * m * m) + n * n)          # V_xx update + symmetrisation
         n_ro = 1.0 + mean_iters
+        if level0 and S > 1:
+            k0, tc0, s0 = level0
+            n0 = min(1.0 + k0, n_ro)                                   # roll-outs on level 0
+            rollout0 = (N / tc0) * s0 * 4 * (uni + live * col) + (N / tc0) * 2 * n * m
+            nc = min(float(coarse_rollouts), n_ro - n0)
+            sweeps = max(mean_iters - 1.0, 1.0)                        # (the transfer iteration has none)
+            sw0 = min(float(k0), sweeps)
+            valu = n0 * rollout0 + nc * rollout / S + (n_ro - n0 - nc) * rollout + (sweeps - sw0) * backward + sw0 * backward / tc0
+            mfma = (sweeps - sw0) * dense + sw0 * dense / tc0
+            return (valu, mfma) if split else valu + mfma
         nc = min(float(coarse_rollouts), n_ro) if S > 1 else 0.0
         valu = (n_ro - nc) * rollout + nc * rollout / S + max(mean_iters, 1.0) * backward
         mfma = max(mean_iters, 1.0) * dense
