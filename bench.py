@@ -296,7 +296,7 @@ def lean_level0(args):
     """(iterations, merged intervals, RK4 steps per merged interval) of level 0 of the lean kernels' mesh continuation (csrc/
     cpdp_common.h LFSD_LEAN_TC_ITERS / LFSD_LEAN_TC / LFSD_LEAN_TC_S and the rule of cpdp_oc.h), None where it does not apply.
     With it the solve's roll-outs are: 1 + 3 on level 0, the transfer + ~1 on the one-step-per-interval level, the rest fine."""
-    return (3, 5, 2) if (args.n_grid % 5 == 0 and args.n_grid // 5 >= 10) else None
+    return (3, 2, 1) if (args.n_grid % 2 == 0 and args.n_grid // 2 >= 10) else None
 
 
 def seeded_f64(args, dtype_name, kernel, warm):

@@ -199,14 +199,18 @@
 #endif
 // lean matrix-core kernels: level 0 of the mesh continuation merges LFSD_LEAN_TC control intervals (1: off) with LFSD_LEAN_TC_S RK4
 // steps per merged interval for the first LFSD_LEAN_TC_ITERS iterations of a cold start; never below LFSD_LEAN_TC_MIN intervals.
-// Measured on the headline (oc_solve per launch, 20 steps; profiles/r04_z_ab_lean_time_coarsening.txt): off 2.57 ms; 2 intervals x 1
-// step for 2 / 3 / 4 iterations 2.34 / 2.38 / 2.61; 5 x 2 for 2 / 3 / 4 / 5 iterations 2.45 / 2.16 / 2.72 / 2.61; 5 x 3 x 3 2.21;
-// 5 x 1 x 2 2.46; 10 x 4 x 3 2.52; 10 x 2 x 3 2.46; 5 x 2 for 4 / 5 iterations and straight to the reference's grid 2.50 / 2.60.
+// Measured on BOTH workloads of the benchmark (oc_solve per launch, 20 steps; profiles/r04_z_ab_lean_time_coarsening.txt) --
+// independent seeds (one start / goal, 4 096 parameter vectors: a homogeneous batch whose trajectories all walk the same path) |
+// shared parameters (4 096 random starts / goals / waypoints, the N > 1 workload: the launch lasts as long as its slowest path):
+//   off 2.57 | 2.70;   2 x 1 step for 2 / 3 / 4 iterations 2.34 / 2.40 / 2.62 | 2.48 / 2.40 / 2.96;
+//   5 x 2 for 2 / 3 iterations 2.45 / 2.16 | 2.43 / 2.90;   5 x 1 for 2 / 3 iterations 2.46 / 2.10 | 2.40 / 2.85.
+// 5 merged intervals for 3 iterations is the best on the homogeneous batch and WORSE than no level 0 on the diverse one; shipped is
+// the setting that gains on both, 2 x 1 x 3.
 #ifndef LFSD_LEAN_TC
-#define LFSD_LEAN_TC 5
+#define LFSD_LEAN_TC 2
 #endif
 #ifndef LFSD_LEAN_TC_S
-#define LFSD_LEAN_TC_S 2
+#define LFSD_LEAN_TC_S 1
 #endif
 #ifndef LFSD_LEAN_TC_ITERS
 #define LFSD_LEAN_TC_ITERS 3
@@ -215,6 +219,9 @@
 #define LFSD_LEAN_TC_MIN 10
 #endif
 // 1: level 0 hands over to the reference's grid directly (no iterations on the one-step-per-interval level in between)
+#ifndef LFSD_LEAN_TC_GRACE
+#define LFSD_LEAN_TC_GRACE 0
+#endif
 #ifndef LFSD_LEAN_TC_TO_FINE
 #define LFSD_LEAN_TC_TO_FINE 0
 #endif

@@ -2170,6 +2170,10 @@ __global__ void __launch_bounds__(64, LFSD_WAVES_OC) oc_solve_kernel(OcArgs<T> a
   bool gn_crawl = false;    // Gauss-Newton is all that is left (Hamiltonian model failed) and its full steps gain < 1 %
   T mu_bad = T(-1);         // largest Levenberg shift that failed recently (<0: none)
   int mu_hold = 0, mu_hold_need = LFSD_MU_HOLD;   // accepted full steps to wait before the shift returns to a level <= mu_bad
+  // accepted steps after the transfer from level 0 during which a refused or shortened full step is NOT read as "past the big
+  // drops, go to the reference's grid": there it only says that the level-0 model and this level disagree, and the line search
+  // it asks for is four times cheaper here
+  int grace = 0;
   if (!t_finite(J)) status = ST_FAILED;
   for (; it < a.max_iter; ++it) {
     if (threadIdx.x == 0) vote[0] = 0;
@@ -2200,6 +2204,7 @@ __global__ void __launch_bounds__(64, LFSD_WAVES_OC) oc_solve_kernel(OcArgs<T> a
         __syncthreads();
         cur ^= 1; J = Jt;
         need_bw = true; hess_ok = false; optimistic = true;
+        grace = coarse ? (LFSD_LEAN_TC_GRACE) : 0;
         g_last = T(-1); dec_last = T(1e30); g_flat = T(-1); J_ref = J; n_acc = 0;
         if (!t_finite(J) && status == ST_RUNNING) {
           if (coarse) { relin = true; relin_hard = true; }      // the reference's discretisation decides
@@ -2348,11 +2353,12 @@ __global__ void __launch_bounds__(64, LFSD_WAVES_OC) oc_solve_kernel(OcArgs<T> a
           accept = true; ia = 0; g_flat = gnorm;
         } else {
           optimistic = false;     // same gains, parallel line search next round
-          if (coarse) { relin = true; relin_hard = true; }      // ... on the fine grid
+          if (coarse && grace == 0) { relin = true; relin_hard = true; }      // ... on the fine grid (right after level 0: on this level)
         }
       }
       if (accept) {
-        if (coarse && (ia != 0 || (J - Jn) < T(LFSD_COARSE_SWITCH) * t_abs(Jn))) { relin = true; if (ia != 0) relin_hard = true; }      // past the first big drops
+        if (coarse && ((ia != 0 && grace == 0) || (J - Jn) < T(LFSD_COARSE_SWITCH) * t_abs(Jn))) { relin = true; if (ia != 0) relin_hard = true; }      // past the first big drops
+        if (grace > 0) --grace;
         cur ^= 1;
         g_last = gnorm; dec_last = (mode >= 1 && mu == T(0)) ? -(dV1 + dV2) : T(1e30);
         if (fine_step) { g_last = T(-1); dec_last = T(1e30); g_flat = T(-1); J_ref = Jn; n_acc = 0; }      // histories start over on the fine grid

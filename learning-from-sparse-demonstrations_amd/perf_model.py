@@ -103,7 +103,7 @@ def kernel_flops(spec, kernel, n_grid, steps_per_grid, substeps, mean_iters=1.0,
     (dense products V_xx [A B], [A B]^T Y -- on the matrix cores in the lean fp32 kernel, reported apart with split=True --
     stage Hessian column, gains, V_xx update) -- plus the initial roll-out.  `coarse_rollouts` of the 1 + mean_iters
     roll-outs run with ONE RK4 step per interval (mesh continuation; 5 on the benchmark).  `level0` = (iterations, merged
-    intervals, RK4 steps per merged interval) of the lean kernels' level 0 (round 4: 3, 5, 2): the initial roll-out and those
+    intervals, RK4 steps per merged interval) of the lean kernels' level 0 (round 4: 3, 2, 1): the initial roll-out and those
     iterations' roll-outs and sweeps run on n_grid / merged stages, and ONE of the counted iterations is the transfer to the
     next level -- a roll-out (counted in `coarse_rollouts`) without a backward sweep.
     aux kernels: per interval `units_per_interval` split units (default `substeps`; bench.py passes the measured mean of the

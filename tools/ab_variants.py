@@ -73,6 +73,18 @@ VARIANTS = {
     "ham01": (("-DLFSD_HAM_SWITCH=0.1",), None, False),
     "tc5s2k3min5": (("-DLFSD_LEAN_TC_MIN=5",), None, False),
     "notc": (("-DLFSD_LEAN_TC=1",), None, False),
+    "tc2k3b": (("-DLFSD_LEAN_TC=2", "-DLFSD_LEAN_TC_S=1", "-DLFSD_LEAN_TC_ITERS=3"), None, False),
+    "tc5k2b": (("-DLFSD_LEAN_TC_ITERS=2",), None, False),
+    "tc5s3": (("-DLFSD_LEAN_TC_S=3",), None, False),
+    "occ_k3": (("-DLFSD_OC_CLOCK=1024",), None, False),
+    "occ_k2": (("-DLFSD_OC_CLOCK=1024", "-DLFSD_LEAN_TC_ITERS=2"), None, False),
+    "grace1": (("-DLFSD_LEAN_TC_GRACE=1",), None, False),
+    "grace2": (("-DLFSD_LEAN_TC_GRACE=2",), None, False),
+    "grace1s1": (("-DLFSD_LEAN_TC_GRACE=1", "-DLFSD_LEAN_TC_S=1"), None, False),
+    "tc2k2b": (("-DLFSD_LEAN_TC=2", "-DLFSD_LEAN_TC_S=1", "-DLFSD_LEAN_TC_ITERS=2"), None, False),
+    "tc2k4b": (("-DLFSD_LEAN_TC=2", "-DLFSD_LEAN_TC_S=1", "-DLFSD_LEAN_TC_ITERS=4"), None, False),
+    "tc5s1k2b": (("-DLFSD_LEAN_TC_S=1", "-DLFSD_LEAN_TC_ITERS=2"), None, False),
+    "tc5s1k3b": (("-DLFSD_LEAN_TC_S=1", "-DLFSD_LEAN_TC_ITERS=3"), None, False),
     "k4ham01": (("-DLFSD_LEAN_TC_ITERS=4", "-DLFSD_HAM_SWITCH=0.05"), None, False),
 }
 
