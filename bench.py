@@ -443,7 +443,7 @@ def main(argv=None):
         tag = PROFILE_TAG if args.config == "quadrotor" else "%s_%s" % (PROFILE_TAG, args.config)
         sources = {}
 
-        def profile(name):
+        def profile(name, key=None):
             """Counter figures that THIS run does not measure: read from a committed fold of separate rocprofv3 --pmc passes
             of the same command, and named as such in the line (file + git blob hash of the file read, and the commit the
             fold was collected at when the fold records it)."""
@@ -457,10 +457,14 @@ def main(argv=None):
                 js = json.loads(raw)
                 sources[name] = {"file": rel, "git_blob": hashlib.sha1(b"blob %d\0" % len(raw) + raw).hexdigest(),
                                  "collected_at_commit": js.get("collected_at_commit")}
+                if key:
+                    return js.get(key) or {}
                 return js.get(dom) or (js.get("oc_solve_wide", {}) if dom == "oc_solve" else {})      # (models solved on the wide mapping)
             except Exception:
                 return {}
         traffic = profile("hbm_traffic").get("hbm_bytes_per_launch")
+        if traffic is not None and it_seed is not None:      # the fp32-seeded fp64 solve: both kernels of `oc_solve` move bytes
+            traffic += profile("hbm_traffic", "oc_solve_seed_f32").get("hbm_bytes_per_launch") or 0.0
         issue = profile("issue_counters")
         executed = issue.get("valu_flops_executed_per_launch")
         peak = VALU_PEAK_TFLOPS[dom_dtype]

@@ -212,8 +212,8 @@ def test_headline_defaults_vs_tight_oracle_at_outer_iteration_12():
     rng = np.random.default_rng(12)
     pick = []
     n2 = int((st == 2).sum())
-    assert n2 >= 6 and int((st == 1).sum()) >= 26, np.bincount(st, minlength=5)        # both exits are really taken on this workload
-    k2 = min(16, n2)                                                                   # (9 of 4096 ended at status 2 in the round-4 run)
+    assert n2 >= 3 and int((st == 1).sum()) >= 26, np.bincount(st, minlength=5)        # both exits are really taken on this workload
+    k2 = min(16, n2)                                                                   # (9 of 4096 ended at status 2 in the round-4 run, 5 with level 0 of the mesh continuation)
     for code, cnt in ((2, k2), (1, 32 - k2)):
         idx = np.where(st == code)[0]
         pick += list(rng.choice(idx, cnt, replace=False))

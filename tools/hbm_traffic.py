@@ -16,6 +16,7 @@ for the 4-8-byte-per-lane accesses of these kernels it is uncalibrated, so the r
 read; WRITE_SIZE is exact for streaming stores.  Both count Infinity-Cache hits: this is memory-side traffic, not DRAM.
 """
 import csv
+import os
 import json
 import re
 import sys
@@ -32,6 +33,9 @@ def classify(name):
     if "oc_solve_kernel" in name:
         # oc_solve_kernel<Model, T, G, EXACT, PK>: EXACT = true is the resume launch of the two-launch solve
         m = re.search(r"oc_solve_kernel<.*?,\s*(float|double),\s*\d+,\s*(true|false)", name)
+        if m and m.group(1) == "float" and os.environ.get("LFSD_PROFILE_DTYPE") == "f64":
+            # the fp32 solve that seeds a cold fp64 solve (lfsd_capi.cpp, coc_solve_seeded), and its (empty) resume launch
+            return "oc_solve_seed_f32_resume" if m.group(2) == "true" else "oc_solve_seed_f32"
         return "oc_solve_resume" if (m and m.group(2) == "true") else "oc_solve"
     if "aux_riccati_kernel" in name:
         return "aux_riccati"
