@@ -295,7 +295,8 @@ def timed_steps(L, steps, warmup, sync, torch):
 def lean_level0(args):
     """(iterations, merged intervals, RK4 steps per merged interval) of level 0 of the lean kernels' mesh continuation (csrc/
     cpdp_common.h LFSD_LEAN_TC_ITERS / LFSD_LEAN_TC / LFSD_LEAN_TC_S and the rule of cpdp_oc.h), None where it does not apply.
-    With it the solve's roll-outs are: 1 + 3 on level 0, the transfer + ~1 on the one-step-per-interval level, the rest fine."""
+    With it the solve's 1 + 6.3 roll-outs are: 1 + 3 on level 0, the transfer on the one-step-per-interval level, the rest (2.3, as
+    before level 0 existed) on the reference's grid -- the mean iteration count did not grow by the transfer iteration."""
     return (3, 2, 1) if (args.n_grid % 2 == 0 and args.n_grid // 2 >= 10) else None
 
 
@@ -316,7 +317,7 @@ def kernel_model(perf_model, spec, args, dtype_name, aux_dtype_name, kernel, kti
     t = ktime[kernel] * 1e-3
     if seeded_f64(args, kd, kernel, warm) and it_seed:
         f32, m32 = perf_model.kernel_flops(spec, kernel, args.n_grid, 4, sub, mean_iters=it_seed, split=True, midpoint=True,
-                                           coarse_rollouts=2 if lean_level0(args) else 5, level0=lean_level0(args))
+                                           coarse_rollouts=1 if lean_level0(args) else 5, level0=lean_level0(args))
         f64, m64 = perf_model.kernel_flops(spec, kernel, args.n_grid, 4, sub, mean_iters=max(it_mean - it_seed, 0.0), split=True,
                                            midpoint=False, coarse_rollouts=0)
         f64 += m64
@@ -327,7 +328,7 @@ def kernel_model(perf_model, spec, args, dtype_name, aux_dtype_name, kernel, kti
     # the solve is warm-started or the model has no coarse phase
     cold_lean = not (warm or kernel != "oc_solve" or args.config != "quadrotor")
     lvl0 = lean_level0(args) if cold_lean else None
-    coarse = 0 if not cold_lean else (2 if lvl0 else 5)
+    coarse = 0 if not cold_lean else (1 if lvl0 else 5)
     flops, mflops = perf_model.kernel_flops(spec, kernel, args.n_grid, 4, sub, mean_iters=it_mean,
                                             units_per_interval=units.get(kernel), split=True, midpoint=(kd == "f32"),
                                             coarse_rollouts=coarse, level0=lvl0)
