@@ -20,23 +20,24 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run by the driver with -m gpu)")
 
 
-def build_emu_library(oc):
+def build_emu_library(oc, extra_flags=(), tag=""):
     """g++ build of the SAME kernel sources against the CPU SIMT emulator (tests/emu/simt_emu.h).
 
-    Test infrastructure only: lets the CPU suite exercise the kernels' logic; never used by the product."""
+    Test infrastructure only: lets the CPU suite exercise the kernels' logic; never used by the product.
+    `extra_flags` + `tag`: a variant build (an experiment switch of csrc/cpdp_common.h set on the command line)."""
     import lfsd_amd
     from lfsd_amd import runtime
     spec = oc.model_spec()
     runtime.write_header(spec)
     os.makedirs(EMU_BUILD, exist_ok=True)
-    out = os.path.join(EMU_BUILD, "liblfsd_%s_emu.so" % spec.hash())
+    out = os.path.join(EMU_BUILD, "liblfsd_%s_emu%s.so" % (spec.hash(), ("_" + tag) if tag else ""))
     deps = [runtime.header_path(spec.hash()), os.path.join(EMU_DIR, "simt_emu.h")] + \
         [os.path.join(runtime.CSRC_DIR, f) for f in runtime.KERNEL_SOURCES]
     if os.path.exists(out) and all(os.path.getmtime(out) >= os.path.getmtime(d) for d in deps):
         return out
     g = runtime.lanes_for(spec.n, spec.m, spec.p)
     cmd = ["g++", "-std=c++17", "-O1", "-fPIC", "-shared", "-DLFSD_EMU", "-DLFSD_POISON_LDS", "-fvisibility=hidden", "-DLFSD_G=%d" % g,
-           '-DLFSD_MODEL_HEADER="gen/%s.h"' % spec.hash(), "-I" + EMU_DIR, "-I" + runtime.CSRC_DIR,
+           '-DLFSD_MODEL_HEADER="gen/%s.h"' % spec.hash(), "-I" + EMU_DIR, "-I" + runtime.CSRC_DIR] + list(extra_flags) + [
            os.path.join(runtime.CSRC_DIR, "lfsd_capi.cpp"), "-o", out + ".tmp"]
     r = subprocess.run(cmd, cwd=runtime.CSRC_DIR, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-3000:]

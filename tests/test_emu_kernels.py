@@ -658,3 +658,41 @@ def test_fp64_solve_seeded_by_fp32_reaches_the_same_kkt_point(emu):
         emu(oc)
         oc.setDevice(dtype=dtype)
     seeded_f64_same_kkt_point(prepare, n_grid=8, batch=5)
+
+
+def test_level0_of_the_mesh_continuation_same_kkt_point_and_partner_independent(emu, monkeypatch):
+    """Level 0 of the lean kernels' mesh continuation (cpdp_oc.h TCL: the first three iterations of a cold start on n_grid / 2
+    merged intervals, then prolongation + a roll-out on the one-step-per-interval level).  Quadrotor, fp32, lock-step mapping,
+    n_grid 20 (level 0 needs an even grid of >= 20 intervals): the same KKT points as a build without it (-DLFSD_LEAN_TC=1) to
+    the fp32 class; and the schedule is a fixed iteration count, so a trajectory's result does not depend on its partners in
+    the wavefront -- the same problem placed in two different wavefronts (rows 1 and 6 of a ragged batch of 7, four per
+    wavefront) comes back bit-identical, also next to a row that is warm-started (its workgroup then skips level 0)."""
+    from conftest import build_emu_library
+    monkeypatch.setattr(CPDP.COCSys, "mapping_override", "lockstep")
+    rng = np.random.default_rng(5)
+    out = {}
+    for tag, flags in (("", ()), ("notc", ("-DLFSD_LEAN_TC=1",))):
+        oc, env, d = models.quadrotor(n_grid=20)
+        oc.use_library(build_emu_library(oc, flags, tag)); oc.compile(); oc.setDevice(dtype=torch.float32)
+        if not tag:
+            th = np.asarray(d["theta0"])[None, :] * (1 + 0.1 * rng.standard_normal((7, len(d["theta0"]))))
+            th[:, 0] = np.abs(th[:, 0]) + 0.2
+            x0 = np.tile(d["ini_state"], (7, 1)); x0[:, :3] += 0.3 * rng.standard_normal((7, 3))
+            th[6], x0[6] = th[1], x0[1]
+        out[tag] = oc.cocSolverBatch(x0, d["horizon"], th)
+        assert ((out[tag]["status"] == 1) | (out[tag]["status"] == 2)).all(), out[tag]["status"]
+    a, b = out[""], out["notc"]
+    assert rel(a["cost"].double(), b["cost"].double()) < 2e-5
+    assert rel(a["state_grid"].double(), b["state_grid"].double()) < 5e-4 and rel(a["control_grid"].double(), b["control_grid"].double()) < 5e-3
+    assert (a["iters"] <= b["iters"] + 1).all()      # one counted iteration is the transfer roll-out
+    for k in ("cost", "state_grid", "control_grid", "costate_grid"):
+        assert torch.equal(a[k][1], a[k][6]), k
+    # a warm-started row in the first wavefront: that workgroup runs without level 0, the duplicate in the second one with it --
+    # both end in the same KKT point
+    oc, env, d = models.quadrotor(n_grid=20)
+    emu(oc); oc.setDevice(dtype=torch.float32)
+    u0 = torch.zeros(7, 20, 4)
+    u0[0] = a["control_grid"][0, :20]
+    w = oc.cocSolverBatch(x0, d["horizon"], th, u_init=u0)
+    assert ((w["status"] == 1) | (w["status"] == 2)).all()
+    assert rel(w["cost"].double(), a["cost"].double()) < 2e-5
