@@ -219,6 +219,11 @@
 #define LFSD_LEAN_TC_MIN 10
 #endif
 // 1: level 0 hands over to the reference's grid directly (no iterations on the one-step-per-interval level in between)
+// lean kernels: the convergence histories (last gradient norm, last predicted decrease) survive the step that leaves the coarse grid
+// when the coarse problem had converged (cpdp_oc.h); 0 = they always start over on the reference's grid
+#ifndef LFSD_EXIT_KEEP_HISTORY
+#define LFSD_EXIT_KEEP_HISTORY 1
+#endif
 #ifndef LFSD_LEAN_TC_GRACE
 #define LFSD_LEAN_TC_GRACE 0
 #endif

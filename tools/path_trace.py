@@ -41,6 +41,9 @@ if x0n.ndim == 1:
 os.makedirs("gpurun_out", exist_ok=True)
 np.savez("gpurun_out/%s_theta.npz" % tag, theta=th[order], x0=x0n[order], iters=it[order], status=st[order], horizon=float(d["horizon"]))      # slowest first
 print("iteration histogram (bins of 20):", np.bincount(it // 20).tolist())
+if it.max() < 40:      # the lean kernels: exact counts, and the slowest trajectory of every group of four (one wavefront)
+    print("iterations:", np.bincount(it).tolist(), "| per wavefront of four, the maximum:", np.bincount(it[:len(it) // 4 * 4].reshape(-1, 4).max(1)).tolist())
+    print("status by iterations:", {int(k): np.bincount(st[it == k], minlength=5).tolist() for k in np.unique(it)})
 oc2, _, _ = models.ZOO[w["kind"]](n_grid=args.n_grid)
 oc2.use_library(oc_trace.variant_path(oc2.model_spec(), "trace")); oc2.setDevice("cuda:0", TD[args.dtype])
 oc2.setSolverOptions(mapping=oc.mapping if oc.mapping != "auto" else ("wide" if oc.exact_after == 0 else "lockstep"))
