@@ -222,7 +222,7 @@
 // lean kernels: the convergence histories (last gradient norm, last predicted decrease) survive the step that leaves the coarse grid
 // when the coarse problem had converged (cpdp_oc.h); 0 = they always start over on the reference's grid
 #ifndef LFSD_EXIT_KEEP_HISTORY
-#define LFSD_EXIT_KEEP_HISTORY 1
+#define LFSD_EXIT_KEEP_HISTORY 2      // 1: only when the coarse problem had passed a convergence test; 2: also when the exit step predicted a decrease below the cost's resolution
 #endif
 #ifndef LFSD_LEAN_TC_GRACE
 #define LFSD_LEAN_TC_GRACE 0

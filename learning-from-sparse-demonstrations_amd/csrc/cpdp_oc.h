@@ -2368,7 +2368,10 @@ __global__ void __launch_bounds__(64, LFSD_WAVES_OC) oc_solve_kernel(OcArgs<T> a
         // gradient on the reference's grid lands between 1x and 2x the tolerance (the fp32 floor of this problem is 0.5x) pays
         // one more iteration for nothing the cost can resolve, and holds its launch (2 % of the benchmark's trajectories, 0.35 ms
         // of 2.4 for all of them: profiles/r04_av_headline_eighth_iteration.txt)
-        if (fine_step && !((LFSD_EXIT_KEEP_HISTORY) != 0 && conv_coarse)) { g_last = T(-1); dec_last = T(1e30); }
+        // (... or, the same situation reached by the gain rule: the step that left the coarse grid was a Newton-like step without a
+        //  shift that itself predicted a decrease below the resolution of the cost)
+        const bool below_res = mode >= 1 && mu == T(0) && -(dV1 + dV2) <= T(2) * Eps<T>::v() * t_abs(J);
+        if (fine_step && !((LFSD_EXIT_KEEP_HISTORY) != 0 && (conv_coarse || ((LFSD_EXIT_KEEP_HISTORY) > 1 && below_res)))) { g_last = T(-1); dec_last = T(1e30); }
         if (fine_step) { g_flat = T(-1); J_ref = Jn; n_acc = 0; }
         need_bw = true;
         hess_ok = false;

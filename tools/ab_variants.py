@@ -74,6 +74,7 @@ VARIANTS = {
     "tc5s2k3min5": (("-DLFSD_LEAN_TC_MIN=5",), None, False),
     "notc": (("-DLFSD_LEAN_TC=1",), None, False),
     "nokeephist": (("-DLFSD_EXIT_KEEP_HISTORY=0",), None, False),
+    "keephist1": (("-DLFSD_EXIT_KEEP_HISTORY=1",), None, False),
     "tc2k3b": (("-DLFSD_LEAN_TC=2", "-DLFSD_LEAN_TC_S=1", "-DLFSD_LEAN_TC_ITERS=3"), None, False),
     "tc5k2b": (("-DLFSD_LEAN_TC_ITERS=2",), None, False),
     "tc5s3": (("-DLFSD_LEAN_TC_S=3",), None, False),
