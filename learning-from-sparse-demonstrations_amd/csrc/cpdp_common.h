@@ -224,8 +224,10 @@
 #ifndef LFSD_EXIT_KEEP_HISTORY
 #define LFSD_EXIT_KEEP_HISTORY 2      // 1: only when the coarse problem had passed a convergence test; 2: also when the exit step predicted a decrease below the cost's resolution
 #endif
+// lean kernels: accepted steps after the transfer from level 0 during which a refused or shortened full step is answered by a line
+// search on the one-step-per-interval level instead of by leaving for the reference's grid (profiles/r04_bc_ab_grace_after_transfer.txt)
 #ifndef LFSD_LEAN_TC_GRACE
-#define LFSD_LEAN_TC_GRACE 0
+#define LFSD_LEAN_TC_GRACE 2
 #endif
 #ifndef LFSD_LEAN_TC_TO_FINE
 #define LFSD_LEAN_TC_TO_FINE 0
