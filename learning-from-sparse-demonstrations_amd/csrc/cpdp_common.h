@@ -251,6 +251,10 @@
 #ifndef LFSD_COARSE_TIME
 #define LFSD_COARSE_TIME 4
 #endif
+// wide kernel: 1 = between the merged-interval coarse level and the reference's grid, a level with one RK4 step per interval
+#ifndef LFSD_COARSE_MID_LEVEL
+#define LFSD_COARSE_MID_LEVEL 1
+#endif
 // RK4 steps per merged interval of that phase (0: as many as merged intervals, i.e. the step of one step per interval)
 #ifndef LFSD_COARSE_TIME_S
 #define LFSD_COARSE_TIME_S 2

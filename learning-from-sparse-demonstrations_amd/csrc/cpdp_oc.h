@@ -2550,9 +2550,12 @@ __global__ void __launch_bounds__(64, 1) oc_solve_wide_kernel(OcArgs<T> a) {
     if (coarse && (relin || it + 4 >= a.max_iter)) {
       // leave the coarse grid: the same controls rolled out (open loop) and linearised on the reference's discretisation; an
       // iteration without a sweep.  Every convergence test below only ever passes on this grid.
-      coarse = false; relin = false;
+      // (LFSD_COARSE_MID_LEVEL: a coarse phase with merged intervals first hands over to the full control grid with ONE RK4 step per
+      //  interval -- the lean kernels' coarse level -- and leaves that one by the same rules)
+      const bool to_mid = (LFSD_COARSE_MID_LEVEL) != 0 && tc > 1 && a.steps_per_grid > 1 && it + 8 < a.max_iter;
+      coarse = to_mid; relin = false;
 #if defined(LFSD_OC_CLOCK)
-      wck_exit = clock64() - wck_t0; wck_it_exit = it;
+      if (!to_mid) { wck_exit = clock64() - wck_t0; wck_it_exit = it; }
 #endif
       if (tc > 1) {
         // prolongation: control k of the reference grid = control k / tc of the coarse one (in place: sources into registers first)
@@ -2568,7 +2571,7 @@ __global__ void __launch_bounds__(64, 1) oc_solve_wide_kernel(OcArgs<T> a) {
         }
         s.N = N_full; s.dgrid = dgrid_full; tc = 1;
       }
-      s.S = a.steps_per_grid; s.DT = s.dgrid / T(s.S);
+      s.S = to_mid ? 1 : a.steps_per_grid; s.DT = s.dgrid / T(s.S);
       const T Jr = s.rollout_alphas(cur, false, alpha_l);
       ldsRed[s.lane] = Jr;
       __syncthreads();
@@ -2579,7 +2582,7 @@ __global__ void __launch_bounds__(64, 1) oc_solve_wide_kernel(OcArgs<T> a) {
       cur ^= 1;
       hess_ok = false; costates_ok = false;
       g_last = T(-1); dec_last = T(1e30); g_flat = T(-1); J_ref = J; n_acc = 0;
-      if (!t_finite(J)) { status = ST_FAILED; break; }
+      if (!t_finite(J)) { if (coarse) { relin = true; continue; } status = ST_FAILED; break; }      // (the mid level cannot integrate it: the reference's grid decides)
       continue;
     }
     if (EXACT && a.exact_after >= 0 && mode < 2 && (it >= a.exact_after || gn_crawl)) mode = 2;
