@@ -487,6 +487,8 @@ def main(argv=None):
                                     "shared theta, summed d(theta)+loss all-reduced over the ranks every iteration and "
                                     "driving the update (SparseDemoLearner mode='shared')"),
                        "name": args.config, "mode": mode, "batch_per_gpu": B, "n_grid": args.n_grid, "steps_per_grid": 4,
+                       # backend of the initialised torch.distributed group the shared-mode all-reduce went through (None: no group)
+                       "process_group": (str(dist.get_backend()) if dist.is_initialized() else None),
                        "aux_substeps": args.substeps, "aux_rtol": args.aux_rtol,
                        "aux_integration": ("error-controlled split-step + Richardson sweeps, rtol %g on the un-extrapolated "
                                            "estimate (the reference integrates the same ODEs with solve_ivp at rtol 1e-3), from %d unit(s) per interval" %

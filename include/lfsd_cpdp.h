@@ -100,11 +100,13 @@ size_t lfsd_coc_workspace_bytes(int dtype, int batch, int n_grid, int exact_afte
  *   loop is host code (COCSys.cocSolverBatch).  The returned costates include the bound multipliers, as IPOPT's lam_g
  *   do.  With state bounds the control-bound arrays must be given too (entries of +-1e20 where there is none).
  *   mapping: LFSD_MAP_AUTO, or force one of the two mappings of the same algorithm (same KKT points either way).
- *   dtype LFSD_F64, lock-step mapping, 32-lane models (quadrotor class), u_init == NULL, no bounds, exact_after != 0: the cold
- *   start is solved in fp32 first and the fp64 kernel starts from those controls (a trajectory the fp32 solve failed on starts
- *   cold).  Every output and every convergence test is the fp64 kernel's; iters[] counts both solves (so it may exceed
- *   max_iter, which bounds each of them); lfsd_coc_workspace_bytes includes the staging area.  LFSD_F64_SEED=0 in the
- *   environment switches the seeding off.   */
+ *   dtype LFSD_F64, lock-step mapping, 32-lane models (quadrotor class), no bounds, exact_after != 0: the problem is solved in
+ *   fp32 first -- from u_init as well when one is given: an all-zero row of u_init is a cold start, so a caller that hands zeros
+ *   for every row it does not continue gets every row seeded -- and the fp64 kernel starts from those controls (a trajectory
+ *   the fp32 solve failed on starts from its own row of u_init, or cold).  Every output and every convergence test is the fp64
+ *   kernel's; iters[] counts both solves (so it may exceed max_iter, which bounds each of them); lfsd_coc_workspace_bytes
+ *   includes the staging area.  LFSD_F64_SEED=0 in the environment switches the seeding off; a workspace without room for the
+ *   staging area (sized while the switch was off) makes the call solve unseeded rather than fail.   */
 int lfsd_coc_solve(int dtype, int batch, int n_grid, int steps_per_grid,
                    const void* ini_state, const void* horizon, const void* auxvar,
                    const void* consts, int const_per_traj, const void* u_init,
@@ -140,8 +142,8 @@ int lfsd_coc_solve(int dtype, int batch, int n_grid, int steps_per_grid,
  *           whose error estimate exceeds the tolerance asked for.
  *   oc_status [B] int32 or NULL, skip_status_mask (ABI 8): the status[] lfsd_coc_solve wrote for these trajectories and a
  *           bit mask over its values (bit s set = skip rows with status s, e.g. 1 << LFSD_ST_FAILED).  A skipped row costs
- *           nothing: neither sweep runs for it, its loss and gradient are NaN, its stats 0, its Z_grid / auxX / auxU rows
- *           are left untouched.  Without it a solve that FAILED (non-finite grids) or ran out of iterations on a problem
+ *           nothing: neither sweep runs for it, its loss, gradient and its Z_grid / auxX_grid / auxU_grid rows are NaN
+ *           (never what the caller's buffers held before), its stats 0.  Without it a solve that FAILED (non-finite grids) or ran out of iterations on a problem
  *           without a minimiser still goes through the error-controlled sweeps, refines to the cap and holds its launch
  *           many times longer than the well-posed batch needs.  NULL (or mask 0): every row is differentiated, as the
  *           reference does.                                                                   */

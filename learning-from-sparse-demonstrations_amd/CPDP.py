@@ -327,7 +327,8 @@ class COCSys:
             gu, gl = X - sub, slb - X                                        # <= 0 when feasible
             new_u = torch.clamp(mult[:, :, 0] + rho * gu, min=0.0)
             new_l = torch.clamp(mult[:, :, 1] + rho * gl, min=0.0)
-            moved = max(float((new_u - mult[:, :, 0]).abs().max()), float((new_l - mult[:, :, 1]).abs().max()))
+            moved_b = torch.maximum((new_u - mult[:, :, 0]).abs().amax(dim=(1, 2)), (new_l - mult[:, :, 1]).abs().amax(dim=(1, 2)))      # per trajectory
+            moved = float(moved_b.max())
             # the plain objective: the node terms the kernel added, at the multipliers and penalty it was called with
             pen = ((torch.clamp(mult[:, :, 0] + rho * gu, min=0.0) ** 2 - mult[:, :, 0] ** 2
                     + torch.clamp(mult[:, :, 1] + rho * gl, min=0.0) ** 2 - mult[:, :, 1] ** 2) / (2.0 * rho)).sum(dim=(1, 2))
@@ -335,6 +336,7 @@ class COCSys:
             viol_b = torch.clamp(torch.maximum(gu, gl), min=0.0).amax(dim=(1, 2))       # per trajectory
             viol = float(viol_b.max())
             solved = bool(((sol["status"] == 1) | (sol["status"] == 2)).all())
+            rho_last = rho
             if solved and viol <= tol * scale and moved <= tol * scale * rho:
                 met = True
                 break
@@ -345,7 +347,9 @@ class COCSys:
         sol["iters"] = iters_total
         sol["cost_objective"] = sol["cost"] - pen.to(sol["cost"].dtype)
         if not met:         # outer-iteration limit or penalty cap: infeasible / non-KKT rows must not pass for solved
-            bad = (viol_b > tol * scale) | ~((sol["status"] == 1) | (sol["status"] == 2))
+            # (a row whose own multipliers were still moving in the last update is not a KKT point of the bounded NLP either,
+            #  however feasible and converged its last subproblem was)
+            bad = (viol_b > tol * scale) | (moved_b > tol * scale * rho_last) | ~((sol["status"] == 1) | (sol["status"] == 2))
             sol["status"] = torch.where(bad & (sol["status"] != 4), torch.full_like(sol["status"], 3), sol["status"])
         sol["state_mult"], sol["state_rho"], sol["al_outer"], sol["state_violation"] = mult, rho, outer + 1, viol
         sol["state_violation_rows"] = viol_b

@@ -670,6 +670,11 @@ __global__ void __launch_bounds__(64, (sizeof(T) == 4 ? LFSD_WAVES_RIC : 1)) aux
   const long long traj = valid ? slot : (long long)a.batch - 1;
   if (a.skipped(traj)) {                          // a solve the caller does not want differentiated: this lane group is done
     if (valid && a.stats && threadIdx.x % G == 0) { a.stats[traj * 4 + 0] = 0; a.stats[traj * 4 + 1] = 0; }
+    if (valid) {                                  // its [P W] is NaN, not whatever the buffer held (include/lfsd_cpdp.h)
+      T* Zs = a.Z_grid + traj * (long long)(a.n_grid + 1) * NZ * NX;
+      const T nan = T(0) / T(0);
+      for (int i = threadIdx.x % G; i < (a.n_grid + 1) * NZ * NX; i += G) Zs[i] = nan;
+    }
     return;                                       // (its lanes leave together; the other groups of the wavefront share nothing with it)
   }
   Ctx s;
@@ -820,12 +825,14 @@ __global__ void __launch_bounds__(64, (sizeof(T) == 4 ? LFSD_WAVES_FWD : 1)) aux
   const long long slot = (long long)blockIdx.x * GPB + threadIdx.x / G;
   const bool valid = slot < a.batch;
   const long long traj = valid ? slot : (long long)a.batch - 1;
-  if (a.skipped(traj)) {                          // not differentiated: NaN loss / gradient, nothing else touched
+  if (a.skipped(traj)) {                          // not differentiated: NaN loss / gradient / sensitivity grids
     const int l = threadIdx.x % G;
     const T nan = T(0) / T(0);
     if (valid) {
       if (l == 0) { a.loss[traj] = nan; if (a.stats) { a.stats[traj * 4 + 2] = 0; a.stats[traj * 4 + 3] = 0; } }
       if (l < NP) a.grad[traj * NP + l] = nan;
+      if (a.auxX_grid) { T* o = a.auxX_grid + traj * (long long)(a.n_grid + 1) * NP * NX; for (int i = l; i < (a.n_grid + 1) * NP * NX; i += G) o[i] = nan; }
+      if (a.auxU_grid) { T* o = a.auxU_grid + traj * (long long)(a.n_grid + 1) * NP * NU; for (int i = l; i < (a.n_grid + 1) * NP * NU; i += G) o[i] = nan; }
     }
     return;
   }

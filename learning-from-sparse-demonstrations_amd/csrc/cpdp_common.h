@@ -3,6 +3,7 @@
 #pragma once
 
 
+#include <type_traits>
 #if defined(LFSD_EMU)
 #include "simt_emu.h"
 #define LFSD_LAMBDA_INLINE
@@ -241,6 +242,22 @@
 // keeps that seed and loses the gain (24.3 ms).
 #ifndef LFSD_COARSE_SMALL_MODELS
 #define LFSD_COARSE_SMALL_MODELS 0
+#endif
+// wide kernel: the interval-parallel (multiple-shooting) iteration of OcWide::ms_* (cpdp_oc.h) -- the reference's own lifted
+// formulation, CPDP.py:136-172 -- for unbounded problems with at least LFSD_MS_MIN_GRID intervals; 0: single shooting only.
+// The phase hands over to the single-shooting iteration through a closed-loop roll-out, so every convergence test is unchanged.
+#ifndef LFSD_MS
+#define LFSD_MS 1
+#endif
+#ifndef LFSD_MS_MIN_GRID
+#define LFSD_MS_MIN_GRID 40
+#endif
+// ... consecutive accepted SHORT steps (step length < 1) after which the phase ends on the current level (cpdp_oc.h)
+#ifndef LFSD_MS_NEWTON
+#define LFSD_MS_NEWTON 0
+#endif
+#ifndef LFSD_MS_SHORT_STEPS
+#define LFSD_MS_SHORT_STEPS 3
 #endif
 // wide kernel (one trajectory per wavefront): smallest n_grid with a coarse phase
 #ifndef LFSD_COARSE_MIN_GRID

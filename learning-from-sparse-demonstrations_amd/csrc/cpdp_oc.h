@@ -137,6 +137,10 @@ template <class M, typename T, int G, bool EXACT, bool BND = false> struct OcSol
   T *pkx = nullptr, *pkm = nullptr;      // rk4_step_parked: LDS homes of (x, sum of k) of the group and of this lane's (m, sum of dk)
   T* yz64 = nullptr;                     // backward_sc without matrix cores: [16][ZC] exchange rows (the LDS_M region holds the live columns there)
   bool reuse_hess = false;   // exact stage Hessians in Hws belong to the nominal being swept (a retry with another shift)
+  // Multiple-shooting iterate (wide kernel, OcWide::ms_*): the node states of buffer `cur` are variables of their own and
+  // gap[k] = F(x_k, u_k) - x_k+1 ([N][NX]) is what the shooting constraints of CPDP.py:166-169 still miss; nullptr: a roll-out (no gaps)
+  const T* gap = nullptr;
+  T lam_max = T(0);          // backward(): largest |costate| of the sweep (sizes the penalty of the multiple-shooting merit function)
   T* lam_out;   // costate grid of this trajectory (or scratch when invalid)
 
   LFSD_DEV T tk(int k) const { return M::TIME_VARYING ? dgrid * T(k) : T(0); }
@@ -545,8 +549,9 @@ template <class M, typename T, int G, bool EXACT, bool BND = false> struct OcSol
       for (int i = 0; i < NX; ++i) xk[i] = xN[i];
       M::final_grad(tk(N), xk, e, c, Vx);
       T ox[NX], oe[NP];
+      lam_max = T(0);
 #pragma unroll
-      for (int i = 0; i < NX; ++i) { ox[i] = (lane == i) ? T(1) : T(0); lam[i] = Vx[i]; }
+      for (int i = 0; i < NX; ++i) { ox[i] = (lane == i) ? T(1) : T(0); lam[i] = Vx[i]; lam_max = t_max(lam_max, t_abs(lam[i])); }
 #pragma unroll
       for (int i = 0; i < NP; ++i) oe[i] = T(0);
       M::final_hess_mul(tk(N), xk, e, c, ox, oe, vcol);
@@ -611,6 +616,21 @@ template <class M, typename T, int G, bool EXACT, bool BND = false> struct OcSol
         for (int i = 0; i < NX; ++i) { if (QS) ldsM[i * NXU + lane] = m[i]; else ldsM[lane * NX + i] = m[i]; }      // QS: transposed, row i = entries (i, all columns)
       }
       LFSD_STAGE_SYNC_GEN();
+      if (gap != nullptr) {
+        // multiple shooting: the linearised interval ends d_k away from node k+1, so the value function of that node is entered
+        // at delta x_k+1 = A dx + B du + d_k:  V_x <- V_x + V_xx d_k  (the costate recursion below stays the exact adjoint one)
+        const T* dk = gap + (long long)k * NX;
+        T dv[NX];
+#pragma unroll
+        for (int j = 0; j < NX; ++j) dv[j] = dk[j];
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+          T sacc = T(0);
+#pragma unroll
+          for (int j = 0; j < NX; ++j) sacc += ldsV[j * NX + i] * dv[j];
+          Vx[i] += sacc;
+        }
+      }
       if (PFG && k > 0) {
         load_stage(k - 1, mN, mqN, xkN, ukN);
         if (EXACT && mode == 2 && reuse_hess) {      // ... and its column of the cached stage Hessian
@@ -873,6 +893,7 @@ template <class M, typename T, int G, bool EXACT, bool BND = false> struct OcSol
         vcol[i] = s;
         Vx[i] = ldsVx[i];
         lam[i] = ldsLam[i];
+        lam_max = t_max(lam_max, t_abs(lam[i]));
       }
       if (BND && xm != nullptr && k > 0) {   // state-bound term of node k (x_0 is given, not bounded: CPDP.py:131-134)
 #pragma unroll
@@ -1891,6 +1912,216 @@ template <class M, typename T, bool EXACT, bool BND = false> struct OcWide : OcS
     }
     __syncthreads();
   }
+
+  // ---- the interval-parallel iteration: multiple shooting, the reference's own formulation (CPDP.py:136-172) ----------------
+  // The reference hands IPOPT the LIFTED problem: every node state X_k is a variable, every interval an equality constraint
+  // F(X_k, U_k) - X_k+1 = 0.  Given an iterate of that problem -- node states xb, controls ub, gaps d_k = F(x_k, u_k) - x_k+1 --
+  // all N intervals integrate their RK4 steps and sensitivities CONCURRENTLY from the node states (ms_trial: the 64 lanes take
+  // (interval, column pair) items, as linearise_parallel does), and the only sequential parts of an iteration are the
+  // Riccati-type recursion with gap terms (OcSolver::backward with `gap` set) and a LINEAR forward pass (ms_forward):
+  //     du_k = k_k + K_k dx_k,   dx_k+1 = A_k dx_k + B_k du_k + d_k,   dx_0 = 0
+  // -- the Newton step of the lifted KKT system (Gauss-Newton multiple shooting / the step of an SQP method on the NLP above).
+  // Where the single-shooting iteration of this kernel pays N x S sequentially dependent RK4 steps for its roll-outs, this one
+  // pays S (per round of 64 items).  Globalisation: the l1 exact penalty function  J + rho sum_k |d_k|_1  with rho above the
+  // largest costate (IPOPT uses a filter on the same two quantities); a step scales the whole Newton direction (it is linear).
+  // Convergence is never declared here: the phase ends in a closed-loop roll-out (gaps closed by construction) from which the
+  // single-shooting iteration above continues and applies its own tests (oc_solve_wide_kernel).
+  T *gapb[2] = {nullptr, nullptr}, *dxw = nullptr, *duw = nullptr;      // [N][NX] gaps of the two nominal buffers; Newton step [N+1][NX], [N][NU]
+  LFSD_DEV T* gapp(int i) const { return i ? gapb[1] : gapb[0]; }
+  LFSD_DEV T wave_sum(T v) {
+    T* ldsRed = lds + Lay::LDS_RED;
+    ldsRed[lane] = v;
+    __syncthreads();
+    T r = T(0);
+    for (int l = 0; l < 64; ++l) r += ldsRed[l];
+    __syncthreads();
+    return r;
+  }
+  LFSD_DEV T wave_max(T v) {
+    T* ldsRed = lds + Lay::LDS_RED;
+    ldsRed[lane] = v;
+    __syncthreads();
+    T r = ldsRed[0];
+    for (int l = 1; l < 64; ++l) r = (ldsRed[l] > r || !t_finite(ldsRed[l])) ? ldsRed[l] : r;      // (a NaN / inf wins: the caller tests finiteness)
+    __syncthreads();
+    return r;
+  }
+  // buffer `cur` holds a roll-out: no gaps
+  LFSD_DEV void ms_zero_gaps(int cur) {
+    for (int i = lane; i < N * NX; i += 64) gapp(cur)[i] = T(0);
+    __syncthreads();
+  }
+  // The Newton step (for step length 1) of the lifted problem from the gains of the last backward sweep, into dxw / duw.
+  // Returns its first-order change of the cost,  sum_k q_k^T (dx_k, du_k) + h_x^T dx_N.
+  LFSD_DEV T ms_forward(int cur, T& lamd) {
+    T* ldsDx = lds + Lay::LDS_VX;                 // (NX words, free between backward sweeps)
+    const T* Mc = Mwp(cur);
+    const T* gp = gapp(cur);
+    T dxv[NX], dl = T(0), ld = T(0);
+#pragma unroll
+    for (int i = 0; i < NX; ++i) dxv[i] = T(0);
+    if (lane < NX) dxw[lane] = T(0);
+    const int row = lane < NX ? lane : 0, col = lane < NXU ? lane : 0;
+    // operands of one stage, loaded one stage ahead (nothing else runs on the SIMD to hide a global load behind)
+    T ar[2][NXU], qj[2], Kk[2][NX * NU], kk[2][NU], dk[2];
+    auto load = [&](int k_, T* ar_, T& qj_, T* Kk_, T* kk_, T& dk_) LFSD_LAMBDA_INLINE {
+      const T* Mk = Mc + (long long)k_ * Lay::M_ELEMS;
+#pragma unroll
+      for (int j = 0; j < NXU; ++j) ar_[j] = Mk[row * Lay::NXUP + j];
+      qj_ = Mk[NX * Lay::NXUP + col];
+      const T* Kg = this->Kws + (long long)k_ * NX * NU;
+#pragma unroll
+      for (int i = 0; i < NX * NU; ++i) Kk_[i] = Kg[i];
+#pragma unroll
+      for (int a = 0; a < NU; ++a) kk_[a] = this->kws[k_ * NU + a];
+      dk_ = gp[k_ * NX + row];
+    };
+    // (two operand sets used alternately: every index is a constant, nothing lands in scratch)
+    auto stage = [&](int k, const T* arC, T qjC, const T* KkC, const T* kkC, T dkC, T* arN, T& qjN, T* KkN, T* kkN, T& dkN) LFSD_LAMBDA_INLINE {
+      if (k + 1 < N) { load(k + 1, arN, qjN, KkN, kkN, dkN); LFSD_ISSUE_FENCE(); }
+      T duv[NU];
+#pragma unroll
+      for (int a = 0; a < NU; ++a) duv[a] = kkC[a];
+#pragma unroll
+      for (int i = 0; i < NX; ++i) {
+#pragma unroll
+        for (int a = 0; a < NU; ++a) duv[a] += KkC[i * NU + a] * dxv[i];
+      }
+      T nx = dkC, zj = T(0);
+#pragma unroll
+      for (int j = 0; j < NX; ++j) { nx += arC[j] * dxv[j]; if (lane == j) zj = dxv[j]; }
+#pragma unroll
+      for (int a = 0; a < NU; ++a) { nx += arC[NX + a] * duv[a]; if (lane == NX + a) zj = duv[a]; }
+      if (lane < NXU) dl += qjC * zj;
+      if (lane < NX) { ldsDx[lane] = nx; dxw[(k + 1) * NX + lane] = nx; ld += lam_out[(k + 1) * NX + lane] * dkC; }
+      else if (lane < NXU) duw[k * NU + (lane - NX)] = zj;
+      LFSD_STAGE_SYNC_GEN();
+#pragma unroll
+      for (int i = 0; i < NX; ++i) dxv[i] = ldsDx[i];
+      LFSD_STAGE_SYNC_GEN();
+    };
+    load(0, ar[0], qj[0], Kk[0], kk[0], dk[0]);
+    for (int k = 0; k < N; k += 2) {
+      stage(k, ar[0], qj[0], Kk[0], kk[0], dk[0], ar[1], qj[1], Kk[1], kk[1], dk[1]);
+      if (k + 1 < N) stage(k + 1, ar[1], qj[1], Kk[1], kk[1], dk[1], ar[0], qj[0], Kk[0], kk[0], dk[0]);
+    }
+    {
+      T xN[NX], hx[NX];
+#pragma unroll
+      for (int i = 0; i < NX; ++i) xN[i] = xbp(cur)[N * NX + i];
+      M::final_grad(this->tk(N), xN, e, c, hx);
+      if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < NX; ++i) dl += hx[i] * dxv[i];
+      }
+    }
+    const T D = wave_sum(dl);        // (its barriers also publish dxw / duw to every lane)
+    lamd = wave_sum(ld);
+    return D;
+  }
+  // The iterate  (xb, ub)[cur] + alpha (dxw, duw)  into buffer `nxt`: every interval integrated and linearised from its own node
+  // state, all intervals at once (lane <- (interval, column pair) as in linearise_parallel), its gaps into gapb[nxt].
+  // J: cost of the iterate (interval costs + final cost of its last node); g1 / gm: l1 norm / largest entry of its gaps.
+  // lamd: sum_k lambda_k+1^T d_k with the costates of the CURRENT iterate (lam_out: the multipliers the merit function holds fixed
+  // along a line search); g2: sum of squares of the gaps
+  LFSD_DEV void ms_trial(int cur, int nxt, T alpha, T& J, T& lamd, T& g2, T& g1, T& gm) {
+    T Jl = T(0), g1l = T(0), gml = T(0), ldl = T(0), g2l = T(0);
+    constexpr bool PK2 = sizeof(T) == 4;
+    constexpr int NCT = PK2 ? (NXU + 1) / 2 : NXU;
+    using V = typename std::conditional<PK2, pk2<T>, T>::type;
+    for (int t = lane; t < N * NCT; t += 64) {
+      const int k = t / NCT, c0 = PK2 ? 2 * (t % NCT) : (t % NCT), c1 = c0 + 1;
+      T x[NX], u[NU], q = T(0);
+      V m[NX], du[NU], mq = V(T(0));
+#pragma unroll
+      for (int i = 0; i < NX; ++i) {
+        x[i] = xbp(cur)[k * NX + i] + alpha * dxw[k * NX + i];
+        if constexpr (PK2) m[i] = mk2<T>((c0 == i) ? T(1) : T(0), (c1 == i) ? T(1) : T(0)); else m[i] = (c0 == i) ? T(1) : T(0);
+      }
+#pragma unroll
+      for (int a = 0; a < NU; ++a) {
+        u[a] = ubp(cur)[k * NU + a] + alpha * duw[k * NU + a];
+        if constexpr (PK2) du[a] = mk2<T>((c0 == NX + a) ? T(1) : T(0), (c1 == NX + a) ? T(1) : T(0)); else du[a] = (c0 == NX + a) ? T(1) : T(0);
+      }
+      if (c0 == 0) {
+#pragma unroll
+        for (int i = 0; i < NX; ++i) xbp(nxt)[k * NX + i] = x[i];
+#pragma unroll
+        for (int a = 0; a < NU; ++a) ubp(nxt)[k * NU + a] = u[a];
+      }
+      const T tt = this->tk(k);
+      for (int s = 0; s < S; ++s) this->template rk4_step<true, V>(tt, x, q, u, m, mq, du);
+      if constexpr (PK2) {
+        V* Mk = reinterpret_cast<V*>(Mwp(nxt) + (long long)k * Lay::M_ELEMS + c0);
+#pragma unroll
+        for (int i = 0; i < NX; ++i) Mk[i * (Lay::NXUP / 2)] = m[i];
+        Mk[NX * (Lay::NXUP / 2)] = mq;
+      } else {
+        T* Mk = Mwp(nxt) + (long long)k * Lay::M_ELEMS + c0;
+#pragma unroll
+        for (int i = 0; i < NX; ++i) Mk[i * Lay::NXUP] = m[i];
+        Mk[NX * Lay::NXUP] = mq;
+      }
+      if (c0 == 0) {
+        Jl += q;
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+          const T xn = xbp(cur)[(k + 1) * NX + i] + alpha * dxw[(k + 1) * NX + i];
+          const T g = x[i] - xn;
+          gapp(nxt)[k * NX + i] = g;
+          g1l += t_abs(g); g2l += g * g; ldl += lam_out[(k + 1) * NX + i] * g;
+          gml = (t_abs(g) > gml || !t_finite(g)) ? t_abs(g) : gml;
+          if (k == N - 1) xbp(nxt)[N * NX + i] = xn;
+        }
+        if (k == N - 1) {
+          T xN[NX];
+#pragma unroll
+          for (int i = 0; i < NX; ++i) xN[i] = xbp(cur)[N * NX + i] + alpha * dxw[N * NX + i];
+          Jl += M::final_cost(this->tk(N), xN, e, c);
+        }
+      }
+    }
+    J = wave_sum(Jl);
+    lamd = wave_sum(ldl);
+    g2 = wave_sum(g2l);
+    g1 = wave_sum(g1l);
+    gm = wave_max(gml);
+  }
+  // Cost and gap norm of the iterates at FOUR step lengths a0 2^-j, j = 0..3, without sensitivities: lane <- (interval,
+  // step length), 16 intervals per round.  J4 / g4: in every lane.
+  LFSD_DEV void ms_trial_alphas(int cur, T a0, T rho, T* phi4) {
+    T* ldsRed = lds + Lay::LDS_RED;
+    const int ia = lane & 3;
+    T alpha = a0;
+    for (int j = 0; j < ia; ++j) alpha *= T(0.5);
+    T Jl = T(0), dummy = T(0);
+    for (int k = lane >> 2; k < N; k += 16) {
+      T x[NX], u[NU], q = T(0);
+#pragma unroll
+      for (int i = 0; i < NX; ++i) x[i] = xbp(cur)[k * NX + i] + alpha * dxw[k * NX + i];
+#pragma unroll
+      for (int a = 0; a < NU; ++a) u[a] = ubp(cur)[k * NU + a] + alpha * duw[k * NU + a];
+      const T tt = this->tk(k);
+      for (int s = 0; s < S; ++s) this->template rk4_step<false>(tt, x, q, u, x, dummy, u);
+      Jl += q;
+#pragma unroll
+      for (int i = 0; i < NX; ++i) {
+        const T g = x[i] - (xbp(cur)[(k + 1) * NX + i] + alpha * dxw[(k + 1) * NX + i]);
+        Jl += lam_out[(k + 1) * NX + i] * g + T(0.5) * rho * g * g;       // (the merit function: J + lambda^T d + rho/2 |d|^2)
+      }
+      if (k == N - 1) {
+        T xN[NX];
+#pragma unroll
+        for (int i = 0; i < NX; ++i) xN[i] = xbp(cur)[N * NX + i] + alpha * dxw[N * NX + i];
+        Jl += M::final_cost(this->tk(N), xN, e, c);
+      }
+    }
+    ldsRed[lane] = Jl;
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { T r = T(0); for (int l = j; l < 64; l += 4) r += ldsRed[l]; phi4[j] = r; }
+    __syncthreads();
+  }
 };
 
 // Point a solver view at one trajectory: its LDS region, its scratch slot and its costate rows.  GL is the lane-group
@@ -2443,6 +2674,8 @@ __global__ void __launch_bounds__(64, 1) oc_solve_wide_kernel(OcArgs<T> a) {
   {
     T* w2 = a.ws + traj * a.ws_stride + Lay::template ws_elems<64>(N);
     s.xa = w2; s.ua = s.xa + (long long)NAL * (N + 1) * NX; s.exwu = s.ua + (long long)NAL * N * NU;
+    // the multiple-shooting iterate's gaps and Newton step live in the region of the parked step-length roll-outs (never in use together)
+    s.gapb[0] = s.xa; s.gapb[1] = s.xa + (long long)N * NX; s.dxw = s.xa + 2LL * N * NX; s.duw = s.dxw + (long long)(N + 1) * NX;
     T* le = s.lds + Lay::template lds_e<64>();
     T* lc = s.lds + Lay::template lds_c<64>();
     T* lx = s.lds + Lay::template lds_x0<64>();
@@ -2539,6 +2772,20 @@ __global__ void __launch_bounds__(64, 1) oc_solve_wide_kernel(OcArgs<T> a) {
   }
   s.adopt_alpha(0, 0);
   s.linearise_parallel(0);
+  // Multiple-shooting phase (OcWide::ms_*): from here the node states are variables of their own; every level of the mesh
+  // continuation starts it from a roll-out (no gaps), the last one ends it with a closed-loop roll-out (`ms_exit`) after which the
+  // single-shooting iteration below applies its convergence tests (`ms_check`: the cheap costate-only gradient test first).
+  // Not for solves that run Newton from their first iteration (exact_after == 0, the rocket): their steps are regularised Newton
+  // steps at Levenberg shifts of 10^2 - 10^4 through strongly curved attitude dynamics; the linear prediction of the node states
+  // then leaves gaps as large as the step closes, the line search settles on steps of 1/4, and the phase needs as many or more
+  // iterations than the closed-loop nonlinear roll-out while saving only the roll-outs' 20 % of an iteration (measured:
+  // DESIGN.md; -DLFSD_MS_NEWTON=1 switches it on there as well).
+  bool ms = !BND && (LFSD_MS) != 0 && a.n_grid >= (LFSD_MS_MIN_GRID) && a.max_iter > 8 && (a.exact_after != 0 || (LFSD_MS_NEWTON) != 0);
+  bool ms_exit = false, ms_check = false, ms_floor = false, gains_cur = false;
+  const bool ms_on = ms;
+  int n_short = 0, n_acc_need = 4;
+  T rho = T(0), g1c = T(0), g2c = T(0), gmc = T(0), gain_acc = T(0);
+  if (ms) { s.ms_zero_gaps(0); s.gap = s.gapp(0); }
   T mu = T(0);
   int mode = (EXACT && a.exact_after == 0) ? 2 : 0;
   bool ham_ok = true, hess_ok = false, gn_crawl = false, costates_ok = false;
@@ -2582,8 +2829,42 @@ __global__ void __launch_bounds__(64, 1) oc_solve_wide_kernel(OcArgs<T> a) {
       cur ^= 1;
       hess_ok = false; costates_ok = false;
       g_last = T(-1); dec_last = T(1e30); g_flat = T(-1); J_ref = J; n_acc = 0;
+      ms = ms_on; ms_exit = false; n_short = 0;
+      if (ms) { s.ms_zero_gaps(cur); s.gap = s.gapp(cur); g1c = T(0); g2c = T(0); gmc = T(0); gains_cur = false; gain_acc = T(0); }      // (a roll-out: the new level starts without gaps)
       if (!t_finite(J)) { if (coarse) { relin = true; continue; } status = ST_FAILED; break; }      // (the mid level cannot integrate it: the reference's grid decides)
       continue;
+    }
+    if (ms && (ms_exit || it + 3 >= a.max_iter)) {
+      // end of the multiple-shooting phase: closed-loop roll-outs of the 16 step lengths around the node states (the gains and the
+      // feed-forward of the last sweep; open loop when there is no sweep of this iterate) close the gaps by construction; the
+      // cheapest one becomes the single-shooting nominal.  An iteration without a sweep.
+      const T Jc = s.rollout_alphas(cur, gains_cur, alpha_l);
+      ldsRed[s.lane] = Jc;
+      __syncthreads();
+      int ic = -1;
+      T Jb = T(0);
+      for (int l = 0; l < NAL; ++l) { const T Jl = ldsRed[l]; if (t_finite(Jl) && (ic < 0 || Jl < Jb)) { ic = l; Jb = Jl; } }
+      __syncthreads();
+      ms = false; ms_exit = false; s.gap = nullptr;
+      if (ic < 0) { status = ST_FAILED; break; }
+      s.adopt_alpha(ic, cur ^ 1);
+      s.linearise_parallel(cur ^ 1);
+      cur ^= 1;
+      J = Jb;
+      hess_ok = false; costates_ok = false;
+      g_last = T(-1); dec_last = T(1e30); g_flat = T(-1); J_ref = J; n_acc = 0;
+      ms_check = true;
+#if defined(LFSD_TRACE)
+      if (s.lane == 0 && traj == 0) printf("wide it %d: multiple-shooting phase closed with step length index %d, J %.12e\n", it, ic, (double)J);
+#endif
+      continue;
+    }
+    if (ms_check) {
+      // first test after the hand-over: the gradient of the closed trajectory from a costate sweep alone (no gains, no Hessians)
+      ms_check = false;
+      const T gn = s.costate_sweep(cur);
+      costates_ok = true;
+      if (gn < a.tol * (T(1) + t_abs(J))) { gnorm = gn; if (coarse) { relin = true; continue; } status = ST_CONVERGED; break; }
     }
     if (EXACT && a.exact_after >= 0 && mode < 2 && (it >= a.exact_after || gn_crawl)) mode = 2;
     if (EXACT && mode == 2 && !hess_ok) {
@@ -2606,10 +2887,131 @@ __global__ void __launch_bounds__(64, 1) oc_solve_wide_kernel(OcArgs<T> a) {
       }
       continue;
     }
+    gains_cur = true;
+    if (ms) {
+      // ---- one multiple-shooting step (OcWide::ms_*) ---------------------------------------------------------------------
+      const T epsT = Eps<T>::v();
+      const T lam_mx = s.lam_max;
+      // stationary and the gaps closed to the resolution of the cost (a gap d costs lambda^T d to first order): this level is done
+      if (gnorm < a.tol * (T(1) + t_abs(J)) && lam_mx * g1c <= T(8) * epsT * (T(1) + t_abs(J))) {
+        if (coarse) relin = true; else { ms_exit = true; ms_floor = true; }
+        continue;
+      }
+      T lamd0;
+      const T Dlin = s.ms_forward(cur, lamd0);
+      // merit function of this line search:  m = J + lambda^T d + rho/2 |d|^2  with the costates of this iterate held fixed (the
+      // augmented Lagrangian of the lifted NLP: lambda^T d is what closing the gaps costs to first order).  The linearised gaps of
+      // the Newton step close in proportion to the step length, so  m'(0) = Dlin - lambda^T d - rho |d|^2.
+      rho = t_max(lam_mx, T(1));      // (per line search: the multipliers shrink by orders of magnitude on the way from a cold start)
+      const T dl0 = Dlin - lamd0;
+      if (g2c > T(0) && !(dl0 - rho * g2c < T(-0.5) * rho * g2c)) rho = T(4) * t_abs(dl0) / g2c;
+      const T pred = rho * g2c - dl0;                  // first-order decrease of the merit function along the full step
+      const T phi0 = J + lamd0 + T(0.5) * rho * g2c;
+      const T flat = T(8) * epsT * t_abs(phi0);
+      if (!t_finite(pred) || !(pred > T(2) * epsT * t_abs(phi0))) {
+        // nothing the merit function can resolve is left to gain here (or the direction is no descent direction of it)
+        if (coarse) relin = true; else { ms_exit = true; ms_floor = t_finite(pred); }
+        continue;
+      }
+      T Jt, ldt, g2t, g1t, gmt;
+      s.ms_trial(cur, cur ^ 1, T(1), Jt, ldt, g2t, g1t, gmt);
+      T phit = Jt + ldt + T(0.5) * rho * g2t, alpha_t = T(1), phimin = phi0;
+      const bool flat_full = t_finite(phit) && t_abs(phit - phi0) <= T(64) * epsT * t_abs(phi0);
+      bool accept = t_finite(phit) && (phi0 - phit) >= T(1e-4) * pred - flat && phit < phi0;
+      if (t_finite(phit)) phimin = t_min(phimin, phit);
+      int ia = accept ? 0 : -1;
+      if (!accept) {
+        // shorter steps along the same (linear) direction: four step lengths per round, no sensitivities; then the chosen one with them
+        T a0 = T(0.5);
+        for (int round = 0; round < 2 && ia < 0; ++round) {
+          T p4[4], aa = a0;
+          s.ms_trial_alphas(cur, a0, rho, p4);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const T pj = p4[j];
+            if (t_finite(pj)) phimin = t_min(phimin, pj);
+            if (ia < 0 && t_finite(pj) && (phi0 - pj) >= T(1e-4) * aa * pred - flat && pj < phi0) { ia = 1 + 4 * round + j; alpha_t = aa; }
+            aa *= T(0.5);
+          }
+          a0 *= T(0.0625);
+        }
+        if (ia >= 0) {
+          s.ms_trial(cur, cur ^ 1, alpha_t, Jt, ldt, g2t, g1t, gmt);
+          phit = Jt + ldt + T(0.5) * rho * g2t;
+          accept = t_finite(phit) && phit < phi0 + flat;
+          if (!accept) ia = -1;
+        }
+      }
+      if (!accept) {
+        if (mode >= 1 && flat_full && (g_flat < T(0) || gnorm < T(0.7) * g_flat)) {
+          if (ia != 0) { s.ms_trial(cur, cur ^ 1, T(1), Jt, ldt, g2t, g1t, gmt); phit = Jt + ldt + T(0.5) * rho * g2t; }
+          accept = t_finite(phit); ia = 0; alpha_t = T(1); g_flat = gnorm;      // Newton-like step below rounding noise, gradient still contracting
+        } else if (mode == 1 && !LFSD_HAM_SHIFT) {
+          mode = 0; ham_ok = false;
+        } else if (mu > T(1e10) || ((phi0 - phimin) <= T(8) * epsT * t_abs(phi0) && (mode == 0 || flat_full || mu > T(1e6)))) {
+          if (coarse) relin = true; else ms_exit = true;
+        } else {
+          mu_bad = mu; mu_hold = 0;
+          mu = t_max(mu * T(LFSD_MU_UP), mode == 2 ? T(1e-4) : T(1e-6));
+        }
+      }
+#if defined(LFSD_TRACE)
+      if (s.lane == 0 && traj == 0) printf("wide ms it %d mode %d g %.6e J %.12e gap1 %.4e gapmax %.3e lam %.3e rho %.3e phi0 %.10e pred %.4e ia %d alpha %g accept %d mu %g -> J %.12e gap1 %.4e phi %.10e\n", it, mode, (double)gnorm, (double)J, (double)g1c, (double)gmc, (double)lam_mx, (double)rho, (double)phi0, (double)pred, ia, (double)alpha_t, (int)accept, (double)mu, (double)Jt, (double)g1t, (double)phit);
+#endif
+      if (accept) {
+        const T mu_taken = mu;
+        const T gain = phi0 - phit;
+        cur ^= 1;
+        s.gap = s.gapp(cur);
+        gains_cur = false;
+        g_last = gnorm; dec_last = T(1e30);
+        hess_ok = false; costates_ok = false;
+        if (ia == 0) {
+          const T mu_next = (mu > T(1e-8)) ? mu * T(LFSD_MU_DOWN) : T(0);
+          if (mu > T(0) && mu_bad >= T(0) && mu_next <= mu_bad && mu_hold < mu_hold_need) ++mu_hold;
+          else { mu = mu_next; mu_hold = 0; }
+          if (mode == 0 && ham_ok && gain < T(LFSD_HAM_SWITCH) * t_abs(Jt)) mode = 1;
+          else if (LFSD_GN_CRAWL && mode == 0 && !ham_ok && gain < T(1e-2) * t_abs(Jt)) gn_crawl = true;
+        } else if (gain < T(0.1) * t_abs(Jt)) {
+          // a SHORT step of little gain: here a full step is worth more than in single shooting -- it closes the linearised gaps
+          // entirely, a short one leaves (1 - alpha) of them and adds those of its own nonlinearity -- so the answer to a model
+          // that needed its step cut is a larger Levenberg shift (a more damped, shorter direction), as a trust region would
+          mu_bad = mu; mu_hold = 0;
+          mu = t_max(mu * T(LFSD_MU_UP), mode == 2 ? T(1e-4) : T(1e-6));
+        }
+        if (coarse && gain < T(LFSD_COARSE_SWITCH) * t_abs(Jt)) {
+          if ((LFSD_COARSE_EXIT_RULE) == 0 || ((LFSD_COARSE_EXIT_RULE) == 1 && ia == 0) ||
+              ((LFSD_COARSE_EXIT_RULE) == 2 && ia == 0 && mu_taken <= T(LFSD_COARSE_EXIT_MU))) relin = true;
+        }
+        J = Jt; g1c = g1t; g2c = g2t; gmc = gmt;
+        // The linear forward pass predicts the node states; where the dynamics bend more than that prediction allows (the rocket's
+        // attitude under aggressive controls) the trial's gaps grow as fast as the step closes them and the line search settles on
+        // short steps -- iterations the closed-loop NONLINEAR roll-out of the single-shooting iteration does not need.  A run of
+        // accepted short steps that each gain less than 2 % of the cost ends the phase on this level (the next level of the mesh
+        // continuation starts it again); short steps that halve the cost of a cold start are not that pattern.
+        n_short = (ia == 0) ? 0 : ((gain < T(0.02) * t_abs(Jt)) ? n_short + 1 : n_short);
+        if (n_short >= (LFSD_MS_SHORT_STEPS)) ms_exit = true;
+        // (the merit function changes with its multipliers from one line search to the next: the stall test sums the gains instead)
+        gain_acc += gain;
+        if (++n_acc >= 4) {
+          if (gain_acc <= T(16) * epsT * t_abs(phit)) { if (coarse) relin = true; else ms_exit = true; }
+          gain_acc = T(0); n_acc = 0;
+        }
+      }
+      continue;
+    }
     if (gnorm < a.tol * (T(1) + t_abs(J))) { if (coarse) { relin = true; continue; } status = ST_CONVERGED; break; }
     if (at_working_precision(mode, mu, gnorm, g_last, dec_last, dV1, dV2, J, a.tol)) {
       if (coarse) { relin = true; continue; }
       status = ST_STALLED; ++it; break;      // (this iteration's sweep counts)
+    }
+    // first sweep after a multiple-shooting phase that ended because its Newton step could gain nothing the (merit) function
+    // resolves: when the Newton-like step of the closed trajectory predicts a decrease below the resolution of the cost as well,
+    // ONE accepted step that gains nothing the cost resolves ends the solve as "at working precision" (the rule below waits for
+    // four; flat problems -- pendulum, robot arm -- keep their gradient tests: no step is skipped on the prediction alone)
+    if (ms_floor) {
+      ms_floor = false;
+      if (mode >= 1 && mu == T(0) && -(dV1 + dV2) <= T(2) * Eps<T>::v() * t_abs(J)) n_acc_need = 1;
     }
     // all step lengths at once; the largest one that passes the Armijo test is taken
     T Ja;
@@ -2675,9 +3077,9 @@ __global__ void __launch_bounds__(64, 1) oc_solve_wide_kernel(OcArgs<T> a) {
             ((LFSD_COARSE_EXIT_RULE) == 2 && ia == 0 && mu_taken <= T(LFSD_COARSE_EXIT_MU))) relin = true;
       }
       J = Jn;
-      if (++n_acc >= 4) {
+      if (++n_acc >= n_acc_need) {
         if (J_ref - J <= T(16) * Eps<T>::v() * t_abs(J)) { if (coarse) relin = true; else status = ST_STALLED; }
-        J_ref = J; n_acc = 0;
+        J_ref = J; n_acc = 0; n_acc_need = 4;
       }
     }
   }
@@ -2712,15 +3114,16 @@ template <typename Tag> __global__ void cast_kernel(CastArgs a) {
 }
 
 // controls of the fp32 solve [B][N+1][NU] -> initial guess of the fp64 solve [B][N][NU]; a trajectory the fp32 solve FAILED
-// on (or whose cost is not finite) gets the all-zero row, which the kernels read as "cold start" (mesh continuation and all)
-struct SeedArgs { const float* u32; const float* cost32; const int* status32; double* u0; int batch, n_grid, nu; };
+// on (or whose cost is not finite) gets the caller's own row (`uc`, may be NULL) or else the all-zero row, which the kernels read
+// as "cold start" (mesh continuation and all)
+struct SeedArgs { const float* u32; const float* cost32; const int* status32; const double* uc; double* u0; int batch, n_grid, nu; };
 template <typename Tag> __global__ void seed_controls_kernel(SeedArgs a) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const long long row = (long long)a.n_grid * a.nu;
   if (i >= (long long)a.batch * row) return;
   const long long b = i / row, j = i % row;
   const bool usable = a.status32[b] != ST_FAILED && t_finite(a.cost32[b]);
-  a.u0[i] = usable ? (double)a.u32[b * (row + a.nu) + j] : 0.0;
+  a.u0[i] = usable ? (double)a.u32[b * (row + a.nu) + j] : (a.uc ? a.uc[i] : 0.0);
 }
 
 struct AddItersArgs { int* iters; const int* more; int batch; };

@@ -75,7 +75,7 @@ static bool seeded_f64(int dtype, int batch, int exact_after, int mapping, bool 
 }
 // staging area behind the fp64 scratch (byte offsets from its end, 256-byte aligned)
 struct SeedLayout {
-  size_t ws32, x0, hz, th, cs, xs, us, ls, cost, it, st, u0, end;
+  size_t ws32, x0, hz, th, cs, xs, us, ls, cost, it, st, u0, ui, end;
   SeedLayout(int batch, int n_grid, int const_rows) {
     const size_t B = (size_t)batch, N1 = (size_t)n_grid + 1;
     size_t o = 0;
@@ -86,6 +86,7 @@ struct SeedLayout {
     xs = take(B * N1 * Model::NX * 4); us = take(B * N1 * Model::NU * 4); ls = take(B * N1 * Model::NX * 4);
     cost = take(B * 4); it = take(B * 4); st = take(B * 4);
     u0 = take(B * (size_t)n_grid * Model::NU * 8);
+    ui = take(B * (size_t)n_grid * Model::NU * 4);      // the caller's initial guess in fp32 (rows of zeros = cold start)
     end = o; (void)const_rows;
   }
   size_t total(size_t f64_bytes) const { return (f64_bytes + 255) / 256 * 256 + end; }
@@ -105,9 +106,9 @@ LFSD_API size_t lfsd_coc_workspace_bytes(int dtype, int batch, int n_grid, int e
 }
 
 static int coc_solve_seeded(int batch, int n_grid, int steps_per_grid, const void* ini_state, const void* horizon,
-                            const void* auxvar, const void* consts, int const_per_traj, void* state_grid, void* control_grid,
-                            void* costate_grid, void* cost, int* iters, int* status, int max_iter, double tol, int exact_after,
-                            int mapping, void* workspace, size_t workspace_bytes, void* stream);
+                            const void* auxvar, const void* consts, int const_per_traj, const void* u_init, void* state_grid,
+                            void* control_grid, void* costate_grid, void* cost, int* iters, int* status, int max_iter, double tol,
+                            int exact_after, int mapping, void* workspace, size_t workspace_bytes, void* stream);
 
 template <typename T>
 static int coc_solve_t(int batch, int n_grid, int steps_per_grid, const void* ini_state, const void* horizon,
@@ -118,8 +119,12 @@ static int coc_solve_t(int batch, int n_grid, int steps_per_grid, const void* in
                        int max_iter, double tol, int exact_after, int mapping, void* workspace, size_t workspace_bytes,
                        void* stream, int start_mode = 0) {
   if constexpr (sizeof(T) == 8) {
-    if (!u_init && seeded_f64(LFSD_F64, batch, exact_after, mapping, control_lb != nullptr))
-      return coc_solve_seeded(batch, n_grid, steps_per_grid, ini_state, horizon, auxvar, consts, const_per_traj, state_grid,
+    // (start_mode 1 marks the fp64 half of a seeded solve: it must not seed itself again)
+    // (and a caller-held workspace sized while LFSD_F64_SEED=0 was in the environment has no staging area: that solve runs
+    //  unseeded instead of failing with LFSD_ENOSPC -- the seed changes the path to the KKT point, not the point)
+    if (start_mode == 0 && seeded_f64(LFSD_F64, batch, exact_after, mapping, control_lb != nullptr) &&
+        workspace_bytes >= SeedLayout(batch, n_grid, 1).total((size_t)padded_batch(batch) * (size_t)lfsd::OcLayout<Model>::template ws_elems<G>(n_grid) * 8))
+      return coc_solve_seeded(batch, n_grid, steps_per_grid, ini_state, horizon, auxvar, consts, const_per_traj, u_init, state_grid,
                               control_grid, costate_grid, cost, iters, status, max_iter, tol, exact_after, mapping, workspace,
                               workspace_bytes, stream);
   }
@@ -174,10 +179,13 @@ static int coc_solve_t(int batch, int n_grid, int steps_per_grid, const void* in
   return launch_status();
 }
 
+// `u_init` (may be NULL): the caller's initial guess.  The fp32 solve starts from it too -- an all-zero row is a cold start for both
+// kernels, so a learner that hands zeros for every row but the ones it continues (SparseDemoLearner with skip_unconverged) gets
+// every row seeded -- and a row the fp32 solve failed on starts the fp64 kernel from the caller's row.
 static int coc_solve_seeded(int batch, int n_grid, int steps_per_grid, const void* ini_state, const void* horizon,
-                            const void* auxvar, const void* consts, int const_per_traj, void* state_grid, void* control_grid,
-                            void* costate_grid, void* cost, int* iters, int* status, int max_iter, double tol, int exact_after,
-                            int mapping, void* workspace, size_t workspace_bytes, void* stream) {
+                            const void* auxvar, const void* consts, int const_per_traj, const void* u_init, void* state_grid,
+                            void* control_grid, void* costate_grid, void* cost, int* iters, int* status, int max_iter, double tol,
+                            int exact_after, int mapping, void* workspace, size_t workspace_bytes, void* stream) {
   const size_t f64_bytes = (size_t)padded_batch(batch) * (size_t)lfsd::OcLayout<Model>::template ws_elems<G>(n_grid) * 8;
   const SeedLayout L(batch, n_grid, 1);
   if (workspace_bytes < L.total(f64_bytes)) return LFSD_ENOSPC;
@@ -190,17 +198,18 @@ static int coc_solve_seeded(int batch, int n_grid, int steps_per_grid, const voi
   cast(horizon, base + L.hz, batch, 1);
   cast(auxvar, base + L.th, (long long)batch * Model::NP, 1);
   if (consts) cast(consts, base + L.cs, const_per_traj ? (long long)batch * Model::NC : (long long)Model::NC, 1);
+  if (u_init) cast(u_init, base + L.ui, (long long)batch * n_grid * Model::NU, 1);
   int rc = launch_status();
   if (rc) return rc;
   const double tol32 = tol > 1e-6 ? tol : 1e-6;      // (runtime.py's default for an fp32 solve)
   rc = coc_solve_t<float>(batch, n_grid, steps_per_grid, base + L.x0, base + L.hz, base + L.th, consts ? base + L.cs : nullptr,
-                          const_per_traj, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0.0, base + L.xs, base + L.us,
+                          const_per_traj, u_init ? base + L.ui : nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0.0, base + L.xs, base + L.us,
                           base + L.ls, base + L.cost, (int*)(base + L.it), (int*)(base + L.st), max_iter, tol32, exact_after,
                           LFSD_MAP_LOCKSTEP, base + L.ws32, L.x0 - L.ws32, stream);
   if (rc) return rc;
   {
-    lfsd::SeedArgs sa{(const float*)(base + L.us), (const float*)(base + L.cost), (const int*)(base + L.st), (double*)(base + L.u0),
-                      batch, n_grid, Model::NU};
+    lfsd::SeedArgs sa{(const float*)(base + L.us), (const float*)(base + L.cost), (const int*)(base + L.st), (const double*)u_init,
+                      (double*)(base + L.u0), batch, n_grid, Model::NU};
     const long long n = (long long)batch * n_grid * Model::NU;
     LFSD_LAUNCH(lfsd::seed_controls_kernel<void>, (unsigned)((n + 255) / 256), 256, stream, sa);
   }
@@ -271,7 +280,7 @@ static int aux_phase_t(int phases, int batch, int n_grid, const void* horizon, c
   // a fixed learning rate has driven to parameters of 1e14 refined EVERY interval to the cap (8 864 units against the 565 of
   // a well-posed robot-arm row: Riccati launch 35 ms against 2.1, profiles/r04_l_steps_robotarm_fast_trig.txt); what they
   // return is flagged in `stats`.  Converged rows are never budgeted (a stiff last interval alone may need thousands of units).
-  a.unit_budget = (int)std::min<long long>(64LL * n_grid * a.substeps * (long long)tight, 1LL << 30);
+  a.unit_budget = (int)std::min<double>(64.0 * n_grid * a.substeps * tight, (double)(1LL << 30));      // (in double: the fourth-root factor must not truncate to 1)
   a.horizon = (const T*)horizon; a.auxvar = (const T*)auxvar;
   a.consts = consts ? (const T*)consts : (const T*)horizon;
   a.const_stride = (consts && const_per_traj) ? Model::NC : 0;

@@ -602,8 +602,8 @@ def test_state_bounds_vs_independent_bounded_solve(emu):
 
 
 def test_aux_pass_skips_rows_by_oc_status(emu):
-    """ABI 8: rows whose OC-solve status is in `skip_status` are not differentiated -- NaN loss / gradient, zero stats, their
-    Z_grid rows untouched -- and every other row is bit-identical to the unskipped call (Examples/robotarm_random.py:60-73
+    """ABI 8: rows whose OC-solve status is in `skip_status` are not differentiated -- NaN loss / gradient / [P W] / dx/dtheta /
+    du/dtheta rows (never what the caller's buffers happened to hold), zero stats -- and every other row is bit-identical to the unskipped call (Examples/robotarm_random.py:60-73
     applies every gradient; a learner that freezes unconverged rows does not pay for their sweeps)."""
     oc, env, d = models.pendulum(n_grid=10)
     emu(oc)
@@ -618,8 +618,11 @@ def test_aux_pass_skips_rows_by_oc_status(emu):
     st[1], st[3] = 4, 3                            # pretend: row 1 failed, row 3 ran out of iterations
     sol2["status"] = st
     Z = torch.full_like(ref_Z, 7.0)
-    a4 = oc.auxSysSolverBatch(sol2, taus, wps, d["interface"], Z_grid=Z)             # default: FAILED rows only
-    assert torch.isnan(a4["loss"][1]) and torch.isnan(a4["grad"][1]).all() and bool((a4["Z_grid"][1] == 7.0).all())
+    keep0 = [0, 2, 3, 4]
+    a4 = oc.auxSysSolverBatch(sol2, taus, wps, d["interface"], Z_grid=Z, want_grids=True)             # default: FAILED rows only
+    assert torch.isnan(a4["loss"][1]) and torch.isnan(a4["grad"][1]).all() and bool(torch.isnan(a4["Z_grid"][1]).all())
+    assert bool(torch.isnan(a4["auxX_grid"][1]).all()) and bool(torch.isnan(a4["auxU_grid"][1]).all())
+    assert bool(torch.isfinite(a4["auxX_grid"][keep0]).all()) and bool(torch.isfinite(a4["auxU_grid"][keep0]).all())
     assert a4["stats"][1].tolist() == [0, 0, 0, 0]
     keep = [0, 2, 3, 4]
     assert torch.equal(a4["loss"][keep], ref_l[keep]) and torch.equal(a4["grad"][keep], ref_g[keep])

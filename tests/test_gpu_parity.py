@@ -278,6 +278,43 @@ def test_bench_two_ranks_share_theta_through_the_allreduce(backend):
     assert np.abs(np.array(out["config"]["theta"]) - th).max() < 1e-10 * np.abs(th).max(), (out["config"]["theta"], th.tolist())
 
 
+def test_rccl_one_rank_allreduce_of_the_summed_gradient_is_bit_identical():
+    """First RCCL bytes on the box's one GPU: `python -m torch.distributed.run --nproc-per-node 1 bench.py --gpus 1 --mode shared
+    --backend nccl` as a FRESH child (this pytest process has touched the GPU; nothing is re-executed from it).  Under a launcher
+    bench.py initialises the process group whatever the world size, and SparseDemoLearner.step takes the all-reduce branch whenever a
+    group is initialised (CPDP.py `torch.distributed.all_reduce(buf, group=self.pg)`): RCCL loads, creates a communicator on the
+    device and reduces the p+2 numbers (summed d(theta), loss, masked-row count) every outer iteration.  A one-rank sum must leave the
+    buffer unchanged, so theta after warmup + steps iterations equals -- bit for bit -- the same command without a process group."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    argv = ["--gpus", "1", "--mode", "shared", "--backend", "nccl", "--batch", "256", "--steps", "2", "--warmup", "1", "--dtype", "f64",
+            "--no-cpu-baseline"]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR"):
+        env.pop(k, None)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    launcher = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                "--master-port", str(port)]
+    outs = []
+    for cmd in (launcher + [os.path.join(root, "bench.py")] + argv, [sys.executable, os.path.join(root, "bench.py")] + argv):
+        r = subprocess.run(cmd, capture_output=True, text=True, env=dict(env, NCCL_DEBUG="VERSION"), timeout=900)
+        assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-3000:])
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        assert len(lines) == 1, r.stdout[-2000:]
+        outs.append((json.loads(lines[0]), r.stdout + r.stderr))
+    (with_pg, log_pg), (without, _) = outs
+    assert with_pg["n_gpus"] == 1 and with_pg["config"]["mode"] == "shared" and with_pg["config"]["process_group"] == "nccl"
+    assert without["config"]["process_group"] is None
+    assert "RCCL" in log_pg or "NCCL version" in log_pg, log_pg[-2000:]          # the communicator really came up (NCCL_DEBUG=VERSION banner)
+    assert with_pg["config"]["n_unconverged_last_step"] == 0
+    assert with_pg["config"]["theta"] == without["config"]["theta"], (with_pg["config"]["theta"], without["config"]["theta"])
+
+
 def test_shared_theta_gradient_is_sum_over_demonstrations():
     oc, d = gpu_model("pendulum", torch.float64, 10, substeps=8)
     B = 37                                            # ragged: not a multiple of the 8 groups per wavefront
@@ -511,8 +548,9 @@ def test_robotarm_theta1_vs_oracle_16_seeds():
         else:
             # next to a conjugate point the fp32 gradient is a property of the rounding, not of the kernel: the SAME seed measured
             # 0.27 (round 3), 0.45 and 0.66 (round 4, after sin / cos changed by an ulp) against a bound of 0.7.  Asserted per
-            # seed the figure is only recorded; the class is asserted through its median and its 80th percentile (below)
-            parity_record("robot arm theta1 seed %d fp32 vs oracle (large sensitivity)" % b, "grad (recorded)", e32, 1e9)
+            # seed a finite cap of 1.0 -- an fp32 gradient that is off by more than its own size is a regression whatever the
+            # conditioning --; the class is asserted through its median and its 80th percentile (below)
+            parity_record("robot arm theta1 seed %d fp32 vs oracle (large sensitivity)" % b, "grad", e32, 1.0)
             large_err.append(e32)
     assert compared >= 16, compared
     assert len(large_err) >= 6

@@ -17,6 +17,8 @@ args = bench.parse_args(["--config", cfg, "--no-cpu-baseline"])
 w = bench.WORKLOADS[cfg]
 TD = {"f32": torch.float32, "f64": torch.float64}
 oc, env, d = models.ZOO[w["kind"]](n_grid=args.n_grid)
+if os.environ.get("LFSD_TOOL_LIBRARY"):      # a build variant (tools/model_ab.py build <model> <tag> ...): csrc/build/trace_<hash>_<tag>.so
+    oc.use_library(os.environ["LFSD_TOOL_LIBRARY"])
 oc.setDevice("cuda:0", TD[args.dtype], aux_dtype=TD[w["aux_dtype"]] if w["aux_dtype"] else None)
 lib = oc.compile()
 d = dict(d)

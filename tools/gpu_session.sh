@@ -7,7 +7,7 @@
 #   configs  bench.py --config robotarm / rocket: lines with CPU legs + their evidence sets
 #   f64      the same for bench.py --dtype f64
 #   ab       tools/ab_variants.py run <names...>   (variants built beforehand with `ab_variants.py build`)
-S=${1:-quick}; TAG=${2:-r04_$S}; OUT=gpurun_out/$TAG
+S=${1:-quick}; TAG=${2:-r05_$S}; OUT=gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
 line() { python3 -c "
@@ -49,6 +49,20 @@ final)        # the round's closing record: evidence sets (headline, fp64, the t
   python3 bench.py --batch 32768 --steps 3 --warmup 1 --dtype f64 --no-cpu-baseline > $OUT/bench_f64_32768.json 2> /dev/null; line $OUT/bench_f64_32768.json
   python3 bench.py --mode shared --no-cpu-baseline > $OUT/bench_shared_one_gpu.json 2> /dev/null; line $OUT/bench_shared_one_gpu.json
   bash tools/gpu_session.sh tier ${TAG}_tier ;;
+ms)           # round 5: the multiple-shooting phase of the wide kernel, product vs variants (tools/model_ab.py build robotarm noms -DLFSD_MS=0; ... rocket msnewton -DLFSD_MS_NEWTON=1)
+  vp() { python3 -c "
+import sys; sys.path.insert(0,'tools'); import oc_trace
+from lfsd_amd import models
+print(oc_trace.variant_path(models.ZOO[sys.argv[1]]()[0].model_spec(), sys.argv[2]))" $1 $2; }
+  for c in robotarm rocket; do
+    python3 bench.py --config $c --steps 5 --warmup 1 --no-cpu-baseline > $OUT/bench_$c.json 2> $OUT/bench_$c.err; line $OUT/bench_$c.json
+  done
+  python3 bench.py --config robotarm --steps 5 --warmup 1 --no-cpu-baseline --library $(vp robotarm noms) > $OUT/bench_robotarm_noms.json 2> $OUT/bench_robotarm_noms.err; line $OUT/bench_robotarm_noms.json
+  python3 bench.py --config rocket --steps 5 --warmup 1 --no-cpu-baseline --library $(vp rocket msnewton) > $OUT/bench_rocket_msnewton.json 2> $OUT/bench_rocket_msnewton.err; line $OUT/bench_rocket_msnewton.json
+  python3 tools/config_steps.py robotarm 6 > $OUT/steps_robotarm.txt 2>&1; cat $OUT/steps_robotarm.txt
+  LFSD_TOOL_LIBRARY=$(vp robotarm noms) python3 tools/config_steps.py robotarm 6 > $OUT/steps_robotarm_noms.txt 2>&1; cat $OUT/steps_robotarm_noms.txt
+  LFSD_PARITY_REPORT=$PWD/$OUT/parity_floors.jsonl timeout 2400 python3 -m pytest tests -m gpu -q -k "${K:-robotarm or rccl or rocket or two_ranks}" > $OUT/pytest_gpu.txt 2>&1
+  tail -15 $OUT/pytest_gpu.txt ;;
 ab)
   shift; shift; python3 tools/ab_variants.py run "$@" > $OUT/ab.txt 2>&1; cat $OUT/ab.txt ;;
 *) echo "unknown session $S"; exit 2 ;;
