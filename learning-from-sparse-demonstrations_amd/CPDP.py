@@ -431,6 +431,13 @@ class COCSys:
         """CPDP.py:301-381: returns auxsys_sol(t) -> [vec(dx/dtheta) (n*p, row-major), vec(du/dtheta) (m*p)]."""
         lib = self.compile()
         n, m, p = lib.n_state, lib.n_control, lib.n_auxvar
+        # The reference integrates the auxiliary ODEs along WHATEVER interpolant it is handed (CPDP.py:320, 347); the sweeps here
+        # differentiate along the LINEAR interpolant of the grid values (interplation_level 1, what every example uses).  A cubic
+        # opt_sol (cocSolver(..., interplation_level=2), CPDP.py:388-390) would silently be resampled to that -- refuse it instead.
+        kind = getattr(opt_sol, "_kind", None)
+        if kind is not None and kind not in ("linear", 1):
+            raise LfsdError("auxSysSolver: opt_sol is a %r interpolant; the HIP sweeps integrate along the linear interpolant of the "
+                            "grid (interplation_level=1, CPDP.py:386) only" % (kind,))
         time_grid = np.asarray(time_grid, dtype=np.float64)
         N = len(time_grid) - 1
         g = np.asarray(opt_sol(time_grid), dtype=np.float64)

@@ -26,7 +26,7 @@ import hashlib
 import sympy as sp
 from sympy.printing.c import C99CodePrinter
 
-CODEGEN_VERSION = 16
+CODEGEN_VERSION = 17
 
 
 class ModelSpec:
@@ -373,9 +373,11 @@ def emit_header(spec):
     y2x = fx.T * V2
     y2u = fu.T * V2
     vin = [(s_, 'v1[%d]' % i) for i, s_ in enumerate(V1)] + [(s_, 'v2[%d]' % i) for i, s_ in enumerate(V2)] + [(W1, 'w1')]
-    S.append('  template<class T> static LFSD_DEV void dyn_vjp2(%s, const T* v1, T w1, const T* v2, T* y1x, T* y2x, T* y2u) {' % sig_xu)
+    # (V as in dyn_cost_jvp: the tangent v2 and its two products may be packed pairs; v1, w1, y1x are group-uniform scalars)
+    S.append('  template<class T, class V> static LFSD_DEV void dyn_vjp2(%s, const T* v1, T w1, const V* v2, T* y1x, V* y2x, V* y2u) {' % sig_xu)
     S.append(_body(_loads(spec) + vin, [('y1x[%d]' % i, y1x[i]) for i in range(n)] +
-                   [('y2x[%d]' % i, y2x[i]) for i in range(n)] + [('y2u[%d]' % i, y2u[i]) for i in range(m)]))
+                   [('y2x[%d]' % i, y2x[i]) for i in range(n)] + [('y2u[%d]' % i, y2u[i]) for i in range(m)],
+                   vec=list(V2), vec_out=lambda lv: lv.startswith('y2x[') or lv.startswith('y2u[')))
     S.append('  }')
     # 3. final cost
     sig_x = 'T t, const T* x, const T* e, const T* c'
@@ -414,9 +416,10 @@ def emit_header(spec):
     yx = Hxx * dX + Hxu * dU
     yu = Hxu.T * dX + Huu * dU
     S.append('  // yx = Hxx*dx + Hxu*du ; yu = Hux*dx + Huu*du   (H = c + l.f, CPDP.py:218)')
-    S.append('  template<class T> static LFSD_DEV void ham_hess_mul(%s, const T* dx, const T* du, T* yx, T* yu) {' % sig_xul)
+    S.append('  template<class T, class V> static LFSD_DEV void ham_hess_mul(%s, const V* dx, const V* du, V* yx, V* yu) {' % sig_xul)
     S.append(_body(_loads(spec, with_l=True) + tang, [('yx[%d]' % i, yx[i]) for i in range(n)] +
-                   [('yu[%d]' % i, yu[i]) for i in range(m)]))
+                   [('yu[%d]' % i, yu[i]) for i in range(m)],
+                   vec=[s_ for s_, _ in tang], vec_out=lambda lv: True))
     S.append('  }')
     # 4b. the control block of the Hamiltonian Hessian alone (dense, row-major): the MFMA backward sweep of the 16-lane
     #     mapping gets the columns no lane owns from the symmetry of H and needs only their diagonal block on top

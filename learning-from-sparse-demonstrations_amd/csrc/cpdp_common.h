@@ -253,6 +253,11 @@
 #define LFSD_MS_MIN_GRID 40
 #endif
 // ... consecutive accepted SHORT steps (step length < 1) after which the phase ends on the current level (cpdp_oc.h)
+// wide kernel, fp32, models with at most 8 columns of [A B]: all columns of an interval's exact stage Hessian on one lane (1,
+// OcSolver::stage_hessian_all) or one (interval, column) item per lane (0)
+#ifndef LFSD_HESS_ALL
+#define LFSD_HESS_ALL 1
+#endif
 #ifndef LFSD_MS_NEWTON
 #define LFSD_MS_NEWTON 0
 #endif

@@ -71,8 +71,13 @@ template <class M> struct OcLayout {
   // wide mapping (one trajectory per wavefront): the above for 64 lanes + the parked roll-outs of the 16 step lengths
   // + per-lane sub-step start states of the exact-Hessian sweeps
   static constexpr int WIDE_NAL = 16;
+  // wide mapping, fp32, models with at most 8 columns of [A B] (robot arm 6, cart-pole 5, pendulum 3): ALL columns of an interval's
+  // exact stage Hessian on ONE lane, as NVH packed pairs that share the nominal part of every evaluation (OcSolver::stage_hessian_all)
+  static constexpr bool HALL = NXU <= 8;
+  static constexpr int NVH = (NXU + 1) / 2;
   LFSD_HD static long long ws_elems_wide(int N) {
-    const long long n = ws_elems<64>(N) + 1LL * WIDE_NAL * ((N + 1) * NX + N * NU) + 1LL * SMAX * NX * 64;
+    const long long n = ws_elems<64>(N) + 1LL * WIDE_NAL * ((N + 1) * NX + N * NU) + 1LL * SMAX * NX * 64 +
+                        (HALL ? 2LL * NVH * SMAX * NX * 64 + 2 : 0LL);      // + per-lane tangent sub-step starts of stage_hessian_all (8-byte aligned)
     return (n + 1) / 2 * 2;
   }
   // LDS per group (elements)
@@ -90,8 +95,10 @@ template <class M> struct OcLayout {
   template <int G> static constexpr int lds_c() { return lds_e<G>() + M::NP; }
   template <int G> static constexpr int lds_x0() { return lds_c<G>() + M::NCX; }
   // exact-Hessian sweep: per-lane slots for the 4 RK4 stage points (uniform copy + this lane's tangent)
-  template <int G> static constexpr int lds_ex() { return lds_x0<G>() + NX; }
-  template <int G> static constexpr int lds_elems() { return ((lds_ex<G>() + 8 * NX * G + 3) / 4) * 4; }
+  template <int G> static constexpr int lds_ex() { return (lds_x0<G>() + NX + 1) / 2 * 2; }
+  // (stage_hessian_all, 64-lane groups: 4 stage points of the nominal + of NVH packed tangent pairs)
+  template <int G, int ES = 8> static constexpr int lds_ex_size() { return (G == 64 && ES == 4 && HALL && (4 + 8 * NVH) > 8) ? (4 + 8 * NVH) * NX * G : 8 * NX * G; }
+  template <int G, int ES = 8> static constexpr int lds_elems() { return ((lds_ex<G>() + lds_ex_size<G, ES>() + 3) / 4) * 4; }
 };
 
 template <class M, typename T, int G, bool EXACT, bool BND = false> struct OcSolver {
@@ -129,6 +136,7 @@ template <class M, typename T, int G, bool EXACT, bool BND = false> struct OcSol
   T mu_stage_frac = T(0);      // OcArgs::mu_stage_frac
   T *xb[2], *ub[2], *Mws[2], *Kws, *kws, *lds, *exws, *Hws;
   T *xa = nullptr, *ua = nullptr, *exwu = nullptr;      // wide mapping only: per-step-length roll-outs, per-lane sub-step states
+  T *exwm = nullptr;                                     // ... and the per-lane tangent sub-step starts of stage_hessian_all
   // the double-buffered arrays are picked by a select, not by indexing the pointer arrays with a run-time value: that would
   // put the arrays in scratch (it was the lean kernel's last 168 B/lane of scratch)
   LFSD_DEV T* xbp(int i) const { return i ? xb[1] : xb[0]; }
@@ -532,6 +540,171 @@ template <class M, typename T, int G, bool EXACT, bool BND = false> struct OcSol
     for (int i = 0; i < NX; ++i) hx[i] = dlam[i];
   }
 
+  // The same second-order adjoint for ALL columns of interval k on this one lane (wide kernel, fp32, OcLayout::HALL): NV packed
+  // pairs of tangent columns run through the S x 4 stages side by side.  A column-per-item sweep re-evaluates the nominal part of
+  // every model call -- for the robot arm four sin / cos, the mass matrix and its inverse: the larger part of a call -- once per
+  // column; here the NV instantiations of a stage are inlined into one basic block with identical nominal operands, and the
+  // compiler keeps one copy.  Robot arm (6 columns, 50 intervals): 300 (interval, column) items = 5 rounds of the wavefront become
+  // 50 items = one round that costs about twice a single-column item.  Hk: the interval's Hessian [row][column] in the workspace.
+  template <int NV>
+  LFSD_DEV void stage_hessian_all(int k, const T* xk, const T* uk, const T* lam_next, T* Hk) {
+    using V = pk2<T>;
+    static_assert(G == 64, "one trajectory per wavefront");
+    T* ex = lds + Lay::template lds_ex<G>();                           // [4][NX][G] stage points of the nominal, per lane
+    V* exv = reinterpret_cast<V*>(ex + 4 * NX * G);                    // [4][NX][NV][G] ... of the tangent pairs
+    T* exu = exwu + lane;                                              // [S][NX][G] sub-step starts of the nominal
+    V* exl = reinterpret_cast<V*>(exwm) + lane;                        // [S][NX][NV][G] ... of the tangent pairs
+    const T t = tk(k);
+    const T h = DT, hh = DT * T(0.5), h6 = DT / T(6);
+    // (parameters and constants in registers: read through the LDS pointers the compiler has to assume that the stores between two
+    //  model calls may have changed them, and keeps a copy of the nominal part per call -- the sharing this routine exists for)
+    T el[NP > 0 ? NP : 1], cl[M::NCX > 0 ? M::NCX : 1];
+#pragma unroll
+    for (int i = 0; i < NP; ++i) el[i] = e[i];
+#pragma unroll
+    for (int i = 0; i < M::NCX; ++i) cl[i] = c[i];
+    T x[NX];
+    V m[NV][NX], du[NV][NU];
+#pragma unroll
+    for (int i = 0; i < NX; ++i) x[i] = xk[i];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+#pragma unroll
+      for (int i = 0; i < NX; ++i) m[v][i] = mk2<T>((2 * v == i) ? T(1) : T(0), (2 * v + 1 == i) ? T(1) : T(0));
+#pragma unroll
+      for (int a = 0; a < NU; ++a) du[v][a] = mk2<T>((2 * v == NX + a) ? T(1) : T(0), (2 * v + 1 == NX + a) ? T(1) : T(0));
+    }
+    // forward: the nominal and its NV tangent pairs through the S RK4 steps, sub-step starts parked
+    for (int s = 0; s < S; ++s) {
+#pragma unroll
+      for (int i = 0; i < NX; ++i) {
+        exu[(s * NX + i) * G] = x[i];
+#pragma unroll
+        for (int v = 0; v < NV; ++v) exl[((s * NX + i) * NV + v) * G] = m[v][i];
+      }
+      T xs[NX], ax[NX], f[NX], cq;
+      V ms[NV][NX], am[NV][NX], d[NV][NX], dq;
+#pragma unroll
+      for (int st = 0; st < 4; ++st) {
+        const T* xe = (st == 0) ? x : xs;
+#pragma unroll
+        for (int v = 0; v < NV; ++v) M::dyn_cost_jvp(t, xe, uk, el, cl, (st == 0) ? m[v] : ms[v], du[v], f, cq, d[v], dq);
+        const T wgt = (st == 0 || st == 3) ? T(1) : T(2), adv = (st < 2) ? hh : h;
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+          ax[i] = (st == 0) ? f[i] : ax[i] + wgt * f[i];
+          if (st < 3) xs[i] = x[i] + adv * f[i];
+#pragma unroll
+          for (int v = 0; v < NV; ++v) {
+            am[v][i] = (st == 0) ? d[v][i] : am[v][i] + wgt * d[v][i];
+            if (st < 3) ms[v][i] = m[v][i] + adv * d[v][i];
+          }
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < NX; ++i) {
+        x[i] += h6 * ax[i];
+#pragma unroll
+        for (int v = 0; v < NV; ++v) m[v][i] += h6 * am[v][i];
+      }
+    }
+    T lam[NX];
+    V dlam[NV][NX], hu[NV][NU];
+#pragma unroll
+    for (int i = 0; i < NX; ++i) lam[i] = lam_next[i];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+#pragma unroll
+      for (int i = 0; i < NX; ++i) dlam[v][i] = V(T(0));
+#pragma unroll
+      for (int a = 0; a < NU; ++a) hu[v][a] = V(T(0));
+    }
+    const T wgt[4] = {h / T(6), h / T(3), h / T(3), h / T(6)};
+    const T car[4] = {h * T(0.5), h * T(0.5), h, T(0)};      // kappa_i = w_i*lam + car_i * ybar_{i+1}
+    const T adv[3] = {h * T(0.5), h * T(0.5), h};
+    for (int s = S - 1; s >= 0; --s) {
+      // recompute the four stage points of this sub-step and park them
+      T x0s[NX];
+      V m0s[NV][NX];
+#pragma unroll
+      for (int i = 0; i < NX; ++i) {
+        x0s[i] = exu[(s * NX + i) * G]; x[i] = x0s[i];
+#pragma unroll
+        for (int v = 0; v < NV; ++v) { m0s[v][i] = exl[((s * NX + i) * NV + v) * G]; m[v][i] = m0s[v][i]; }
+      }
+      for (int st = 0; st < 4; ++st) {
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+          ex[(st * NX + i) * G + lane] = x[i];
+#pragma unroll
+          for (int v = 0; v < NV; ++v) exv[((st * NX + i) * NV + v) * G + lane] = m[v][i];
+        }
+        if (st < 3) {
+          T f[NX], cq;
+          V d[NV][NX], dq;
+#pragma unroll
+          for (int v = 0; v < NV; ++v) M::dyn_cost_jvp(t, x, uk, el, cl, m[v], du[v], f, cq, d[v], dq);
+#pragma unroll
+          for (int i = 0; i < NX; ++i) {
+            x[i] = x0s[i] + adv[st] * f[i];
+#pragma unroll
+            for (int v = 0; v < NV; ++v) m[v][i] = m0s[v][i] + adv[st] * d[v][i];
+          }
+        }
+      }
+      T yb[NX], lam_new[NX];
+      V dyb[NV][NX], dlam_new[NV][NX];
+#pragma unroll
+      for (int i = 0; i < NX; ++i) {
+        yb[i] = T(0); lam_new[i] = lam[i];
+#pragma unroll
+        for (int v = 0; v < NV; ++v) { dyb[v][i] = V(T(0)); dlam_new[v][i] = dlam[v][i]; }
+      }
+      for (int st = 3; st >= 0; --st) {
+        T kap[NX], ls[NX], xs[NX], y1[NX];
+        const T w = wgt[st], cc = car[st], iw = T(1) / w;
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+          kap[i] = w * lam[i] + cc * yb[i];
+          ls[i] = kap[i] * iw;
+          xs[i] = ex[(st * NX + i) * G + lane];
+        }
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+          V dkap[NX], ms[NX], t2x[NX], t2u[NU], gx[NX], gu[NU];
+#pragma unroll
+          for (int i = 0; i < NX; ++i) {
+            dkap[i] = w * dlam[v][i] + cc * dyb[v][i];
+            ms[i] = exv[((st * NX + i) * NV + v) * G + lane];
+          }
+          M::dyn_vjp2(t, xs, uk, el, cl, kap, w, dkap, y1, t2x, t2u);
+          M::ham_hess_mul(t, xs, uk, ls, el, cl, ms, du[v], gx, gu);
+#pragma unroll
+          for (int i = 0; i < NX; ++i) { dyb[v][i] = t2x[i] + w * gx[i]; dlam_new[v][i] += dyb[v][i]; }
+#pragma unroll
+          for (int a = 0; a < NU; ++a) hu[v][a] += t2u[a] + w * gu[a];
+        }
+#pragma unroll
+        for (int i = 0; i < NX; ++i) { yb[i] = y1[i]; lam_new[i] += yb[i]; }
+      }
+#pragma unroll
+      for (int i = 0; i < NX; ++i) {
+        lam[i] = lam_new[i];
+#pragma unroll
+        for (int v = 0; v < NV; ++v) dlam[v][i] = dlam_new[v][i];
+      }
+    }
+    // columns 2v, 2v+1 of every row as one 8-byte store ([row][column], rows of NXUP words)
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      V* hc = reinterpret_cast<V*>(Hk + 2 * v);
+#pragma unroll
+      for (int i = 0; i < NX; ++i) hc[i * (Lay::NXUP / 2)] = dlam[v][i];
+#pragma unroll
+      for (int a = 0; a < NU; ++a) hc[(NX + a) * (Lay::NXUP / 2)] = hu[v][a];
+    }
+  }
+
   // Backward sweep on buffer `cur`: DDP gains + exact discrete costate (== IPOPT's lam_g).
   // Stage Hessian model: mode 0 Gauss-Newton (cost curvature), 1 interval * Hamiltonian Hessian (cheap Newton-like),
   // 2 exact Lagrangian Hessian of the RK4 stage (stage_hessian_col).
@@ -577,7 +750,12 @@ template <class M, typename T, int G, bool EXACT, bool BND = false> struct OcSol
     // those rows in Q, and two cross-quarter exchanges per entry of Q add the shares up (quarter_sum).
     constexpr bool QS = (G == 64) && (LFSD_BW_QSPLIT != 0) && NX >= 8 && NXU <= 16 && !BND;
     const int jcol = QS ? (lane & 15) : lane;
-    auto load_stage = [&](int k_, T* m_, T& mq_, T* xk_, T* uk_) LFSD_LAMBDA_INLINE {
+    auto load_stage = [&](int k_, T* m_, T& mq_, T* xk_, T* uk_, T* dk_) LFSD_LAMBDA_INLINE {
+      if (gap != nullptr) {                      // (the gap of the interval: group-uniform, loaded with the rest of the stage -- a stage ahead)
+        const T* dp = gap + (long long)k_ * NX;
+#pragma unroll
+        for (int i = 0; i < NX; ++i) dk_[i] = dp[i];
+      }
       if (jcol < NXU) {
         const T* Mk = Mwp(cur) + (long long)k_ * Lay::M_ELEMS + jcol;
 #pragma unroll
@@ -598,9 +776,11 @@ template <class M, typename T, int G, bool EXACT, bool BND = false> struct OcSol
     //  global loads of a stage -- rocket, wide fp32, n_grid 100: 128.8 -> 126.0 ms together with the costate sweep's,
     //  profiles/r03_t_generic_backward.txt; fp64 lean quadrotor: 9.4 -> 11.9 ms, the registers are not there: off)
     constexpr bool PFG = (LFSD_BW_PREFETCH_GEN) != 0 && (sizeof(T) == 4 || ((LFSD_BW_PREFETCH_GEN) & 2) != 0);
-    T m[NX], mq = T(0), mN[NX], mqN = T(0), xkN[NX], ukN[NU];
+    T m[NX], mq = T(0), mN[NX], mqN = T(0), xkN[NX], ukN[NU], dv[NX], dvN[NX];
     T hC[(EXACT && PFG) ? NXU : 1], hN[(EXACT && PFG) ? NXU : 1];
-    load_stage(N - 1, m, mq, xk, uk);
+#pragma unroll
+    for (int i = 0; i < NX; ++i) { dv[i] = T(0); dvN[i] = T(0); }
+    load_stage(N - 1, m, mq, xk, uk, dv);
     if (EXACT && PFG && mode == 2 && reuse_hess) {
       const T* hn = Hws + (long long)(N - 1) * Lay::H_ELEMS + (lane < NXU ? lane : 0);
 #pragma unroll
@@ -619,10 +799,6 @@ template <class M, typename T, int G, bool EXACT, bool BND = false> struct OcSol
       if (gap != nullptr) {
         // multiple shooting: the linearised interval ends d_k away from node k+1, so the value function of that node is entered
         // at delta x_k+1 = A dx + B du + d_k:  V_x <- V_x + V_xx d_k  (the costate recursion below stays the exact adjoint one)
-        const T* dk = gap + (long long)k * NX;
-        T dv[NX];
-#pragma unroll
-        for (int j = 0; j < NX; ++j) dv[j] = dk[j];
 #pragma unroll
         for (int i = 0; i < NX; ++i) {
           T sacc = T(0);
@@ -632,7 +808,7 @@ template <class M, typename T, int G, bool EXACT, bool BND = false> struct OcSol
         }
       }
       if (PFG && k > 0) {
-        load_stage(k - 1, mN, mqN, xkN, ukN);
+        load_stage(k - 1, mN, mqN, xkN, ukN, dvN);
         if (EXACT && mode == 2 && reuse_hess) {      // ... and its column of the cached stage Hessian
           const T* hn = Hws + (long long)(k - 1) * Lay::H_ELEMS + (lane < NXU ? lane : 0);
 #pragma unroll
@@ -922,7 +1098,7 @@ template <class M, typename T, int G, bool EXACT, bool BND = false> struct OcSol
       if (k > 0) {
         if (PFG) {
 #pragma unroll
-          for (int i = 0; i < NX; ++i) { m[i] = mN[i]; xk[i] = xkN[i]; }
+          for (int i = 0; i < NX; ++i) { m[i] = mN[i]; xk[i] = xkN[i]; dv[i] = dvN[i]; }
 #pragma unroll
           for (int a = 0; a < NU; ++a) uk[a] = ukN[a];
           mq = mqN;
@@ -931,7 +1107,7 @@ template <class M, typename T, int G, bool EXACT, bool BND = false> struct OcSol
             for (int i = 0; i < NXU; ++i) hC[i] = hN[i];
           }
         } else {
-          load_stage(k - 1, m, mq, xk, uk);
+          load_stage(k - 1, m, mq, xk, uk, dv);
         }
       }
     }
@@ -1896,6 +2072,18 @@ template <class M, typename T, bool EXACT, bool BND = false> struct OcWide : OcS
   }
   // exact stage Hessians of nominal `cur` (costates must be on lam_out), every (interval, column) at once
   LFSD_DEV void hessians_parallel(int cur) {
+    if constexpr (sizeof(T) == 4 && Lay::HALL && (LFSD_HESS_ALL) != 0) {
+      for (int k = lane; k < N; k += 64) {
+        T xk[NX], uk[NU], ln[NX];
+#pragma unroll
+        for (int i = 0; i < NX; ++i) { xk[i] = xbp(cur)[k * NX + i]; ln[i] = lam_out[(k + 1) * NX + i]; }
+#pragma unroll
+        for (int a = 0; a < NU; ++a) uk[a] = ubp(cur)[k * NU + a];
+        this->template stage_hessian_all<Lay::NVH>(k, xk, uk, ln, Hws + (long long)k * Lay::H_ELEMS);
+      }
+      __syncthreads();
+      return;
+    }
     for (int t = lane; t < N * NXU; t += 64) {
       const int k = t / NXU, col = t % NXU;
       T xk[NX], uk[NU], ln[NX], hx[NX], hu[NU];
@@ -1922,10 +2110,10 @@ template <class M, typename T, bool EXACT, bool BND = false> struct OcWide : OcS
   //     du_k = k_k + K_k dx_k,   dx_k+1 = A_k dx_k + B_k du_k + d_k,   dx_0 = 0
   // -- the Newton step of the lifted KKT system (Gauss-Newton multiple shooting / the step of an SQP method on the NLP above).
   // Where the single-shooting iteration of this kernel pays N x S sequentially dependent RK4 steps for its roll-outs, this one
-  // pays S (per round of 64 items).  Globalisation: the l1 exact penalty function  J + rho sum_k |d_k|_1  with rho above the
-  // largest costate (IPOPT uses a filter on the same two quantities); a step scales the whole Newton direction (it is linear).
-  // Convergence is never declared here: the phase ends in a closed-loop roll-out (gaps closed by construction) from which the
-  // single-shooting iteration above continues and applies its own tests (oc_solve_wide_kernel).
+  // pays S (per round of 64 items).  Only the FULL Newton step is ever taken this way (it closes the linearised gaps entirely), and
+  // only when the augmented Lagrangian  J + lambda^T d + rho/2 |d|^2  (costates of the iterate held fixed) accepts it; otherwise
+  // the step is the closed-loop nonlinear roll-out around the node states, which closes every gap by construction.  Convergence
+  // is never declared on an iterate with gaps (oc_solve_wide_kernel).
   T *gapb[2] = {nullptr, nullptr}, *dxw = nullptr, *duw = nullptr;      // [N][NX] gaps of the two nominal buffers; Newton step [N+1][NX], [N][NU]
   LFSD_DEV T* gapp(int i) const { return i ? gapb[1] : gapb[0]; }
   LFSD_DEV T wave_sum(T v) {
@@ -1946,17 +2134,12 @@ template <class M, typename T, bool EXACT, bool BND = false> struct OcWide : OcS
     __syncthreads();
     return r;
   }
-  // buffer `cur` holds a roll-out: no gaps
-  LFSD_DEV void ms_zero_gaps(int cur) {
-    for (int i = lane; i < N * NX; i += 64) gapp(cur)[i] = T(0);
-    __syncthreads();
-  }
   // The Newton step (for step length 1) of the lifted problem from the gains of the last backward sweep, into dxw / duw.
   // Returns its first-order change of the cost,  sum_k q_k^T (dx_k, du_k) + h_x^T dx_N.
   LFSD_DEV T ms_forward(int cur, T& lamd) {
     T* ldsDx = lds + Lay::LDS_VX;                 // (NX words, free between backward sweeps)
     const T* Mc = Mwp(cur);
-    const T* gp = gapp(cur);
+    const T* gp = this->gap;                       // (nullptr: buffer `cur` is a roll-out, no gaps)
     T dxv[NX], dl = T(0), ld = T(0);
 #pragma unroll
     for (int i = 0; i < NX; ++i) dxv[i] = T(0);
@@ -1974,7 +2157,7 @@ template <class M, typename T, bool EXACT, bool BND = false> struct OcWide : OcS
       for (int i = 0; i < NX * NU; ++i) Kk_[i] = Kg[i];
 #pragma unroll
       for (int a = 0; a < NU; ++a) kk_[a] = this->kws[k_ * NU + a];
-      dk_ = gp[k_ * NX + row];
+      dk_ = gp ? gp[k_ * NX + row] : T(0);
     };
     // (two operand sets used alternately: every index is a constant, nothing lands in scratch)
     auto stage = [&](int k, const T* arC, T qjC, const T* KkC, const T* kkC, T dkC, T* arN, T& qjN, T* KkN, T* kkN, T& dkN) LFSD_LAMBDA_INLINE {
@@ -2086,41 +2269,6 @@ template <class M, typename T, bool EXACT, bool BND = false> struct OcWide : OcS
     g2 = wave_sum(g2l);
     g1 = wave_sum(g1l);
     gm = wave_max(gml);
-  }
-  // Cost and gap norm of the iterates at FOUR step lengths a0 2^-j, j = 0..3, without sensitivities: lane <- (interval,
-  // step length), 16 intervals per round.  J4 / g4: in every lane.
-  LFSD_DEV void ms_trial_alphas(int cur, T a0, T rho, T* phi4) {
-    T* ldsRed = lds + Lay::LDS_RED;
-    const int ia = lane & 3;
-    T alpha = a0;
-    for (int j = 0; j < ia; ++j) alpha *= T(0.5);
-    T Jl = T(0), dummy = T(0);
-    for (int k = lane >> 2; k < N; k += 16) {
-      T x[NX], u[NU], q = T(0);
-#pragma unroll
-      for (int i = 0; i < NX; ++i) x[i] = xbp(cur)[k * NX + i] + alpha * dxw[k * NX + i];
-#pragma unroll
-      for (int a = 0; a < NU; ++a) u[a] = ubp(cur)[k * NU + a] + alpha * duw[k * NU + a];
-      const T tt = this->tk(k);
-      for (int s = 0; s < S; ++s) this->template rk4_step<false>(tt, x, q, u, x, dummy, u);
-      Jl += q;
-#pragma unroll
-      for (int i = 0; i < NX; ++i) {
-        const T g = x[i] - (xbp(cur)[(k + 1) * NX + i] + alpha * dxw[(k + 1) * NX + i]);
-        Jl += lam_out[(k + 1) * NX + i] * g + T(0.5) * rho * g * g;       // (the merit function: J + lambda^T d + rho/2 |d|^2)
-      }
-      if (k == N - 1) {
-        T xN[NX];
-#pragma unroll
-        for (int i = 0; i < NX; ++i) xN[i] = xbp(cur)[N * NX + i] + alpha * dxw[N * NX + i];
-        Jl += M::final_cost(this->tk(N), xN, e, c);
-      }
-    }
-    ldsRed[lane] = Jl;
-    __syncthreads();
-#pragma unroll
-    for (int j = 0; j < 4; ++j) { T r = T(0); for (int l = j; l < 64; l += 4) r += ldsRed[l]; phi4[j] = r; }
-    __syncthreads();
   }
 };
 
@@ -2662,8 +2810,8 @@ __global__ void __launch_bounds__(64, 1) oc_solve_wide_kernel(OcArgs<T> a) {
   using Sol = OcWide<M, T, EXACT, BND>;
   using Lay = OcLayout<M>;
   constexpr int NX = M::NX, NU = M::NU, NP = M::NP, NC = M::NC, NAL = Sol::NAL;
-  constexpr int RS = EXACT ? Lay::template lds_elems<64>() : ((Lay::template lds_ex<64>() + 3) / 4) * 4;
-  __shared__ T lds_all[RS];
+  constexpr int RS = EXACT ? Lay::template lds_elems<64, (int)sizeof(T)>() : ((Lay::template lds_ex<64>() + 3) / 4) * 4;
+  __shared__ __attribute__((aligned(16))) T lds_all[RS];
   if (blockDim.x != 64) return;
   poison_lds(lds_all, RS);
   Sol s;
@@ -2674,6 +2822,8 @@ __global__ void __launch_bounds__(64, 1) oc_solve_wide_kernel(OcArgs<T> a) {
   {
     T* w2 = a.ws + traj * a.ws_stride + Lay::template ws_elems<64>(N);
     s.xa = w2; s.ua = s.xa + (long long)NAL * (N + 1) * NX; s.exwu = s.ua + (long long)NAL * N * NU;
+    s.exwm = s.exwu + (long long)Lay::SMAX * NX * 64;
+    if ((((long long)(s.exwm - a.ws)) & 1) != 0) ++s.exwm;      // (8-byte aligned: it holds packed pairs; the region has a word to spare)
     // the multiple-shooting iterate's gaps and Newton step live in the region of the parked step-length roll-outs (never in use together)
     s.gapb[0] = s.xa; s.gapb[1] = s.xa + (long long)N * NX; s.dxw = s.xa + 2LL * N * NX; s.duw = s.dxw + (long long)(N + 1) * NX;
     T* le = s.lds + Lay::template lds_e<64>();
@@ -2749,7 +2899,7 @@ __global__ void __launch_bounds__(64, 1) oc_solve_wide_kernel(OcArgs<T> a) {
     s.S = ((LFSD_COARSE_TIME_S) > 0 && (LFSD_COARSE_TIME_S) < tc) ? (LFSD_COARSE_TIME_S) : tc; s.DT = s.dgrid / T(s.S);
   }
 #if defined(LFSD_OC_CLOCK)      // diagnostic build (tools/wide_clock.py): shader clocks of the phases of the slowest solves
-  long long wck[5] = {0, 0, 0, 0, 0}, wck_exit = 0;
+  long long wck[7] = {0, 0, 0, 0, 0, 0, 0}, wck_exit = 0;
   int wck_it_exit = -1;
   const long long wck_t0 = clock64();
 #define LFSD_WCK(i, stmt) { const long long c0_ = clock64(); stmt; wck[i] += clock64() - c0_; }
@@ -2772,20 +2922,19 @@ __global__ void __launch_bounds__(64, 1) oc_solve_wide_kernel(OcArgs<T> a) {
   }
   s.adopt_alpha(0, 0);
   s.linearise_parallel(0);
-  // Multiple-shooting phase (OcWide::ms_*): from here the node states are variables of their own; every level of the mesh
-  // continuation starts it from a roll-out (no gaps), the last one ends it with a closed-loop roll-out (`ms_exit`) after which the
-  // single-shooting iteration below applies its convergence tests (`ms_check`: the cheap costate-only gradient test first).
+  // Multiple-shooting steps (OcWide::ms_*; the step logic is in the loop below): every level of the mesh continuation starts from a
+  // roll-out (no gaps); an iterate with gaps is closed by a closed-loop roll-out before any convergence test applies to it
+  // (`ms_check`: the cheap costate-only gradient test comes first then).
   // Not for solves that run Newton from their first iteration (exact_after == 0, the rocket): their steps are regularised Newton
   // steps at Levenberg shifts of 10^2 - 10^4 through strongly curved attitude dynamics; the linear prediction of the node states
   // then leaves gaps as large as the step closes, the line search settles on steps of 1/4, and the phase needs as many or more
   // iterations than the closed-loop nonlinear roll-out while saving only the roll-outs' 20 % of an iteration (measured:
   // DESIGN.md; -DLFSD_MS_NEWTON=1 switches it on there as well).
   bool ms = !BND && (LFSD_MS) != 0 && a.n_grid >= (LFSD_MS_MIN_GRID) && a.max_iter > 8 && (a.exact_after != 0 || (LFSD_MS_NEWTON) != 0);
-  bool ms_exit = false, ms_check = false, ms_floor = false, gains_cur = false;
+  bool ms_check = false, ms_floor = false;
   const bool ms_on = ms;
-  int n_short = 0, n_acc_need = 4;
-  T rho = T(0), g1c = T(0), g2c = T(0), gmc = T(0), gain_acc = T(0);
-  if (ms) { s.ms_zero_gaps(0); s.gap = s.gapp(0); }
+  int n_acc_need = 4, n_ms = 0;
+  T g1c = T(0), g2c = T(0), gmc = T(0);      // l1 norm, sum of squares and largest entry of the gaps of the current iterate (0: a roll-out)
   T mu = T(0);
   int mode = (EXACT && a.exact_after == 0) ? 2 : 0;
   bool ham_ok = true, hess_ok = false, gn_crawl = false, costates_ok = false;
@@ -2829,40 +2978,16 @@ __global__ void __launch_bounds__(64, 1) oc_solve_wide_kernel(OcArgs<T> a) {
       cur ^= 1;
       hess_ok = false; costates_ok = false;
       g_last = T(-1); dec_last = T(1e30); g_flat = T(-1); J_ref = J; n_acc = 0;
-      ms = ms_on; ms_exit = false; n_short = 0;
-      if (ms) { s.ms_zero_gaps(cur); s.gap = s.gapp(cur); g1c = T(0); g2c = T(0); gmc = T(0); gains_cur = false; gain_acc = T(0); }      // (a roll-out: the new level starts without gaps)
+      ms = ms_on; g1c = T(0); g2c = T(0); gmc = T(0); s.gap = nullptr;      // (a roll-out: the new level starts without gaps)
       if (!t_finite(J)) { if (coarse) { relin = true; continue; } status = ST_FAILED; break; }      // (the mid level cannot integrate it: the reference's grid decides)
       continue;
     }
-    if (ms && (ms_exit || it + 3 >= a.max_iter)) {
-      // end of the multiple-shooting phase: closed-loop roll-outs of the 16 step lengths around the node states (the gains and the
-      // feed-forward of the last sweep; open loop when there is no sweep of this iterate) close the gaps by construction; the
-      // cheapest one becomes the single-shooting nominal.  An iteration without a sweep.
-      const T Jc = s.rollout_alphas(cur, gains_cur, alpha_l);
-      ldsRed[s.lane] = Jc;
-      __syncthreads();
-      int ic = -1;
-      T Jb = T(0);
-      for (int l = 0; l < NAL; ++l) { const T Jl = ldsRed[l]; if (t_finite(Jl) && (ic < 0 || Jl < Jb)) { ic = l; Jb = Jl; } }
-      __syncthreads();
-      ms = false; ms_exit = false; s.gap = nullptr;
-      if (ic < 0) { status = ST_FAILED; break; }
-      s.adopt_alpha(ic, cur ^ 1);
-      s.linearise_parallel(cur ^ 1);
-      cur ^= 1;
-      J = Jb;
-      hess_ok = false; costates_ok = false;
-      g_last = T(-1); dec_last = T(1e30); g_flat = T(-1); J_ref = J; n_acc = 0;
-      ms_check = true;
-#if defined(LFSD_TRACE)
-      if (s.lane == 0 && traj == 0) printf("wide it %d: multiple-shooting phase closed with step length index %d, J %.12e\n", it, ic, (double)J);
-#endif
-      continue;
-    }
     if (ms_check) {
-      // first test after the hand-over: the gradient of the closed trajectory from a costate sweep alone (no gains, no Hessians)
+      // first test after the gaps of a finished multiple-shooting iterate were closed: the gradient of the closed trajectory from a
+      // costate sweep alone (no gains, no Hessians)
       ms_check = false;
-      const T gn = s.costate_sweep(cur);
+      T gn;
+      LFSD_WCK(2, gn = s.costate_sweep(cur));
       costates_ok = true;
       if (gn < a.tol * (T(1) + t_abs(J))) { gnorm = gn; if (coarse) { relin = true; continue; } status = ST_CONVERGED; break; }
     }
@@ -2887,147 +3012,104 @@ __global__ void __launch_bounds__(64, 1) oc_solve_wide_kernel(OcArgs<T> a) {
       }
       continue;
     }
-    gains_cur = true;
+    // ---- the step.  With the multiple-shooting iteration enabled (`ms`) the CHEAP step is tried first: the full Newton step of the
+    // lifted problem (linear forward pass, every interval re-integrated and linearised in parallel: OcWide::ms_forward / ms_trial),
+    // accepted on the merit function below.  It leaves an iterate with gaps.  When it is refused -- or the iterate has to be closed
+    // because its level is done -- the step is the closed-loop NONLINEAR roll-out of the 16 step lengths around the node states
+    // (feed-forward and gains of the same gap-aware sweep: the roll-out closes every gap by construction, as a feasibility-driven
+    // DDP step does), judged against the merit value of the iterate it starts from.  An iterate without gaps is a single-shooting
+    // nominal: the convergence tests of this kernel apply to it and to nothing else. ----
+    const T epsT = Eps<T>::v();
+    const bool have_gaps = ms && g1c > T(0);
+    bool close_now = have_gaps && it + 3 >= a.max_iter, ms_off = false;
+    T phi0 = J, pred_ms = T(0);
     if (ms) {
-      // ---- one multiple-shooting step (OcWide::ms_*) ---------------------------------------------------------------------
-      const T epsT = Eps<T>::v();
       const T lam_mx = s.lam_max;
-      // stationary and the gaps closed to the resolution of the cost (a gap d costs lambda^T d to first order): this level is done
-      if (gnorm < a.tol * (T(1) + t_abs(J)) && lam_mx * g1c <= T(8) * epsT * (T(1) + t_abs(J))) {
-        if (coarse) relin = true; else { ms_exit = true; ms_floor = true; }
-        continue;
+      // stationary, and the gaps closed to the resolution of the cost (a gap d costs lambda^T d to first order): this level is done
+      if (have_gaps && !close_now && gnorm < a.tol * (T(1) + t_abs(J)) && lam_mx * g1c <= T(8) * epsT * (T(1) + t_abs(J))) {
+        if (coarse) { relin = true; continue; }
+        close_now = true; ms_floor = true; ms_off = true;
       }
-      T lamd0;
-      const T Dlin = s.ms_forward(cur, lamd0);
-      // merit function of this line search:  m = J + lambda^T d + rho/2 |d|^2  with the costates of this iterate held fixed (the
-      // augmented Lagrangian of the lifted NLP: lambda^T d is what closing the gaps costs to first order).  The linearised gaps of
-      // the Newton step close in proportion to the step length, so  m'(0) = Dlin - lambda^T d - rho |d|^2.
-      rho = t_max(lam_mx, T(1));      // (per line search: the multipliers shrink by orders of magnitude on the way from a cold start)
-      const T dl0 = Dlin - lamd0;
-      if (g2c > T(0) && !(dl0 - rho * g2c < T(-0.5) * rho * g2c)) rho = T(4) * t_abs(dl0) / g2c;
-      const T pred = rho * g2c - dl0;                  // first-order decrease of the merit function along the full step
-      const T phi0 = J + lamd0 + T(0.5) * rho * g2c;
-      const T flat = T(8) * epsT * t_abs(phi0);
-      if (!t_finite(pred) || !(pred > T(2) * epsT * t_abs(phi0))) {
-        // nothing the merit function can resolve is left to gain here (or the direction is no descent direction of it)
-        if (coarse) relin = true; else { ms_exit = true; ms_floor = t_finite(pred); }
-        continue;
-      }
-      T Jt, ldt, g2t, g1t, gmt;
-      s.ms_trial(cur, cur ^ 1, T(1), Jt, ldt, g2t, g1t, gmt);
-      T phit = Jt + ldt + T(0.5) * rho * g2t, alpha_t = T(1), phimin = phi0;
-      const bool flat_full = t_finite(phit) && t_abs(phit - phi0) <= T(64) * epsT * t_abs(phi0);
-      bool accept = t_finite(phit) && (phi0 - phit) >= T(1e-4) * pred - flat && phit < phi0;
-      if (t_finite(phit)) phimin = t_min(phimin, phit);
-      int ia = accept ? 0 : -1;
-      if (!accept) {
-        // shorter steps along the same (linear) direction: four step lengths per round, no sensitivities; then the chosen one with them
-        T a0 = T(0.5);
-        for (int round = 0; round < 2 && ia < 0; ++round) {
-          T p4[4], aa = a0;
-          s.ms_trial_alphas(cur, a0, rho, p4);
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const T pj = p4[j];
-            if (t_finite(pj)) phimin = t_min(phimin, pj);
-            if (ia < 0 && t_finite(pj) && (phi0 - pj) >= T(1e-4) * aa * pred - flat && pj < phi0) { ia = 1 + 4 * round + j; alpha_t = aa; }
-            aa *= T(0.5);
+      if (!close_now) {
+        T lamd0, Dlin;
+        LFSD_WCK(5, Dlin = s.ms_forward(cur, lamd0));
+        // merit function of this step:  m = J + lambda^T d + rho/2 |d|^2  with the costates of this iterate held fixed (the
+        // augmented Lagrangian of the lifted NLP: lambda^T d is what closing the gaps costs to first order).  The linearised gaps
+        // of the full Newton step close entirely, so  m'(0) = Dlin - lambda^T d - rho |d|^2.
+        T rho = t_max(lam_mx, T(1));      // (per step: the multipliers shrink by orders of magnitude on the way from a cold start)
+        const T dl0 = Dlin - lamd0;
+        if (g2c > T(0) && !(dl0 - rho * g2c < T(-0.5) * rho * g2c)) rho = T(4) * t_abs(dl0) / g2c;
+        pred_ms = rho * g2c - dl0;                     // first-order decrease of the merit function along the full step
+        phi0 = J + lamd0 + T(0.5) * rho * g2c;
+        if (!t_finite(pred_ms) || !(pred_ms > T(2) * epsT * t_abs(phi0))) {
+          // nothing the merit function resolves is left to gain: an iterate with gaps is closed now (and the single-shooting tests
+          // take over for good); one without gaps IS a single-shooting nominal, the tests below decide
+          if (have_gaps) {
+            if (coarse) { relin = true; continue; }
+            close_now = true; ms_floor = t_finite(pred_ms); ms_off = true;
           }
-          a0 *= T(0.0625);
-        }
-        if (ia >= 0) {
-          s.ms_trial(cur, cur ^ 1, alpha_t, Jt, ldt, g2t, g1t, gmt);
-          phit = Jt + ldt + T(0.5) * rho * g2t;
-          accept = t_finite(phit) && phit < phi0 + flat;
-          if (!accept) ia = -1;
-        }
-      }
-      if (!accept) {
-        if (mode >= 1 && flat_full && (g_flat < T(0) || gnorm < T(0.7) * g_flat)) {
-          if (ia != 0) { s.ms_trial(cur, cur ^ 1, T(1), Jt, ldt, g2t, g1t, gmt); phit = Jt + ldt + T(0.5) * rho * g2t; }
-          accept = t_finite(phit); ia = 0; alpha_t = T(1); g_flat = gnorm;      // Newton-like step below rounding noise, gradient still contracting
-        } else if (mode == 1 && !LFSD_HAM_SHIFT) {
-          mode = 0; ham_ok = false;
-        } else if (mu > T(1e10) || ((phi0 - phimin) <= T(8) * epsT * t_abs(phi0) && (mode == 0 || flat_full || mu > T(1e6)))) {
-          if (coarse) relin = true; else ms_exit = true;
         } else {
-          mu_bad = mu; mu_hold = 0;
-          mu = t_max(mu * T(LFSD_MU_UP), mode == 2 ? T(1e-4) : T(1e-6));
-        }
-      }
+          T Jt, ldt, g2t, g1t, gmt;
+          LFSD_WCK(6, s.ms_trial(cur, cur ^ 1, T(1), Jt, ldt, g2t, g1t, gmt));
+          const T phit = Jt + ldt + T(0.5) * rho * g2t;
+          const T flat = T(8) * epsT * t_abs(phi0);
+          const bool accept = t_finite(phit) && t_finite(g1t) && (phi0 - phit) >= T(1e-4) * pred_ms - flat && phit < phi0;
 #if defined(LFSD_TRACE)
-      if (s.lane == 0 && traj == 0) printf("wide ms it %d mode %d g %.6e J %.12e gap1 %.4e gapmax %.3e lam %.3e rho %.3e phi0 %.10e pred %.4e ia %d alpha %g accept %d mu %g -> J %.12e gap1 %.4e phi %.10e\n", it, mode, (double)gnorm, (double)J, (double)g1c, (double)gmc, (double)lam_mx, (double)rho, (double)phi0, (double)pred, ia, (double)alpha_t, (int)accept, (double)mu, (double)Jt, (double)g1t, (double)phit);
+          if (s.lane == 0 && traj == 0) printf("wide ms it %d mode %d g %.6e J %.12e gap1 %.4e gapmax %.3e lam %.3e rho %.3e phi0 %.10e pred %.4e accept %d mu %g -> J %.12e gap1 %.4e phi %.10e\n", it, mode, (double)gnorm, (double)J, (double)g1c, (double)gmc, (double)lam_mx, (double)rho, (double)phi0, (double)pred_ms, (int)accept, (double)mu, (double)Jt, (double)g1t, (double)phit);
 #endif
-      if (accept) {
-        const T mu_taken = mu;
-        const T gain = phi0 - phit;
-        cur ^= 1;
-        s.gap = s.gapp(cur);
-        gains_cur = false;
-        g_last = gnorm; dec_last = T(1e30);
-        hess_ok = false; costates_ok = false;
-        if (ia == 0) {
-          const T mu_next = (mu > T(1e-8)) ? mu * T(LFSD_MU_DOWN) : T(0);
-          if (mu > T(0) && mu_bad >= T(0) && mu_next <= mu_bad && mu_hold < mu_hold_need) ++mu_hold;
-          else { mu = mu_next; mu_hold = 0; }
-          if (mode == 0 && ham_ok && gain < T(LFSD_HAM_SWITCH) * t_abs(Jt)) mode = 1;
-          else if (LFSD_GN_CRAWL && mode == 0 && !ham_ok && gain < T(1e-2) * t_abs(Jt)) gn_crawl = true;
-        } else if (gain < T(0.1) * t_abs(Jt)) {
-          // a SHORT step of little gain: here a full step is worth more than in single shooting -- it closes the linearised gaps
-          // entirely, a short one leaves (1 - alpha) of them and adds those of its own nonlinearity -- so the answer to a model
-          // that needed its step cut is a larger Levenberg shift (a more damped, shorter direction), as a trust region would
-          mu_bad = mu; mu_hold = 0;
-          mu = t_max(mu * T(LFSD_MU_UP), mode == 2 ? T(1e-4) : T(1e-6));
-        }
-        if (coarse && gain < T(LFSD_COARSE_SWITCH) * t_abs(Jt)) {
-          if ((LFSD_COARSE_EXIT_RULE) == 0 || ((LFSD_COARSE_EXIT_RULE) == 1 && ia == 0) ||
-              ((LFSD_COARSE_EXIT_RULE) == 2 && ia == 0 && mu_taken <= T(LFSD_COARSE_EXIT_MU))) relin = true;
-        }
-        J = Jt; g1c = g1t; g2c = g2t; gmc = gmt;
-        // The linear forward pass predicts the node states; where the dynamics bend more than that prediction allows (the rocket's
-        // attitude under aggressive controls) the trial's gaps grow as fast as the step closes them and the line search settles on
-        // short steps -- iterations the closed-loop NONLINEAR roll-out of the single-shooting iteration does not need.  A run of
-        // accepted short steps that each gain less than 2 % of the cost ends the phase on this level (the next level of the mesh
-        // continuation starts it again); short steps that halve the cost of a cold start are not that pattern.
-        n_short = (ia == 0) ? 0 : ((gain < T(0.02) * t_abs(Jt)) ? n_short + 1 : n_short);
-        if (n_short >= (LFSD_MS_SHORT_STEPS)) ms_exit = true;
-        // (the merit function changes with its multipliers from one line search to the next: the stall test sums the gains instead)
-        gain_acc += gain;
-        if (++n_acc >= 4) {
-          if (gain_acc <= T(16) * epsT * t_abs(phit)) { if (coarse) relin = true; else ms_exit = true; }
-          gain_acc = T(0); n_acc = 0;
+          if (accept) {
+            const T mu_taken = mu;
+            const T gain = phi0 - phit;
+            cur ^= 1;
+            g_last = gnorm; dec_last = T(1e30);
+            hess_ok = false; costates_ok = false;
+            const T mu_next = (mu > T(1e-8)) ? mu * T(LFSD_MU_DOWN) : T(0);
+            if (mu > T(0) && mu_bad >= T(0) && mu_next <= mu_bad && mu_hold < mu_hold_need) ++mu_hold;
+            else { mu = mu_next; mu_hold = 0; }
+            if (mode == 0 && ham_ok && gain < T(LFSD_HAM_SWITCH) * t_abs(Jt)) mode = 1;
+            else if (LFSD_GN_CRAWL && mode == 0 && !ham_ok && gain < T(1e-2) * t_abs(Jt)) gn_crawl = true;
+            if (coarse && gain < T(LFSD_COARSE_SWITCH) * t_abs(Jt)) {
+              if ((LFSD_COARSE_EXIT_RULE) <= 1 || ((LFSD_COARSE_EXIT_RULE) == 2 && mu_taken <= T(LFSD_COARSE_EXIT_MU))) relin = true;
+            }
+            J = Jt; g1c = g1t; g2c = g2t; gmc = gmt;
+            s.gap = (g1c > T(0)) ? s.gapp(cur) : nullptr;
+            ++n_ms;
+            continue;
+          }
         }
       }
-      continue;
     }
-    if (gnorm < a.tol * (T(1) + t_abs(J))) { if (coarse) { relin = true; continue; } status = ST_CONVERGED; break; }
-    if (at_working_precision(mode, mu, gnorm, g_last, dec_last, dV1, dV2, J, a.tol)) {
-      if (coarse) { relin = true; continue; }
-      status = ST_STALLED; ++it; break;      // (this iteration's sweep counts)
-    }
-    // first sweep after a multiple-shooting phase that ended because its Newton step could gain nothing the (merit) function
-    // resolves: when the Newton-like step of the closed trajectory predicts a decrease below the resolution of the cost as well,
-    // ONE accepted step that gains nothing the cost resolves ends the solve as "at working precision" (the rule below waits for
-    // four; flat problems -- pendulum, robot arm -- keep their gradient tests: no step is skipped on the prediction alone)
-    if (ms_floor) {
-      ms_floor = false;
-      if (mode >= 1 && mu == T(0) && -(dV1 + dV2) <= T(2) * Eps<T>::v() * t_abs(J)) n_acc_need = 1;
+    if (!have_gaps) {
+      if (gnorm < a.tol * (T(1) + t_abs(J))) { if (coarse) { relin = true; continue; } status = ST_CONVERGED; break; }
+      if (at_working_precision(mode, mu, gnorm, g_last, dec_last, dV1, dV2, J, a.tol)) {
+        if (coarse) { relin = true; continue; }
+        status = ST_STALLED; ++it; break;      // (this iteration's sweep counts)
+      }
+      // first sweep after a multiple-shooting iterate that was closed because its Newton step could gain nothing the merit function
+      // resolves: when the Newton-like step of the closed trajectory predicts a decrease below the resolution of the cost as well,
+      // ONE accepted step that gains nothing the cost resolves ends the solve as "at working precision" (the rule below waits for
+      // four; flat problems -- pendulum, robot arm -- keep their gradient tests: no step is skipped on the prediction alone)
+      if (ms_floor) {
+        ms_floor = false;
+        if (mode >= 1 && mu <= T(0.1) && -(dV1 + dV2) <= T(2) * epsT * t_abs(J)) n_acc_need = 1;      // (a shift left over from the ladder's way down: small against Q_uu)
+      }
     }
     // all step lengths at once; the largest one that passes the Armijo test is taken
     T Ja;
     LFSD_WCK(0, Ja = s.rollout_alphas(cur, true, alpha_l));
     ldsRed[s.lane] = Ja;
     __syncthreads();
-    int ia = -1;
-    T Jmin = J, Jn = J, aa = T(1);
-    const T flat = T(8) * Eps<T>::v() * t_abs(J);
-    const bool flat_full = t_finite(ldsRed[0]) && t_abs(ldsRed[0] - J) <= T(64) * Eps<T>::v() * t_abs(J);
+    int ia = -1, ib = -1;
+    const T Jr = have_gaps ? phi0 : J;                  // an iterate with gaps is worth its merit value: what it costs once they are closed
+    T Jmin = Jr, Jn = Jr, Jb = T(0), aa = T(1);
+    const T flat = T(8) * epsT * t_abs(Jr);
+    const bool flat_full = t_finite(ldsRed[0]) && t_abs(ldsRed[0] - Jr) <= T(64) * epsT * t_abs(Jr);
     for (int l = 0; l < NAL; ++l) {
       const T Jl = ldsRed[l];
-      const T expected = -(aa * dV1 + aa * aa * dV2);
-      const bool okl = t_finite(Jl) && ((J - Jl) >= T(1e-4) * expected - flat) && (Jl < J);
+      const T expected = have_gaps ? aa * pred_ms : -(aa * dV1 + aa * aa * dV2);
+      const bool okl = t_finite(Jl) && ((Jr - Jl) >= T(1e-4) * expected - flat) && (Jl < Jr);
       if (okl && ia < 0) { ia = l; Jn = Jl; }
-      if (t_finite(Jl)) Jmin = t_min(Jmin, Jl);
+      if (t_finite(Jl)) { Jmin = t_min(Jmin, Jl); if (ib < 0 || Jl < Jb) { ib = l; Jb = Jl; } }
       aa *= T(0.5);
     }
     __syncthreads();
@@ -3035,50 +3117,59 @@ __global__ void __launch_bounds__(64, 1) oc_solve_wide_kernel(OcArgs<T> a) {
     if (!accept) {
       if (mode >= 1 && flat_full && (g_flat < T(0) || gnorm < T(0.7) * g_flat)) {
         accept = true; ia = 0; Jn = ldsRed[0]; g_flat = gnorm;      // Newton-like step below rounding noise, gradient still contracting
+      } else if (close_now) {
+        // (the gaps of a finished iterate have to go whatever the roll-outs cost: the cheapest one)
+        if (ib >= 0) { accept = true; ia = ib; Jn = Jb; } else status = ST_FAILED;
       } else if (mode == 1 && !LFSD_HAM_SHIFT) {
         mode = 0; ham_ok = false;
-      } else if (mu > T(1e10) || ((J - Jmin) <= T(8) * Eps<T>::v() * t_abs(J) && ((mode == 0 && !BND) || flat_full || mu > T(1e6)))) {
+      } else if (mu > T(1e10) || ((Jr - Jmin) <= T(8) * epsT * t_abs(Jr) && ((mode == 0 && !BND) || flat_full || mu > T(1e6)))) {
         // (with a box on the controls the clamped closed loop can fail every step length although the Gauss-Newton
         //  direction is a descent direction of the unclamped model: that is a reason to shorten the step, not to stop)
-        if (coarse) relin = true; else status = ST_STALLED;
+        if (coarse) relin = true;
+        else if (!have_gaps) status = ST_STALLED;
+        else if (ib >= 0) { accept = true; ia = ib; Jn = Jb; ms_off = true; }      // (an iterate with gaps cannot be the answer: close it, single shooting from here)
+        else status = ST_FAILED;
       } else {
         mu_bad = mu; mu_hold = 0;
         mu = t_max(mu * T(LFSD_MU_UP), mode == 2 ? T(1e-4) : T(1e-6));
       }
     }
 #if defined(LFSD_TRACE)
-    if (s.lane == 0 && traj == 0) printf("wide it %d st %d mode %d g %.6e J %.12e ia %d accept %d mu %g dV1 %.4e dV2 %.4e Jmin %.12e\n", it, status, mode, (double)gnorm, (double)J, ia, (int)accept, (double)mu, (double)dV1, (double)dV2, (double)Jmin);
+    if (s.lane == 0 && traj == 0) printf("wide it %d st %d mode %d g %.6e J %.12e (ref %.10e gaps %d close %d) ia %d accept %d mu %g dV1 %.4e dV2 %.4e Jmin %.12e\n", it, status, mode, (double)gnorm, (double)J, (double)Jr, (int)have_gaps, (int)close_now, ia, (int)accept, (double)mu, (double)dV1, (double)dV2, (double)Jmin);
 #endif
     if (accept) {
       const T mu_taken = mu;
       s.adopt_alpha(ia, cur ^ 1);
       LFSD_WCK(1, s.linearise_parallel(cur ^ 1));
       cur ^= 1;
-      g_last = gnorm; dec_last = (mode >= 1 && mu == T(0)) ? -(dV1 + dV2) : T(1e30);
+      g_last = gnorm; dec_last = (mode >= 1 && mu == T(0) && !have_gaps) ? -(dV1 + dV2) : T(1e30);
       hess_ok = false; costates_ok = false;
+      g1c = T(0); g2c = T(0); gmc = T(0); s.gap = nullptr;      // a roll-out has no gaps
+      if (ms_off) { ms = false; ms_check = true; }
       if (ia == 0) {
         // gain ratio of the full step (actual / predicted decrease of the shifted model): a step that gains at least
         // LFSD_MU_GAIN_RHO of its prediction says the shift is larger than the model needs -- it falls by LFSD_MU_DOWN_GOOD
         // instead of LFSD_MU_DOWN and does not wait out the hold (the rocket's long solves are accepted full steps that gain
         // 1.5-2x their prediction at shifts that decay one sqrt(10) rung per step)
-        const T pred = -(dV1 + dV2);
-        const bool good = (LFSD_MU_DOWN_GOOD < LFSD_MU_DOWN) && pred > T(0) && (J - Jn) >= T(LFSD_MU_GAIN_RHO) * pred;
+        const T pred = have_gaps ? pred_ms : -(dV1 + dV2);
+        const bool good = (LFSD_MU_DOWN_GOOD < LFSD_MU_DOWN) && pred > T(0) && (Jr - Jn) >= T(LFSD_MU_GAIN_RHO) * pred;
         const T mu_next = (mu > T(1e-8)) ? mu * (good ? T(LFSD_MU_DOWN_GOOD) : T(LFSD_MU_DOWN)) : T(0);
         if (!good && mu > T(0) && mu_bad >= T(0) && mu_next <= mu_bad && mu_hold < mu_hold_need) ++mu_hold;
         else { mu = mu_next; mu_hold = 0; }
-        if (mode == 0 && ham_ok && (J - Jn) < T(LFSD_HAM_SWITCH) * t_abs(Jn)) mode = 1;
-        else if (LFSD_GN_CRAWL && mode == 0 && !ham_ok && (J - Jn) < T(1e-2) * t_abs(Jn)) gn_crawl = true;
+        if (mode == 0 && ham_ok && (Jr - Jn) < T(LFSD_HAM_SWITCH) * t_abs(Jn)) mode = 1;
+        else if (LFSD_GN_CRAWL && mode == 0 && !ham_ok && (Jr - Jn) < T(1e-2) * t_abs(Jn)) gn_crawl = true;
       }
       // past the big drops: the reference's grid.  LFSD_COARSE_EXIT_RULE 0: any accepted step that gains less than the switch;
       // 1: full steps only (a short step through a badly modelled patch gains little too, and is no sign of convergence);
       // 2: full steps at a shift below LFSD_COARSE_EXIT_MU; 3: never by the gain (only the convergence tests above)
-      if (coarse && (J - Jn) < T(LFSD_COARSE_SWITCH) * t_abs(Jn)) {
+      if (coarse && (Jr - Jn) < T(LFSD_COARSE_SWITCH) * t_abs(Jn)) {
         if ((LFSD_COARSE_EXIT_RULE) == 0 || ((LFSD_COARSE_EXIT_RULE) == 1 && ia == 0) ||
             ((LFSD_COARSE_EXIT_RULE) == 2 && ia == 0 && mu_taken <= T(LFSD_COARSE_EXIT_MU))) relin = true;
       }
       J = Jn;
-      if (++n_acc >= n_acc_need) {
-        if (J_ref - J <= T(16) * Eps<T>::v() * t_abs(J)) { if (coarse) relin = true; else status = ST_STALLED; }
+      if (have_gaps) { J_ref = J; n_acc = 0; }             // (the stall test compares costs of roll-outs)
+      else if (++n_acc >= n_acc_need) {
+        if (J_ref - J <= T(16) * epsT * t_abs(J)) { if (coarse) relin = true; else status = ST_STALLED; }
         J_ref = J; n_acc = 0; n_acc_need = 4;
       }
     }
@@ -3086,8 +3177,8 @@ __global__ void __launch_bounds__(64, 1) oc_solve_wide_kernel(OcArgs<T> a) {
   if (status == ST_RUNNING) status = ST_MAXITER;
 #if defined(LFSD_OC_CLOCK)
   if (threadIdx.x == 0 && (it >= LFSD_OC_CLOCK || blockIdx.x == 0))
-    printf("wide clock traj %d: iterations %d total %lld rollout_alphas %lld linearise %lld costates %lld hessians %lld backward %lld | left the coarse grid at iteration %d, clock %lld\n",
-           (int)blockIdx.x, it, clock64() - wck_t0, wck[0], wck[1], wck[2], wck[3], wck[4], wck_it_exit, wck_exit);
+    printf("wide clock traj %d: iterations %d (%d multiple-shooting steps) total %lld rollout_alphas %lld linearise %lld costates %lld hessians %lld backward %lld ms_forward %lld ms_trial %lld | left the coarse grid at iteration %d, clock %lld\n",
+           (int)blockIdx.x, it, n_ms, clock64() - wck_t0, wck[0], wck[1], wck[2], wck[3], wck[4], wck[5], wck[6], wck_it_exit, wck_exit);
 #endif
 #undef LFSD_WCK
   if (!costates_ok) s.costate_sweep(cur);                 // costates of the final nominal

@@ -45,6 +45,37 @@ def build_emu_library(oc, extra_flags=(), tag=""):
     return out
 
 
+def build_variant_library(oc, tag, flags):
+    """hipcc build of a VARIANT of a model library (experiment switches of csrc/cpdp_common.h set on the command line) into
+    csrc/build/ab_<hash>_<tag>.so, rebuilt when a kernel source is newer.  Test infrastructure: the A/B tests compare the product
+    build with it; __graft_entry__.build() prebuilds the ones the GPU tier uses so that they travel with the tree."""
+    from lfsd_amd import runtime
+    spec = oc.model_spec()
+    runtime.write_header(spec)
+    out = os.path.join(runtime.BUILD_DIR, "ab_%s_%s.so" % (spec.hash(), tag))
+    deps = [runtime.header_path(spec.hash())] + [os.path.join(runtime.CSRC_DIR, f) for f in runtime.KERNEL_SOURCES]
+    if os.path.exists(out) and all(os.path.getmtime(out) >= os.path.getmtime(p) for p in deps):
+        return out
+    os.makedirs(runtime.BUILD_DIR, exist_ok=True)
+    cmds, objs = runtime.hipcc_commands(spec, out, list(flags))
+    try:
+        for c in cmds:
+            r = subprocess.run(c, cwd=runtime.CSRC_DIR, capture_output=True, text=True)
+            assert r.returncode == 0, r.stderr[-3000:]
+    finally:
+        for o in objs:
+            if os.path.exists(o):
+                os.remove(o)
+    return out
+
+
+# build variants the -m gpu tier compares the product with (kind, tag, flags)
+PLAIN_SCHEDULE = ("-DLFSD_LEAN_TC=1", "-DLFSD_COARSE_START=0", "-DLFSD_COARSE_TIME=1", "-DLFSD_MS=0")
+GPU_TIER_VARIANTS = (("quadrotor", "nocoarse", ("-DLFSD_COARSE_START=0",)),
+                     ("quadrotor", "plain", PLAIN_SCHEDULE), ("cartpole", "plain", PLAIN_SCHEDULE), ("rocket", "plain", PLAIN_SCHEDULE),
+                     ("robotarm", "plain", PLAIN_SCHEDULE))
+
+
 @pytest.fixture(params=["lockstep", "wide"])
 def oc_mapping(request, monkeypatch):
     """Both mappings of the OC solve: several trajectories per wavefront with the intervals in sequence (lfsd_coc_solve's

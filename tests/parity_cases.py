@@ -119,6 +119,15 @@ def single_trajectory_api(prepare, kind="robotarm", dtype=torch.float64):
     tm = 0.5 * (time_grid[3] + time_grid[4])
     assert np.allclose(opt_sol(tm), 0.5 * (g[3] + g[4]), rtol=1e-12, atol=1e-14)
     assert np.allclose(auxsys_sol(tm), 0.5 * (a[3] + a[4]), rtol=1e-12, atol=1e-14)
+    # interplation_level=2 (CPDP.py:388-390): cocSolver returns the cubic interpolant of the same grid values, as the reference does;
+    # auxSysSolver refuses it loudly -- the HIP sweeps differentiate along the linear interpolant only (no reference example asks
+    # for level 2, and silently resampling it would return numbers the reference's cubic path does not)
+    tg2, cubic = oc.cocSolver(d["ini_state"], d["horizon"], th, interplation_level=2)
+    assert np.allclose(cubic(time_grid), g, rtol=1e-9, atol=1e-11) and not np.allclose(cubic(tm), 0.5 * (g[3] + g[4]), rtol=1e-9, atol=1e-12)
+    import pytest
+    from lfsd_amd.runtime import LfsdError
+    with pytest.raises(LfsdError):
+        oc.auxSysSolver(tg2, cubic, th)
 
 
 def configs0_pendulum(prepare, dtype=torch.float64):

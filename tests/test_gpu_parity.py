@@ -101,6 +101,38 @@ def test_quadrotor_vs_reference_golden_run(dtype, ltol, oc_mapping):
         assert np.abs(tr[:, 13:17] - G["opt_control_traj"]).max() < 1e-6
 
 
+def test_level0_of_the_mesh_continuation_on_the_saved_runs_problem_even_grid():
+    """The reference's saved run was made at n_grid 25 -- a grid on which level 0 of the lean kernels' mesh continuation (merged
+    intervals: even n_grid >= 20) never runs.  The same PROBLEM (the run's start, goal, horizon, waypoints, and 12 parameter vectors
+    of its trace) at n_grid 26, fp32 at the library defaults on the lock-step mapping (level 0, the coarse level, the working-
+    precision stops, error-controlled sweeps), against (a) the tight oracle at n_grid 26 -- headline tolerances -- and (b) the
+    reference's own saved loss at n_grid 25: the two discretisations of one continuous problem differ by 5e-5 ... 5e-3 of the loss
+    (oracle at 25 vs 26: 4e-5 at theta_0, 4.7e-3 at iteration 60), asserted at 1e-2."""
+    n_grid = 26
+    oc, d = gpu_model("quadrotor", torch.float32, n_grid, substeps=0)
+    oc.setSolverOptions(mapping="lockstep")
+    consts = oc.consts_tensor(overrides=dict(goal_r0=G["goal_r"][0], goal_r1=G["goal_r"][1], goal_r2=G["goal_r"][2]))
+    idx = [0, 3, 7, 12, 20, 30, 40, 50, 60, 75, 90, 99]
+    pad = 4096                                                    # (a batch the lock-step lean kernel is the library's own choice for)
+    th = np.tile(G["lookahead_theta"][idx], (pad // len(idx) + 1, 1))[:pad]
+    sol = oc.cocSolverBatch(np.tile(G["ini_state"], (pad, 1)), float(G["horizon"]), th, consts=consts)
+    aux = oc.auxSysSolverBatch(sol, G["taus"], G["waypoints"], [0, 1, 2], want_grids=True)
+    assert set(sol["status"].tolist()) <= {1, 2}
+    assert float(sol["iters"].float().mean()) >= 5.0              # (cold starts: level 0 + coarse + fine iterations, not a warm path)
+    refs = oracle_parallel([dict(kind="quadrotor", n_grid=n_grid, ini_state=list(G["ini_state"]), horizon=float(G["horizon"]),
+                                 theta=list(G["lookahead_theta"][j]), taus=list(G["taus"]), wps=G["waypoints"].tolist(), iface=[0, 1, 2],
+                                 make_kw=dict(goal=tuple(float(v) for v in G["goal_r"]))) for j in idx])
+    # (du/dtheta: its value at T carries the last interval's discretisation error times one gain, parity_cases.dudtheta_refinement; an
+    #  interval of this grid is twice as long as the headline's -- measured 5.7e-2 against the headline's 1.6e-2)
+    tol = dict(grid=3e-4, costate=5e-3, Z=3e-3, aux=3e-3, auxU=1.5e-1, loss=5e-5, grad=2e-3)
+    for k, j in enumerate(idx):
+        assert_grids_match(sol, aux, k, refs[k], 13, 4, 7, tol, what="saved run's problem at n_grid 26, trace point %d" % j)
+        parity_record("saved run's problem at n_grid 26 vs the reference's loss at n_grid 25, trace point %d" % j, "loss",
+                      abs(float(aux["loss"][k]) - G["loss_trace"][j]) / G["loss_trace"][j], 1e-2)
+        # duplicates of a problem anywhere in the batch come back bit-identical (level 0's schedule does not depend on partners)
+        assert torch.equal(sol["state_grid"][k], sol["state_grid"][k + len(idx)])
+
+
 def test_quadrotor_loss_trace_parity_with_nesterov():
     """Loss-vs-iteration parity with the CasADi CPU path: replay the reference's 100 Nesterov iterations
     (lib/QuadAlgorithm.py:469-495, lr 0.01, mu 0.9) on the GPU in fp64 and compare the whole loss trace."""
@@ -186,8 +218,12 @@ def test_headline_workload_has_no_stragglers_and_stops_at_the_fp64_answer():
     parity_record("headline fp32 vs fp64 HIP, 48 seeds at outer iteration 12", "grad", (np.abs(g32 - g64).max(axis=1) / np.abs(g64).max(axis=1)).max(), 3e-3)
 
 
-def test_headline_defaults_vs_tight_oracle_at_outer_iteration_12():
-    """Where the work-saving shortcuts of the shipped fp32 path act -- the working-precision stop of the OC solve (status 2,
+@pytest.mark.parametrize("n_outer", [12, 25])
+def test_headline_defaults_vs_tight_oracle_at_outer_iteration_12(n_outer):
+    """(n_outer = 25, round 5: the regime the DRIVER times -- `bench.py --warmup 5 --steps 20` ends at outer iteration 25, where a
+    third of the batch ends at working precision (status 2) against a few per cent at iteration 12; there the sample is 16 rows of
+    each status, at the same tolerances.)
+    Where the work-saving shortcuts of the shipped fp32 path act -- the working-precision stop of the OC solve (status 2,
     cpdp_oc.h at_working_precision / the costate-only last sweep), the error-controlled unit count and the midpoint rule
     of the auxiliary sweeps (library defaults: rtol 1e-3 from one unit) -- they are compared with the TIGHT ORACLE, not
     with fp64 HIP: the benchmark's own learner runs 12 outer iterations, and at the parameters of the 12th (later
@@ -204,15 +240,15 @@ def test_headline_defaults_vs_tight_oracle_at_outer_iteration_12():
     oc = gpu_prepare(oc, torch.float32)
     oc.setSolverOptions(aux_substeps=args.substeps, aux_rtol=args.aux_rtol)        # the library defaults bench.py runs
     L, theta0, x0 = bench.build_learner(args, oc, d, oc.compile(), 0, 1, "independent")
-    for k in range(12):
+    for k in range(n_outer):
         th = oc.compile().lookahead(L.theta, L.m, L.mu).clone()
         L.step()
     st = L._sol["status"].cpu().numpy()
     assert np.isin(st, (1, 2)).all(), np.bincount(st, minlength=5)
-    rng = np.random.default_rng(12)
+    rng = np.random.default_rng(n_outer)
     pick = []
     n2 = int((st == 2).sum())
-    assert n2 >= 3 and int((st == 1).sum()) >= 26, np.bincount(st, minlength=5)        # both exits are really taken on this workload
+    assert n2 >= (3 if n_outer == 12 else 16) and int((st == 1).sum()) >= 26, np.bincount(st, minlength=5)        # both exits are really taken on this workload
     k2 = min(16, n2)                                                                   # (9 of 4096 ended at status 2 in the round-4 run, 5 with level 0 of the mesh continuation)
     for code, cnt in ((2, k2), (1, 32 - k2)):
         idx = np.where(st == code)[0]
@@ -223,7 +259,7 @@ def test_headline_defaults_vs_tight_oracle_at_outer_iteration_12():
     tol = dict(grid=2e-4, costate=5e-3, loss=5e-5, grad=2e-3)
     for b, r in zip(pick, refs):
         assert_grids_match(L._sol, L._aux, int(b), r, 13, 4, 7, tol,
-                           what="headline fp32 defaults, outer iteration 12, seed %d, status %d" % (b, st[b]))
+                           what="headline fp32 defaults, outer iteration %d, seed %d, status %d" % (n_outer, b, st[b]))
 
 
 def test_configs0_pendulum_horizon50_single_seed():
@@ -589,8 +625,10 @@ def test_robotarm_12_vanilla_steps_every_gradient_applied():
         J = L._sol["cost"].double().cpu().numpy()
         bad = ~np.isin(st, (1, 2))                     # every solve that did not converge (all of them excluded above) ...
         blown = ~np.isfinite(th).all(1) | (np.abs(th) >= 1e3).any(1)
-        assert (blown[bad] | ~np.isfinite(J[bad]) | (J[bad] < -50.0)).all(), (k, J[bad], st[bad])      # ... is a cost running away
-        assert J[adm].min() > -50.0, (k, J[adm].min())
+        # (round 5: how far a diverging cost gets within the iteration limit depends on the path -- with the multiple-shooting steps
+        #  one such row stood at -45.7 when its 120 iterations were spent; the bound between the two populations is now -42 / -40)
+        assert (blown[bad] | ~np.isfinite(J[bad]) | (J[bad] < -42.0)).all(), (k, J[bad], st[bad])      # ... is a cost running away
+        assert J[adm].min() > -40.0, (k, J[adm].min())
 
 
 
@@ -709,22 +747,9 @@ def test_mesh_continuation_ends_at_the_same_kkt_point(dtype, xtol, jtol):
     library and by a build without the coarse phase (-DLFSD_COARSE_START=0, compiled here if the tree does not carry it)
     reach the same KKT point of the NLP of CPDP.py:110-175 -- states, controls, costates and cost to the precision class of
     the arithmetic -- and both report convergence on the reference's discretisation."""
-    import subprocess
+    from conftest import build_variant_library
     oc, env, d = models.quadrotor(n_grid=50)
-    spec = oc.model_spec()
-    runtime.write_header(spec)
-    variant = os.path.join(runtime.BUILD_DIR, "ab_%s_nocoarse.so" % spec.hash())
-    deps = [runtime.header_path(spec.hash())] + [os.path.join(runtime.CSRC_DIR, f) for f in runtime.KERNEL_SOURCES]
-    if not os.path.exists(variant) or any(os.path.getmtime(variant) < os.path.getmtime(p) for p in deps):
-        cmds, objs = runtime.hipcc_commands(spec, variant, ["-DLFSD_COARSE_START=0"])
-        try:
-            for c in cmds:
-                r = subprocess.run(c, cwd=runtime.CSRC_DIR, capture_output=True, text=True)
-                assert r.returncode == 0, r.stderr[-3000:]
-        finally:
-            for o in objs:
-                if os.path.exists(o):
-                    os.remove(o)
+    variant = build_variant_library(oc, "nocoarse", ["-DLFSD_COARSE_START=0"])
     rng = np.random.default_rng(1234)
     th = np.array(d["theta0"])[None, :] + 0.05 * rng.standard_normal((4096, 7))
     th[:, 0] = np.abs(th[:, 0]) + 0.5
@@ -745,6 +770,88 @@ def test_mesh_continuation_ends_at_the_same_kkt_point(dtype, xtol, jtol):
         parity_record("mesh continuation on/off %s" % dtype, k, rel(a[k], b[k].double().cpu().numpy()), t)
     ja, jb = a["cost"].double().cpu().numpy(), b["cost"].double().cpu().numpy()
     parity_record("mesh continuation on/off %s" % dtype, "cost", float(np.abs(ja - jb).max() / np.abs(jb).max()), jtol)
+
+
+HELD_OUT = {
+    # workloads NO schedule constant of csrc/cpdp_common.h was tuned on (the tuning workloads are bench.py's: the quad_example start /
+    # goal at n_grid 50, its random demonstrations, the robot arm and the rocket of the examples at n_grid 50 / 100)
+    "quadrotor_n20": dict(kind="quadrotor", n_grid=20, B=256, mapping="lockstep", horizon=1.4, spread=0.08,
+                          ini=[-1.0, 0.5, 0.3, 0.2, 0, 0, 1, 0, 0, 0, 0, 0, 0], theta0=[1.5, 0.3, 0.2, 0.1, 0.2, 0.05, -0.5],
+                          consts=dict(goal_r0=2.0, goal_r1=-2.0, goal_r2=2.0, Jx=0.5, Jy=0.8, Jz=1.2, mass=1.4)),
+    "quadrotor_n30": dict(kind="quadrotor", n_grid=30, B=256, mapping="lockstep", horizon=0.8, spread=0.08,
+                          ini=[0.5, 2.0, 1.5, 0, -0.3, 0, 1, 0, 0, 0, 0, 0, 0], theta0=[2.0, 0.2, 0.2, 0.3, 0.1, 0.1, 0.5],
+                          consts=dict(goal_r0=-1.0, goal_r1=-1.0, goal_r2=0.5, Jx=1.5, Jy=1.5, Jz=0.7, mass=0.8)),
+    "quadrotor_n100": dict(kind="quadrotor", n_grid=100, B=256, mapping="lockstep", horizon=1.0, spread=0.08,
+                           ini=[1.0, -1.0, 1.0, 0, 0, 0.2, 1, 0, 0, 0, 0, 0, 0], theta0=[1.2, 0.15, 0.15, 0.15, 0.05, 0.05, -1.5],
+                           consts=dict(goal_r0=4.0, goal_r1=1.0, goal_r2=2.5, Jx=1.0, Jy=0.6, Jz=1.4, mass=1.1)),
+    "cartpole_n40": dict(kind="cartpole", n_grid=40, B=256, mapping="wide", horizon=1.0, spread=0.05, ini=[0, 0.3, 0, 0], theta0=None, consts={}),
+    "rocket_other_landing_n40": dict(kind="rocket", n_grid=40, B=128, mapping="auto", horizon=3.0, spread=0.05,
+                                     ini=[8.0, 5.0, -4.0, -0.2, 0.1, 0.0, 0.9238795, 0.0, 0.2705981, -0.2705981, 0, 0, 0], theta0=None, consts={}),
+}
+
+
+@pytest.mark.parametrize("name", sorted(HELD_OUT))
+def test_schedule_constants_on_held_out_workloads(name):
+    """The solver's schedules -- level 0 / coarse phase of the mesh continuation, the merged-interval levels of the wide kernel, the
+    multiple-shooting steps -- were chosen by A/B on bench.py's own workloads.  Here: workloads never used for that (other starts,
+    goals, horizons, inertias and masses, other grids; a cart-pole; a rocket with another landing approach), the PRODUCT build
+    against a build with every schedule switched off (-DLFSD_LEAN_TC=1 -DLFSD_COARSE_START=0 -DLFSD_COARSE_TIME=1 -DLFSD_MS=0):
+    both must end at KKT points (status 1 / 2) and at the SAME one -- asserted at the mesh-continuation test's fp32 tolerances on
+    the quadrotor workloads, on >= 90 % of the trajectories where the problem has several minima (cart-pole, rocket: which one a
+    cold start reaches depends on the path) --, and the time ratio of the two is RECORDED (LFSD_PARITY_REPORT's
+    directory, held_out_schedule_ab.jsonl -> profiles/), not asserted: a workload where the tuned schedule is slower than none
+    is named in DESIGN.md."""
+    import json
+    import time
+    from conftest import build_variant_library, PLAIN_SCHEDULE
+    w = HELD_OUT[name]
+    oc0, env, d = models.ZOO[w["kind"]](n_grid=w["n_grid"])
+    variant = build_variant_library(oc0, "plain", PLAIN_SCHEDULE)
+    B = w["B"]
+    p = len(d["theta0"])
+    rng = np.random.default_rng(77)
+    th0 = np.array(w["theta0"] if w["theta0"] is not None else d["theta0"], dtype=np.float64)
+    th = th0[None, :] * (1 + w["spread"] * rng.standard_normal((B, p)))
+    th[:, 0] = np.abs(th[:, 0]) + 0.1
+    x0 = np.tile(np.array(w["ini"], dtype=np.float64), (B, 1))
+    out, ms = [], []
+    for lib in (None, variant):
+        o2, _, _ = models.ZOO[w["kind"]](n_grid=w["n_grid"])
+        if lib:
+            o2.use_library(lib)
+        o2 = gpu_prepare(o2, torch.float32)
+        if w["mapping"] != "auto":
+            o2.setSolverOptions(mapping=w["mapping"])
+        consts = o2.consts_tensor(overrides=w["consts"]) if w["consts"] else None
+        sol = o2.cocSolverBatch(x0, w["horizon"], th, consts=consts)            # (first call: allocations, code object load)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            sol = o2.cocSolverBatch(x0, w["horizon"], th, consts=consts, workspace=sol["workspace"])
+        torch.cuda.synchronize()
+        ms.append((time.perf_counter() - t0) / 3 * 1e3)
+        out.append(sol)
+    a, b = out
+    sa, sb = a["status"].cpu().numpy(), b["status"].cpu().numpy()
+    ok = np.isin(sa, (1, 2)) & np.isin(sb, (1, 2))
+    ja, jb = a["cost"].double().cpu().numpy(), b["cost"].double().cpu().numpy()
+    xa, xb = a["state_grid"].double().cpu().numpy(), b["state_grid"].double().cpu().numpy()
+    xerr = np.abs(xa - xb).max(axis=(1, 2)) / np.maximum(np.abs(xb).max(axis=(1, 2)), 1e-300)
+    jerr = np.abs(ja - jb) / np.maximum(np.abs(jb), 1e-300)
+    same = ok & (xerr < 3e-3) & (jerr < 2e-5)
+    rec = dict(workload=name, batch=B, n_grid=w["n_grid"], ms_product=ms[0], ms_plain=ms[1], ratio_product_over_plain=ms[0] / ms[1],
+               iters_product=float(a["iters"].double().mean()), iters_plain=float(b["iters"].double().mean()),
+               iters_max_product=int(a["iters"].max()), iters_max_plain=int(b["iters"].max()),
+               status_product=np.bincount(sa, minlength=5).tolist(), status_plain=np.bincount(sb, minlength=5).tolist(),
+               same_kkt_point=float(same.mean()), cost_rel_diff_max_where_same=float(jerr[same].max()) if same.any() else None)
+    rep = os.environ.get("LFSD_PARITY_REPORT")
+    if rep:
+        with open(os.path.join(os.path.dirname(rep), "held_out_schedule_ab.jsonl"), "a") as f:
+            f.write(json.dumps(rec) + "\n")
+    print(rec)
+    multi_minima = w["kind"] in ("cartpole", "rocket")
+    assert ok.mean() >= (0.97 if multi_minima else 1.0), rec
+    assert same.mean() >= (0.9 if multi_minima else 1.0), rec
 
 
 @pytest.mark.parametrize("cfg,words", [("robotarm", ("configs[1]", "RobotArm")), ("rocket", ("configs[4]", "Rocket"))])

@@ -57,12 +57,16 @@ print(oc_trace.variant_path(models.ZOO[sys.argv[1]]()[0].model_spec(), sys.argv[
   for c in robotarm rocket; do
     python3 bench.py --config $c --steps 5 --warmup 1 --no-cpu-baseline > $OUT/bench_$c.json 2> $OUT/bench_$c.err; line $OUT/bench_$c.json
   done
-  python3 bench.py --config robotarm --steps 5 --warmup 1 --no-cpu-baseline --library $(vp robotarm noms) > $OUT/bench_robotarm_noms.json 2> $OUT/bench_robotarm_noms.err; line $OUT/bench_robotarm_noms.json
-  python3 bench.py --config rocket --steps 5 --warmup 1 --no-cpu-baseline --library $(vp rocket msnewton) > $OUT/bench_rocket_msnewton.json 2> $OUT/bench_rocket_msnewton.err; line $OUT/bench_rocket_msnewton.json
-  python3 tools/config_steps.py robotarm 6 > $OUT/steps_robotarm.txt 2>&1; cat $OUT/steps_robotarm.txt
-  LFSD_TOOL_LIBRARY=$(vp robotarm noms) python3 tools/config_steps.py robotarm 6 > $OUT/steps_robotarm_noms.txt 2>&1; cat $OUT/steps_robotarm_noms.txt
-  LFSD_PARITY_REPORT=$PWD/$OUT/parity_floors.jsonl timeout 2400 python3 -m pytest tests -m gpu -q -k "${K:-robotarm or rccl or rocket or two_ranks}" > $OUT/pytest_gpu.txt 2>&1
-  tail -15 $OUT/pytest_gpu.txt ;;
+  for v in ${VARIANTS:-noms nohall}; do
+    python3 bench.py --config robotarm --steps 5 --warmup 1 --no-cpu-baseline --library $(vp robotarm $v) > $OUT/bench_robotarm_$v.json 2> $OUT/bench_robotarm_$v.err; line $OUT/bench_robotarm_$v.json
+  done
+  python3 tools/config_steps.py robotarm 6 > $OUT/steps_robotarm.txt 2>&1; grep "^step" $OUT/steps_robotarm.txt
+  LFSD_TOOL_LIBRARY=$(vp robotarm noms) python3 tools/config_steps.py robotarm 6 > $OUT/steps_robotarm_noms.txt 2>&1; grep "^step" $OUT/steps_robotarm_noms.txt
+  python3 tools/wide_clock.py run robotarm 50 1024 f32 > $OUT/robotarm_wide_clock.txt 2>&1; grep -c "wide clock" $OUT/robotarm_wide_clock.txt; sort -t' ' -k6 -n -r $OUT/robotarm_wide_clock.txt | head -6; sort -t' ' -k6 -n $OUT/robotarm_wide_clock.txt | sed -n '500,503p'
+  if [ -n "$K" ]; then
+    LFSD_PARITY_REPORT=$PWD/$OUT/parity_floors.jsonl timeout 2400 python3 -m pytest tests -m gpu -q -k "$K" > $OUT/pytest_gpu.txt 2>&1
+    tail -15 $OUT/pytest_gpu.txt
+  fi ;;
 ab)
   shift; shift; python3 tools/ab_variants.py run "$@" > $OUT/ab.txt 2>&1; cat $OUT/ab.txt ;;
 *) echo "unknown session $S"; exit 2 ;;
