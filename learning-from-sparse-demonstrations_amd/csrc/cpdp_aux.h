@@ -8,14 +8,8 @@ namespace lfsd {
 // =====================================================================================
 //  Auxiliary control system (differentiated maximum principle)
 // =====================================================================================
-// EXPERIMENT (round 3, profiles/r03_mfma_aux.txt): the Z-dependent product  A^T Z = fx^T Z (+ ...)  of the Riccati right-hand
-// side on the matrix cores -- v_mfma_f32_16x16x1_4b_f32 rank-1 updates with this lane's column of fx gathered dense from
-// the staged coefficients -- instead of the generated sparse operator (43 of 169 entries for the quadrotor).  Needs all
-// 64 lanes (EXEC is ignored by the matrix pipe and the result is spread over the wavefront), so it only runs where the
-// two trajectories of the wavefront are in step; otherwise the sparse operator.  Off in every shipped build.
-#ifndef LFSD_RIC_MFMA
-#define LFSD_RIC_MFMA 0
-#endif
+// (Measured and removed: the Z-dependent product fx^T Z of the Riccati right-hand side on the matrix cores -- +12 % -- and the stiff
+//  update's Gram matrix by m lanes + an LDS hand-over -- +1.5 %: profiles/HISTORY.md, profiles/r03_mfma_aux.txt, r04_h_*.)
 
 template <typename T> struct AuxArgs {
   int batch, n_grid, substeps;    // substeps = minimum coarse split-steps per grid interval (fine = 2x, Richardson)
@@ -89,11 +83,9 @@ template <class M, int LAY = 0> struct AuxLayout {
   // ... and the reductions of the step control (one word per lane, twice)
   static constexpr int FWD_RED = FWD_XCH + 2 * NX * NP;
   static constexpr int lds_elems_fwd() { return ((FWD_RED + 128 + 3) / 4) * 4; }
-  // Riccati kernel only: per node and lane, this lane's column of [Hxx Hxe] and of Huu^-1 [Hux Hue]
-  static constexpr int RIC_ROWS = LFSD_RIC_CACHE == 1 ? NX + NU : (LFSD_RIC_CACHE == 2 ? NU : 0);
-  // ... plus one parking slot per lane for a column of Z (row i of lane l at [i*G + l]): of the unit's start value and
+  // Riccati kernel only: one parking slot per lane for a column of Z (row i of lane l at [i*G + l]): of the unit's start value and
   // the coarse Richardson result only one has to be in registers at a time
-  template <int G> static constexpr int ric_park() { return LDS_END + NNODE * RIC_ROWS * G; }
+  template <int G> static constexpr int ric_park() { return LDS_END; }
   template <int G> static constexpr int lds_elems_ric() { return ((ric_park<G>() + NX * G + 3) / 4) * 4; }
 };
 
@@ -128,7 +120,6 @@ template <class M, typename T, int G, int LAY> struct AuxCtx {
   // zeros point at the node's zero word): `y += H e_lane` is a gather of NX words, not a product with a one-hot vector
   const T* hcol[LAY == 0 ? NX : 1];
   const T* ucol[LAY == 0 ? NU : 1];
-  int fxo[(LFSD_RIC_MFMA != 0) ? NX : 1];      // experiment: offsets of column (lane % 16) of fx in the packed coefficients
 
   LFSD_DEV void load_interval(const AuxArgs<T>& a, long long traj, int k, int N) {
     const T* xs = a.state_grid + (traj * (N + 1) + k) * NX;
@@ -213,26 +204,9 @@ template <class M, typename T, int G, int LAY> struct AuxCtx {
     LFSD_WAVE_SYNC();
     T Gm[NU * NU];
     const T idt = T(1) / dt;
-    if constexpr (LFSD_RIC_GRAM_ROWS != 0) {
-      // Huu/dt + fu^T (P fu) is the same m x m matrix in every lane of the group: lane a < m computes ROW a (= fu^T applied to
-      // column a of P fu: m x nnz(fu)/m FMAs on m lanes instead of m x nnz(fu) on all) and hands it over through LDS
-      T* ldsG = lds + Lay::LDS_T;      // (the transposed exchange of the right-hand side is idle during a stiff step)
-      if (lane < NU) {
-        T col[NX], g[NU];
 #pragma unroll
-        for (int i = 0; i < NX; ++i) col[i] = ldsS[i * NU + lane];
-        M::template fu_mulT<false, LAY>(L, col, g);
-#pragma unroll
-        for (int b = 0; b < NU; ++b) ldsG[lane * NU + b] = g[b] + L[M::OFF_HUU_L[LAY] + lane * NU + b] * idt;
-      }
-      LFSD_WAVE_SYNC();
-#pragma unroll
-      for (int i = 0; i < NU * NU; ++i) Gm[i] = ldsG[i];
-    } else {
-#pragma unroll
-      for (int i = 0; i < NU * NU; ++i) Gm[i] = L[M::OFF_HUU_L[LAY] + i] * idt;
-      M::template fu_gram<true, LAY>(L, ldsS, Gm);
-    }
+    for (int i = 0; i < NU * NU; ++i) Gm[i] = L[M::OFF_HUU_L[LAY] + i] * idt;
+    M::template fu_gram<true, LAY>(L, ldsS, Gm);
     lu_factor<NU>(Gm);
     lu_solve<NU>(Gm, s);
 #pragma unroll
@@ -244,72 +218,24 @@ template <class M, typename T, int G, int LAY> struct AuxCtx {
     }
     LFSD_WAVE_SYNC();
   }
-  // The columns of [Hxx Hxe] and Huu^-1 [Hux Hue] this lane needs do not depend on Z: once per staged node
-  // instead of once per right-hand-side evaluation (12 per unit).  Parked per lane at [(node*(NX+NU)+r)*G + lane].
-  LFSD_DEV void ric_cols() {
-    if (Lay::RIC_ROWS == 0) return;
-    constexpr int R = Lay::RIC_ROWS, HX = LFSD_RIC_CACHE == 1 ? NX : 0;
-    T* hc = lds + Lay::LDS_END;
-    LFSD_RIC_NODE_LOOP
-    for (int nd = 0; nd < Lay::NNODE; ++nd) {
-      const T* L = node(nd);
-      T hu[NU], wq[NU];
-      if (LFSD_RIC_CACHE == 1) {
-        T hx[NX];
-        M::template Hxx_mul<false, LAY>(L, ox, hx);
-        M::template Hxe_mul<true, LAY>(L, oe, hx);
-#pragma unroll
-        for (int i = 0; i < NX; ++i) hc[(nd * R + i) * G + lane] = hx[i];
-      }
-      M::template Hxu_mulT<false, LAY>(L, ox, hu);
-      M::template Hue_mul<true, LAY>(L, oe, hu);
-      M::template ihuu_mul<LAY>(L, hu, wq);
-#pragma unroll
-      for (int a = 0; a < NU; ++a) hc[(nd * R + HX + a) * G + lane] = wq[a];
-    }
-  }
   // non-stiff part  dZ/dtau = [Qt qt] + A^T Z + P [A rt]   (A, Qt, rt, qt of CPDP.py:265-269)
   LFSD_DEV void ric_rhs(const T* z, int nd, T* y) {
-    constexpr int R = Lay::RIC_ROWS, HX = LFSD_RIC_CACHE == 1 ? NX : 0;
     T* ldsT = lds + Lay::LDS_T;
     const T* L = node(nd);
-    const T* hc = lds + Lay::LDS_END + nd * R * G;
     T s[NU], v[NU], w[NU], nv[NU], r[NP], wq[NU];
-    if (R == 0) {
+    {
+      // (this lane's column of Huu^-1 [Hux Hue] is recomputed per right-hand side: with the midpoint rule's six per unit that is
+      //  cheaper than parking it per node and lane -- measured 1.37 against 1.47 / 2.30 ms, profiles/HISTORY.md)
       T hu[NU];
 #pragma unroll
       for (int a = 0; a < NU; ++a) hu[a] = ucol[a][nd * Lay::NCOEF];      // (Hux | Hue) e_lane
       M::template ihuu_mul<LAY>(L, hu, wq);
-    } else {
-#pragma unroll
-      for (int a = 0; a < NU; ++a) wq[a] = hc[(HX + a) * G + lane];
     }
     M::template fu_mulT<false, LAY>(L, z, s);
     M::template ihuu_mul<LAY>(L, s, v);
 #pragma unroll
     for (int a = 0; a < NU; ++a) { nv[a] = -v[a]; w[a] = -(wq[a] + v[a]); }
-#if LFSD_RIC_MFMA && !defined(LFSD_EMU)
-    bool on_matrix_cores = false;
-    if constexpr (sizeof(T) == 4 && LAY == 0 && G >= 16 && NX <= 16) {
-      if (__builtin_amdgcn_read_exec() == ~0ull) {
-        on_matrix_cores = true;
-        T ac[NX];
-#pragma unroll
-        for (int kk = 0; kk < NX; ++kk) ac[kk] = L[fxo[kk]];          // fx[kk][lane % 16]: row kk of this lane's column
-        f32x16 acc;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-#pragma unroll
-        for (int kk = 0; kk < NX; ++kk) mfma4b(ac[kk], z[kk], acc);   // D_b[i][j] = sum_kk fx[kk][i] z_j[kk] = (fx^T z_j)[i]
-        tile_transpose(acc);
-#pragma unroll
-        for (int i = 0; i < NX; ++i) y[i] = acc[i];
-      }
-    }
-    if (!on_matrix_cores) M::template fx_mulT<false, LAY>(L, z, y);
-#else
     M::template fx_mulT<false, LAY>(L, z, y);
-#endif
     if (lane < NX) {
       T tv[NX];
 #pragma unroll
@@ -322,13 +248,8 @@ template <class M, typename T, int G, int LAY> struct AuxCtx {
 #pragma unroll
       for (int i = 0; i < NP; ++i) ldsT[lane * NZ + NX + i] = r[i];
     }
-    if (LFSD_RIC_CACHE == 1) {
 #pragma unroll
-      for (int i = 0; i < NX; ++i) y[i] += hc[i * G + lane];
-    } else {
-#pragma unroll
-      for (int i = 0; i < NX; ++i) y[i] += hcol[i][nd * Lay::NCOEF];      // [Hxx Hxe] e_lane
-    }
+    for (int i = 0; i < NX; ++i) y[i] += hcol[i][nd * Lay::NCOEF];      // [Hxx Hxe] e_lane
     M::template Hxu_mul<true, LAY>(L, w, y);
     LFSD_WAVE_SYNC();
     if (lane < NZ) {
@@ -663,7 +584,7 @@ __global__ void __launch_bounds__(64, (sizeof(T) == 4 ? LFSD_WAVES_RIC : 1)) aux
   constexpr int NX = M::NX, NP = M::NP, NZ = NX + NP;
   constexpr int GPB = 64 / G;
   static_assert(64 % G == 0 && G >= NZ && G >= Lay::NNODE, "lane group must hold one column of [P W] per lane");
-  __shared__ T lds_all[GPB * Lay::template lds_elems_ric<G>() + LFSD_AUX_LDS_PAD];
+  __shared__ T lds_all[GPB * Lay::template lds_elems_ric<G>()];
   poison_lds(lds_all, GPB * Lay::template lds_elems_ric<G>());
   const long long slot = (long long)blockIdx.x * GPB + threadIdx.x / G;
   const bool valid = slot < a.batch;
@@ -681,10 +602,6 @@ __global__ void __launch_bounds__(64, (sizeof(T) == 4 ? LFSD_WAVES_RIC : 1)) aux
   aux_setup<M, T, G, 0>(s, a, traj, lds_all, Lay::template lds_elems_ric<G>());
   const int N = a.n_grid, Sa = a.substeps;
   const int lane = s.lane;
-#if LFSD_RIC_MFMA && !defined(LFSD_EMU)
-#pragma unroll
-  for (int kk = 0; kk < NX; ++kk) s.fxo[kk] = ((lane & 15) < NX) ? M::fx_off0(kk, lane & 15) : M::OFF_ZERO;
-#endif
   {
     const int col = lane < NZ ? lane : 0;
     const T* n0 = s.lds + Lay::LDS_L;
@@ -743,7 +660,6 @@ __global__ void __launch_bounds__(64, (sizeof(T) == 4 ? LFSD_WAVES_RIC : 1)) aux
         const T s_hi = T(1) - T(unit) / T(units);
         if (!(staged && unit == 0)) s.stage_nodes(s_hi, -ds);      // node i sits at fraction s_hi - i/(4 units)
         staged = false;
-        s.ric_cols();
         // coarse chain in place, then the fine chain in place from the parked start value (the barriers inside the chains
         // keep the compiler from carrying the parked column in registers)
         T* zpark = s.lds + Lay::template ric_park<G>();
@@ -820,7 +736,7 @@ __global__ void __launch_bounds__(64, (sizeof(T) == 4 ? LFSD_WAVES_FWD : 1)) aux
   constexpr int GPB = 64 / G;
   static_assert(64 % G == 0 && G >= NX && G >= 2 * NP && G >= Lay::NNODE && G >= 3 * sub_lanes<NU <= 4 ? NU : 1>(),
                 "forward lane group: one P column per lane, and one X column per lane in each half (fine / coarse chain)");
-  __shared__ T lds_all[GPB * Lay::lds_elems_fwd() + LFSD_AUX_LDS_PAD];
+  __shared__ T lds_all[GPB * Lay::lds_elems_fwd()];
   poison_lds(lds_all, GPB * Lay::lds_elems_fwd());
   const long long slot = (long long)blockIdx.x * GPB + threadIdx.x / G;
   const bool valid = slot < a.batch;

@@ -15,19 +15,9 @@
 #define LFSD_DEV __device__ __forceinline__
 #define LFSD_HD __host__ __device__
 // lambdas inside kernels must be inlined as well: a real call passes their by-reference captures through scratch
-// (experiment knob LFSD_PHASE_CALLS: bit 0 keeps the backward sweep of oc_solve_kernel a real call, bit 1 the roll-out, so
-// that each phase gets its own register allocation; profiles/r02_e_phase_calls.txt)
 #define LFSD_LAMBDA_INLINE __attribute__((always_inline))
-#if defined(LFSD_PHASE_CALLS) && (LFSD_PHASE_CALLS & 1)
-#define LFSD_LAMBDA_BW __attribute__((noinline))
-#else
 #define LFSD_LAMBDA_BW __attribute__((always_inline))
-#endif
-#if defined(LFSD_PHASE_CALLS) && (LFSD_PHASE_CALLS & 2)
-#define LFSD_LAMBDA_RO __attribute__((noinline))
-#else
 #define LFSD_LAMBDA_RO __attribute__((always_inline))
-#endif
 #endif
 
 // register budget: measured on MI355X (tools/tune.py) 1 wave/SIMD with all 512 VGPR+AGPR beats 2-3 waves with scratch spills
@@ -44,10 +34,6 @@
 // round instead of two, 8.2 -> 7.1 ms with 0.4 KB/lane of spills, and 5.7 ms with none (246 VGPRs) once the coarse and the
 // fine Richardson chain run in place with the other column parked in LDS.  The forward sweep stays at one wave per SIMD
 // (256 + 256 registers) and keeps its two chains as independent instruction streams: in place it is 20 % slower.
-// tuning only: extra LDS elements per workgroup of the aux kernels, to lower their occupancy (tools/tune.py)
-#ifndef LFSD_AUX_LDS_PAD
-#define LFSD_AUX_LDS_PAD 0
-#endif
 // Error-controlled sub-stepping of the auxiliary sweeps: the next interval starts with HALF the units of this one when
 // this one's worst per-unit estimate is at most 1/LFSD_AUX_DOWN of its tolerance.  The estimate is the local error of
 // one split unit, O(h^3): measured on the headline workload it grows 7.4-8x when the units are halved
@@ -72,14 +58,6 @@
 #ifndef LFSD_AUX_DOWN
 #define LFSD_AUX_DOWN 8
 #endif
-// Riccati kernel: which Z-independent columns are parked per lane in LDS (0 none, 1 [Hxx Hxe] and Huu^-1 [Hux Hue],
-// 2 only Huu^-1 [Hux Hue]).  Mode 2 leaves 16 KB of LDS per workgroup, which admits the second wave per SIMD below; it
-// paid while a unit evaluated 12 right-hand sides per node set.  With the midpoint rule (6, LFSD_AUX_RK32) recomputing
-// the columns costs less than parking them: measured on the benchmark, Riccati 1.47 ms (mode 2) / 2.30 ms (mode 1) /
-// 1.37 ms (mode 0).
-#ifndef LFSD_RIC_CACHE
-#define LFSD_RIC_CACHE 0
-#endif
 // outer per-node loops of the once-per-unit preparation (ric_cols; fwd_prep, fwd_cols): rolled.  Measured: 6 % faster in
 // the Riccati sweep; the forward sweep preferred them unrolled (7 %) until it was compiled with the max-ILP scheduler,
 // since then rolled is 5 % faster there too (profiles/r01_tune_aux_occupancy.txt, r01_tune_compiler_flags.txt)
@@ -96,13 +74,6 @@
 // reading its operands where it uses them.
 #ifndef LFSD_FWD_FETCH
 #define LFSD_FWD_FETCH 1
-#endif
-// Riccati sweep, stiff update: the m x m matrix Huu/dt + fu^T P fu by m lanes, one row each, handed over through LDS (1) or
-// by every lane on its own (0).  Measured (profiles/r04_h_*): 338 fewer vector instructions in the kernel, and SLOWER --
-// fp32 1.474 -> 1.496 ms, fp64 4.61 -> 4.71 ms: the extra LDS hand-over of a stiff step (five per unit) costs more than the
-// 55 redundant FMAs it removes from a sweep that issues 37 % of its cycles.  Off.
-#ifndef LFSD_RIC_GRAM_ROWS
-#define LFSD_RIC_GRAM_ROWS 0
 #endif
 #ifndef LFSD_WAVES_RIC
 #define LFSD_WAVES_RIC 2
@@ -124,14 +95,6 @@
 #ifndef LFSD_MU_DOWN
 #define LFSD_MU_DOWN 0.31623
 #endif
-// wide kernel: factor by which the shift falls after a full step that gained at least LFSD_MU_GAIN_RHO of its predicted
-// decrease (>= LFSD_MU_DOWN switches the rule off)
-#ifndef LFSD_MU_DOWN_GOOD
-#define LFSD_MU_DOWN_GOOD 1.0
-#endif
-#ifndef LFSD_MU_GAIN_RHO
-#define LFSD_MU_GAIN_RHO 0.8
-#endif
 // generic backward sweep of a solve that runs Newton from its first iteration (exact_after == 0, the rocket): fraction of the
 // Levenberg shift a stage keeps when its Q_uu factorises with it (0: one shift for all stages).  Measured on the rocket learner
 // step with the coarse time grid: 0 -> 207 ms, 0.01 -> 191, 0.003 -> 149, 0.001 -> 150, 1e-4 -> 214 (profiles/r04_s_*).  Solves
@@ -141,9 +104,6 @@
 #endif
 #ifndef LFSD_MU_HOLD
 #define LFSD_MU_HOLD 1
-#endif
-#ifndef LFSD_MU_HOLD_BACKOFF
-#define LFSD_MU_HOLD_BACKOFF 0
 #endif
 #ifndef LFSD_GN_CRAWL
 #define LFSD_GN_CRAWL 1
@@ -168,9 +128,6 @@
 // stages of look-ahead of the wide kernel's costate sweep (0: load where used)
 #ifndef LFSD_CS_AHEAD
 #define LFSD_CS_AHEAD 3
-#endif
-#ifndef LFSD_BW_PREFETCH
-#define LFSD_BW_PREFETCH 0
 #endif
 // lean fp32 kernel of the 32-lane models: backward sweep on the matrix cores (1) or relayed on the vector pipe (0)
 #ifndef LFSD_MFMA_BACKWARD
@@ -219,7 +176,6 @@
 #ifndef LFSD_LEAN_TC_MIN
 #define LFSD_LEAN_TC_MIN 10
 #endif
-// 1: level 0 hands over to the reference's grid directly (no iterations on the one-step-per-interval level in between)
 // lean kernels: the convergence histories (last gradient norm, last predicted decrease) survive the step that leaves the coarse grid
 // when the coarse problem had converged (cpdp_oc.h); 0 = they always start over on the reference's grid
 #ifndef LFSD_EXIT_KEEP_HISTORY
@@ -230,19 +186,9 @@
 #ifndef LFSD_LEAN_TC_GRACE
 #define LFSD_LEAN_TC_GRACE 2
 #endif
-#ifndef LFSD_LEAN_TC_TO_FINE
-#define LFSD_LEAN_TC_TO_FINE 0
-#endif
-// wide kernel: 1 = the models below 32 lanes get a coarse phase too (one RK4 step per interval, no merged intervals), at n_grid >=
-// LFSD_COARSE_MIN_GRID as the others.  Measured on the robot arm and left OFF (profiles/r04_ah_robotarm_coarse_phase_ab.txt, r04_aj_*):
-// the OC solve of the benchmark's learner goes 21.2 -> 12.7 ms with the same minima on 1 023 of 1 024 seeds, but a seed with a
-// quadratic weight of 0.06 crawls on the coarse discretisation to a minimum the reference's does not have (J = -63 on one RK4 step
-// per interval, 390 for the same controls on four) and runs out of iterations -- a seed the plain solve converges on -- and the rows
-// it pushes out make the auxiliary sweeps slower than the solve gained; ending the phase at the hand-over to the exact Hessians
-// keeps that seed and loses the gain (24.3 ms).
-#ifndef LFSD_COARSE_SMALL_MODELS
-#define LFSD_COARSE_SMALL_MODELS 0
-#endif
+// (a coarse phase for the wide kernel's models below 32 lanes was measured on the robot arm and removed: 21.2 -> 12.7 ms with the same
+//  minima on 1 023 of 1 024 seeds, but one seed follows the coarse discretisation to a minimum the reference's does not have:
+//  profiles/HISTORY.md, r04_ah_robotarm_coarse_phase_ab.txt)
 // wide kernel: the interval-parallel (multiple-shooting) iteration of OcWide::ms_* (cpdp_oc.h) -- the reference's own lifted
 // formulation, CPDP.py:136-172 -- for unbounded problems with at least LFSD_MS_MIN_GRID intervals; 0: single shooting only.
 // The phase hands over to the single-shooting iteration through a closed-loop roll-out, so every convergence test is unchanged.
@@ -257,6 +203,9 @@
 // OcSolver::stage_hessian_all) or one (interval, column) item per lane (0)
 #ifndef LFSD_HESS_ALL
 #define LFSD_HESS_ALL 1
+#endif
+#ifndef LFSD_MS_JFEAS
+#define LFSD_MS_JFEAS 1
 #endif
 #ifndef LFSD_MS_NEWTON
 #define LFSD_MS_NEWTON 0
@@ -296,29 +245,10 @@
 #ifndef LFSD_COARSE_EXIT_MU
 #define LFSD_COARSE_EXIT_MU 1e-2
 #endif
-// leaving the coarse grid: 1 = always by a roll-out + linearisation of the nominal without a step, 0 = with the next full step
-#ifndef LFSD_COARSE_RELIN
-#define LFSD_COARSE_RELIN 0
-#endif
 #ifndef LFSD_REG_CONSISTENT
 #define LFSD_REG_CONSISTENT 1
 #endif
-#ifndef LFSD_HAM_SHIFT
-#define LFSD_HAM_SHIFT 0
-#endif
 
-// structural backward sweep, fp32: V_x and the costate read from their LDS images where used (1) or carried in registers (0).
-// In fp64 the LDS form is what made the one-pass sweep pay (11.1 -> 9.2 ms); in fp32 it frees 21 accumulator registers and
-// costs 2 % (oc_solve 2.58 -> 2.63 ms, profiles/r03_aa_ab_vx_lds.txt): the registers are there.
-// structural backward sweep, fp32: gain rows / Q_ux rows of the V_xx update fetched into registers first (1) or read where used (0).
-// Measured (profiles/r04_p_ab_vupdate_fetch.txt): oc_solve 2.589 -> 2.633 ms with the fetch -- the sweep runs at 256 + 142 registers and
-// the 52 extra live values turn into accumulator-register moves; what lds_fetch bought the forward auxiliary sweep it does not buy here.
-#ifndef LFSD_SC_VUP_FETCH
-#define LFSD_SC_VUP_FETCH 0
-#endif
-#ifndef LFSD_SC_VX_LDS
-#define LFSD_SC_VX_LDS 0
-#endif
 // ---- fp64 OC kernels (round 3; profiles/r03_o_fp64_backward.txt, r03_q_fp64_live_park.txt) --------------------------------
 // fp64 lean OC kernel of the 32-lane models on 16-lane groups (four trajectories per wavefront); 0: 32-lane groups (round 2)
 #ifndef LFSD_FP64_LIVE
@@ -356,15 +286,9 @@
 // defined.  No-ops in the emulator build.
 #if defined(LFSD_EMU)
 #define LFSD_ROW_FENCE()
-#define LFSD_SCHED_FENCE()
 #define LFSD_SCHED_FENCE64(T)
 #else
 #define LFSD_ROW_FENCE() __builtin_amdgcn_sched_barrier(0)
-#if defined(LFSD_USE_SCHED_FENCE)
-#define LFSD_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
-#else
-#define LFSD_SCHED_FENCE()
-#endif
 #define LFSD_SCHED_FENCE64(T) do { if constexpr (((LFSD_FENCE64) & 2) != 0 && sizeof(T) == 8) __builtin_amdgcn_sched_barrier(0); } while (0)
 #endif
 
@@ -373,24 +297,8 @@
 // flight are not drained) around a wave_barrier, which emits nothing and only keeps the compiler from moving LDS accesses
 // across it.  Unlike __syncthreads() it is well defined under control flow that differs between the lanes of the wavefront.
 // The CPU emulator runs every lane as a fiber and needs a real rendez-vous there.
-// LFSD_SYNC_LIGHT (experiment, round 4): the hand-over as a COMPILER barrier only.  The release fence above costs an
-// `s_waitcnt lgkmcnt(0)` -- the wavefront parks until every LDS operation it has in flight is acknowledged -- although the
-// LDS pipeline executes the DS instructions of one wavefront in issue order: a ds_read issued after a ds_write of the same
-// wavefront sees the written data without any wait, whichever lanes wrote and read (the wait the READ's consumer needs
-// is inserted by the compiler as for any load).  With the knob the macro only keeps the compiler from moving LDS accesses
-// across the point.
-#ifndef LFSD_SYNC_LIGHT
-#define LFSD_SYNC_LIGHT 0
-#endif
 #if defined(LFSD_EMU)
 #define LFSD_WAVE_SYNC() __syncthreads()
-#elif LFSD_SYNC_LIGHT
-#define LFSD_WAVE_SYNC()                   \
-  do {                                     \
-    asm volatile("" ::: "memory");         \
-    __builtin_amdgcn_wave_barrier();       \
-    asm volatile("" ::: "memory");         \
-  } while (0)
 #else
 #define LFSD_WAVE_SYNC()                                            \
   do {                                                              \

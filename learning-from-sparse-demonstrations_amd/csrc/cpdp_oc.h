@@ -171,7 +171,7 @@ template <class M, typename T, int G, bool EXACT, bool BND = false> struct OcSol
     }
 #pragma unroll
     for (int i = 0; i < NX; ++i) { ax[i] = f[i]; xs[i] = x[i] + hh * f[i]; if (SENS) { am[i] = d[i]; ms[i] = m[i] + hh * d[i]; } }
-    LFSD_SCHED_FENCE(); LFSD_SCHED_FENCE64(T);
+    LFSD_SCHED_FENCE64(T);
     if (SENS) M::dyn_cost_jvp(t, xs, u, e, c, ms, du, f, cq, d, dq); else M::dyn_cost(t, xs, u, e, c, f, cq);
     aq += T(2) * cq; if (SENS) adq += T(2) * dq;
     if (NZ) {
@@ -181,7 +181,7 @@ template <class M, typename T, int G, bool EXACT, bool BND = false> struct OcSol
     }
 #pragma unroll
     for (int i = 0; i < NX; ++i) { ax[i] += T(2) * f[i]; xs[i] = x[i] + hh * f[i]; if (SENS) { am[i] += T(2) * d[i]; ms[i] = m[i] + hh * d[i]; } }
-    LFSD_SCHED_FENCE(); LFSD_SCHED_FENCE64(T);
+    LFSD_SCHED_FENCE64(T);
     if (SENS) M::dyn_cost_jvp(t, xs, u, e, c, ms, du, f, cq, d, dq); else M::dyn_cost(t, xs, u, e, c, f, cq);
     aq += T(2) * cq; if (SENS) adq += T(2) * dq;
     if (NZ) {
@@ -191,7 +191,7 @@ template <class M, typename T, int G, bool EXACT, bool BND = false> struct OcSol
     }
 #pragma unroll
     for (int i = 0; i < NX; ++i) { ax[i] += T(2) * f[i]; xs[i] = x[i] + DT * f[i]; if (SENS) { am[i] += T(2) * d[i]; ms[i] = m[i] + DT * d[i]; } }
-    LFSD_SCHED_FENCE(); LFSD_SCHED_FENCE64(T);
+    LFSD_SCHED_FENCE64(T);
     if (SENS) M::dyn_cost_jvp(t, xs, u, e, c, ms, du, f, cq, d, dq); else M::dyn_cost(t, xs, u, e, c, f, cq);
     aq += cq; if (SENS) adq += dq;
     const T h6 = DT / T(6);
@@ -901,7 +901,7 @@ template <class M, typename T, int G, bool EXACT, bool BND = false> struct OcSol
         for (int kk = 0; kk < NX; ++kk) s += ldsV[i * NX + kk] * m[kk];
         pin64(s);
         Y[i] = s;
-        LFSD_SCHED_FENCE(); LFSD_SCHED_FENCE64(T);
+        LFSD_SCHED_FENCE64(T);
       }
 #pragma unroll
       for (int r = 0; r < NXU; ++r) {
@@ -910,7 +910,7 @@ template <class M, typename T, int G, bool EXACT, bool BND = false> struct OcSol
         for (int i = 0; i < NX; ++i) s += ldsM[r * NX + i] * Y[i];
         pin64(s);
         Qcol[r] = s;
-        LFSD_SCHED_FENCE(); LFSD_SCHED_FENCE64(T);
+        LFSD_SCHED_FENCE64(T);
       }
       }
       if (EXACT && mode == 2) {
@@ -1032,6 +1032,10 @@ template <class M, typename T, int G, bool EXACT, bool BND = false> struct OcSol
         chol_solve<NU>(Lf, Kj);
       } else {
         if (ok) ok = chol_factor<NU>(Lc, dmin); else { T dd = T(0); chol_factor<NU>(Lc, dd); }   // first failing pivot sizes the shift
+        // wide kernel (the wavefront is one trajectory, `ok` is uniform; its stage Hessians are computed before the sweep): a sweep
+        // whose Q_uu + mu I is not positive definite is over -- the caller only reads the failing pivot -- and the stages below it
+        // are the larger part of a retry ladder's cost (several shifts in a row on the way up)
+        if constexpr (G == 64) { if (!ok) break; }
 #pragma unroll
         for (int a = 0; a < NU; ++a) { kff[a] = -Qu[a]; Kj[a] = -Quxj[a]; }
         chol_solve<NU>(Lc, kff);
@@ -1181,13 +1185,12 @@ template <class M, typename T, int G, bool EXACT, bool BND = false> struct OcSol
     // this lane's column of [A B; q], its row of the LDS-carried column and the nominal (x_k, u_k) of one interval: the
     // loads of interval k-1 are issued while interval k is being processed (one wave per SIMD: nothing else would hide
     // the latency of the workspace, which does not fit the caches)
-    T m[NX], mq = T(0), me = T(0), mN[NX], mqN = T(0), meN = T(0), xkN[NX], ukN[NU];
+    T m[NX], mq = T(0), me = T(0);
     mf_load_stage(cur, N - 1, m, mq, me, xk, uk);
     for (int k = N - 1; k >= 0; --k) {
       if (NEXT) {                                  // column NCL of [A B; q]: row `lane` of it, parked in LDS
         if (lane <= NX) ldsME[lane] = me;
       }
-      if (LFSD_BW_PREFETCH) { if (k > 0) { mf_load_stage(cur, k - 1, mN, mqN, meN, xkN, ukN); LFSD_ISSUE_FENCE(); } }
       // Y = V_xx [A B](:, 0..15)
       f32x16 acc;
 #pragma unroll
@@ -1339,17 +1342,7 @@ template <class M, typename T, int G, bool EXACT, bool BND = false> struct OcSol
         for (int i = 0; i < NX; ++i) vcol[i] = (lane < NX) ? T(0.5) * (vcol[i] + vt[i]) : T(0);
       }
       __syncthreads();
-      if (k > 0) {
-        if (LFSD_BW_PREFETCH) {
-#pragma unroll
-          for (int i = 0; i < NX; ++i) { m[i] = mN[i]; xk[i] = xkN[i]; }
-#pragma unroll
-          for (int a = 0; a < NU; ++a) uk[a] = ukN[a];
-          mq = mqN; me = meN;
-        } else {
-          mf_load_stage(cur, k - 1, m, mq, me, xk, uk);
-        }
-      }
+      if (k > 0) mf_load_stage(cur, k - 1, m, mq, me, xk, uk);
     }
     ldsRed[lane] = gl_max;
     __syncthreads();
@@ -1513,7 +1506,7 @@ template <class M, typename T, int G, bool EXACT, bool BND = false> struct OcSol
     // roles: V_xx (symmetric, natural row order) and this stage's live columns are published in LDS, every lane reads the rows
     // it needs two row buffers ahead -- ONE pass for the wavefront's four trajectories where the generic sweep took two.
     constexpr bool MM = sizeof(T) == 4;
-    constexpr bool VXR = MM && (LFSD_SC_VX_LDS == 0);      // V_x and the costate carried in registers through the stage (else: read from their LDS images)
+    constexpr bool VXR = MM;      // fp32 (matrix cores): V_x and the costate carried in registers through the stage; fp64: read from their LDS images where used
     T* ldsMl = lds + Lay::LDS_M;              // !MM: [LIVE][NX] live column r of [A B] as row r   (LDS_M region: NXU*NX words)
     T* ldsYZ = MM ? lds + Lay::LDS_M : yz64;  // [16 lanes][ZC] rows Y(Z, column of the lane)
     const bool has_v = lane < NX;                       // V-role: lanes < LX live state ZC + lane, lanes LX.. constant state lane - LX
@@ -1550,13 +1543,12 @@ template <class M, typename T, int G, bool EXACT, bool BND = false> struct OcSol
       }
     }
     __syncthreads();
-    T m[NX], mq = T(0), qzl = T(0), mN[NX], mqN = T(0), qzN = T(0), xkN[NX], ukN[NU];
+    T m[NX], mq = T(0), qzl = T(0);
     sc_load_stage(cur, N - 1, m, mq, qzl, xk, uk);
 #if defined(LFSD_BW_CLOCK) && !defined(LFSD_EMU)
     long long bwc_t = clock64();
 #endif
     for (int k = N - 1; k >= 0; --k) {
-      if (LFSD_BW_PREFETCH == 1) { if (k > 0) { sc_load_stage(cur, k - 1, mN, mqN, qzN, xkN, ukN); LFSD_ISSUE_FENCE(); } }
       if constexpr (LFSD_OC_LDS_SYNC != 0) {
         // every global load of the stage lands HERE.  Loads and stores share one in-order counter on this hardware: the stage's
         // nominal control, first used in the middle of the stage, was waited for behind the global stores of the gains -- i.e.
@@ -1646,7 +1638,6 @@ template <class M, typename T, int G, bool EXACT, bool BND = false> struct OcSol
       }
       if constexpr (MM) tile_transpose(acc);
       LFSD_STAGE_SYNC();                             // ldsYZ visible
-      if (LFSD_BW_PREFETCH == 2) { if (k > 0) { sc_load_stage(cur, k - 1, mN, mqN, qzN, xkN, ukN); LFSD_ISSUE_FENCE(); } }      // (experiment: behind the MFMA chains)
       LFSD_BWC(1)                                  // MFMA #2, gradient dot products, transpose
       // column of Q (natural row order) of this lane's V-role, control rows of its M-role
       T Qcol[NX], mu_rows[NU], Quxj[NU];
@@ -1730,29 +1721,6 @@ template <class M, typename T, int G, bool EXACT, bool BND = false> struct OcSol
       matvec<NU>(Quu0, Kj, t1);
 #pragma unroll
       for (int a = 0; a < NU; ++a) t1[a] += Quxj[a];
-      if constexpr ((LFSD_SC_VUP_FETCH) != 0 && sizeof(T) == 4) {
-        // EXPERIMENT (round 4): the gain rows and Q_ux rows of the update fetched with back-to-back LDS reads first (lds_fetch),
-        // in two halves of the rows
-        constexpr int H1 = (NX + 1) / 2;
-        T kr[H1 * NU], qr[H1 * NU];
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          const int i0 = h * H1;
-          lds_issue<H1 * NU>(ldsK + i0 * NU, kr); lds_issue<H1 * NU>(ldsQux + i0 * NU, qr);
-          lds_land<H1 * NU>(kr); lds_land<H1 * NU>(qr);
-#pragma unroll
-          for (int ii = 0; ii < H1; ++ii) {
-            const int i = i0 + ii;
-            if (i < NX) {
-              T sacc = Qcol[i];
-#pragma unroll
-              for (int a = 0; a < NU; ++a) { sacc += kr[ii * NU + a] * t1[a]; sacc += qr[ii * NU + a] * Kj[a]; }
-              vcol[i] = sacc;
-              if (VXR) { Vx[i] = ldsVx[i]; lam[i] = ldsLam[i]; }
-            }
-          }
-        }
-      } else {
 #pragma unroll
       for (int i = 0; i < NX; ++i) {
         T sacc = Qcol[i];
@@ -1760,7 +1728,6 @@ template <class M, typename T, int G, bool EXACT, bool BND = false> struct OcSol
         for (int a = 0; a < NU; ++a) { sacc += ldsK[i * NU + a] * t1[a]; sacc += ldsQux[i * NU + a] * Kj[a]; }      // (two FMAs; one statement compiles to mul + fma + add)
         vcol[i] = sacc;
         if (VXR) { Vx[i] = ldsVx[i]; lam[i] = ldsLam[i]; }
-      }
       }
       if (lane == 0 && live) {
 #pragma unroll
@@ -1788,17 +1755,7 @@ template <class M, typename T, int G, bool EXACT, bool BND = false> struct OcSol
         for (int i = 0; i < NX; ++i) ldsV[sv * NX + i] = vcol[i];
       }
       LFSD_BWC(5)                                  // symmetrisation
-      if (k > 0) {
-        if (LFSD_BW_PREFETCH) {
-#pragma unroll
-          for (int i = 0; i < NX; ++i) { m[i] = mN[i]; xk[i] = xkN[i]; }
-#pragma unroll
-          for (int a = 0; a < NU; ++a) uk[a] = ukN[a];
-          mq = mqN; qzl = qzN;
-        } else {
-          sc_load_stage(cur, k - 1, m, mq, qzl, xk, uk);
-        }
-      }
+      if (k > 0) sc_load_stage(cur, k - 1, m, mq, qzl, xk, uk);
     }
     ldsRed[lane] = gl_max;
     __syncthreads();
@@ -2111,7 +2068,7 @@ template <class M, typename T, bool EXACT, bool BND = false> struct OcWide : OcS
   // -- the Newton step of the lifted KKT system (Gauss-Newton multiple shooting / the step of an SQP method on the NLP above).
   // Where the single-shooting iteration of this kernel pays N x S sequentially dependent RK4 steps for its roll-outs, this one
   // pays S (per round of 64 items).  Only the FULL Newton step is ever taken this way (it closes the linearised gaps entirely), and
-  // only when the augmented Lagrangian  J + lambda^T d + rho/2 |d|^2  (costates of the iterate held fixed) accepts it; otherwise
+  // only when the l1 penalty function  J + 2 sum |lambda_i| |d_i|  (one weight per constraint: the costates of the iterate) accepts it; otherwise
   // the step is the closed-loop nonlinear roll-out around the node states, which closes every gap by construction.  Convergence
   // is never declared on an iterate with gaps (oc_solve_wide_kernel).
   T *gapb[2] = {nullptr, nullptr}, *dxw = nullptr, *duw = nullptr;      // [N][NX] gaps of the two nominal buffers; Newton step [N+1][NX], [N][NU]
@@ -2136,11 +2093,11 @@ template <class M, typename T, bool EXACT, bool BND = false> struct OcWide : OcS
   }
   // The Newton step (for step length 1) of the lifted problem from the gains of the last backward sweep, into dxw / duw.
   // Returns its first-order change of the cost,  sum_k q_k^T (dx_k, du_k) + h_x^T dx_N.
-  LFSD_DEV T ms_forward(int cur, T& lamd) {
+  LFSD_DEV T ms_forward(int cur, T& lamd, T& lamabs) {
     T* ldsDx = lds + Lay::LDS_VX;                 // (NX words, free between backward sweeps)
     const T* Mc = Mwp(cur);
     const T* gp = this->gap;                       // (nullptr: buffer `cur` is a roll-out, no gaps)
-    T dxv[NX], dl = T(0), ld = T(0);
+    T dxv[NX], dl = T(0), ld = T(0), la = T(0);
 #pragma unroll
     for (int i = 0; i < NX; ++i) dxv[i] = T(0);
     if (lane < NX) dxw[lane] = T(0);
@@ -2176,7 +2133,7 @@ template <class M, typename T, bool EXACT, bool BND = false> struct OcWide : OcS
 #pragma unroll
       for (int a = 0; a < NU; ++a) { nx += arC[NX + a] * duv[a]; if (lane == NX + a) zj = duv[a]; }
       if (lane < NXU) dl += qjC * zj;
-      if (lane < NX) { ldsDx[lane] = nx; dxw[(k + 1) * NX + lane] = nx; ld += lam_out[(k + 1) * NX + lane] * dkC; }
+      if (lane < NX) { ldsDx[lane] = nx; dxw[(k + 1) * NX + lane] = nx; const T lk = lam_out[(k + 1) * NX + lane]; ld += lk * dkC; la += t_abs(lk * dkC); }
       else if (lane < NXU) duw[k * NU + (lane - NX)] = zj;
       LFSD_STAGE_SYNC_GEN();
 #pragma unroll
@@ -2200,15 +2157,15 @@ template <class M, typename T, bool EXACT, bool BND = false> struct OcWide : OcS
     }
     const T D = wave_sum(dl);        // (its barriers also publish dxw / duw to every lane)
     lamd = wave_sum(ld);
+    lamabs = wave_sum(la);
     return D;
   }
   // The iterate  (xb, ub)[cur] + alpha (dxw, duw)  into buffer `nxt`: every interval integrated and linearised from its own node
   // state, all intervals at once (lane <- (interval, column pair) as in linearise_parallel), its gaps into gapb[nxt].
   // J: cost of the iterate (interval costs + final cost of its last node); g1 / gm: l1 norm / largest entry of its gaps.
-  // lamd: sum_k lambda_k+1^T d_k with the costates of the CURRENT iterate (lam_out: the multipliers the merit function holds fixed
-  // along a line search); g2: sum of squares of the gaps
-  LFSD_DEV void ms_trial(int cur, int nxt, T alpha, T& J, T& lamd, T& g2, T& g1, T& gm) {
-    T Jl = T(0), g1l = T(0), gml = T(0), ldl = T(0), g2l = T(0);
+  // lamabs: sum_k sum_i |lambda_k+1,i| |d_k,i| with the costates of the CURRENT iterate (lam_out: the weights of the merit function)
+  LFSD_DEV void ms_trial(int cur, int nxt, T alpha, T& J, T& lamabs, T& lamd, T& g2, T& g1, T& gm) {
+    T Jl = T(0), g1l = T(0), gml = T(0), lal = T(0), ldl = T(0), g2l = T(0);
     constexpr bool PK2 = sizeof(T) == 4;
     constexpr int NCT = PK2 ? (NXU + 1) / 2 : NXU;
     using V = typename std::conditional<PK2, pk2<T>, T>::type;
@@ -2252,7 +2209,7 @@ template <class M, typename T, bool EXACT, bool BND = false> struct OcWide : OcS
           const T xn = xbp(cur)[(k + 1) * NX + i] + alpha * dxw[(k + 1) * NX + i];
           const T g = x[i] - xn;
           gapp(nxt)[k * NX + i] = g;
-          g1l += t_abs(g); g2l += g * g; ldl += lam_out[(k + 1) * NX + i] * g;
+          g1l += t_abs(g); g2l += g * g; { const T lg = lam_out[(k + 1) * NX + i] * g; lal += t_abs(lg); ldl += lg; }
           gml = (t_abs(g) > gml || !t_finite(g)) ? t_abs(g) : gml;
           if (k == N - 1) xbp(nxt)[N * NX + i] = xn;
         }
@@ -2265,6 +2222,7 @@ template <class M, typename T, bool EXACT, bool BND = false> struct OcWide : OcS
       }
     }
     J = wave_sum(Jl);
+    lamabs = wave_sum(lal);
     lamd = wave_sum(ldl);
     g2 = wave_sum(g2l);
     g1 = wave_sum(g1l);
@@ -2488,7 +2446,7 @@ __global__ void __launch_bounds__(64, LFSD_WAVES_OC) oc_solve_kernel(OcArgs<T> a
   constexpr bool CS = !EXACT && (PK || (G == 32 && sizeof(T) == 8)) && (LFSD_COARSE_START != 0);
   bool coarse = CS && a.steps_per_grid > 1 && !a.resume && a.max_iter > 4 && !warm;      // (a caller's initial guess starts next to its answer)
   bool relin = false;       // leave the coarse grid at the next iteration ...
-  bool relin_hard = LFSD_COARSE_RELIN != 0;      // ... by a roll-out + linearisation of the nominal without a step (else: with the step)
+  bool relin_hard = false;      // ... by a roll-out + linearisation of the nominal without a step (else: with the step)
   if (coarse) { s.S = 1; s.DT = s.dgrid; }
   // Level 0 of the mesh continuation (round 4; the matrix-core kernels only): the first LFSD_LEAN_TC_ITERS iterations of a
   // workgroup whose trajectories are ALL cold also merge LFSD_LEAN_TC control intervals into one (n_grid / tc stages in the
@@ -2577,7 +2535,7 @@ __global__ void __launch_bounds__(64, LFSD_WAVES_OC) oc_solve_kernel(OcArgs<T> a
         }
         s.N = N_full; s.dgrid = dgrid_full; tc = 1;
         // a trajectory that already asked for the reference's grid goes there directly
-        if ((relin || (LFSD_LEAN_TC_TO_FINE) != 0) && status == ST_RUNNING) { s.S = a.steps_per_grid; coarse = false; relin = false; } else { s.S = 1; }
+        if (relin && status == ST_RUNNING) { s.S = a.steps_per_grid; coarse = false; relin = false; } else { s.S = 1; }
         s.DT = s.dgrid / T(s.S);
         T Jt;
         LFSD_CLK(clk_ro, Jt = do_rollout(cur, cur ^ 1, T(0), false));
@@ -2642,7 +2600,7 @@ __global__ void __launch_bounds__(64, LFSD_WAVES_OC) oc_solve_kernel(OcArgs<T> a
       my_iters = it + 1 + it_off;
       if (!bw_ok) {
         // indefinite Q_uu: the cheap Newton-like model hands over to the exact one; otherwise Levenberg shift
-        if (mode == 1 && !LFSD_HAM_SHIFT) { mode = 0; ham_ok = false; }     // back to Gauss-Newton until the exact model takes over
+        if (mode == 1) { mode = 0; ham_ok = false; }     // back to Gauss-Newton until the exact model takes over
         else {
           mu_bad = mu; mu_hold = 0;
           if (mu == T(0) && mode >= 1 && t_finite(dmin))
@@ -2686,7 +2644,7 @@ __global__ void __launch_bounds__(64, LFSD_WAVES_OC) oc_solve_kernel(OcArgs<T> a
         // Newton-like step whose cost change is below rounding noise: take it as long as the
         // gradient norm keeps contracting (this is what lets fp32 reach its gradient floor)
         accept = true; ia = 0; alpha = T(1); g_flat = gnorm;
-      } else if (mode == 1 && !LFSD_HAM_SHIFT) {
+      } else if (mode == 1) {
         mode = 0; ham_ok = false;
       } else if (mu > T(1e10) ||
                  ((J - Jmin) <= T(8) * Eps<T>::v() * t_abs(J) && (mode == 0 || flat_full || mu > T(1e6)))) {
@@ -2763,7 +2721,6 @@ __global__ void __launch_bounds__(64, LFSD_WAVES_OC) oc_solve_kernel(OcArgs<T> a
           if (mu > T(0) && mu_bad >= T(0) && mu_next <= mu_bad && mu_hold < mu_hold_need) {
             ++mu_hold;
           } else {
-            if (LFSD_MU_HOLD_BACKOFF && mu > T(0) && mu_bad >= T(0) && mu_next <= mu_bad) mu_hold_need = mu_hold_need < 16 ? 2 * mu_hold_need : 16;
             mu = mu_next; mu_hold = 0;
           }
           if (mode == 0 && ham_ok && (J - Jn) < T(LFSD_HAM_SWITCH) * t_abs(Jn)) mode = 1;      // past the first big drops: Newton-like
@@ -2875,7 +2832,7 @@ __global__ void __launch_bounds__(64, 1) oc_solve_wide_kernel(OcArgs<T> a) {
   // r03_f_rocket_trace_head.txt, and every one of them pays a second-order adjoint sweep through S x 4 RK4 stages per
   // interval); never with an initial guess from the caller or with bounds (warm-started subproblems start next to their
   // answer).  Smaller models keep the reference's grid: their parity cases follow the oracle's path into one of several minima.
-  constexpr bool CSW = !BND && (LFSD_COARSE_START != 0) && ((NX + (NU > NP ? NU : NP) > 16) || (LFSD_COARSE_SMALL_MODELS) != 0);
+  constexpr bool CSW = !BND && (LFSD_COARSE_START != 0) && (NX + (NU > NP ? NU : NP) > 16);
   // ... and only where the coarse grid still has as many RK4 steps as the reference's example grids have in all (n_grid
   // 10-15 x 4): at n_grid 15 the rocket's coarse path ends in ANOTHER stationary point than the fine one (one with a
   // conjugate point inside the horizon, where the Riccati sweep of the auxiliary pass has a finite escape; emulator tier,
@@ -2935,6 +2892,7 @@ __global__ void __launch_bounds__(64, 1) oc_solve_wide_kernel(OcArgs<T> a) {
   const bool ms_on = ms;
   int n_acc_need = 4, n_ms = 0;
   T g1c = T(0), g2c = T(0), gmc = T(0);      // l1 norm, sum of squares and largest entry of the gaps of the current iterate (0: a roll-out)
+  T J_feas = J;                              // cost of the last iterate WITHOUT gaps (a roll-out)
   T mu = T(0);
   int mode = (EXACT && a.exact_after == 0) ? 2 : 0;
   bool ham_ok = true, hess_ok = false, gn_crawl = false, costates_ok = false;
@@ -2978,7 +2936,7 @@ __global__ void __launch_bounds__(64, 1) oc_solve_wide_kernel(OcArgs<T> a) {
       cur ^= 1;
       hess_ok = false; costates_ok = false;
       g_last = T(-1); dec_last = T(1e30); g_flat = T(-1); J_ref = J; n_acc = 0;
-      ms = ms_on; g1c = T(0); g2c = T(0); gmc = T(0); s.gap = nullptr;      // (a roll-out: the new level starts without gaps)
+      ms = ms_on; g1c = T(0); g2c = T(0); gmc = T(0); s.gap = nullptr; J_feas = J;      // (a roll-out: the new level starts without gaps)
       if (!t_finite(J)) { if (coarse) { relin = true; continue; } status = ST_FAILED; break; }      // (the mid level cannot integrate it: the reference's grid decides)
       continue;
     }
@@ -3001,9 +2959,9 @@ __global__ void __launch_bounds__(64, 1) oc_solve_wide_kernel(OcArgs<T> a) {
     T dmin = T(0);
     bool bw_ok;
     LFSD_WCK(4, bw_ok = s.backward(cur, mode, mu, gnorm, dV1, dV2, dmin));
-    costates_ok = true;
+    costates_ok = bw_ok;                              // (a sweep that failed stopped at the failing stage)
     if (!bw_ok) {
-      if (mode == 1 && !LFSD_HAM_SHIFT) { mode = 0; ham_ok = false; }
+      if (mode == 1) { mode = 0; ham_ok = false; }
       else {
         mu_bad = mu; mu_hold = 0;
         if (mu == T(0) && mode >= 1 && t_finite(dmin)) mu = t_min(t_max(T(-2) * dmin, T(1e-4)), T(1e6));
@@ -3031,16 +2989,22 @@ __global__ void __launch_bounds__(64, 1) oc_solve_wide_kernel(OcArgs<T> a) {
         close_now = true; ms_floor = true; ms_off = true;
       }
       if (!close_now) {
-        T lamd0, Dlin;
-        LFSD_WCK(5, Dlin = s.ms_forward(cur, lamd0));
-        // merit function of this step:  m = J + lambda^T d + rho/2 |d|^2  with the costates of this iterate held fixed (the
-        // augmented Lagrangian of the lifted NLP: lambda^T d is what closing the gaps costs to first order).  The linearised gaps
-        // of the full Newton step close entirely, so  m'(0) = Dlin - lambda^T d - rho |d|^2.
-        T rho = t_max(lam_mx, T(1));      // (per step: the multipliers shrink by orders of magnitude on the way from a cold start)
+        T lamd0, lamabs0, Dlin;
+        LFSD_WCK(5, Dlin = s.ms_forward(cur, lamd0, lamabs0));
+        // Merit function of the multiple-shooting step: the augmented Lagrangian of the lifted NLP with the costates of THIS iterate,
+        //     m = J + lambda^T d + rho/2 |d|^2,   rho = max(|lambda|_inf, 1)
+        // (lambda^T d is what closing the gaps costs to first order).  The full Newton step closes the linearised gaps entirely:
+        // m'(0) = Dlin - lambda^T d - rho |d|^2.  Measured against it (128 robot-arm seeds, CPU emulator, cost in units of 10^6
+        // clocks with the GPU's per-phase clocks: mean / slowest): this function 13.6 / 23.9; no penalty at all 14.0 / 21.5; the l1
+        // penalty with one weight |lambda_i| per constraint x 0.1 / 0.25 / 1: 16.2 / 18.7 / 27.9 (single shooting: 29.3 / 39.6) -- a
+        // function that counts every gap as a cost refuses most of the steps that work.  Two safeguards make up for its optimism
+        // about gaps of the "right" sign: a step is only taken to an iterate whose cost is not above the last CLOSED trajectory's
+        // (`J_feas`), and the roll-outs that close an iterate are judged against that closed cost, not against an estimate.
+        const T rho = t_max(lam_mx, T(1));
         const T dl0 = Dlin - lamd0;
-        if (g2c > T(0) && !(dl0 - rho * g2c < T(-0.5) * rho * g2c)) rho = T(4) * t_abs(dl0) / g2c;
         pred_ms = rho * g2c - dl0;                     // first-order decrease of the merit function along the full step
         phi0 = J + lamd0 + T(0.5) * rho * g2c;
+        (void)lamabs0;
         if (!t_finite(pred_ms) || !(pred_ms > T(2) * epsT * t_abs(phi0))) {
           // nothing the merit function resolves is left to gain: an iterate with gaps is closed now (and the single-shooting tests
           // take over for good); one without gaps IS a single-shooting nominal, the tests below decide
@@ -3049,11 +3013,12 @@ __global__ void __launch_bounds__(64, 1) oc_solve_wide_kernel(OcArgs<T> a) {
             close_now = true; ms_floor = t_finite(pred_ms); ms_off = true;
           }
         } else {
-          T Jt, ldt, g2t, g1t, gmt;
-          LFSD_WCK(6, s.ms_trial(cur, cur ^ 1, T(1), Jt, ldt, g2t, g1t, gmt));
+          T Jt, lat, ldt, g2t, g1t, gmt;
+          LFSD_WCK(6, s.ms_trial(cur, cur ^ 1, T(1), Jt, lat, ldt, g2t, g1t, gmt));
           const T phit = Jt + ldt + T(0.5) * rho * g2t;
           const T flat = T(8) * epsT * t_abs(phi0);
-          const bool accept = t_finite(phit) && t_finite(g1t) && (phi0 - phit) >= T(1e-4) * pred_ms - flat && phit < phi0;
+          const bool accept = t_finite(phit) && t_finite(g1t) && (phi0 - phit) >= T(1e-4) * pred_ms - flat && phit < phi0 &&
+                              ((LFSD_MS_JFEAS) == 0 || Jt <= J_feas + T(8) * epsT * t_abs(J_feas));
 #if defined(LFSD_TRACE)
           if (s.lane == 0 && traj == 0) printf("wide ms it %d mode %d g %.6e J %.12e gap1 %.4e gapmax %.3e lam %.3e rho %.3e phi0 %.10e pred %.4e accept %d mu %g -> J %.12e gap1 %.4e phi %.10e\n", it, mode, (double)gnorm, (double)J, (double)g1c, (double)gmc, (double)lam_mx, (double)rho, (double)phi0, (double)pred_ms, (int)accept, (double)mu, (double)Jt, (double)g1t, (double)phit);
 #endif
@@ -3063,9 +3028,10 @@ __global__ void __launch_bounds__(64, 1) oc_solve_wide_kernel(OcArgs<T> a) {
             cur ^= 1;
             g_last = gnorm; dec_last = T(1e30);
             hess_ok = false; costates_ok = false;
-            const T mu_next = (mu > T(1e-8)) ? mu * T(LFSD_MU_DOWN) : T(0);
-            if (mu > T(0) && mu_bad >= T(0) && mu_next <= mu_bad && mu_hold < mu_hold_need) ++mu_hold;
-            else { mu = mu_next; mu_hold = 0; }
+            // (no hold on the way down after a multiple-shooting step: a shift that turns out too small costs one backward sweep on
+            //  cached Hessians, a held rung costs a whole iteration -- 128 seeds, emulator: mean 21.1 -> 19.8, slowest 33 -> 30
+            //  iterations; dropping by 10 after steps that gain half their prediction: one seed at 52)
+            mu = (mu > T(1e-8)) ? mu * T(LFSD_MU_DOWN) : T(0); mu_hold = 0;
             if (mode == 0 && ham_ok && gain < T(LFSD_HAM_SWITCH) * t_abs(Jt)) mode = 1;
             else if (LFSD_GN_CRAWL && mode == 0 && !ham_ok && gain < T(1e-2) * t_abs(Jt)) gn_crawl = true;
             if (coarse && gain < T(LFSD_COARSE_SWITCH) * t_abs(Jt)) {
@@ -3100,19 +3066,20 @@ __global__ void __launch_bounds__(64, 1) oc_solve_wide_kernel(OcArgs<T> a) {
     ldsRed[s.lane] = Ja;
     __syncthreads();
     int ia = -1, ib = -1;
-    const T Jr = have_gaps ? phi0 : J;                  // an iterate with gaps is worth its merit value: what it costs once they are closed
+    const T Jr = have_gaps ? J_feas : J;                // roll-outs that close an iterate with gaps: progress is measured from the last CLOSED trajectory
     T Jmin = Jr, Jn = Jr, Jb = T(0), aa = T(1);
     const T flat = T(8) * epsT * t_abs(Jr);
     const bool flat_full = t_finite(ldsRed[0]) && t_abs(ldsRed[0] - Jr) <= T(64) * epsT * t_abs(Jr);
     for (int l = 0; l < NAL; ++l) {
       const T Jl = ldsRed[l];
-      const T expected = have_gaps ? aa * pred_ms : -(aa * dV1 + aa * aa * dV2);
+      const T expected = have_gaps ? T(0) : -(aa * dV1 + aa * aa * dV2);
       const bool okl = t_finite(Jl) && ((Jr - Jl) >= T(1e-4) * expected - flat) && (Jl < Jr);
       if (okl && ia < 0) { ia = l; Jn = Jl; }
       if (t_finite(Jl)) { Jmin = t_min(Jmin, Jl); if (ib < 0 || Jl < Jb) { ib = l; Jb = Jl; } }
       aa *= T(0.5);
     }
     __syncthreads();
+    if (have_gaps && ia >= 0) { ia = ib; Jn = Jb; }     // (closing an iterate: the cheapest of the roll-outs below the last closed cost, not the longest)
     bool accept = ia >= 0;
     if (!accept) {
       if (mode >= 1 && flat_full && (g_flat < T(0) || gnorm < T(0.7) * g_flat)) {
@@ -3120,7 +3087,7 @@ __global__ void __launch_bounds__(64, 1) oc_solve_wide_kernel(OcArgs<T> a) {
       } else if (close_now) {
         // (the gaps of a finished iterate have to go whatever the roll-outs cost: the cheapest one)
         if (ib >= 0) { accept = true; ia = ib; Jn = Jb; } else status = ST_FAILED;
-      } else if (mode == 1 && !LFSD_HAM_SHIFT) {
+      } else if (mode == 1) {
         mode = 0; ham_ok = false;
       } else if (mu > T(1e10) || ((Jr - Jmin) <= T(8) * epsT * t_abs(Jr) && ((mode == 0 && !BND) || flat_full || mu > T(1e6)))) {
         // (with a box on the controls the clamped closed loop can fail every step length although the Gauss-Newton
@@ -3147,14 +3114,10 @@ __global__ void __launch_bounds__(64, 1) oc_solve_wide_kernel(OcArgs<T> a) {
       g1c = T(0); g2c = T(0); gmc = T(0); s.gap = nullptr;      // a roll-out has no gaps
       if (ms_off) { ms = false; ms_check = true; }
       if (ia == 0) {
-        // gain ratio of the full step (actual / predicted decrease of the shifted model): a step that gains at least
-        // LFSD_MU_GAIN_RHO of its prediction says the shift is larger than the model needs -- it falls by LFSD_MU_DOWN_GOOD
-        // instead of LFSD_MU_DOWN and does not wait out the hold (the rocket's long solves are accepted full steps that gain
-        // 1.5-2x their prediction at shifts that decay one sqrt(10) rung per step)
-        const T pred = have_gaps ? pred_ms : -(dV1 + dV2);
-        const bool good = (LFSD_MU_DOWN_GOOD < LFSD_MU_DOWN) && pred > T(0) && (Jr - Jn) >= T(LFSD_MU_GAIN_RHO) * pred;
-        const T mu_next = (mu > T(1e-8)) ? mu * (good ? T(LFSD_MU_DOWN_GOOD) : T(LFSD_MU_DOWN)) : T(0);
-        if (!good && mu > T(0) && mu_bad >= T(0) && mu_next <= mu_bad && mu_hold < mu_hold_need) ++mu_hold;
+        // (a ratio-tested faster descent of the shift was measured on the rocket and needs MORE iterations in every variant --
+        //  a shift that falls faster fails the next factorisation more often: profiles/HISTORY.md, r04_e_rocket_gain_ratio_ab.txt)
+        const T mu_next = (mu > T(1e-8)) ? mu * T(LFSD_MU_DOWN) : T(0);
+        if (mu > T(0) && mu_bad >= T(0) && mu_next <= mu_bad && mu_hold < mu_hold_need) ++mu_hold;
         else { mu = mu_next; mu_hold = 0; }
         if (mode == 0 && ham_ok && (Jr - Jn) < T(LFSD_HAM_SWITCH) * t_abs(Jn)) mode = 1;
         else if (LFSD_GN_CRAWL && mode == 0 && !ham_ok && (Jr - Jn) < T(1e-2) * t_abs(Jn)) gn_crawl = true;
@@ -3167,6 +3130,7 @@ __global__ void __launch_bounds__(64, 1) oc_solve_wide_kernel(OcArgs<T> a) {
             ((LFSD_COARSE_EXIT_RULE) == 2 && ia == 0 && mu_taken <= T(LFSD_COARSE_EXIT_MU))) relin = true;
       }
       J = Jn;
+      J_feas = J;
       if (have_gaps) { J_ref = J; n_acc = 0; }             // (the stall test compares costs of roll-outs)
       else if (++n_acc >= n_acc_need) {
         if (J_ref - J <= T(16) * epsT * t_abs(J)) { if (coarse) relin = true; else status = ST_STALLED; }
@@ -3175,8 +3139,14 @@ __global__ void __launch_bounds__(64, 1) oc_solve_wide_kernel(OcArgs<T> a) {
     }
   }
   if (status == ST_RUNNING) status = ST_MAXITER;
+#if defined(LFSD_MS_STATS)      // development aid (tools/ms_dev.py): iterations and multiple-shooting steps per trajectory
+  if (threadIdx.x == 0) printf("msstat %d %d %d\n", (int)blockIdx.x, it, n_ms);
+#endif
 #if defined(LFSD_OC_CLOCK)
-  if (threadIdx.x == 0 && (it >= LFSD_OC_CLOCK || blockIdx.x == 0))
+#ifndef LFSD_OC_CLOCK_TOTAL
+#define LFSD_OC_CLOCK_TOTAL (1LL << 62)
+#endif
+  if (threadIdx.x == 0 && (it >= LFSD_OC_CLOCK || blockIdx.x == 0 || clock64() - wck_t0 >= (long long)(LFSD_OC_CLOCK_TOTAL)))
     printf("wide clock traj %d: iterations %d (%d multiple-shooting steps) total %lld rollout_alphas %lld linearise %lld costates %lld hessians %lld backward %lld ms_forward %lld ms_trial %lld | left the coarse grid at iteration %d, clock %lld\n",
            (int)blockIdx.x, it, n_ms, clock64() - wck_t0, wck[0], wck[1], wck[2], wck[3], wck[4], wck[5], wck[6], wck_it_exit, wck_exit);
 #endif

@@ -54,7 +54,7 @@ ms)           # round 5: the multiple-shooting phase of the wide kernel, product
 import sys; sys.path.insert(0,'tools'); import oc_trace
 from lfsd_amd import models
 print(oc_trace.variant_path(models.ZOO[sys.argv[1]]()[0].model_spec(), sys.argv[2]))" $1 $2; }
-  for c in robotarm rocket; do
+  for c in ${CFGS:-robotarm rocket}; do
     python3 bench.py --config $c --steps 5 --warmup 1 --no-cpu-baseline > $OUT/bench_$c.json 2> $OUT/bench_$c.err; line $OUT/bench_$c.json
   done
   for v in ${VARIANTS:-noms nohall}; do
@@ -62,6 +62,7 @@ print(oc_trace.variant_path(models.ZOO[sys.argv[1]]()[0].model_spec(), sys.argv[
   done
   python3 tools/config_steps.py robotarm 6 > $OUT/steps_robotarm.txt 2>&1; grep "^step" $OUT/steps_robotarm.txt
   LFSD_TOOL_LIBRARY=$(vp robotarm noms) python3 tools/config_steps.py robotarm 6 > $OUT/steps_robotarm_noms.txt 2>&1; grep "^step" $OUT/steps_robotarm_noms.txt
+  python3 tools/oc_trace.py run robotarm 50 1024 f32 ${NTRACE:-0} > $OUT/robotarm_trace.txt 2>&1; grep -c "wide" $OUT/robotarm_trace.txt
   python3 tools/wide_clock.py run robotarm 50 1024 f32 > $OUT/robotarm_wide_clock.txt 2>&1; grep -c "wide clock" $OUT/robotarm_wide_clock.txt; sort -t' ' -k6 -n -r $OUT/robotarm_wide_clock.txt | head -6; sort -t' ' -k6 -n $OUT/robotarm_wide_clock.txt | sed -n '500,503p'
   if [ -n "$K" ]; then
     LFSD_PARITY_REPORT=$PWD/$OUT/parity_floors.jsonl timeout 2400 python3 -m pytest tests -m gpu -q -k "$K" > $OUT/pytest_gpu.txt 2>&1

@@ -15,9 +15,13 @@ trace = len(sys.argv) > 5 and sys.argv[5] == "trace"
 off = int(sys.argv[6]) if len(sys.argv) > 6 else 0
 rng = np.random.default_rng(1234)
 res = {}
-for tag, flags in (("ms", ()), ("ss", ("-DLFSD_MS=0",))):
+VAR = {"ms": (), "ss": ("-DLFSD_MS=0",), "nojf": ("-DLFSD_MS_JFEAS=0",)}
+import os as _os
+for tag in _os.environ.get("VARIANTS", "ms ss").split():
+  flags = VAR[tag]
+  if True:
     oc, env, d = models.ZOO[kind](n_grid=n_grid)
-    fl = list(flags) + (["-DLFSD_TRACE"] if trace else [])
+    fl = list(flags) + (["-DLFSD_TRACE"] if trace else ["-DLFSD_MS_STATS"])
     oc.use_library(build_emu_library(oc, extra_flags=fl, tag="dev_" + tag + ("_tr" if trace else "")))
     oc.compile()
     oc.setDevice(dtype=dt)
@@ -31,5 +35,6 @@ for tag, flags in (("ms", ()), ("ss", ("-DLFSD_MS=0",))):
     res[tag] = sol
     print(tag, "time %.1fs" % (time.time() - t0), "iters", sol["iters"].tolist(), "status", sol["status"].tolist())
     print("   cost", ["%.8g" % v for v in sol["cost"].tolist()])
-a, b = res["ms"], res["ss"]
-print("max |dx| between the two:", (a["state_grid"] - b["state_grid"]).abs().amax(dim=(1, 2)).tolist())
+tags = list(res)
+for t in tags[1:]:
+    print("max |dx| %s vs %s:" % (tags[0], t), (res[tags[0]]["state_grid"] - res[t]["state_grid"]).abs().amax(dim=(1, 2)).tolist())

@@ -56,7 +56,8 @@ def run(kind, n_grid, B, dt, n_slow=2, tag="trace", library=None):
     oc2, _, _ = models.ZOO[kind](n_grid=n_grid)
     oc2.use_library(variant_path(oc2.model_spec(), tag)); oc2.setDevice("cuda:0", dtype)
     oc2.setSolverOptions(mapping=oc.mapping if oc.mapping != "auto" else ("wide" if oc.exact_after == 0 else "lockstep"))
-    for j in np.argsort(-it)[:n_slow]:
+    pick = [int(v) for v in os.environ["LFSD_TRACE_IDX"].split(",")] if os.environ.get("LFSD_TRACE_IDX") else np.argsort(-it)[:n_slow]
+    for j in pick:
         print("=== trajectory %d (%d iterations in the batch), theta %s" % (j, it[j], np.array2string(th[j], precision=4)), flush=True)
         s1 = oc2.cocSolverBatch(x0[j:j + 1], d["horizon"], th[j:j + 1]); torch.cuda.synchronize()
         print("=== iterations %d status %d cost %.8g" % (int(s1["iters"][0]), int(s1["status"][0]), float(s1["cost"][0])), flush=True)
