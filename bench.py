@@ -40,7 +40,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
 VALU_PEAK_TFLOPS = {"f32": 157.3, "f64": 78.6}
-PROFILE_TAG = "r04"            # profiles/<tag>_hbm_traffic.json, <tag>_issue_counters.json feed the roofline object
+PROFILE_TAG = "r05"            # profiles/<tag>_hbm_traffic.json, <tag>_issue_counters.json feed the roofline object
 
 # The workloads of BASELINE.json's configs that bench.py can emit a line for.  `batch` is per GPU.
 WORKLOADS = {
@@ -60,8 +60,10 @@ WORKLOADS = {
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    # (defaults = the window the round driver times: every BENCH_r0*.json records `--steps 20 --warmup 5`; until round 4 the defaults
+    #  were 10 / 2, a cheaper window -- earlier outer iterations need fewer split units -- that the docs then called the driver's)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", default="quadrotor", choices=sorted(WORKLOADS),
                     help="BASELINE configuration: quadrotor = configs[2] / [3] (headline), robotarm = configs[1], rocket = configs[4]")
     ap.add_argument("--batch", type=int, default=None, help="trajectories per GPU (default: the configuration's)")
@@ -301,9 +303,11 @@ def lean_level0(args):
 
 
 def seeded_f64(args, dtype_name, kernel, warm):
-    """lfsd_coc_solve in fp64 on the lock-step mapping of the quadrotor class solves a cold start in fp32 first and starts the
-    fp64 kernel from those controls (csrc/lfsd_capi.cpp, coc_solve_seeded): `oc_solve` is then two kernels in two precisions."""
-    return (kernel == "oc_solve" and dtype_name == "f64" and args.config == "quadrotor" and not warm
+    """lfsd_coc_solve in fp64 on the lock-step mapping of the quadrotor class solves the problem in fp32 first and starts the
+    fp64 kernel from those controls (csrc/lfsd_capi.cpp, coc_solve_seeded): `oc_solve` is then two kernels in two precisions.
+    Since round 5 that holds with an initial guess from the caller as well (an all-zero row is a cold start for both kernels), i.e.
+    for `--mode shared` (whose learner hands zeros for every row it does not continue) and for `--warm-start`."""
+    return (kernel == "oc_solve" and dtype_name == "f64" and args.config == "quadrotor"
             and os.environ.get("LFSD_F64_SEED", "1") != "0")
 
 

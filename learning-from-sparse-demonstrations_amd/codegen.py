@@ -26,7 +26,7 @@ import hashlib
 import sympy as sp
 from sympy.printing.c import C99CodePrinter
 
-CODEGEN_VERSION = 17
+CODEGEN_VERSION = 18
 
 
 class ModelSpec:
@@ -159,6 +159,44 @@ def _body(inputs, outputs, indent='    ', vec=(), vec_out=None):
             lines.append('%s%s = V(%s);' % (indent, lv, _pr(r)))
         else:
             lines.append('%s%s = %s;' % (indent, lv, _pr(r)))
+    return '\n'.join(lines)
+
+
+def _body_multi(inputs, outputs, vec, indent='    '):
+    """The same straight-line code for NV tangents at once (template parameter NV of the emitted function): every statement that
+    does not depend on a tangent symbol -- the NOMINAL part: for the robot arm four sin / cos, the mass matrix and its inverse,
+    the larger part of a call -- is emitted once, the tangent-dependent statements inside `for (v < NV)`.  (Calling the
+    one-tangent function NV times from one basic block does not get there: measured on gfx950, the compiler keeps a copy of the
+    nominal part per call.)  inputs: (symbol, load) with `v` free in the loads of tangent symbols; outputs: (lvalue, expr) with `v`
+    free in tangent lvalues; vec: the tangent symbols."""
+    exprs = [sp.sympify(e) for _, e in outputs]
+    repl, red = sp.cse(exprs, symbols=sp.numbered_symbols('w_'), order='none')
+    used = set()
+    for _, r in repl:
+        used |= r.free_symbols
+    for r in red:
+        used |= r.free_symbols
+    vt = set(vec)
+    nom, tan = [], []
+    for sym, load in inputs:
+        if sym in used:
+            (tan if sym in vt else nom).append('const %s %s = %s;' % ('V' if sym in vt else 'T', sym, load))
+    for s_, r in repl:
+        isv = bool(r.free_symbols & vt)
+        if isv:
+            vt.add(s_)
+        (tan if isv else nom).append('const %s %s = %s;' % ('V' if isv else 'T', s_, _pr(r)))
+    for (lv, _), r in zip(outputs, red):
+        if 'v' in lv.replace('dv', ''):           # a per-tangent output
+            tan.append('%s = %s;' % (lv, _pr(r)) if (r.free_symbols & vt) else '%s = V(%s);' % (lv, _pr(r)))
+        else:
+            assert not (r.free_symbols & vt), lv
+            nom.append('%s = %s;' % (lv, _pr(r)))
+    lines = [indent + l for l in nom]
+    lines.append('#pragma unroll')
+    lines.append(indent + 'for (int v = 0; v < NV; ++v) {')
+    lines += [indent + '  ' + l for l in tan]
+    lines.append(indent + '}')
     return '\n'.join(lines)
 
 
@@ -379,6 +417,18 @@ def emit_header(spec):
                    [('y2x[%d]' % i, y2x[i]) for i in range(n)] + [('y2u[%d]' % i, y2u[i]) for i in range(m)],
                    vec=list(V2), vec_out=lambda lv: lv.startswith('y2x[') or lv.startswith('y2u[')))
     S.append('  }')
+    # 2c. the same two for NV tangents at once, nominal part shared (wide kernel, all columns of an interval on one lane)
+    tang_n = [(s_, 'dx[v * %d + %d]' % (n, i)) for i, s_ in enumerate(dX)] + [(s_, 'du[v * %d + %d]' % (m, i)) for i, s_ in enumerate(dU)]
+    S.append('  template<int NV, class T, class V> static LFSD_DEV void dyn_cost_jvp_n(%s, const V* dx, const V* du, T* f, T& q, V* df, V* dq) {' % sig_xu)
+    S.append(_body_multi(_loads(spec) + tang_n, [('f[%d]' % i, f[i]) for i in range(n)] + [('q', c)] +
+                         [('df[v * %d + %d]' % (n, i), df[i]) for i in range(n)] + [('dq[v]', dq)], vec=[s_ for s_, _ in tang_n]))
+    S.append('  }')
+    vin_n = [(s_, 'v1[%d]' % i) for i, s_ in enumerate(V1)] + [(s_, 'v2[v * %d + %d]' % (n, i)) for i, s_ in enumerate(V2)] + [(W1, 'w1')]
+    S.append('  template<int NV, class T, class V> static LFSD_DEV void dyn_vjp2_n(%s, const T* v1, T w1, const V* v2, T* y1x, V* y2x, V* y2u) {' % sig_xu)
+    S.append(_body_multi(_loads(spec) + vin_n, [('y1x[%d]' % i, y1x[i]) for i in range(n)] +
+                         [('y2x[v * %d + %d]' % (n, i), y2x[i]) for i in range(n)] + [('y2u[v * %d + %d]' % (m, i), y2u[i]) for i in range(m)],
+                         vec=list(V2)))
+    S.append('  }')
     # 3. final cost
     sig_x = 'T t, const T* x, const T* e, const T* c'
     S.append('  template<class T> static LFSD_DEV T final_cost(%s) {\n    T hval;' % sig_x)
@@ -420,6 +470,10 @@ def emit_header(spec):
     S.append(_body(_loads(spec, with_l=True) + tang, [('yx[%d]' % i, yx[i]) for i in range(n)] +
                    [('yu[%d]' % i, yu[i]) for i in range(m)],
                    vec=[s_ for s_, _ in tang], vec_out=lambda lv: True))
+    S.append('  }')
+    S.append('  template<int NV, class T, class V> static LFSD_DEV void ham_hess_mul_n(%s, const V* dx, const V* du, V* yx, V* yu) {' % sig_xul)
+    S.append(_body_multi(_loads(spec, with_l=True) + tang_n, [('yx[v * %d + %d]' % (n, i), yx[i]) for i in range(n)] +
+                         [('yu[v * %d + %d]' % (m, i), yu[i]) for i in range(m)], vec=[s_ for s_, _ in tang_n]))
     S.append('  }')
     # 4b. the control block of the Hamiltonian Hessian alone (dense, row-major): the MFMA backward sweep of the 16-lane
     #     mapping gets the columns no lane owns from the symmetry of H and needs only their diagonal block on top

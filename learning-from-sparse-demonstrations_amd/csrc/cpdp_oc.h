@@ -540,11 +540,78 @@ template <class M, typename T, int G, bool EXACT, bool BND = false> struct OcSol
     for (int i = 0; i < NX; ++i) hx[i] = dlam[i];
   }
 
+  // One interval integrated and linearised with ALL its tangent columns on this lane -- NV packed pairs side by side that share the
+  // nominal part of every model call, as in stage_hessian_all below (wide kernel, fp32, OcLayout::HALL: one item per interval
+  // instead of one per (interval, column pair): the robot arm's 150 items = 3 rounds of the wavefront become 50 = one round that
+  // costs less than two).  x is advanced in place, q is the interval's cost, [A B; q] of the interval goes to Mk ([row][column]).
+  template <int NV>
+  LFSD_DEV void interval_sens_all(T t, T* x, T& q, const T* u, T* Mk) const {
+    using V = pk2<T>;
+    const T hh = DT * T(0.5), h6 = DT / T(6);
+    T el[NP > 0 ? NP : 1], cl[M::NCX > 0 ? M::NCX : 1];      // (in registers: see stage_hessian_all)
+#pragma unroll
+    for (int i = 0; i < NP; ++i) el[i] = e[i];
+#pragma unroll
+    for (int i = 0; i < M::NCX; ++i) cl[i] = c[i];
+    V m[NV][NX], du[NV][NU], mq[NV];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      mq[v] = V(T(0));
+#pragma unroll
+      for (int i = 0; i < NX; ++i) m[v][i] = mk2<T>((2 * v == i) ? T(1) : T(0), (2 * v + 1 == i) ? T(1) : T(0));
+#pragma unroll
+      for (int a = 0; a < NU; ++a) du[v][a] = mk2<T>((2 * v == NX + a) ? T(1) : T(0), (2 * v + 1 == NX + a) ? T(1) : T(0));
+    }
+    q = T(0);
+    for (int s = 0; s < S; ++s) {
+      T xs[NX], ax[NX], f[NX], cq, aq = T(0);
+      V ms[NV][NX], am[NV][NX], d[NV][NX], dq[NV], adq[NV];
+#pragma unroll
+      for (int st = 0; st < 4; ++st) {
+        const T* xe = (st == 0) ? x : xs;
+        M::template dyn_cost_jvp_n<NV>(t, xe, u, el, cl, (st == 0) ? &m[0][0] : &ms[0][0], &du[0][0], f, cq, &d[0][0], dq);
+        const T wgt = (st == 0 || st == 3) ? T(1) : T(2), adv = (st < 2) ? hh : DT;
+        aq = (st == 0) ? cq : aq + wgt * cq;
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+          ax[i] = (st == 0) ? f[i] : ax[i] + wgt * f[i];
+          if (st < 3) xs[i] = x[i] + adv * f[i];
+        }
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+          adq[v] = (st == 0) ? dq[v] : adq[v] + wgt * dq[v];
+#pragma unroll
+          for (int i = 0; i < NX; ++i) {
+            am[v][i] = (st == 0) ? d[v][i] : am[v][i] + wgt * d[v][i];
+            if (st < 3) ms[v][i] = m[v][i] + adv * d[v][i];
+          }
+        }
+      }
+      q += h6 * aq;
+#pragma unroll
+      for (int i = 0; i < NX; ++i) x[i] += h6 * ax[i];
+#pragma unroll
+      for (int v = 0; v < NV; ++v) {
+        mq[v] += h6 * adq[v];
+#pragma unroll
+        for (int i = 0; i < NX; ++i) m[v][i] += h6 * am[v][i];
+      }
+    }
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      V* mc = reinterpret_cast<V*>(Mk + 2 * v);
+#pragma unroll
+      for (int i = 0; i < NX; ++i) mc[i * (Lay::NXUP / 2)] = m[v][i];
+      mc[NX * (Lay::NXUP / 2)] = mq[v];
+    }
+  }
+
   // The same second-order adjoint for ALL columns of interval k on this one lane (wide kernel, fp32, OcLayout::HALL): NV packed
   // pairs of tangent columns run through the S x 4 stages side by side.  A column-per-item sweep re-evaluates the nominal part of
   // every model call -- for the robot arm four sin / cos, the mass matrix and its inverse: the larger part of a call -- once per
-  // column; here the NV instantiations of a stage are inlined into one basic block with identical nominal operands, and the
-  // compiler keeps one copy.  Robot arm (6 columns, 50 intervals): 300 (interval, column) items = 5 rounds of the wavefront become
+  // column; here the generated multi-tangent functions (codegen.py _body_multi: dyn_cost_jvp_n, dyn_vjp2_n, ham_hess_mul_n) emit the
+  // nominal part once and the tangent part per pair.  (NV inlined calls of the one-tangent functions in one basic block do NOT get
+  // there: measured on gfx950, the all-columns routines then cost exactly NV times the one-pair item.)  Robot arm (6 columns, 50 intervals): 300 (interval, column) items = 5 rounds of the wavefront become
   // 50 items = one round that costs about twice a single-column item.  Hk: the interval's Hessian [row][column] in the workspace.
   template <int NV>
   LFSD_DEV void stage_hessian_all(int k, const T* xk, const T* uk, const T* lam_next, T* Hk) {
@@ -583,12 +650,11 @@ template <class M, typename T, int G, bool EXACT, bool BND = false> struct OcSol
         for (int v = 0; v < NV; ++v) exl[((s * NX + i) * NV + v) * G] = m[v][i];
       }
       T xs[NX], ax[NX], f[NX], cq;
-      V ms[NV][NX], am[NV][NX], d[NV][NX], dq;
+      V ms[NV][NX], am[NV][NX], d[NV][NX], dq[NV];
 #pragma unroll
       for (int st = 0; st < 4; ++st) {
         const T* xe = (st == 0) ? x : xs;
-#pragma unroll
-        for (int v = 0; v < NV; ++v) M::dyn_cost_jvp(t, xe, uk, el, cl, (st == 0) ? m[v] : ms[v], du[v], f, cq, d[v], dq);
+        M::template dyn_cost_jvp_n<NV>(t, xe, uk, el, cl, (st == 0) ? &m[0][0] : &ms[0][0], &du[0][0], f, cq, &d[0][0], dq);
         const T wgt = (st == 0 || st == 3) ? T(1) : T(2), adv = (st < 2) ? hh : h;
 #pragma unroll
         for (int i = 0; i < NX; ++i) {
@@ -641,9 +707,8 @@ template <class M, typename T, int G, bool EXACT, bool BND = false> struct OcSol
         }
         if (st < 3) {
           T f[NX], cq;
-          V d[NV][NX], dq;
-#pragma unroll
-          for (int v = 0; v < NV; ++v) M::dyn_cost_jvp(t, x, uk, el, cl, m[v], du[v], f, cq, d[v], dq);
+          V d[NV][NX], dq[NV];
+          M::template dyn_cost_jvp_n<NV>(t, x, uk, el, cl, &m[0][0], &du[0][0], f, cq, &d[0][0], dq);
 #pragma unroll
           for (int i = 0; i < NX; ++i) {
             x[i] = x0s[i] + adv[st] * f[i];
@@ -669,20 +734,24 @@ template <class M, typename T, int G, bool EXACT, bool BND = false> struct OcSol
           ls[i] = kap[i] * iw;
           xs[i] = ex[(st * NX + i) * G + lane];
         }
+        V dkap[NV][NX], msv[NV][NX], t2x[NV][NX], t2u[NV][NU], gx[NV][NX], gu[NV][NU];
 #pragma unroll
         for (int v = 0; v < NV; ++v) {
-          V dkap[NX], ms[NX], t2x[NX], t2u[NU], gx[NX], gu[NU];
 #pragma unroll
           for (int i = 0; i < NX; ++i) {
-            dkap[i] = w * dlam[v][i] + cc * dyb[v][i];
-            ms[i] = exv[((st * NX + i) * NV + v) * G + lane];
+            dkap[v][i] = w * dlam[v][i] + cc * dyb[v][i];
+            msv[v][i] = exv[((st * NX + i) * NV + v) * G + lane];
           }
-          M::dyn_vjp2(t, xs, uk, el, cl, kap, w, dkap, y1, t2x, t2u);
-          M::ham_hess_mul(t, xs, uk, ls, el, cl, ms, du[v], gx, gu);
+        }
+        // (one call each for the NV tangent pairs: the nominal part of the evaluation is computed once, codegen.py _body_multi)
+        M::template dyn_vjp2_n<NV>(t, xs, uk, el, cl, kap, w, &dkap[0][0], y1, &t2x[0][0], &t2u[0][0]);
+        M::template ham_hess_mul_n<NV>(t, xs, uk, ls, el, cl, &msv[0][0], &du[0][0], &gx[0][0], &gu[0][0]);
 #pragma unroll
-          for (int i = 0; i < NX; ++i) { dyb[v][i] = t2x[i] + w * gx[i]; dlam_new[v][i] += dyb[v][i]; }
+        for (int v = 0; v < NV; ++v) {
 #pragma unroll
-          for (int a = 0; a < NU; ++a) hu[v][a] += t2u[a] + w * gu[a];
+          for (int i = 0; i < NX; ++i) { dyb[v][i] = t2x[v][i] + w * gx[v][i]; dlam_new[v][i] += dyb[v][i]; }
+#pragma unroll
+          for (int a = 0; a < NU; ++a) hu[v][a] += t2u[v][a] + w * gu[v][a];
         }
 #pragma unroll
         for (int i = 0; i < NX; ++i) { yb[i] = y1[i]; lam_new[i] += yb[i]; }
@@ -1883,14 +1952,57 @@ template <class M, typename T, bool EXACT, bool BND = false> struct OcWide : OcS
   using Base::Mws; using Base::Hws; using Base::lds; using Base::xa; using Base::ua; using Base::lam_out; using Base::DT;
 
   // lane l < NAL rolls the closed loop out with step length 2^-l and parks states / controls at [k][component][l]
+  // (the operands of the control law -- nominal, feed-forward, gains: group-uniform global loads -- are fetched one interval ahead:
+  //  nothing else runs on the SIMD to hide their ~1 500 clocks behind, and there are n_grid of them in a row)
   LFSD_DEV T rollout_alphas(int cur, bool gains, T& alpha) {
     alpha = T(0);
     if (lane < NAL) { alpha = T(1); for (int i = 0; i < lane; ++i) alpha *= T(0.5); }
     T x[NX], u[NU], Ja = T(0), dummy = T(0);
 #pragma unroll
     for (int i = 0; i < NX; ++i) x[i] = x0[i];
+    T ubC[NU], ubN[NU], xbC[NX], xbN[NX], KC[NX * NU], KN[NX * NU], kC[NU], kN[NU];
+    auto load_ctl = [&](int k_, T* ub_, T* xb_, T* K_, T* k_ff) LFSD_LAMBDA_INLINE {
+      const T* ubk = ubp(cur) + k_ * NU;
+#pragma unroll
+      for (int a = 0; a < NU; ++a) ub_[a] = ubk[a];
+      if (gains) {
+        const T* xbk = xbp(cur) + k_ * NX;
+        const T* Kk = this->Kws + (long long)k_ * NX * NU;
+        const T* kk = this->kws + k_ * NU;
+#pragma unroll
+        for (int i = 0; i < NX; ++i) xb_[i] = xbk[i];
+#pragma unroll
+        for (int i = 0; i < NX * NU; ++i) K_[i] = Kk[i];
+#pragma unroll
+        for (int a = 0; a < NU; ++a) k_ff[a] = kk[a];
+      }
+    };
+    load_ctl(0, ubN, xbN, KN, kN);
     for (int k = 0; k < N; ++k) {
-      this->control(cur, k, x, alpha, gains, u);
+#pragma unroll
+      for (int a = 0; a < NU; ++a) { ubC[a] = ubN[a]; kC[a] = kN[a]; }
+#pragma unroll
+      for (int i = 0; i < NX; ++i) xbC[i] = xbN[i];
+#pragma unroll
+      for (int i = 0; i < NX * NU; ++i) KC[i] = KN[i];
+      if (k + 1 < N) { load_ctl(k + 1, ubN, xbN, KN, kN); LFSD_ISSUE_FENCE(); }
+      // closed-loop control  u = ubar + alpha*kff + K (x - xbar)  (OcSolver::control, on the operands fetched above)
+#pragma unroll
+      for (int a = 0; a < NU; ++a) u[a] = ubC[a];
+      if (gains) {
+#pragma unroll
+        for (int a = 0; a < NU; ++a) u[a] += alpha * kC[a];
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+          const T dx = x[i] - xbC[i];
+#pragma unroll
+          for (int a = 0; a < NU; ++a) u[a] += KC[i * NU + a] * dx;
+        }
+      }
+      if (BND) {
+#pragma unroll
+        for (int a = 0; a < NU; ++a) u[a] = t_min(t_max(u[a], this->ulb[a]), this->uub[a]);
+      }
       if (lane < NAL) {
 #pragma unroll
         for (int i = 0; i < NX; ++i) xa[(k * NX + i) * NAL + lane] = x[i];
@@ -1919,6 +2031,18 @@ template <class M, typename T, bool EXACT, bool BND = false> struct OcWide : OcS
   }
   // linearise the shooting map along nominal `nxt`, all intervals at once
   LFSD_DEV void linearise_parallel(int nxt) {
+    if constexpr (sizeof(T) == 4 && Lay::HALL && (LFSD_HESS_ALL) != 0) {
+      for (int k = lane; k < N; k += 64) {
+        T x[NX], u[NU], q;
+#pragma unroll
+        for (int i = 0; i < NX; ++i) x[i] = xbp(nxt)[k * NX + i];
+#pragma unroll
+        for (int a = 0; a < NU; ++a) u[a] = ubp(nxt)[k * NU + a];
+        this->template interval_sens_all<Lay::NVH>(this->tk(k), x, q, u, Mwp(nxt) + (long long)k * Lay::M_ELEMS);
+      }
+      __syncthreads();
+      return;
+    }
     if constexpr (sizeof(T) == 4) {
       using V = pk2<T>;
       constexpr int NCT = (NXU + 1) / 2;
@@ -2094,6 +2218,98 @@ template <class M, typename T, bool EXACT, bool BND = false> struct OcWide : OcS
   // The Newton step (for step length 1) of the lifted problem from the gains of the last backward sweep, into dxw / duw.
   // Returns its first-order change of the cost,  sum_k q_k^T (dx_k, du_k) + h_x^T dx_N.
   LFSD_DEV T ms_forward(int cur, T& lamd, T& lamabs) {
+    // small models (robot arm 4 x 6, cart-pole 4 x 5, pendulum 2 x 3) whose whole recursion fits the idle LDS region of the Hessian
+    // sweeps: ALL operands of all stages -- [A_k B_k; q_k], gains, feed-forward, gap, costate -- are copied there first, by all 64
+    // lanes at once (one global round trip instead of one per stage: the recursion was waiting ~1 300 clocks per stage for operands
+    // it had asked for one stage earlier); then every lane carries the whole dx and runs the recursion on group-uniform LDS reads,
+    // without any exchange between lanes.
+    constexpr int STG = Lay::M_ELEMS + NX * NU + NU + 2 * NX;      // words per stage
+    if constexpr (EXACT && NX * NXU <= 32) {      // (EXACT: the instantiations that have that LDS region)
+      if (N * STG <= Lay::template lds_ex_size<64, (int)sizeof(T)>()) {
+        T* st = lds + Lay::template lds_ex<64>();
+        const T* gp = this->gap;
+        // five straight copies, eight loads per lane in flight (a copy loop that stores what it has just loaded waits one global
+        // round trip per element and lane: 38 of them in a row cost as much as the recursion it was meant to feed)
+        T* sM = st;                                   // [N][M_ELEMS]  as in the workspace
+        T* sK = sM + N * Lay::M_ELEMS;                // [N][NX][NU]
+        T* sk = sK + N * NX * NU;                     // [N][NU]
+        T* sd = sk + N * NU;                          // [N][NX] gaps (zero for a roll-out)
+        T* sl = sd + N * NX;                          // [N][NX] costates of nodes 1..N
+        auto copy = [&](T* dst, const T* src, int n) LFSD_LAMBDA_INLINE {
+          for (int b = lane; b < n; b += 64 * 8) {
+            T v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = (src != nullptr && b + 64 * j < n) ? src[b + 64 * j] : T(0);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { if (b + 64 * j < n) dst[b + 64 * j] = v[j]; }
+          }
+        };
+        copy(sM, Mwp(cur), N * Lay::M_ELEMS);
+        copy(sK, this->Kws, N * NX * NU);
+        copy(sk, this->kws, N * NU);
+        copy(sd, gp, N * NX);
+        copy(sl, lam_out + NX, N * NX);
+        if (lane < NX) dxw[lane] = T(0);
+        __syncthreads();
+        T dxv[NX], dl = T(0), ld = T(0), la = T(0);
+#pragma unroll
+        for (int i = 0; i < NX; ++i) dxv[i] = T(0);
+        for (int k = 0; k < N; ++k) {
+          const T* mk = sM + k * Lay::M_ELEMS;       // (rows of NXUP words)
+          const T* Kk = sK + k * NX * NU;
+          const T* kk = sk + k * NU;
+          const T* dk = sd + k * NX;
+          const T* lk = sl + k * NX;
+          T duv[NU], nx[NX];
+#pragma unroll
+          for (int a = 0; a < NU; ++a) duv[a] = kk[a];
+#pragma unroll
+          for (int i = 0; i < NX; ++i) {
+#pragma unroll
+            for (int a = 0; a < NU; ++a) duv[a] += Kk[i * NU + a] * dxv[i];
+          }
+#pragma unroll
+          for (int i = 0; i < NX; ++i) {
+            T sacc = dk[i];
+#pragma unroll
+            for (int j = 0; j < NX; ++j) sacc += mk[i * Lay::NXUP + j] * dxv[j];
+#pragma unroll
+            for (int a = 0; a < NU; ++a) sacc += mk[i * Lay::NXUP + NX + a] * duv[a];
+            nx[i] = sacc;
+            const T lg = lk[i] * dk[i];
+            ld += lg; la += t_abs(lg);
+          }
+#pragma unroll
+          for (int j = 0; j < NX; ++j) dl += mk[NX * Lay::NXUP + j] * dxv[j];
+#pragma unroll
+          for (int a = 0; a < NU; ++a) dl += mk[NX * Lay::NXUP + NX + a] * duv[a];
+          if (lane < NX) {
+            T v = T(0);
+#pragma unroll
+            for (int i = 0; i < NX; ++i) { if (lane == i) v = nx[i]; }
+            dxw[(k + 1) * NX + lane] = v;
+          } else if (lane < NXU) {
+            T v = T(0);
+#pragma unroll
+            for (int a = 0; a < NU; ++a) { if (lane == NX + a) v = duv[a]; }
+            duw[k * NU + (lane - NX)] = v;
+          }
+#pragma unroll
+          for (int i = 0; i < NX; ++i) dxv[i] = nx[i];
+        }
+        {
+          T xN[NX], hx[NX];
+#pragma unroll
+          for (int i = 0; i < NX; ++i) xN[i] = xbp(cur)[N * NX + i];
+          M::final_grad(this->tk(N), xN, e, c, hx);
+#pragma unroll
+          for (int i = 0; i < NX; ++i) dl += hx[i] * dxv[i];
+        }
+        __syncthreads();                               // (dxw / duw visible to every lane; the staging region is free again)
+        lamd = ld; lamabs = la;
+        return dl;
+      }
+    }
     T* ldsDx = lds + Lay::LDS_VX;                 // (NX words, free between backward sweeps)
     const T* Mc = Mwp(cur);
     const T* gp = this->gap;                       // (nullptr: buffer `cur` is a roll-out, no gaps)
@@ -2167,7 +2383,8 @@ template <class M, typename T, bool EXACT, bool BND = false> struct OcWide : OcS
   LFSD_DEV void ms_trial(int cur, int nxt, T alpha, T& J, T& lamabs, T& lamd, T& g2, T& g1, T& gm) {
     T Jl = T(0), g1l = T(0), gml = T(0), lal = T(0), ldl = T(0), g2l = T(0);
     constexpr bool PK2 = sizeof(T) == 4;
-    constexpr int NCT = PK2 ? (NXU + 1) / 2 : NXU;
+    constexpr bool ALLC = PK2 && Lay::HALL && (LFSD_HESS_ALL) != 0;      // one item per interval, all column pairs on its lane
+    constexpr int NCT = ALLC ? 1 : (PK2 ? (NXU + 1) / 2 : NXU);
     using V = typename std::conditional<PK2, pk2<T>, T>::type;
     for (int t = lane; t < N * NCT; t += 64) {
       const int k = t / NCT, c0 = PK2 ? 2 * (t % NCT) : (t % NCT), c1 = c0 + 1;
@@ -2190,6 +2407,9 @@ template <class M, typename T, bool EXACT, bool BND = false> struct OcWide : OcS
         for (int a = 0; a < NU; ++a) ubp(nxt)[k * NU + a] = u[a];
       }
       const T tt = this->tk(k);
+      if constexpr (ALLC) {
+        this->template interval_sens_all<Lay::NVH>(tt, x, q, u, Mwp(nxt) + (long long)k * Lay::M_ELEMS);
+      } else {
       for (int s = 0; s < S; ++s) this->template rk4_step<true, V>(tt, x, q, u, m, mq, du);
       if constexpr (PK2) {
         V* Mk = reinterpret_cast<V*>(Mwp(nxt) + (long long)k * Lay::M_ELEMS + c0);
@@ -2201,6 +2421,7 @@ template <class M, typename T, bool EXACT, bool BND = false> struct OcWide : OcS
 #pragma unroll
         for (int i = 0; i < NX; ++i) Mk[i * Lay::NXUP] = m[i];
         Mk[NX * Lay::NXUP] = mq;
+      }
       }
       if (c0 == 0) {
         Jl += q;

@@ -87,4 +87,5 @@ template <class F> void launch(dim3 grid, dim3 block, F f) {
 #define blockDim (emu::st().block_dim)
 #define gridDim (emu::st().grid_dim)
 inline void __syncthreads() { emu::barrier(); }
+inline long long clock64() { return 0; }      // (the diagnostic clock builds of the kernels compile on the CPU too)
 using std::sin; using std::cos; using std::tan; using std::exp; using std::log; using std::sqrt; using std::pow;

@@ -45,7 +45,7 @@ def test_world_size_must_match_gpus(monkeypatch):
 def test_default_workload_per_world_size():
     import bench
     a = bench.parse_args([])
-    assert a.gpus == 1 and a.steps == 10 and a.warmup == 2 and a.batch == 4096 and a.mode is None
+    assert a.gpus == 1 and a.steps == 20 and a.warmup == 5 and a.batch == 4096 and a.mode is None
     # mode None -> independent seeds (configs[2]) at N = 1, shared theta + all-reduce (configs[3]) at N > 1: see bench.main
     src = open(os.path.join(ROOT, "bench.py")).read()
     assert 'args.mode or ("shared" if world > 1 else "independent")' in src
