@@ -5,7 +5,8 @@
 #include <cstdlib>
 int main() {
   lfsd_model_info mi; lfsd_get_model_info(&mi);
-  const int B = 5, N = 6, n = mi.n_state, m = mi.n_control, p = mi.n_auxvar, nc = mi.n_const, nw = 2, ni = 1;
+  const int N = getenv("LFSD_SAN_N") ? atoi(getenv("LFSD_SAN_N")) : 6;      // (>= 40: the wide kernel's multiple-shooting steps run)
+  const int B = 5, n = mi.n_state, m = mi.n_control, p = mi.n_auxvar, nc = mi.n_const, nw = 2, ni = 1;
   for (int pass = 0; pass < 4; ++pass) {         // both arithmetic types x both mappings of the OC solve (lock-step, wide)
     const int dtype = pass & 1;
     const int mapping = (pass & 2) ? LFSD_MAP_WIDE : LFSD_MAP_LOCKSTEP;

@@ -699,3 +699,36 @@ def test_level0_of_the_mesh_continuation_same_kkt_point_and_partner_independent(
     w = oc.cocSolverBatch(x0, d["horizon"], th, u_init=u0)
     assert ((w["status"] == 1) | (w["status"] == 2)).all()
     assert rel(w["cost"].double(), a["cost"].double()) < 2e-5
+
+
+@pytest.mark.parametrize("kind,n_grid,dtype", [("robotarm", 40, torch.float64), ("robotarm", 40, torch.float32), ("cartpole", 40, torch.float64),
+                                               ("pendulum", 40, torch.float32)])
+def test_multiple_shooting_steps_end_at_the_single_shooting_kkt_point(kind, n_grid, dtype):
+    """Wide kernel at >= 40 intervals: the product build (multiple-shooting steps of the lifted problem tried first, closed-loop
+    roll-outs as fallback and to close the gaps, cpdp_oc.h OcWide::ms_*) against a build with -DLFSD_MS=0 (single shooting only) on
+    the CPU emulator: both end at KKT points (status 1 / 2) of the NLP of CPDP.py:110-175 and at the SAME one, the answer does not
+    depend on where a problem sits in the batch (duplicates bit-identical), and the costates returned are those of a gap-free
+    trajectory (the shooting constraints hold to rounding when the product's controls are rolled out by the other build's nodes)."""
+    from conftest import build_emu_library
+    rng = np.random.default_rng(5)
+    sols = []
+    for flags, tag in (((), ""), (("-DLFSD_MS=0",), "noms")):
+        oc, env, d = models.ZOO[kind](n_grid=n_grid)
+        oc.use_library(build_emu_library(oc, extra_flags=flags, tag=tag))
+        oc.compile()
+        oc.setDevice(dtype=dtype)
+        oc.setSolverOptions(mapping="wide")
+        p = len(d["theta0"])
+        th = np.array(d["theta0"])[None, :] * (1 + 0.05 * np.random.default_rng(5).standard_normal((3, p)))
+        th[:, 0] = np.abs(th[:, 0]) + 0.1
+        th = np.concatenate([th, th[:1]])                 # a duplicate of problem 0 at the end of the batch
+        sols.append(oc.cocSolverBatch(np.tile(d["ini_state"], (4, 1)), d["horizon"], th))
+    a, b = sols
+    assert set(a["status"].tolist()) <= {1, 2} and set(b["status"].tolist()) <= {1, 2}, (a["status"], b["status"])
+    assert torch.equal(a["state_grid"][0], a["state_grid"][3]) and torch.equal(a["costate_grid"][0], a["costate_grid"][3])
+    f64 = dtype == torch.float64
+    xt, jt = (2e-6, 1e-9) if f64 else (3e-3, 2e-5)
+    assert float((a["state_grid"] - b["state_grid"]).abs().max() / b["state_grid"].abs().max()) < xt
+    assert float((a["control_grid"] - b["control_grid"]).abs().max() / b["control_grid"].abs().max()) < 10 * xt
+    assert float((a["costate_grid"] - b["costate_grid"]).abs().max() / b["costate_grid"].abs().max()) < 20 * xt
+    assert float(((a["cost"] - b["cost"]).abs() / b["cost"].abs()).max()) < jt

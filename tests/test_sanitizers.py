@@ -17,13 +17,16 @@ EMU = os.path.join(ROOT, "tests", "emu")
 # (emulated), 16-lane forward sweep.  Batch 5 leaves a partial workgroup.  Every model runs the lock-step AND the wide (one
 # trajectory per wavefront) OC kernels.  (The robot arm -- 16-lane groups, 8-lane forward sweep -- ran clean in rounds 1-2;
 # its sanitizer build alone takes 3.5 minutes and is left to `pytest --sanitize-all`.)
+# (round 5: ("pendulum", 40) -- at 40 intervals the wide kernel takes its multiple-shooting steps: gap-aware sweep, forward pass on
+#  operands staged in LDS, all-columns trial integration and stage Hessians on the multi-tangent generated code)
 def _kinds():
     import sys
-    return ["pendulum", "robotarm", "quadrotor"] if "--sanitize-all" in sys.argv else ["pendulum", "quadrotor"]
+    return [("pendulum", 6), ("pendulum", 40), ("robotarm", 6), ("robotarm", 40), ("quadrotor", 6)] if "--sanitize-all" in sys.argv else \
+        [("pendulum", 6), ("pendulum", 40), ("quadrotor", 6)]
 
 
-@pytest.mark.parametrize("kind", _kinds())
-def test_asan_ubsan_clean(tmp_path, kind):
+@pytest.mark.parametrize("kind,n_grid", _kinds())
+def test_asan_ubsan_clean(tmp_path, kind, n_grid):
     oc, _, _ = models.ZOO[kind]()
     spec = oc.model_spec()
     runtime.write_header(spec)
@@ -33,7 +36,7 @@ def test_asan_ubsan_clean(tmp_path, kind):
            '-DLFSD_MODEL_HEADER="gen/%s.h"' % spec.hash(), os.path.join(EMU, "sanitize_main.cpp"), "-o", exe]
     r = subprocess.run(cmd, cwd=runtime.CSRC_DIR, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-3000:]
-    env = dict(os.environ, ASAN_OPTIONS="detect_stack_use_after_return=0:detect_leaks=0")
+    env = dict(os.environ, ASAN_OPTIONS="detect_stack_use_after_return=0:detect_leaks=0", LFSD_SAN_N=str(n_grid))
     r = subprocess.run([exe], capture_output=True, text=True, env=env, timeout=600)
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
     assert "ERROR: AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stderr[-4000:]
