@@ -204,6 +204,17 @@
 #ifndef LFSD_HESS_ALL
 #define LFSD_HESS_ALL 1
 #endif
+#ifndef LFSD_LEAN_CTL_PREFETCH
+#define LFSD_LEAN_CTL_PREFETCH 1
+#endif
+// ... shorter multiple-shooting steps: after a refused full step, at most LFSD_MS_HALF HALF steps in a row are tried before the
+// closed-loop roll-outs (0: none).  A trial costs 25 k clocks against a roll-out's 580 k.  Measured on the robot-arm learner
+// (1 024 seeds, MI355X, oc_solve of outer iterations 0 / 1 / 4 / 5 / 6 / 7; profiles/r05_o_*): none 12.5 / 11.1 / 17.8 / 7.5 / 7.9 / 8.2 ms,
+// one 10.9 / 10.2 / 8.7 / 7.2 / 5.5 / 5.2, two in a row 9.6 / 9.8 / 9.6 / 8.2 / 5.7 / 5.5.  (A full line search along the linear
+// direction -- built first, removed -- lets the gaps pile up: 1 % of the trajectories then need 45-50 iterations.)
+#ifndef LFSD_MS_HALF
+#define LFSD_MS_HALF 1
+#endif
 #ifndef LFSD_MS_JFEAS
 #define LFSD_MS_JFEAS 1
 #endif

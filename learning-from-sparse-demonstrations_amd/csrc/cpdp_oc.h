@@ -1502,8 +1502,47 @@ template <class M, typename T, int G, bool EXACT, bool BND = false> struct OcSol
 #pragma unroll
     for (int i = 0; i < NX; ++i) x[i] = x0[i];
     const int c0 = ZC + 2 * lane, c1 = c0 + 1;             // original column indices of this lane's pair of live columns
+#if LFSD_LEAN_CTL_PREFETCH
+    // the operands of the control law (nominal, feed-forward, gains of interval k: group-uniform global loads) are fetched while
+    // interval k-1 is integrated: on the one-step-per-interval levels of the mesh continuation an interval is ~4 000 clocks of
+    // arithmetic, and its control law otherwise starts by waiting a global round trip for 73 words
+    T ubN[NU], xbN[NX], KN[NX * NU], kN[NU];
+    auto load_ctl = [&](int k_) LFSD_LAMBDA_INLINE {
+      const T* ubk = ubp(cur) + k_ * NU;
+#pragma unroll
+      for (int a = 0; a < NU; ++a) ubN[a] = ubk[a];
+      if (gains) {
+        const T* xbk = xbp(cur) + k_ * NX;
+        const T* Kk = Kws + (long long)k_ * NX * NU;
+        const T* kk = kws + k_ * NU;
+#pragma unroll
+        for (int i = 0; i < NX; ++i) xbN[i] = xbk[i];
+#pragma unroll
+        for (int i = 0; i < NX * NU; ++i) KN[i] = Kk[i];
+#pragma unroll
+        for (int a = 0; a < NU; ++a) kN[a] = kk[a];
+      }
+    };
+    load_ctl(0);
+#endif
     for (int k = 0; k < N; ++k) {
+#if LFSD_LEAN_CTL_PREFETCH
+#pragma unroll
+      for (int a = 0; a < NU; ++a) u[a] = ubN[a];
+      if (gains) {
+#pragma unroll
+        for (int a = 0; a < NU; ++a) u[a] += alpha * kN[a];
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+          const T dx = x[i] - xbN[i];
+#pragma unroll
+          for (int a = 0; a < NU; ++a) u[a] += KN[i * NU + a] * dx;
+        }
+      }
+      if (k + 1 < N) { load_ctl(k + 1); LFSD_ISSUE_FENCE(); }
+#else
       control(cur, k, x, alpha, gains, u);
+#endif
       if (lane == 0) {
 #pragma unroll
         for (int i = 0; i < NX; ++i) xbp(nxt)[k * NX + i] = x[i];
@@ -3111,7 +3150,7 @@ __global__ void __launch_bounds__(64, 1) oc_solve_wide_kernel(OcArgs<T> a) {
   bool ms = !BND && (LFSD_MS) != 0 && a.n_grid >= (LFSD_MS_MIN_GRID) && a.max_iter > 8 && (a.exact_after != 0 || (LFSD_MS_NEWTON) != 0);
   bool ms_check = false, ms_floor = false;
   const bool ms_on = ms;
-  int n_acc_need = 4, n_ms = 0;
+  int n_acc_need = 4, n_ms = 0, n_half = 0;
   T g1c = T(0), g2c = T(0), gmc = T(0);      // l1 norm, sum of squares and largest entry of the gaps of the current iterate (0: a roll-out)
   T J_feas = J;                              // cost of the last iterate WITHOUT gaps (a roll-out)
   T mu = T(0);
@@ -3236,10 +3275,22 @@ __global__ void __launch_bounds__(64, 1) oc_solve_wide_kernel(OcArgs<T> a) {
         } else {
           T Jt, lat, ldt, g2t, g1t, gmt;
           LFSD_WCK(6, s.ms_trial(cur, cur ^ 1, T(1), Jt, lat, ldt, g2t, g1t, gmt));
-          const T phit = Jt + ldt + T(0.5) * rho * g2t;
+          T phit = Jt + ldt + T(0.5) * rho * g2t;
           const T flat = T(8) * epsT * t_abs(phi0);
-          const bool accept = t_finite(phit) && t_finite(g1t) && (phi0 - phit) >= T(1e-4) * pred_ms - flat && phit < phi0 &&
-                              ((LFSD_MS_JFEAS) == 0 || Jt <= J_feas + T(8) * epsT * t_abs(J_feas));
+          bool accept = t_finite(phit) && t_finite(g1t) && (phi0 - phit) >= T(1e-4) * pred_ms - flat && phit < phi0 &&
+                        ((LFSD_MS_JFEAS) == 0 || Jt <= J_feas + T(8) * epsT * t_abs(J_feas));
+          bool half = false;
+#if LFSD_MS_HALF
+          if (!accept && n_half < (LFSD_MS_HALF)) {
+            // ONE shorter step along the same linear direction before the closed-loop roll-outs (an item of 25 k clocks against
+            // 580 k): half the Newton step, same tests; it leaves half of the old gaps, so no second one follows it directly
+            LFSD_WCK(6, s.ms_trial(cur, cur ^ 1, T(0.5), Jt, lat, ldt, g2t, g1t, gmt));
+            phit = Jt + ldt + T(0.5) * rho * g2t;
+            accept = t_finite(phit) && t_finite(g1t) && (phi0 - phit) >= T(0.5e-4) * pred_ms - flat && phit < phi0 &&
+                     ((LFSD_MS_JFEAS) == 0 || Jt <= J_feas + T(8) * epsT * t_abs(J_feas));
+            half = accept;
+          }
+#endif
 #if defined(LFSD_TRACE)
           if (s.lane == 0 && traj == 0) printf("wide ms it %d mode %d g %.6e J %.12e gap1 %.4e gapmax %.3e lam %.3e rho %.3e phi0 %.10e pred %.4e accept %d mu %g -> J %.12e gap1 %.4e phi %.10e\n", it, mode, (double)gnorm, (double)J, (double)g1c, (double)gmc, (double)lam_mx, (double)rho, (double)phi0, (double)pred_ms, (int)accept, (double)mu, (double)Jt, (double)g1t, (double)phit);
 #endif
@@ -3252,7 +3303,8 @@ __global__ void __launch_bounds__(64, 1) oc_solve_wide_kernel(OcArgs<T> a) {
             // (no hold on the way down after a multiple-shooting step: a shift that turns out too small costs one backward sweep on
             //  cached Hessians, a held rung costs a whole iteration -- 128 seeds, emulator: mean 21.1 -> 19.8, slowest 33 -> 30
             //  iterations; dropping by 10 after steps that gain half their prediction: one seed at 52)
-            mu = (mu > T(1e-8)) ? mu * T(LFSD_MU_DOWN) : T(0); mu_hold = 0;
+            if (!half) { mu = (mu > T(1e-8)) ? mu * T(LFSD_MU_DOWN) : T(0); mu_hold = 0; }
+            n_half = half ? n_half + 1 : 0;
             if (mode == 0 && ham_ok && gain < T(LFSD_HAM_SWITCH) * t_abs(Jt)) mode = 1;
             else if (LFSD_GN_CRAWL && mode == 0 && !ham_ok && gain < T(1e-2) * t_abs(Jt)) gn_crawl = true;
             if (coarse && gain < T(LFSD_COARSE_SWITCH) * t_abs(Jt)) {
@@ -3332,7 +3384,7 @@ __global__ void __launch_bounds__(64, 1) oc_solve_wide_kernel(OcArgs<T> a) {
       cur ^= 1;
       g_last = gnorm; dec_last = (mode >= 1 && mu == T(0) && !have_gaps) ? -(dV1 + dV2) : T(1e30);
       hess_ok = false; costates_ok = false;
-      g1c = T(0); g2c = T(0); gmc = T(0); s.gap = nullptr;      // a roll-out has no gaps
+      g1c = T(0); g2c = T(0); gmc = T(0); s.gap = nullptr; n_half = 0;      // a roll-out has no gaps
       if (ms_off) { ms = false; ms_check = true; }
       if (ia == 0) {
         // (a ratio-tested faster descent of the shift was measured on the rocket and needs MORE iterations in every variant --

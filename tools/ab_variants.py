@@ -18,76 +18,13 @@ sys.path.insert(0, ROOT)
 # name -> (extra flags for both units, capi-unit flags or None for the tuned default, drop -fno-slp-vectorize from the capi unit)
 VARIANTS = {
     "base": ((), None, False),
-    "noldssync": (("-DLFSD_OC_LDS_SYNC=0",), None, False),
-    "pf1": (("-DLFSD_BW_PREFETCH=1",), None, False),
-    "vupfetch": (("-DLFSD_SC_VUP_FETCH=1",), None, False),
-    "synclight": (("-DLFSD_SYNC_LIGHT=1",), None, False),
-    "gramrows": (("-DLFSD_RIC_GRAM_ROWS=1",), None, False),
-    "synclight_gram": (("-DLFSD_SYNC_LIGHT=1", "-DLFSD_RIC_GRAM_ROWS=1"), None, False),
-    "noprefetch": (("-DLFSD_BW_PREFETCH=0",), None, False),
+    # round 5 (the switches of rounds 3-4 whose branches were measured negative are gone from csrc/; their results: profiles/HISTORY.md)
+    "ctlpf": (("-DLFSD_LEAN_CTL_PREFETCH=1",), None, False),      # lean roll-out: control-law operands fetched one interval ahead
+    "nocoarse": (("-DLFSD_COARSE_START=0",), None, False),
+    "notc": (("-DLFSD_LEAN_TC=1",), None, False),
     "slp": ((), None, True),
     "nomfma": (("-DLFSD_MFMA_BACKWARD=0",), None, False),
-    "ricmfma": (("-DLFSD_RIC_MFMA=1",), None, False),
-    "dual": (("-DLFSD_OC_DUAL=1",), None, False),
-    "nodual": (("-DLFSD_OC_DUAL=0",), None, False),
     "nostruct": (("-DLFSD_STRUCT_COLS=0",), None, False),
-    "nocoarse": (("-DLFSD_COARSE_START=0",), None, False),
-    "nowidecoarse": (("-DLFSD_COARSE_MIN_GRID=100000",), None, False),
-    "r02like": (("-DLFSD_COARSE_START=0", "-DLFSD_STRUCT_COLS=0"), None, False),
-    "relinhard": (("-DLFSD_COARSE_RELIN=1",), None, False),
-    "cs1e2": (("-DLFSD_COARSE_SWITCH=0.01",), None, False),
-    "cs1e3": (("-DLFSD_COARSE_SWITCH=0.001",), None, False),
-    "cs3": (("-DLFSD_COARSE_SWITCH=3.0",), None, False),
-    "cs1e4": (("-DLFSD_COARSE_SWITCH=0.0001",), None, False),
-    "cs0": (("-DLFSD_COARSE_SWITCH=0.0",), None, False),
-    "bwclock": (("-DLFSD_BW_CLOCK=1",), None, False),
-    "occlock": (("-DLFSD_OC_CLOCK=3",), None, False),
-    "nofence64": (("-DLFSD_FENCE64=0",), None, False),
-    "pin64only": (("-DLFSD_FENCE64=1",), None, False),
-    "fence3": (("-DLFSD_FENCE64=3",), None, False),
-    "nolive64": (("-DLFSD_FP64_LIVE=0",), None, False),
-    "nopark64": (("-DLFSD_FP64_PARK=0",), None, False),
-    "nosc64": (("-DLFSD_FP64_SC=0",), None, False),
-    "vxlds": (("-DLFSD_SC_VX_LDS=1",), None, False),
-    "pflate": (("-DLFSD_BW_PREFETCH=2",), None, False),
-    "pflateclock": (("-DLFSD_BW_PREFETCH=2", "-DLFSD_BW_CLOCK=1"), None, False),
-    # level 0 of the lean kernel's mesh continuation: tc merged control intervals x RK4 steps per merged interval x iterations
-    "tc2k3": (("-DLFSD_LEAN_TC=2", "-DLFSD_LEAN_TC_ITERS=3"), None, False),
-    "tc2k2": (("-DLFSD_LEAN_TC=2", "-DLFSD_LEAN_TC_ITERS=2"), None, False),
-    "tc2k4": (("-DLFSD_LEAN_TC=2", "-DLFSD_LEAN_TC_ITERS=4"), None, False),
-    "tc5k3": (("-DLFSD_LEAN_TC=5", "-DLFSD_LEAN_TC_S=2", "-DLFSD_LEAN_TC_ITERS=3"), None, False),
-    "tc5s1k2": (("-DLFSD_LEAN_TC=5", "-DLFSD_LEAN_TC_S=1", "-DLFSD_LEAN_TC_ITERS=2"), None, False),
-    "tc2s2k3": (("-DLFSD_LEAN_TC=2", "-DLFSD_LEAN_TC_S=2", "-DLFSD_LEAN_TC_ITERS=3"), None, False),
-    "tc5k2": (("-DLFSD_LEAN_TC=5", "-DLFSD_LEAN_TC_S=2", "-DLFSD_LEAN_TC_ITERS=2"), None, False),
-    "tc5k4": (("-DLFSD_LEAN_TC=5", "-DLFSD_LEAN_TC_S=2", "-DLFSD_LEAN_TC_ITERS=4"), None, False),
-    "tc5k5": (("-DLFSD_LEAN_TC=5", "-DLFSD_LEAN_TC_S=2", "-DLFSD_LEAN_TC_ITERS=5"), None, False),
-    "tc5s3k3": (("-DLFSD_LEAN_TC=5", "-DLFSD_LEAN_TC_S=3", "-DLFSD_LEAN_TC_ITERS=3"), None, False),
-    "tc10s4k3": (("-DLFSD_LEAN_TC=10", "-DLFSD_LEAN_TC_S=4", "-DLFSD_LEAN_TC_ITERS=3", "-DLFSD_LEAN_TC_MIN=5"), None, False),
-    "tc10s2k3": (("-DLFSD_LEAN_TC=10", "-DLFSD_LEAN_TC_S=2", "-DLFSD_LEAN_TC_ITERS=3", "-DLFSD_LEAN_TC_MIN=5"), None, False),
-    "tc5k4fine": (("-DLFSD_LEAN_TC=5", "-DLFSD_LEAN_TC_S=2", "-DLFSD_LEAN_TC_ITERS=4", "-DLFSD_LEAN_TC_TO_FINE=1"), None, False),
-    "tc5k5fine": (("-DLFSD_LEAN_TC=5", "-DLFSD_LEAN_TC_S=2", "-DLFSD_LEAN_TC_ITERS=5", "-DLFSD_LEAN_TC_TO_FINE=1"), None, False),
-    # on top of the shipped level 0 (5 x 2 x 3 iterations)
-    "tc5k3fine": (("-DLFSD_LEAN_TC_TO_FINE=1",), None, False),
-    "ham3": (("-DLFSD_HAM_SWITCH=3.0",), None, False),
-    "ham09": (("-DLFSD_HAM_SWITCH=0.9",), None, False),
-    "ham01": (("-DLFSD_HAM_SWITCH=0.1",), None, False),
-    "tc5s2k3min5": (("-DLFSD_LEAN_TC_MIN=5",), None, False),
-    "notc": (("-DLFSD_LEAN_TC=1",), None, False),
-    "nokeephist": (("-DLFSD_EXIT_KEEP_HISTORY=0",), None, False),
-    "keephist1": (("-DLFSD_EXIT_KEEP_HISTORY=1",), None, False),
-    "tc2k3b": (("-DLFSD_LEAN_TC=2", "-DLFSD_LEAN_TC_S=1", "-DLFSD_LEAN_TC_ITERS=3"), None, False),
-    "tc5k2b": (("-DLFSD_LEAN_TC_ITERS=2",), None, False),
-    "tc5s3": (("-DLFSD_LEAN_TC_S=3",), None, False),
-    "occ_k3": (("-DLFSD_OC_CLOCK=1024",), None, False),
-    "occ_k2": (("-DLFSD_OC_CLOCK=1024", "-DLFSD_LEAN_TC_ITERS=2"), None, False),
-    "grace1": (("-DLFSD_LEAN_TC_GRACE=1",), None, False),
-    "grace2": (("-DLFSD_LEAN_TC_GRACE=2",), None, False),
-    "grace1s1": (("-DLFSD_LEAN_TC_GRACE=1", "-DLFSD_LEAN_TC_S=1"), None, False),
-    "tc2k2b": (("-DLFSD_LEAN_TC=2", "-DLFSD_LEAN_TC_S=1", "-DLFSD_LEAN_TC_ITERS=2"), None, False),
-    "tc2k4b": (("-DLFSD_LEAN_TC=2", "-DLFSD_LEAN_TC_S=1", "-DLFSD_LEAN_TC_ITERS=4"), None, False),
-    "tc5s1k2b": (("-DLFSD_LEAN_TC_S=1", "-DLFSD_LEAN_TC_ITERS=2"), None, False),
-    "tc5s1k3b": (("-DLFSD_LEAN_TC_S=1", "-DLFSD_LEAN_TC_ITERS=3"), None, False),
-    "k4ham01": (("-DLFSD_LEAN_TC_ITERS=4", "-DLFSD_HAM_SWITCH=0.05"), None, False),
 }
 
 
