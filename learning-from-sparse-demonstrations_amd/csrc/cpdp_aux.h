@@ -121,18 +121,44 @@ template <class M, typename T, int G, int LAY> struct AuxCtx {
   const T* hcol[LAY == 0 ? NX : 1];
   const T* ucol[LAY == 0 ? NU : 1];
 
-  LFSD_DEV void load_interval(const AuxArgs<T>& a, long long traj, int k, int N) {
-    const T* xs = a.state_grid + (traj * (N + 1) + k) * NX;
-    const T* us = a.control_grid + (traj * (N + 1) + k) * NU;
-    const T* ls = a.costate_grid + (traj * (N + 1) + k) * NX;
-    T* ga = lds + Lay::LDS_GA;
-    T* gb = lds + Lay::LDS_GB;
+  // Grid values (x, u, lambda) of the two nodes of interval k into LDS.  Consecutive intervals share a node, and the sweeps walk
+  // the grid in one direction (`dir` = +1 forward sweep, -1 Riccati sweep): only the NEW node is read from memory, and it is
+  // fetched into registers ONE INTERVAL AHEAD (`gpf`, one or two words per lane) -- an interval is a few thousand clocks of work
+  // on a wavefront that is (nearly) alone on its SIMD, and used to start by waiting a global round trip for 60 words.
+  static constexpr int NR = 2 * NX + NU, GPF = (NR + G - 1) / G;
+  static constexpr bool PF = sizeof(T) == 4;      // (fp64: the registers are not there -- aux_forward 2.03 -> 2.57 ms, aux_riccati 4.60 -> 4.78 with it)
+  T gpf[GPF];
+  T *gA_ = nullptr, *gB_ = nullptr;
+  LFSD_DEV void fetch_node(const AuxArgs<T>& a, long long traj, int node, int N) {
+    const T* xs = a.state_grid + (traj * (N + 1) + node) * NX;
+    const T* us = a.control_grid + (traj * (N + 1) + node) * NU;
+    const T* ls = a.costate_grid + (traj * (N + 1) + node) * NX;
+#pragma unroll
+    for (int j = 0; j < GPF; ++j) {
+      const int idx = lane + j * G;
+      gpf[j] = (idx < NX) ? xs[idx] : ((idx < NX + NU) ? us[idx - NX] : ((idx < NR) ? ls[idx - NX - NU] : T(0)));
+    }
+  }
+  LFSD_DEV void load_interval(const AuxArgs<T>& a, long long traj, int k, int N, int dir) {
     LFSD_WAVE_SYNC();                         // previous interval's readers are done
-    for (int i = lane; i < NX; i += G) { ga[i] = xs[i]; gb[i] = xs[NX + i]; ga[NX + NU + i] = ls[i]; gb[NX + NU + i] = ls[NX + i]; }
-    for (int i = lane; i < NU; i += G) { ga[NX + i] = us[i]; gb[NX + i] = us[NU + i]; }
-    xa_ = ga; ua_ = ga + NX; la_ = ga + NX + NU; xb_ = gb; ub_ = gb + NX; lb_ = gb + NX + NU;
+    if (gA_ == nullptr || !PF) {              // first interval of the sweep: both nodes straight from memory
+      gA_ = lds + Lay::LDS_GA; gB_ = lds + Lay::LDS_GB;
+      const T* xs = a.state_grid + (traj * (N + 1) + k) * NX;
+      const T* us = a.control_grid + (traj * (N + 1) + k) * NU;
+      const T* ls = a.costate_grid + (traj * (N + 1) + k) * NX;
+      for (int i = lane; i < NX; i += G) { gA_[i] = xs[i]; gB_[i] = xs[NX + i]; gA_[NX + NU + i] = ls[i]; gB_[NX + NU + i] = ls[NX + i]; }
+      for (int i = lane; i < NU; i += G) { gA_[NX + i] = us[i]; gB_[NX + i] = us[NU + i]; }
+    } else {                                  // the shared node changes ends, the new node comes out of the registers
+      T* t_ = gA_; gA_ = gB_; gB_ = t_;
+      T* dst = (dir > 0) ? gB_ : gA_;
+#pragma unroll
+      for (int j = 0; j < GPF; ++j) { const int idx = lane + j * G; if (idx < NR) dst[idx] = gpf[j]; }
+    }
+    xa_ = gA_; ua_ = gA_ + NX; la_ = gA_ + NX + NU; xb_ = gB_; ub_ = gB_ + NX; lb_ = gB_ + NX + NU;
     t_a = M::TIME_VARYING ? dgrid * T(k) : T(0);
     LFSD_WAVE_SYNC();
+    const int nn = (dir > 0) ? k + 2 : k - 1;     // the node the NEXT interval adds
+    if (PF && nn >= 0 && nn <= N) fetch_node(a, traj, nn, N);
   }
   // Lane `node` (< 5) evaluates the packed PMP coefficients at its own time node s (fraction of the
   // interval) on the reference's linear interpolant of (x,u,lambda) (CPDP.py:320-323) and stages them in LDS.
@@ -633,7 +659,7 @@ __global__ void __launch_bounds__(64, (sizeof(T) == 4 ? LFSD_WAVES_RIC : 1)) aux
   int n_units = 0, n_unmet = 0;      // (group-uniform) units executed incl. rejected attempts; intervals accepted above tolerance
   const int budget = a.budget(traj);
   for (int k = N - 1; k >= 0; --k) {
-    s.load_interval(a, traj, k, N);
+    s.load_interval(a, traj, k, N, -1);
     // stiffness-aware sub-stepping: P is largest at the later end of the interval (terminal transient).  The coefficients
     // are staged for the first unit of the expected unit count at once: node 0 sits at the interval end either way, and
     // when the stiffness estimate confirms the count the first unit need not stage again
@@ -768,6 +794,9 @@ __global__ void __launch_bounds__(64, (sizeof(T) == 4 ? LFSD_WAVES_FWD : 1)) aux
   for (int i = lane; i < NX; i += G) ldsP0[i] = T(0);
   const T* pA = (lane < NX) ? ldsPA + lane * NX : ldsP0;
   const T* pB = (lane < NX) ? ldsPB + lane * NX : ldsP0;
+  T pN[NX], wN[NX];
+#pragma unroll
+  for (int i = 0; i < NX; ++i) { pN[i] = T(0); wN[i] = T(0); }
   T* xprev = s.lds + Lay::FWD_XPREV;                 // X(t_k), parked in LDS: start value of a redone interval, and the loss needs it
   T* xch = s.lds + Lay::FWD_XCH;
   T* ldsR = s.lds + Lay::FWD_RED;
@@ -782,14 +811,39 @@ __global__ void __launch_bounds__(64, (sizeof(T) == 4 ? LFSD_WAVES_FWD : 1)) aux
     for (int i = 0; i < NX; ++i) Xo[(long long)s.xcol * NX + i] = T(0);
   }
   for (int k = 0; k < N; ++k) {
-    s.load_interval(a, traj, k, N);
-    if (lane < NX) {           // (load_interval's barriers fence the previous interval's readers; stage_nodes' the writers)
+    s.load_interval(a, traj, k, N, +1);
+    // [P W] at the two ends of the interval: the later end of interval k is the earlier end of interval k+1, and the new end is
+    // fetched into registers one interval ahead (pN: this lane's column of P, wN: its column of W) -- as the grid rows above
+    if (k == 0 || !Ctx::PF) {
+      if (lane < NX) {           // (load_interval's barriers fence the previous interval's readers; stage_nodes' the writers)
 #pragma unroll
-      for (int i = 0; i < NX; ++i) { ldsPA[lane * NX + i] = Zt[((long long)k * NZ + lane) * NX + i]; ldsPB[lane * NX + i] = Zt[((long long)(k + 1) * NZ + lane) * NX + i]; }
+        for (int i = 0; i < NX; ++i) { ldsPA[lane * NX + i] = Zt[((long long)k * NZ + lane) * NX + i]; ldsPB[lane * NX + i] = Zt[((long long)(k + 1) * NZ + lane) * NX + i]; }
+      }
+      if (xlane) {
+#pragma unroll
+        for (int i = 0; i < NX; ++i) { wA[i] = Zt[((long long)k * NZ + NX + s.xcol) * NX + i]; wB[i] = Zt[((long long)(k + 1) * NZ + NX + s.xcol) * NX + i]; }
+      }
+    } else {
+      { T* t_ = ldsPA; ldsPA = ldsPB; ldsPB = t_; }
+      pA = (lane < NX) ? ldsPA + lane * NX : ldsP0;
+      pB = (lane < NX) ? ldsPB + lane * NX : ldsP0;
+      if (lane < NX) {
+#pragma unroll
+        for (int i = 0; i < NX; ++i) ldsPB[lane * NX + i] = pN[i];
+      }
+#pragma unroll
+      for (int i = 0; i < NX; ++i) { wA[i] = wB[i]; wB[i] = wN[i]; }
     }
-    if (xlane) {
+    if (Ctx::PF && k + 2 <= N) {
+      if (lane < NX) {
 #pragma unroll
-      for (int i = 0; i < NX; ++i) { wA[i] = Zt[((long long)k * NZ + NX + s.xcol) * NX + i]; wB[i] = Zt[((long long)(k + 1) * NZ + NX + s.xcol) * NX + i]; }
+        for (int i = 0; i < NX; ++i) pN[i] = Zt[((long long)(k + 2) * NZ + lane) * NX + i];
+      }
+      if (xlane) {
+#pragma unroll
+        for (int i = 0; i < NX; ++i) wN[i] = Zt[((long long)(k + 2) * NZ + NX + s.xcol) * NX + i];
+      }
+      LFSD_ISSUE_FENCE();
     }
     if (fine_x) {
 #pragma unroll

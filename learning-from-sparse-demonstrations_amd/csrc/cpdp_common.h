@@ -285,6 +285,11 @@
 // ---- the generic backward sweep in fp32 (wide kernel, lock-step kernels without MFMA; profiles/r03_t_generic_backward.txt) --
 // wide kernel, models with at most 16 columns of [A B] and NX >= 8 (rocket): rows of the backward sweep's dense products
 // split over the four 16-lane quarters of the wavefront (OcSolver::backward, QS)
+// wide kernel, small fp32 models (at most 8 columns, NX * NXU <= 32): the backward sweep on LDS-staged operands, every lane running
+// the whole recursion (OcWide::backward_small)
+#ifndef LFSD_BW_SMALL
+#define LFSD_BW_SMALL 1
+#endif
 #ifndef LFSD_BW_QSPLIT
 #define LFSD_BW_QSPLIT 1
 #endif

@@ -2221,6 +2221,288 @@ template <class M, typename T, bool EXACT, bool BND = false> struct OcWide : OcS
     __syncthreads();
   }
 
+  // ---- the backward sweep of the small models (fp32; robot arm 4 x 6, cart-pole 4 x 5, pendulum 2 x 3) ------------------------
+  // OcSolver::backward keeps one column per lane and hands rows over through LDS five times per stage; with six columns on a
+  // wavefront that is alone on its SIMD a stage is ~2 900 clocks, most of them waiting (LDS round trips, the model call of the
+  // stage Hessian in modes 0 / 1, global operands).  Here
+  //   * all operands of all stages ([A_k B_k; q_k], gaps, cached exact Hessians) are copied into the idle LDS region of the
+  //     Hessian sweeps first, by all 64 lanes, eight loads in flight per lane (as ms_forward does);
+  //   * the stage Hessians of modes 0 / 1 -- one model call per stage in the generic sweep, in sequence -- are computed for all
+  //     intervals at once, one interval per lane, all columns side by side (ham_hess_mul_n); mode 1 needs the costates of the sweep:
+  //     a costate recursion on the staged operands runs first (NX^2 FMAs per stage);
+  //   * the recursion itself runs on EVERY lane (uniform values: no exchange between lanes, no hand-over, no barrier), the dense
+  //     products Y = V_xx [A B], Q = [A B]^T Y with two columns per packed instruction.
+  // Same recursion, same outputs (gains, feed-forward, costates, predicted decrease, failing pivot) as OcSolver::backward.
+  static constexpr bool SMALL_BW = EXACT && !BND && sizeof(T) == 4 && Lay::HALL && NX * NXU <= 32 && (LFSD_BW_SMALL) != 0;
+  static constexpr int BWS_STG = Lay::M_ELEMS + Lay::H_ELEMS + 2 * NX;      // words per stage
+  LFSD_DEV bool small_bw_fits() const { return SMALL_BW && (N + 1) * BWS_STG <= Lay::template lds_ex_size<64, (int)sizeof(T)>(); }
+  LFSD_DEV bool backward_small(int cur, int mode, T mu, T& gnorm, T& dV1, T& dV2, T& dmin) {
+    using V = pk2<T>;
+    constexpr int NP2 = Lay::NXUP / 2, RS = Lay::NXUP, ME = Lay::M_ELEMS, HE = Lay::H_ELEMS, NVH = Lay::NVH;
+    T* st = lds + Lay::template lds_ex<64>();
+    T* sM = st;                           // [N][M_ELEMS]   as in the workspace
+    T* sH = sM + N * ME;                  // [N][H_ELEMS]   stage Hessians [row][column]
+    T* sd = sH + N * HE;                  // [N][NX]        gaps (zero for a roll-out)
+    T* sl = sd + N * NX;                  // [N + 1][NX]    costates (mode 1)
+    auto copy = [&](T* dst, const T* src, int n) LFSD_LAMBDA_INLINE {
+      for (int b = lane; b < n; b += 64 * 8) {
+        T v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = (src != nullptr && b + 64 * j < n) ? src[b + 64 * j] : T(0);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { if (b + 64 * j < n) dst[b + 64 * j] = v[j]; }
+      }
+    };
+    copy(sM, Mwp(cur), N * ME);
+    copy(sd, this->gap, N * NX);
+    if (mode == 2) copy(sH, Hws, N * HE);
+    T Vx[NX], lam[NX], xN[NX], Vxx[NX][NX];
+    {
+      const T* xp = xbp(cur) + N * NX;
+#pragma unroll
+      for (int i = 0; i < NX; ++i) xN[i] = xp[i];
+      M::final_grad(this->tk(N), xN, e, c, Vx);
+      T oe[NP > 0 ? NP : 1];
+#pragma unroll
+      for (int i = 0; i < NP; ++i) oe[i] = T(0);
+#pragma unroll
+      for (int j = 0; j < NX; ++j) {
+        T ox[NX], hc[NX];
+#pragma unroll
+        for (int i = 0; i < NX; ++i) ox[i] = (i == j) ? T(1) : T(0);
+        M::final_hess_mul(this->tk(N), xN, e, c, ox, oe, hc);
+#pragma unroll
+        for (int i = 0; i < NX; ++i) Vxx[i][j] = hc[i];
+      }
+#pragma unroll
+      for (int i = 0; i < NX; ++i) lam[i] = Vx[i];
+      if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < NX; ++i) lam_out[N * NX + i] = lam[i];
+      }
+    }
+    __syncthreads();
+    if (mode != 2) {
+      if (mode == 1) {
+        // the costates of the sweep (the same recursion as in the loop below, on the staged rows)
+        T l[NX];
+#pragma unroll
+        for (int i = 0; i < NX; ++i) l[i] = lam[i];
+        for (int k = N - 1; k >= 0; --k) {
+          const T* mk = sM + k * ME;
+          if (lane == 0) {
+#pragma unroll
+            for (int i = 0; i < NX; ++i) sl[(k + 1) * NX + i] = l[i];
+          }
+          T ln[NX];
+#pragma unroll
+          for (int j = 0; j < NX; ++j) {
+            T s_ = mk[NX * RS + j];
+#pragma unroll
+            for (int i = 0; i < NX; ++i) s_ += mk[i * RS + j] * l[i];
+            ln[j] = s_;
+          }
+#pragma unroll
+          for (int i = 0; i < NX; ++i) l[i] = ln[i];
+        }
+        __syncthreads();
+      }
+      T el[NP > 0 ? NP : 1], cl[M::NCX > 0 ? M::NCX : 1];
+#pragma unroll
+      for (int i = 0; i < NP; ++i) el[i] = e[i];
+#pragma unroll
+      for (int i = 0; i < M::NCX; ++i) cl[i] = c[i];
+      for (int k = lane; k < N; k += 64) {
+        T xk[NX], uk[NU], ls[NX];
+#pragma unroll
+        for (int i = 0; i < NX; ++i) { xk[i] = xbp(cur)[k * NX + i]; ls[i] = (mode == 1) ? sl[(k + 1) * NX + i] : T(0); }
+#pragma unroll
+        for (int a = 0; a < NU; ++a) uk[a] = ubp(cur)[k * NU + a];
+        V ox[NVH][NX], ou[NVH][NU], gx[NVH][NX], gu[NVH][NU];
+#pragma unroll
+        for (int v = 0; v < NVH; ++v) {
+#pragma unroll
+          for (int i = 0; i < NX; ++i) ox[v][i] = mk2<T>((2 * v == i) ? T(1) : T(0), (2 * v + 1 == i) ? T(1) : T(0));
+#pragma unroll
+          for (int a = 0; a < NU; ++a) ou[v][a] = mk2<T>((2 * v == NX + a) ? T(1) : T(0), (2 * v + 1 == NX + a) ? T(1) : T(0));
+        }
+        M::template ham_hess_mul_n<NVH>(this->tk(k), xk, uk, ls, el, cl, &ox[0][0], &ou[0][0], &gx[0][0], &gu[0][0]);
+        V* hk = reinterpret_cast<V*>(sH + k * HE);
+#pragma unroll
+        for (int v = 0; v < NVH; ++v) {
+#pragma unroll
+          for (int i = 0; i < NX; ++i) hk[i * NP2 + v] = this->dgrid * gx[v][i];
+#pragma unroll
+          for (int a = 0; a < NU; ++a) hk[(NX + a) * NP2 + v] = this->dgrid * gu[v][a];
+        }
+      }
+      __syncthreads();
+    }
+    bool ok = true;
+    T gl_max = T(0), lmax = T(0);
+    dV1 = T(0); dV2 = T(0); dmin = T(0);
+#pragma unroll
+    for (int i = 0; i < NX; ++i) lmax = t_max(lmax, t_abs(lam[i]));
+    const bool gaps = this->gap != nullptr;
+    for (int k = N - 1; k >= 0; --k) {
+      const V* mk = reinterpret_cast<const V*>(sM + k * ME);
+      const V* hk = reinterpret_cast<const V*>(sH + k * HE);
+      const T* dk = sd + k * NX;
+      V M2[NX + 1][NP2], Q2[NXU][NP2];
+#pragma unroll
+      for (int i = 0; i <= NX; ++i) {
+#pragma unroll
+        for (int p = 0; p < NP2; ++p) M2[i][p] = mk[i * NP2 + p];
+      }
+#pragma unroll
+      for (int r = 0; r < NXU; ++r) {
+#pragma unroll
+        for (int p = 0; p < NP2; ++p) Q2[r][p] = hk[r * NP2 + p];
+      }
+      if (NXU & 1) {            // (the padding column of the last pair is not part of the problem)
+#pragma unroll
+        for (int i = 0; i <= NX; ++i) M2[i][NP2 - 1].y = T(0);
+#pragma unroll
+        for (int r = 0; r < NXU; ++r) Q2[r][NP2 - 1].y = T(0);
+      }
+      if (gaps) {
+        // multiple shooting: the linearised interval ends d_k away from node k+1:  V_x <- V_x + V_xx d_k
+        T dv[NX];
+#pragma unroll
+        for (int i = 0; i < NX; ++i) dv[i] = dk[i];
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+          T sacc = T(0);
+#pragma unroll
+          for (int j = 0; j < NX; ++j) sacc += Vxx[i][j] * dv[j];
+          Vx[i] += sacc;
+        }
+      }
+      // Y = V_xx [A B];  Q = [A B]^T Y + H;  Q_g = q + [A B]^T V_x;  g_l = q + [A B]^T lambda  (two columns per instruction)
+      V Y2[NX][NP2], Qg2[NP2], gl2[NP2];
+#pragma unroll
+      for (int i = 0; i < NX; ++i) {
+#pragma unroll
+        for (int p = 0; p < NP2; ++p) {
+          V s_ = Vxx[i][0] * M2[0][p];
+#pragma unroll
+          for (int kk = 1; kk < NX; ++kk) s_ += Vxx[i][kk] * M2[kk][p];
+          Y2[i][p] = s_;
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < NXU; ++r) {
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+          const T mir = (r & 1) ? M2[i][r / 2].y : M2[i][r / 2].x;
+#pragma unroll
+          for (int p = 0; p < NP2; ++p) Q2[r][p] += mir * Y2[i][p];
+        }
+      }
+#pragma unroll
+      for (int p = 0; p < NP2; ++p) {
+        V a_ = M2[NX][p], b_ = M2[NX][p];
+#pragma unroll
+        for (int i = 0; i < NX; ++i) { a_ += Vx[i] * M2[i][p]; b_ += lam[i] * M2[i][p]; }
+        Qg2[p] = a_; gl2[p] = b_;
+      }
+      T Q[NXU][NXU], Qg[NXU], gl[NXU];      // Q[row][column]
+#pragma unroll
+      for (int r = 0; r < NXU; ++r) {
+#pragma unroll
+        for (int j = 0; j < NXU; ++j) Q[r][j] = (j & 1) ? Q2[r][j / 2].y : Q2[r][j / 2].x;
+        Qg[r] = (r & 1) ? Qg2[r / 2].y : Qg2[r / 2].x;
+        gl[r] = (r & 1) ? gl2[r / 2].y : gl2[r / 2].x;
+      }
+      T Quu0[NU * NU], Lc[NU * NU], Qu[NU], kff[NU], K[NX][NU], t1[NX][NU];
+#pragma unroll
+      for (int a = 0; a < NU; ++a) {
+        Qu[a] = Qg[NX + a];
+        gl_max = t_max(gl_max, t_abs(gl[NX + a]));
+#pragma unroll
+        for (int b = 0; b < NU; ++b) Quu0[a * NU + b] = T(0.5) * (Q[NX + a][NX + b] + Q[NX + b][NX + a]);
+      }
+      T mu_k = mu;                           // (the shift per stage: see OcSolver::backward)
+      if (mu > T(0) && this->mu_stage_frac > T(0)) {
+        T Lt[NU * NU], dd = T(0);
+#pragma unroll
+        for (int i = 0; i < NU * NU; ++i) Lt[i] = Quu0[i];
+#pragma unroll
+        for (int a = 0; a < NU; ++a) Lt[a * NU + a] += mu * this->mu_stage_frac;
+        if (chol_factor<NU>(Lt, dd)) mu_k = mu * this->mu_stage_frac;
+      }
+#pragma unroll
+      for (int i = 0; i < NU * NU; ++i) Lc[i] = Quu0[i];
+#pragma unroll
+      for (int a = 0; a < NU; ++a) Lc[a * NU + a] += mu_k;
+      if (LFSD_REG_CONSISTENT) {
+#pragma unroll
+        for (int a = 0; a < NU; ++a) Quu0[a * NU + a] += mu_k;
+      }
+      ok = chol_factor<NU>(Lc, dmin);
+      if (!ok) break;                        // (the caller only reads the failing pivot)
+#pragma unroll
+      for (int a = 0; a < NU; ++a) kff[a] = -Qu[a];
+      chol_solve<NU>(Lc, kff);
+#pragma unroll
+      for (int j = 0; j < NX; ++j) {
+#pragma unroll
+        for (int a = 0; a < NU; ++a) K[j][a] = -Q[NX + a][j];
+        chol_solve<NU>(Lc, K[j]);
+      }
+      T qk[NU];
+      matvec<NU>(Quu0, kff, qk);
+#pragma unroll
+      for (int a = 0; a < NU; ++a) { dV1 += kff[a] * Qu[a]; dV2 += T(0.5) * kff[a] * qk[a]; }
+      T Vxn[NX], Vn[NX][NX];
+#pragma unroll
+      for (int j = 0; j < NX; ++j) {
+        T s_ = Qg[j];
+#pragma unroll
+        for (int a = 0; a < NU; ++a) { s_ += K[j][a] * (qk[a] + Qu[a]); s_ += Q[NX + a][j] * kff[a]; }
+        Vxn[j] = s_;
+        matvec<NU>(Quu0, K[j], t1[j]);
+#pragma unroll
+        for (int a = 0; a < NU; ++a) t1[j][a] += Q[NX + a][j];
+      }
+#pragma unroll
+      for (int i = 0; i < NX; ++i) {
+#pragma unroll
+        for (int j = 0; j < NX; ++j) {
+          T s_ = Q[i][j];
+#pragma unroll
+          for (int a = 0; a < NU; ++a) { s_ += K[i][a] * t1[j][a]; s_ += Q[NX + a][i] * K[j][a]; }
+          Vn[i][j] = s_;
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < NX; ++i) {
+#pragma unroll
+        for (int j = 0; j < NX; ++j) Vxx[i][j] = T(0.5) * (Vn[i][j] + Vn[j][i]);
+        Vx[i] = Vxn[i];
+        lam[i] = gl[i];
+        lmax = t_max(lmax, t_abs(lam[i]));
+      }
+      if (lane == 0) {
+        T* Kout = this->Kws + (long long)k * NX * NU;
+#pragma unroll
+        for (int j = 0; j < NX; ++j) {
+#pragma unroll
+          for (int a = 0; a < NU; ++a) Kout[j * NU + a] = K[j][a];
+        }
+#pragma unroll
+        for (int a = 0; a < NU; ++a) this->kws[k * NU + a] = kff[a];
+#pragma unroll
+        for (int i = 0; i < NX; ++i) lam_out[k * NX + i] = lam[i];
+      }
+    }
+    this->lam_max = lmax;
+    __syncthreads();                          // (gains / costates visible to every lane; the staging region is free again)
+    gnorm = gl_max;
+    if (!t_finite(gnorm) || !t_finite(dV1) || !t_finite(dV2)) ok = false;
+    return ok;
+  }
+
   // ---- the interval-parallel iteration: multiple shooting, the reference's own formulation (CPDP.py:136-172) ----------------
   // The reference hands IPOPT the LIFTED problem: every node state X_k is a variable, every interval an equality constraint
   // F(X_k, U_k) - X_k+1 = 0.  Given an iterate of that problem -- node states xb, controls ub, gaps d_k = F(x_k, u_k) - x_k+1 --
@@ -3218,7 +3500,11 @@ __global__ void __launch_bounds__(64, 1) oc_solve_wide_kernel(OcArgs<T> a) {
     s.reuse_hess = EXACT && mode == 2;
     T dmin = T(0);
     bool bw_ok;
-    LFSD_WCK(4, bw_ok = s.backward(cur, mode, mu, gnorm, dV1, dV2, dmin));
+    if constexpr (std::remove_reference<decltype(s)>::type::SMALL_BW) {
+      LFSD_WCK(4, bw_ok = s.small_bw_fits() ? s.backward_small(cur, mode, mu, gnorm, dV1, dV2, dmin) : s.backward(cur, mode, mu, gnorm, dV1, dV2, dmin));
+    } else {
+      LFSD_WCK(4, bw_ok = s.backward(cur, mode, mu, gnorm, dV1, dV2, dmin));
+    }
     costates_ok = bw_ok;                              // (a sweep that failed stopped at the failing stage)
     if (!bw_ok) {
       if (mode == 1) { mode = 0; ham_ok = false; }
