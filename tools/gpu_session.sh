@@ -40,15 +40,16 @@ rocket)       # A/B of build variants on the rocket's cold OC solve (tools/model
   python3 tools/wide_clock.py run rocket 100 1024 f32 > $OUT/rocket_wide_clock.txt 2>&1; grep -c "wide clock" $OUT/rocket_wide_clock.txt; sort -t' ' -k6 -n -r $OUT/rocket_wide_clock.txt | head -4 ;;
 steps)        # CFGS="robotarm rocket": per-outer-iteration kernel times and unit / iteration distributions (tools/config_steps.py)
   for c in ${CFGS:-robotarm}; do python3 tools/config_steps.py $c ${NSTEPS:-6} > $OUT/steps_$c.txt 2>&1; cat $OUT/steps_$c.txt; done ;;
-final)        # the round's closing record: evidence sets (headline, fp64, the two configurations), default line, other batch / mode, tier
-  bash tools/gpu_session.sh profile r04 > $OUT/profile.log 2>&1
-  bash tools/gpu_session.sh f64 r04_f64 > $OUT/f64.log 2>&1
-  bash tools/gpu_session.sh configs r04_c
+final)        # the round's closing record: evidence sets (headline, fp64, the two configurations), default line, other batch / mode, RCCL with one rank, tier
+  bash tools/gpu_session.sh profile r05 > $OUT/profile.log 2>&1
+  bash tools/gpu_session.sh f64 r05_f64 > $OUT/f64.log 2>&1
+  bash tools/gpu_session.sh configs r05_c
   python3 bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err; line $OUT/bench_default.json
   python3 bench.py --batch 32768 --steps 5 --warmup 1 --no-cpu-baseline --no-f64-leg > $OUT/bench_f32_32768.json 2> /dev/null; line $OUT/bench_f32_32768.json
   python3 bench.py --batch 32768 --steps 3 --warmup 1 --dtype f64 --no-cpu-baseline > $OUT/bench_f64_32768.json 2> /dev/null; line $OUT/bench_f64_32768.json
   python3 bench.py --mode shared --no-cpu-baseline > $OUT/bench_shared_one_gpu.json 2> /dev/null; line $OUT/bench_shared_one_gpu.json
-  bash tools/gpu_session.sh tier ${TAG}_tier ;;
+  NCCL_DEBUG=VERSION python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29531 bench.py --gpus 1 --mode shared --backend nccl --no-cpu-baseline --no-f64-leg > $OUT/rccl_one_rank.txt 2>&1; tail -1 $OUT/rccl_one_rank.txt | head -c 300; echo
+  if [ -z "$NO_TIER" ]; then bash tools/gpu_session.sh tier ${TAG}_tier; fi ;;
 ms)           # round 5: the multiple-shooting phase of the wide kernel, product vs variants (tools/model_ab.py build robotarm noms -DLFSD_MS=0; ... rocket msnewton -DLFSD_MS_NEWTON=1)
   vp() { python3 -c "
 import sys; sys.path.insert(0,'tools'); import oc_trace
