@@ -174,7 +174,7 @@
 #define LFSD_LEAN_TC_ITERS 3
 #endif
 #ifndef LFSD_LEAN_TC_MIN
-#define LFSD_LEAN_TC_MIN 10
+#define LFSD_LEAN_TC_MIN 12      // (round 5, held-out A/B: with 10 merged intervals -- n_grid 20 -- level 0 cost 14 % instead of saving; 13 and 15 save: profiles/r05_held_out_schedule_ab.jsonl)
 #endif
 // lean kernels: the convergence histories (last gradient norm, last predicted decrease) survive the step that leaves the coarse grid
 // when the coarse problem had converged (cpdp_oc.h); 0 = they always start over on the reference's grid

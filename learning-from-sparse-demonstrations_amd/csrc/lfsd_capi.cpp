@@ -276,11 +276,13 @@ static int aux_phase_t(int phases, int batch, int n_grid, const void* horizon, c
   a.rate_max = (T)(8.0 / a.substeps / tight);
   a.max_refine = 256;
   while (a.max_refine < 256 * tight && a.max_refine < 16384) a.max_refine *= 2;
-  // a budget of 64 units per interval on average for rows whose OC solve did not converge (status not 1 / 2; needs oc_status): rows
+  // a budget of 24 units per interval on average (twice what a well-posed robot-arm row spends, ten times a quadrotor row; 64 until
+  // round 5: the diverged rows of one learner step then held both sweeps at 12-14 ms against 2.1 / 1.2) for rows whose OC solve did
+  // not converge (status not 1 / 2; needs oc_status): rows
   // a fixed learning rate has driven to parameters of 1e14 refined EVERY interval to the cap (8 864 units against the 565 of
   // a well-posed robot-arm row: Riccati launch 35 ms against 2.1, profiles/r04_l_steps_robotarm_fast_trig.txt); what they
   // return is flagged in `stats`.  Converged rows are never budgeted (a stiff last interval alone may need thousands of units).
-  a.unit_budget = (int)std::min<double>(64.0 * n_grid * a.substeps * tight, (double)(1LL << 30));      // (in double: the fourth-root factor must not truncate to 1)
+  a.unit_budget = (int)std::min<double>(24.0 * n_grid * a.substeps * tight, (double)(1LL << 30));      // (in double: the fourth-root factor must not truncate to 1)
   a.horizon = (const T*)horizon; a.auxvar = (const T*)auxvar;
   a.consts = consts ? (const T*)consts : (const T*)horizon;
   a.const_stride = (consts && const_per_traj) ? Model::NC : 0;

@@ -16,6 +16,7 @@ cpset r05_c_rocket r05_rocket
 for f in bench_default bench_f32_32768 bench_f64_32768 bench_shared_one_gpu; do [ -f gpurun_out/r05_final/$f.json ] && cp gpurun_out/r05_final/$f.json $P/r05_final_$f.json; done
 [ -f gpurun_out/r05_final/rccl_one_rank.txt ] && cp gpurun_out/r05_final/rccl_one_rank.txt $P/r05_rccl_one_rank.txt
 for f in pytest_gpu.txt parity_floors.jsonl smoke.txt; do [ -f gpurun_out/r05_final_tier/$f ] && cp gpurun_out/r05_final_tier/$f $P/r05_final_$f; done
+[ -f gpurun_out/r05_final_tier/held_out_schedule_ab.jsonl ] && cp gpurun_out/r05_final_tier/held_out_schedule_ab.jsonl $P/r05_held_out_schedule_ab.jsonl
 
 
 ls -la $P | grep -c r05_
