@@ -221,9 +221,6 @@
 #ifndef LFSD_MS_NEWTON
 #define LFSD_MS_NEWTON 0
 #endif
-#ifndef LFSD_MS_SHORT_STEPS
-#define LFSD_MS_SHORT_STEPS 3
-#endif
 // wide kernel (one trajectory per wavefront): smallest n_grid with a coarse phase
 #ifndef LFSD_COARSE_MIN_GRID
 #define LFSD_COARSE_MIN_GRID 40
@@ -462,6 +459,22 @@ LFSD_DEV void tile_transpose(f32x16& acc) {
     }
   }
 }
+#endif
+
+// lane_get(v, j): the value lane j of the wavefront holds in v, on every lane (j is the same on all of them: v_readlane_b32).  Must be
+// reached by all 64 lanes.
+#if defined(LFSD_EMU)
+template <typename T> inline T lane_get(T v, int j) {
+  static T sb[64];
+  sb[threadIdx.x] = v;
+  __syncthreads();
+  const T r = sb[j];
+  __syncthreads();
+  return r;
+}
+#else
+LFSD_DEV float lane_get(float v, int j) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), j)); }
+LFSD_DEV double lane_get(double v, int j) { return __shfl(v, j); }
 #endif
 
 // quarter_sum(v): sum of v over the four lanes l, l^16, l^32, l^48 of the wavefront, in every one of them (the wide kernel's

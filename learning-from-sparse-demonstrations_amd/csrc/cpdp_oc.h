@@ -2230,8 +2230,10 @@ template <class M, typename T, bool EXACT, bool BND = false> struct OcWide : OcS
   //   * the stage Hessians of modes 0 / 1 -- one model call per stage in the generic sweep, in sequence -- are computed for all
   //     intervals at once, one interval per lane, all columns side by side (ham_hess_mul_n); mode 1 needs the costates of the sweep:
   //     a costate recursion on the staged operands runs first (NX^2 FMAs per stage);
-  //   * the recursion itself runs on EVERY lane (uniform values: no exchange between lanes, no hand-over, no barrier), the dense
-  //     products Y = V_xx [A B], Q = [A B]^T Y with two columns per packed instruction.
+  //   * the recursion keeps column j of [A B; q], of the stage Hessian and of Q on lane j and V_xx, V_x, the costate uniform on every
+  //     lane; what a lane needs of another lane's column comes through v_readlane (lane_get): no LDS hand-over, no barrier.  410
+  //     instructions per stage.  (First version: the whole recursion on EVERY lane with the dense products packed two columns per
+  //     instruction -- no exchange at all, 525 instructions per stage: oc_solve of the bench's five steps 11.05 ms against 10.38.)
   // Same recursion, same outputs (gains, feed-forward, costates, predicted decrease, failing pivot) as OcSolver::backward.
   static constexpr bool SMALL_BW = EXACT && !BND && sizeof(T) == 4 && Lay::HALL && NX * NXU <= 32 && (LFSD_BW_SMALL) != 0;
   static constexpr int BWS_STG = Lay::M_ELEMS + Lay::H_ELEMS + 2 * NX;      // words per stage
@@ -2344,156 +2346,137 @@ template <class M, typename T, bool EXACT, bool BND = false> struct OcWide : OcS
 #pragma unroll
     for (int i = 0; i < NX; ++i) lmax = t_max(lmax, t_abs(lam[i]));
     const bool gaps = this->gap != nullptr;
-    for (int k = N - 1; k >= 0; --k) {
-      const V* mk = reinterpret_cast<const V*>(sM + k * ME);
-      const V* hk = reinterpret_cast<const V*>(sH + k * HE);
-      const T* dk = sd + k * NX;
-      V M2[NX + 1][NP2], Q2[NXU][NP2];
+    {
+      // Column j of [A B; q], of the stage Hessian and of Q on lane j (< NXU); V_xx, V_x and the costate uniform on every lane; what a
+      // lane needs of another lane's column comes through v_readlane (lane_get): no LDS hand-over, no barrier, and the dense products
+      // cost one column's worth of instructions instead of all of them.
+      constexpr int RS2 = RS;
+      const int jc = lane < NXU ? lane : 0;
+      const bool act = lane < NXU;
+      for (int k = N - 1; k >= 0; --k) {
+        const T* mk = sM + k * ME;
+        const T* hk = sH + k * HE;
+        const T* dk = sd + k * NX;
+        T mj[NX], mqj, hj[NXU], Mu[NX][NXU];
+        // (read unconditionally -- the index is safe on every lane -- and materialised before the select: no branch around a load)
 #pragma unroll
-      for (int i = 0; i <= NX; ++i) {
+        for (int i = 0; i < NX; ++i) mj[i] = mk[i * RS2 + jc];
+        mqj = mk[NX * RS2 + jc];
 #pragma unroll
-        for (int p = 0; p < NP2; ++p) M2[i][p] = mk[i * NP2 + p];
-      }
+        for (int r = 0; r < NXU; ++r) hj[r] = hk[r * RS2 + jc];
 #pragma unroll
-      for (int r = 0; r < NXU; ++r) {
+        for (int i = 0; i < NX; ++i) { pin(mj[i]); mj[i] = act ? mj[i] : T(0); }
+        pin(mqj); mqj = act ? mqj : T(0);
 #pragma unroll
-        for (int p = 0; p < NP2; ++p) Q2[r][p] = hk[r * NP2 + p];
-      }
-      if (NXU & 1) {            // (the padding column of the last pair is not part of the problem)
-#pragma unroll
-        for (int i = 0; i <= NX; ++i) M2[i][NP2 - 1].y = T(0);
-#pragma unroll
-        for (int r = 0; r < NXU; ++r) Q2[r][NP2 - 1].y = T(0);
-      }
-      if (gaps) {
-        // multiple shooting: the linearised interval ends d_k away from node k+1:  V_x <- V_x + V_xx d_k
-        T dv[NX];
-#pragma unroll
-        for (int i = 0; i < NX; ++i) dv[i] = dk[i];
+        for (int r = 0; r < NXU; ++r) { pin(hj[r]); hj[r] = act ? hj[r] : T(0); }
 #pragma unroll
         for (int i = 0; i < NX; ++i) {
-          T sacc = T(0);
 #pragma unroll
-          for (int j = 0; j < NX; ++j) sacc += Vxx[i][j] * dv[j];
-          Vx[i] += sacc;
+          for (int r = 0; r < NXU; ++r) Mu[i][r] = mk[i * RS2 + r];
         }
-      }
-      // Y = V_xx [A B];  Q = [A B]^T Y + H;  Q_g = q + [A B]^T V_x;  g_l = q + [A B]^T lambda  (two columns per instruction)
-      V Y2[NX][NP2], Qg2[NP2], gl2[NP2];
+        if (gaps) {
 #pragma unroll
-      for (int i = 0; i < NX; ++i) {
+          for (int i = 0; i < NX; ++i) {
+            T sacc = T(0);
 #pragma unroll
-        for (int p = 0; p < NP2; ++p) {
-          V s_ = Vxx[i][0] * M2[0][p];
-#pragma unroll
-          for (int kk = 1; kk < NX; ++kk) s_ += Vxx[i][kk] * M2[kk][p];
-          Y2[i][p] = s_;
+            for (int j = 0; j < NX; ++j) sacc += Vxx[i][j] * dk[j];
+            Vx[i] += sacc;
+          }
         }
-      }
-#pragma unroll
-      for (int r = 0; r < NXU; ++r) {
+        T Y[NX], Qc[NXU], Qg = mqj, gl = mqj;
 #pragma unroll
         for (int i = 0; i < NX; ++i) {
-          const T mir = (r & 1) ? M2[i][r / 2].y : M2[i][r / 2].x;
+          T s_ = Vxx[i][0] * mj[0];
 #pragma unroll
-          for (int p = 0; p < NP2; ++p) Q2[r][p] += mir * Y2[i][p];
-        }
-      }
-#pragma unroll
-      for (int p = 0; p < NP2; ++p) {
-        V a_ = M2[NX][p], b_ = M2[NX][p];
-#pragma unroll
-        for (int i = 0; i < NX; ++i) { a_ += Vx[i] * M2[i][p]; b_ += lam[i] * M2[i][p]; }
-        Qg2[p] = a_; gl2[p] = b_;
-      }
-      T Q[NXU][NXU], Qg[NXU], gl[NXU];      // Q[row][column]
-#pragma unroll
-      for (int r = 0; r < NXU; ++r) {
-#pragma unroll
-        for (int j = 0; j < NXU; ++j) Q[r][j] = (j & 1) ? Q2[r][j / 2].y : Q2[r][j / 2].x;
-        Qg[r] = (r & 1) ? Qg2[r / 2].y : Qg2[r / 2].x;
-        gl[r] = (r & 1) ? gl2[r / 2].y : gl2[r / 2].x;
-      }
-      T Quu0[NU * NU], Lc[NU * NU], Qu[NU], kff[NU], K[NX][NU], t1[NX][NU];
-#pragma unroll
-      for (int a = 0; a < NU; ++a) {
-        Qu[a] = Qg[NX + a];
-        gl_max = t_max(gl_max, t_abs(gl[NX + a]));
-#pragma unroll
-        for (int b = 0; b < NU; ++b) Quu0[a * NU + b] = T(0.5) * (Q[NX + a][NX + b] + Q[NX + b][NX + a]);
-      }
-      T mu_k = mu;                           // (the shift per stage: see OcSolver::backward)
-      if (mu > T(0) && this->mu_stage_frac > T(0)) {
-        T Lt[NU * NU], dd = T(0);
-#pragma unroll
-        for (int i = 0; i < NU * NU; ++i) Lt[i] = Quu0[i];
-#pragma unroll
-        for (int a = 0; a < NU; ++a) Lt[a * NU + a] += mu * this->mu_stage_frac;
-        if (chol_factor<NU>(Lt, dd)) mu_k = mu * this->mu_stage_frac;
-      }
-#pragma unroll
-      for (int i = 0; i < NU * NU; ++i) Lc[i] = Quu0[i];
-#pragma unroll
-      for (int a = 0; a < NU; ++a) Lc[a * NU + a] += mu_k;
-      if (LFSD_REG_CONSISTENT) {
-#pragma unroll
-        for (int a = 0; a < NU; ++a) Quu0[a * NU + a] += mu_k;
-      }
-      ok = chol_factor<NU>(Lc, dmin);
-      if (!ok) break;                        // (the caller only reads the failing pivot)
-#pragma unroll
-      for (int a = 0; a < NU; ++a) kff[a] = -Qu[a];
-      chol_solve<NU>(Lc, kff);
-#pragma unroll
-      for (int j = 0; j < NX; ++j) {
-#pragma unroll
-        for (int a = 0; a < NU; ++a) K[j][a] = -Q[NX + a][j];
-        chol_solve<NU>(Lc, K[j]);
-      }
-      T qk[NU];
-      matvec<NU>(Quu0, kff, qk);
-#pragma unroll
-      for (int a = 0; a < NU; ++a) { dV1 += kff[a] * Qu[a]; dV2 += T(0.5) * kff[a] * qk[a]; }
-      T Vxn[NX], Vn[NX][NX];
-#pragma unroll
-      for (int j = 0; j < NX; ++j) {
-        T s_ = Qg[j];
-#pragma unroll
-        for (int a = 0; a < NU; ++a) { s_ += K[j][a] * (qk[a] + Qu[a]); s_ += Q[NX + a][j] * kff[a]; }
-        Vxn[j] = s_;
-        matvec<NU>(Quu0, K[j], t1[j]);
-#pragma unroll
-        for (int a = 0; a < NU; ++a) t1[j][a] += Q[NX + a][j];
-      }
-#pragma unroll
-      for (int i = 0; i < NX; ++i) {
-#pragma unroll
-        for (int j = 0; j < NX; ++j) {
-          T s_ = Q[i][j];
-#pragma unroll
-          for (int a = 0; a < NU; ++a) { s_ += K[i][a] * t1[j][a]; s_ += Q[NX + a][i] * K[j][a]; }
-          Vn[i][j] = s_;
-        }
-      }
-#pragma unroll
-      for (int i = 0; i < NX; ++i) {
-#pragma unroll
-        for (int j = 0; j < NX; ++j) Vxx[i][j] = T(0.5) * (Vn[i][j] + Vn[j][i]);
-        Vx[i] = Vxn[i];
-        lam[i] = gl[i];
-        lmax = t_max(lmax, t_abs(lam[i]));
-      }
-      if (lane == 0) {
-        T* Kout = this->Kws + (long long)k * NX * NU;
-#pragma unroll
-        for (int j = 0; j < NX; ++j) {
-#pragma unroll
-          for (int a = 0; a < NU; ++a) Kout[j * NU + a] = K[j][a];
+          for (int kk = 1; kk < NX; ++kk) s_ += Vxx[i][kk] * mj[kk];
+          Y[i] = s_;
+          Qg += mj[i] * Vx[i]; gl += mj[i] * lam[i];
         }
 #pragma unroll
-        for (int a = 0; a < NU; ++a) this->kws[k * NU + a] = kff[a];
+        for (int r = 0; r < NXU; ++r) {
+          T s_ = hj[r];
 #pragma unroll
-        for (int i = 0; i < NX; ++i) lam_out[k * NX + i] = lam[i];
+          for (int i = 0; i < NX; ++i) s_ += Mu[i][r] * Y[i];
+          Qc[r] = s_;
+        }
+        T Quu0[NU * NU], Lc[NU * NU], Qu[NU], kff[NU], Kj[NU], t1[NU], Qr[NU * NU];
+#pragma unroll
+        for (int a = 0; a < NU; ++a) {
+          Qu[a] = lane_get(Qg, NX + a);
+          gl_max = t_max(gl_max, t_abs(lane_get(gl, NX + a)));
+#pragma unroll
+          for (int b = 0; b < NU; ++b) Qr[a * NU + b] = lane_get(Qc[NX + a], NX + b);      // Q[NX + a][NX + b]
+        }
+#pragma unroll
+        for (int a = 0; a < NU; ++a) {
+#pragma unroll
+          for (int b = 0; b < NU; ++b) Quu0[a * NU + b] = T(0.5) * (Qr[a * NU + b] + Qr[b * NU + a]);
+        }
+        T mu_k = mu;
+        if (mu > T(0) && this->mu_stage_frac > T(0)) {
+          T Lt[NU * NU], dd = T(0);
+#pragma unroll
+          for (int i = 0; i < NU * NU; ++i) Lt[i] = Quu0[i];
+#pragma unroll
+          for (int a = 0; a < NU; ++a) Lt[a * NU + a] += mu * this->mu_stage_frac;
+          if (chol_factor<NU>(Lt, dd)) mu_k = mu * this->mu_stage_frac;
+        }
+#pragma unroll
+        for (int i = 0; i < NU * NU; ++i) Lc[i] = Quu0[i];
+#pragma unroll
+        for (int a = 0; a < NU; ++a) Lc[a * NU + a] += mu_k;
+        if (LFSD_REG_CONSISTENT) {
+#pragma unroll
+          for (int a = 0; a < NU; ++a) Quu0[a * NU + a] += mu_k;
+        }
+        ok = chol_factor<NU>(Lc, dmin);
+        if (!ok) break;
+#pragma unroll
+        for (int a = 0; a < NU; ++a) { kff[a] = -Qu[a]; Kj[a] = -Qc[NX + a]; }
+        chol_solve<NU>(Lc, kff);
+        chol_solve<NU>(Lc, Kj);
+        T qk[NU];
+        matvec<NU>(Quu0, kff, qk);
+        matvec<NU>(Quu0, Kj, t1);
+        T Vxj = Qg;
+#pragma unroll
+        for (int a = 0; a < NU; ++a) {
+          dV1 += kff[a] * Qu[a]; dV2 += T(0.5) * kff[a] * qk[a];
+          Vxj += Kj[a] * (qk[a] + Qu[a]); Vxj += Qc[NX + a] * kff[a];
+          t1[a] += Qc[NX + a];
+        }
+        T Vn[NX];
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+          T s_ = Qc[i];
+#pragma unroll
+          for (int a = 0; a < NU; ++a) { s_ += lane_get(Kj[a], i) * t1[a]; s_ += lane_get(Qc[NX + a], i) * Kj[a]; }
+          Vn[i] = s_;
+        }
+        T U[NX][NX];
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+#pragma unroll
+          for (int j = 0; j < NX; ++j) U[i][j] = lane_get(Vn[i], j);      // row i of column j
+        }
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+#pragma unroll
+          for (int j = 0; j < NX; ++j) Vxx[i][j] = T(0.5) * (U[i][j] + U[j][i]);
+          Vx[i] = lane_get(Vxj, i);
+          lam[i] = lane_get(gl, i);
+          lmax = t_max(lmax, t_abs(lam[i]));
+        }
+        if (lane < NX) {
+          T* Kout = this->Kws + ((long long)k * NX + lane) * NU;
+#pragma unroll
+          for (int a = 0; a < NU; ++a) Kout[a] = Kj[a];
+          lam_out[k * NX + lane] = gl;
+        }
+        if (lane == 0) {
+#pragma unroll
+          for (int a = 0; a < NU; ++a) this->kws[k * NU + a] = kff[a];
+        }
       }
     }
     this->lam_max = lmax;
