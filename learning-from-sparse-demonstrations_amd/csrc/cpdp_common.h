@@ -215,9 +215,6 @@
 #ifndef LFSD_MS_HALF
 #define LFSD_MS_HALF 1
 #endif
-#ifndef LFSD_MS_BACKOFF
-#define LFSD_MS_BACKOFF 0
-#endif
 #ifndef LFSD_MS_JFEAS
 #define LFSD_MS_JFEAS 1
 #endif

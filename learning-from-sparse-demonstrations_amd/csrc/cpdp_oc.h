@@ -3415,7 +3415,7 @@ __global__ void __launch_bounds__(64, 1) oc_solve_wide_kernel(OcArgs<T> a) {
   bool ms = !BND && (LFSD_MS) != 0 && a.n_grid >= (LFSD_MS_MIN_GRID) && a.max_iter > 8 && (a.exact_after != 0 || (LFSD_MS_NEWTON) != 0);
   bool ms_check = false, ms_floor = false;
   const bool ms_on = ms;
-  int n_acc_need = 4, n_ms = 0, n_half = 0, n_ref = 0, ms_skip = 0;      // n_ref: iterations in a row whose trial steps were all refused; ms_skip: iterations the trials are skipped for
+  int n_acc_need = 4, n_ms = 0, n_half = 0;
   T g1c = T(0), g2c = T(0), gmc = T(0);      // l1 norm, sum of squares and largest entry of the gaps of the current iterate (0: a roll-out)
   T J_feas = J;                              // cost of the last iterate WITHOUT gaps (a roll-out)
   T mu = T(0);
@@ -3517,17 +3517,7 @@ __global__ void __launch_bounds__(64, 1) oc_solve_wide_kernel(OcArgs<T> a) {
         if (coarse) { relin = true; continue; }
         close_now = true; ms_floor = true; ms_off = true;
       }
-#if LFSD_MS_BACKOFF
-      // A trajectory in a region where the linear prediction of the node states is useless refuses every trial step (1 of 1 024, 20-25
-      // iterations in a row: profiles/r05_f_robotarm_trace618.txt) and pays a forward pass and two re-integrations per iteration for
-      // nothing: after r refusals in a row the trials of the next min(r, LFSD_MS_BACKOFF) iterations are skipped (closed iterates
-      // only).  A skipped trial that WOULD have been refused changes nothing -- the roll-outs start from the same sweep.
-      const bool skip_trial = !have_gaps && !close_now && ms_skip > 0;
-      if (skip_trial) --ms_skip;
-      if (!close_now && !skip_trial) {
-#else
       if (!close_now) {
-#endif
         T lamd0, lamabs0, Dlin;
         LFSD_WCK(5, Dlin = s.ms_forward(cur, lamd0, lamabs0));
         // Merit function of the multiple-shooting step: the augmented Lagrangian of the lifted NLP with the costates of THIS iterate,
@@ -3591,12 +3581,9 @@ __global__ void __launch_bounds__(64, 1) oc_solve_wide_kernel(OcArgs<T> a) {
             }
             J = Jt; g1c = g1t; g2c = g2t; gmc = gmt;
             s.gap = (g1c > T(0)) ? s.gapp(cur) : nullptr;
-            ++n_ms; n_ref = 0;
+            ++n_ms;
             continue;
           }
-#if LFSD_MS_BACKOFF
-          if (!have_gaps) { ++n_ref; ms_skip = (n_ref < (LFSD_MS_BACKOFF)) ? n_ref - 1 : (LFSD_MS_BACKOFF); }
-#endif
         }
       }
     }
