@@ -732,3 +732,31 @@ def test_multiple_shooting_steps_end_at_the_single_shooting_kkt_point(kind, n_gr
     assert float((a["control_grid"] - b["control_grid"]).abs().max() / b["control_grid"].abs().max()) < 10 * xt
     assert float((a["costate_grid"] - b["costate_grid"]).abs().max() / b["costate_grid"].abs().max()) < 20 * xt
     assert float(((a["cost"] - b["cost"]).abs() / b["cost"].abs()).max()) < jt
+
+
+@pytest.mark.parametrize("kind,n_grid", [("robotarm", 40), ("cartpole", 40), ("pendulum", 20)])
+def test_small_model_backward_sweep_matches_the_generic_one(kind, n_grid):
+    """Wide kernel, fp32, the small models: the backward sweep on LDS-staged operands with one column per lane and v_readlane
+    exchanges (cpdp_oc.h OcWide::backward_small; stage Hessians of modes 0 / 1 precomputed for all intervals, costates of mode 1 by
+    a recursion on the staged rows) against a build with -DLFSD_BW_SMALL=0 (OcSolver::backward: LDS hand-overs, the model called
+    per stage) on the CPU emulator: the same recursion, so the same iterates up to the order of the fp32 sums -- same class of
+    status, iteration counts within three (robot arm, measured: 18 18 25 against 18 20 25), same trajectory at the fp32 tolerance of the solve, with and without multiple-shooting gaps
+    (n_grid 40 runs them, 20 does not)."""
+    from conftest import build_emu_library
+    sols = []
+    for flags, tag in (((), ""), (("-DLFSD_BW_SMALL=0",), "nobws")):
+        oc, env, d = models.ZOO[kind](n_grid=n_grid)
+        oc.use_library(build_emu_library(oc, extra_flags=flags, tag=tag))
+        oc.compile()
+        oc.setDevice(dtype=torch.float32)
+        oc.setSolverOptions(mapping="wide")
+        p = len(d["theta0"])
+        th = np.array(d["theta0"])[None, :] * (1 + 0.05 * np.random.default_rng(11).standard_normal((3, p)))
+        th[:, 0] = np.abs(th[:, 0]) + 0.1
+        sols.append(oc.cocSolverBatch(np.tile(d["ini_state"], (3, 1)), d["horizon"], th))
+    a, b = sols
+    assert set(a["status"].tolist()) <= {1, 2} and set(b["status"].tolist()) <= {1, 2}, (a["status"], b["status"])
+    assert int((a["iters"] - b["iters"]).abs().max()) <= 3, (a["iters"], b["iters"])
+    assert float((a["state_grid"] - b["state_grid"]).abs().max() / b["state_grid"].abs().max()) < 3e-3
+    assert float((a["costate_grid"] - b["costate_grid"]).abs().max() / b["costate_grid"].abs().max()) < 6e-2
+    assert float(((a["cost"] - b["cost"]).abs() / b["cost"].abs()).max()) < 2e-5
