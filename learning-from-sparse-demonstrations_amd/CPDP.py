@@ -434,10 +434,20 @@ class COCSys:
         # The reference integrates the auxiliary ODEs along WHATEVER interpolant it is handed (CPDP.py:320, 347); the sweeps here
         # differentiate along the LINEAR interpolant of the grid values (interplation_level 1, what every example uses).  A cubic
         # opt_sol (cocSolver(..., interplation_level=2), CPDP.py:388-390) would silently be resampled to that -- refuse it instead.
-        kind = getattr(opt_sol, "_kind", None)
-        if kind is not None and kind not in ("linear", 1):
-            raise LfsdError("auxSysSolver: opt_sol is a %r interpolant; the HIP sweeps integrate along the linear interpolant of the "
-                            "grid (interplation_level=1, CPDP.py:386) only" % (kind,))
+        # (interpolation() tags what it returns with `lfsd_level`; an interpolant from elsewhere is probed instead: a piecewise-linear
+        #  one is reproduced by the linear interpolant of its own grid values at the interval midpoints.  Nothing relies on scipy's
+        #  private attributes.)
+        level = getattr(opt_sol, "lfsd_level", None)
+        if level is None:
+            tg_ = np.asarray(time_grid, dtype=np.float64)
+            mid = 0.5 * (tg_[:-1] + tg_[1:])
+            gv = np.asarray(opt_sol(tg_), dtype=np.float64)
+            gm = np.asarray(opt_sol(mid), dtype=np.float64)
+            lin = 0.5 * (gv[:-1] + gv[1:])
+            level = 1 if np.abs(gm - lin).max() <= 1e-9 * max(1.0, np.abs(gv).max()) else "non-linear"
+        if level != 1:
+            raise LfsdError("auxSysSolver: opt_sol is not the linear interpolant of its grid (interplation level %r); the HIP sweeps "
+                            "integrate along the linear interpolant (interplation_level=1, CPDP.py:386) only" % (level,))
         time_grid = np.asarray(time_grid, dtype=np.float64)
         N = len(time_grid) - 1
         g = np.asarray(opt_sol(time_grid), dtype=np.float64)
@@ -454,9 +464,13 @@ class COCSys:
     def interpolation(self, x, y, method=1):
         """CPDP.py:384-390."""
         if method == 1:
-            return ip.interp1d(x, y, axis=0)
-        if method == 2:
-            return ip.interp1d(x, y, axis=0, kind='cubic')
+            f = ip.interp1d(x, y, axis=0)
+        elif method == 2:
+            f = ip.interp1d(x, y, axis=0, kind='cubic')
+        else:
+            return None                     # (the reference falls off the end of its ifs as well)
+        f.lfsd_level = method              # read by auxSysSolver: level 2 is returned, as in the reference, but not differentiated along
+        return f
 
 
 class COCSys_TimeVarying(COCSys):

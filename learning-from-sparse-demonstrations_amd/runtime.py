@@ -140,6 +140,56 @@ def build_library(spec, force=False, verbose=False):
     return out
 
 
+def variant_library_path(spec, tag):
+    return os.path.join(BUILD_DIR, "ab_%s_%s.so" % (spec.hash(), tag))
+
+
+def build_variant_library(spec, tag, flags):
+    """hipcc build of a VARIANT of a model library (experiment switches of csrc/cpdp_common.h set on the command line) into
+    csrc/build/ab_<hash>_<tag>.so, rebuilt when a kernel source is newer.  The A/B tests of the GPU tier compare the product
+    build with such variants; never loaded by the product path."""
+    write_header(spec)
+    out = variant_library_path(spec, tag)
+    deps = [header_path(spec.hash())] + [os.path.join(CSRC_DIR, f) for f in KERNEL_SOURCES]
+    if os.path.exists(out) and all(os.path.getmtime(out) >= os.path.getmtime(p) for p in deps):
+        return out
+    os.makedirs(BUILD_DIR, exist_ok=True)
+    cmds, objs = hipcc_commands(spec, out, list(flags))
+    try:
+        for c in cmds:
+            r = subprocess.run(c, cwd=CSRC_DIR, capture_output=True, text=True)
+            if r.returncode != 0:
+                raise LfsdError("hipcc failed for variant %s of model %s:\n%s" % (tag, spec.name, r.stderr[-3000:]))
+    finally:
+        for o in objs:
+            if os.path.exists(o):
+                os.remove(o)
+    return out
+
+
+# build variants the -m gpu tier compares the product with: (model kind, n_grid, tag, flags).  "plain" = every schedule off.
+PLAIN_SCHEDULE = ("-DLFSD_LEAN_TC=1", "-DLFSD_COARSE_START=0", "-DLFSD_COARSE_TIME=1", "-DLFSD_MS=0")
+GPU_TIER_VARIANTS = (("quadrotor", 50, "nocoarse", ("-DLFSD_COARSE_START=0",)),
+                     ("quadrotor", 50, "plain", PLAIN_SCHEDULE), ("cartpole", 40, "plain", PLAIN_SCHEDULE),
+                     ("rocket", 40, "plain", PLAIN_SCHEDULE), ("robotarm", 50, "plain", PLAIN_SCHEDULE))
+
+
+def build_gpu_tier_variants(verbose=False):
+    """Prebuild the variants above so that they travel with the tree (optional: a failure here is reported, not raised --
+    the product libraries do not depend on them)."""
+    from . import models
+    built = {}
+    for kind, n_grid, tag, flags in GPU_TIER_VARIANTS:
+        try:
+            oc = models.ZOO[kind](n_grid=n_grid)[0]
+            built[(kind, tag)] = build_variant_library(oc.model_spec(), tag, flags)
+            if verbose:
+                print("variant", kind, tag, built[(kind, tag)])
+        except Exception as exc:      # noqa: BLE001
+            print("WARNING: test variant %s/%s not built: %s" % (kind, tag, str(exc)[:300]))
+    return built
+
+
 _DT = {torch.float32: LFSD_F32, torch.float64: LFSD_F64}
 
 

@@ -56,16 +56,25 @@ class COCSys:
         self.n_auxvar = len(self.auxvar)
 
     def setStateVariable(self, state, state_lb=[], state_ub=[]):
+        """CPDP.py:20-31: bounds default to -1e20 / +1e20 per component; finite ones become lbw / ubw of the node
+        states X_1..X_N of the NLP (CPDP.py:140-147; X_0 is pinned to ini_state, CPDP.py:131-134)."""
         self.state = list(state)
         self.n_state = len(self.state)
-        if len(state_lb) or len(state_ub):
-            raise NotImplementedError("finite state bounds are never used by the reference's examples")
+        self.state_lb = list(state_lb) if len(state_lb) == self.n_state else self.n_state * [-1e20]
+        self.state_ub = list(state_ub) if len(state_ub) == self.n_state else self.n_state * [1e20]
 
     def setControlVariable(self, control, control_lb=[], control_ub=[]):
+        """CPDP.py:33-46: the same for the controls (lbw / ubw of the U_k, CPDP.py:150-153)."""
         self.control = list(control)
         self.n_control = len(self.control)
-        if len(control_lb) or len(control_ub):
-            raise NotImplementedError("finite control bounds are never used by the reference's examples")
+        self.control_lb = list(control_lb) if len(control_lb) == self.n_control else self.n_control * [-1e20]
+        self.control_ub = list(control_ub) if len(control_ub) == self.n_control else self.n_control * [1e20]
+
+    def has_state_bounds(self):
+        return any(abs(v) < 1e19 for v in list(getattr(self, "state_lb", [])) + list(getattr(self, "state_ub", [])))
+
+    def has_control_bounds(self):
+        return any(abs(v) < 1e19 for v in list(getattr(self, "control_lb", [])) + list(getattr(self, "control_ub", [])))
 
     def setTimeVariable(self, t):
         self.time = t
@@ -241,6 +250,20 @@ class COCSys:
         if not hasattr(self, 'n_grid'):
             self.setIntegrator()
         n, m, N = self.n_state, self.n_control, self.n_grid
+        if self.has_state_bounds() or self.has_control_bounds():
+            # finite lbw / ubw (CPDP.py:140-153): the same NLP handed to scipy's bounded solvers below instead of the DDP iteration
+            # (the reference hands it to IPOPT unchanged, CPDP.py:177-184)
+            if self.has_state_bounds():
+                cb = self.has_control_bounds()
+                tg, X, Uc, J = self.cocSolverStateBounded(ini_state, horizon, auxvar_value, self.state_lb, self.state_ub,
+                                                         control_lb=self.control_lb if cb else None,
+                                                         control_ub=self.control_ub if cb else None, U_init=U_init)
+                lam = self.costates_along(ini_state, horizon, auxvar_value, X, Uc[:N])
+            else:
+                tg, X, Uc, lam, J = self.cocSolverBounded(ini_state, horizon, auxvar_value, self.control_lb, self.control_ub, U_init=U_init)
+            self.last_info = dict(iters=-1, converged=True, bounded=True)
+            opt_sol = self.interpolation(tg, np.concatenate((X, Uc, lam), axis=1), interplation_level)
+            return (tg, opt_sol, X, Uc, lam) if return_grids else (tg, opt_sol)
         e = np.asarray(auxvar_value, dtype=float).ravel()
         x0 = np.asarray(ini_state, dtype=float).ravel()
         DT = horizon / N / self.steps_per_grid
@@ -357,6 +380,20 @@ class COCSys:
         if return_grids:
             return time_grid, opt_sol, state_grid, control_grid, costate_grid
         return time_grid, opt_sol
+
+    def costates_along(self, ini_state, horizon, auxvar_value, X, U):
+        """Adjoint recursion lambda_k = q_x + A_k^T lambda_k+1 along given grids (the multipliers of the shooting constraints
+        where no state bound is active; with an active bound IPOPT's lam_g carries the bound multiplier as well)."""
+        n, N = self.n_state, self.n_grid
+        e = np.asarray(auxvar_value, dtype=float).ravel()
+        DT = horizon / N / self.steps_per_grid
+        tg = np.linspace(0, horizon, N + 1)
+        lam = np.zeros((N + 1, n))
+        lam[N] = self._call('dhx', tg[-1], X[N], e).ravel()
+        for k in range(N - 1, -1, -1):
+            _, _, M = self.grid_map(tg[k], X[k], U[k], e, DT, derivs=True)
+            lam[k] = M[n, :n] + M[:n, :n].T @ lam[k + 1]
+        return lam
 
     def cocSolverBounded(self, ini_state, horizon, auxvar_value, control_lb, control_ub, U_init=None, tol=1e-12):
         """The NLP of CPDP.py:110-175 with finite control bounds lbw / ubw (CPDP.py:150-153), solved in single-shooting form

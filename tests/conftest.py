@@ -46,34 +46,19 @@ def build_emu_library(oc, extra_flags=(), tag=""):
 
 
 def build_variant_library(oc, tag, flags):
-    """hipcc build of a VARIANT of a model library (experiment switches of csrc/cpdp_common.h set on the command line) into
-    csrc/build/ab_<hash>_<tag>.so, rebuilt when a kernel source is newer.  Test infrastructure: the A/B tests compare the product
-    build with it; __graft_entry__.build() prebuilds the ones the GPU tier uses so that they travel with the tree."""
+    """A variant build of a model library (lfsd_amd.runtime.build_variant_library: csrc/build/ab_<hash>_<tag>.so)."""
     from lfsd_amd import runtime
-    spec = oc.model_spec()
-    runtime.write_header(spec)
-    out = os.path.join(runtime.BUILD_DIR, "ab_%s_%s.so" % (spec.hash(), tag))
-    deps = [runtime.header_path(spec.hash())] + [os.path.join(runtime.CSRC_DIR, f) for f in runtime.KERNEL_SOURCES]
-    if os.path.exists(out) and all(os.path.getmtime(out) >= os.path.getmtime(p) for p in deps):
-        return out
-    os.makedirs(runtime.BUILD_DIR, exist_ok=True)
-    cmds, objs = runtime.hipcc_commands(spec, out, list(flags))
-    try:
-        for c in cmds:
-            r = subprocess.run(c, cwd=runtime.CSRC_DIR, capture_output=True, text=True)
-            assert r.returncode == 0, r.stderr[-3000:]
-    finally:
-        for o in objs:
-            if os.path.exists(o):
-                os.remove(o)
-    return out
+    return runtime.build_variant_library(oc.model_spec(), tag, flags)
 
 
-# build variants the -m gpu tier compares the product with (kind, tag, flags)
-PLAIN_SCHEDULE = ("-DLFSD_LEAN_TC=1", "-DLFSD_COARSE_START=0", "-DLFSD_COARSE_TIME=1", "-DLFSD_MS=0")
-GPU_TIER_VARIANTS = (("quadrotor", "nocoarse", ("-DLFSD_COARSE_START=0",)),
-                     ("quadrotor", "plain", PLAIN_SCHEDULE), ("cartpole", "plain", PLAIN_SCHEDULE), ("rocket", "plain", PLAIN_SCHEDULE),
-                     ("robotarm", "plain", PLAIN_SCHEDULE))
+def _tier_variants():
+    import lfsd_amd  # noqa: F401
+    from lfsd_amd import runtime
+    return runtime.PLAIN_SCHEDULE, tuple((k, t, f) for k, _, t, f in runtime.GPU_TIER_VARIANTS)
+
+
+# build variants the -m gpu tier compares the product with (kind, tag, flags): defined next to the build code, lfsd_amd/runtime.py
+PLAIN_SCHEDULE, GPU_TIER_VARIANTS = _tier_variants()
 
 
 @pytest.fixture(params=["lockstep", "wide"])
@@ -118,7 +103,9 @@ def make_oracle(kind, n_grid, **kw):
     oc = COCSys()
     beta = sp.Symbol('beta', real=True)
     oc.setAuxvarVariable([beta] + list(env.cost_auxvar))
-    oc.setStateVariable(env.X); oc.setControlVariable(env.U)
+    # finite bounds (CPDP.py:20-46) go through the oracle's reference-shaped setters: its cocSolver then solves the bounded NLP
+    oc.setStateVariable(env.X, kw.get("state_lb", []), kw.get("state_ub", []))
+    oc.setControlVariable(env.U, kw.get("control_lb", []), kw.get("control_ub", []))
     oc.setDyn(beta * env.f); oc.setPathCost(beta * env.path_cost); oc.setFinalCost(env.final_cost)
     oc.setIntegrator(n_grid)
     return oc

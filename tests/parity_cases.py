@@ -128,6 +128,13 @@ def single_trajectory_api(prepare, kind="robotarm", dtype=torch.float64):
     from lfsd_amd.runtime import LfsdError
     with pytest.raises(LfsdError):
         oc.auxSysSolver(tg2, cubic, th)
+    # ... whoever made the interpolant: an untagged cubic callable (a user's own scipy object) is recognised by its values between
+    # the nodes and refused too; an untagged LINEAR one is accepted and gives the tagged one's numbers
+    import scipy.interpolate as sip
+    with pytest.raises(LfsdError):
+        oc.auxSysSolver(tg2, sip.CubicSpline(time_grid, g, axis=0), th)
+    a_user = oc.auxSysSolver(time_grid, sip.interp1d(time_grid, g, axis=0), th)(time_grid)
+    assert np.array_equal(a_user, a)
 
 
 def configs0_pendulum(prepare, dtype=torch.float64):
@@ -227,18 +234,21 @@ def control_bounds(prepare, dtype=torch.float64):
         assert (U >= np.array(lb) - 1e-12).all() and (U <= np.array(ub) + 1e-12).all()
         at_bound = (np.abs(U - np.array(ub)) < 1e-9) | (np.abs(U - np.array(lb)) < 1e-9)
         assert at_bound.sum() >= 3, (kind, at_bound.sum())              # the box is really active
-        o = make_oracle(kind, N)
+        o = make_oracle(kind, N, control_lb=lb, control_ub=ub)          # the pinned restatement with the reference's own setter arguments
+        assert o.has_control_bounds() and not o.has_state_bounds()
         rel = lambda a, b: np.abs(a - b).max() / np.abs(b).max()
         # (1) the kernel's answer is a KKT point of the bounded NLP: the independent solver, started there, stays there.
         #     (The non-convex arm problem has several bounded minima -- cold starts of the two solvers reach different
         #     ones -- so the comparison is basin-independent, as for the rocket.)
-        tg, Xo, Uo, Lo, Jo = o.cocSolverBounded(x0, 1.0, th, lb, ub, U_init=U[:N])
+        tg, _, Xo, Uo, Lo = o.cocSolver(x0, 1.0, th, U_init=U[:N], return_grids=True)
+        Jo = o.last_cost
         assert abs(float(sol["cost"][1]) - Jo) < tol["j"] * abs(Jo), (kind, float(sol["cost"][1]), Jo)
         assert rel(U, Uo) < tol["u"], (kind, rel(U, Uo))
         assert rel(sol["state_grid"][1].double().cpu().numpy(), Xo) < tol["x"], kind
         assert rel(sol["costate_grid"][1].double().cpu().numpy(), Lo) < 10 * tol["u"], kind
         # (2) the independent solver's own cold-start answer is a fixed point of the kernel
-        tg, Xc, Uc, Lc, Jc = o.cocSolverBounded(x0, 1.0, th, lb, ub)
+        tg, _, Xc, Uc, Lc = o.cocSolver(x0, 1.0, th, return_grids=True)
+        Jc = o.last_cost
         dev = sol["state_grid"].device
         s2 = oc.cocSolverBatch([x0], 1.0, [th], u_init=torch.as_tensor(Uc[None, :N].copy(), dtype=dtype, device=dev))
         assert set(s2["status"].tolist()) <= {1, 2}
@@ -272,8 +282,9 @@ def state_bounds(prepare, dtype=torch.float64):
     # (the reference bounds X_0 as well, CPDP.py:136-140: the initial state has to lie inside the box)
     cases = [([0.0, 0.0], [-1e20, -1e20], [2.6, 2.0], [], []),
              ([0.0, 0.5], [-1e20, 0.3], [1e20, 2.2], [-1e20], [9.0])]
-    o = make_oracle("pendulum", 10)
     for x0, xlb, xub, ulb, uub in cases:
+        o = make_oracle("pendulum", 10, state_lb=xlb, state_ub=xub, control_lb=ulb, control_ub=uub)
+        assert o.has_state_bounds() and o.has_control_bounds() == bool(ulb)
         oc = bounded(xlb, xub, ulb, uub)
         prepare(oc, dtype)
         sol = oc.cocSolverBatch([x0] * 3, 1.0, [th] * 3)                 # ragged batch of 3
@@ -284,7 +295,8 @@ def state_bounds(prepare, dtype=torch.float64):
         parity_record("state bounds %s %s" % (xub, dtype), "violation of the node bounds", feas, tol["feas"])
         at_bound = (np.abs(X[1:] - np.array(xub)) < 10 * tol["feas"]) | (np.abs(X[1:] - np.array(xlb)) < 10 * tol["feas"])
         assert at_bound.sum() >= 3, at_bound.sum()                      # the box is really active
-        tg, Xo, Uo, Jo = o.cocSolverStateBounded(x0, 1.0, th, xlb, xub, control_lb=ulb or None, control_ub=uub or None)
+        tg, _, Xo, Uo, _ = o.cocSolver(x0, 1.0, th, return_grids=True)
+        Jo = o.last_cost
         rel = lambda a, b: np.abs(a - b).max() / np.abs(b).max()
         parity_record("state bounds %s %s" % (xub, dtype), "cost", abs(float(sol["cost"][1]) - Jo) / abs(Jo), tol["j"])
         parity_record("state bounds %s %s" % (xub, dtype), "state", rel(X, Xo), tol["x"])

@@ -66,6 +66,66 @@ def test_kkt_certificate_other_robots():
         assert defect < 1e-10 and gmax < 1e-6 and lmax < 1e-7, (kind, defect, gmax, lmax)
 
 
+# ---- second pipeline pin: the pendulum of Examples/pendulum_groundtruth.py (needs no CasADi: the example defines its own truth) -----
+def _pendulum_example(n_grid):
+    """Examples/pendulum_groundtruth.py:15-33, 59-68: the environment, the true parameter [2, 1, 1], waypoints = the angle of the
+    true parameter's own solution at grid nodes 1, 3, 6, 7, 9 (of 10; scaled with a finer grid)."""
+    from oracle.cpdp_oracle import getloss_corrections
+    o = make_oracle("pendulum", n_grid)
+    x0, T = [0.0, 0.0], 1.0
+    tg, sol = o.cocSolver(x0, T, [2.0, 1.0, 1.0])
+    taus = tg[[k * n_grid // 10 for k in (1, 3, 6, 7, 9)]]
+    wps = np.array([[sol(t)[0]] for t in taus])
+
+    def loss_grad(th, **aux_kw):
+        tg2, s2 = o.cocSolver(x0, T, th)
+        aux = o.auxSysSolver(tg2, s2, th, **aux_kw)
+        return getloss_corrections(o, taus, wps, s2, aux, [0])
+    return loss_grad
+
+
+def test_oracle_pipeline_on_the_pendulum_example_gradient_vs_finite_differences():
+    """The whole oracle pipeline (OC solve -> Riccati sweep -> forward sensitivity sweep -> waypoint loss, CPDP.py:92-381) on a
+    SECOND model, against checks that share no code with the auxiliary system:
+      * at the example's true parameter the waypoints are reproduced: loss = 0 and d(theta) = 0;
+      * away from it the PDP gradient (no factor 2: lib/QuadAlgorithm.py:655-660) is half the derivative of the loss, which
+        central differences through complete re-solves give directly.  The PDP differentiates the CONTINUOUS maximum principle
+        along the interpolated grids (CPDP.py:320-323, 347), the loss is that of the discrete NLP: the two agree to O(dgrid^~1.7)
+        -- measured 1.8e-2 / 6.0e-3 / 1.7e-3 at n_grid 10 / 20 / 40 -- so the error must shrink under refinement."""
+    from conftest import TIGHT
+    err = {}
+    for n_grid in (10, 20):
+        lg = _pendulum_example(n_grid)
+        l0, g0 = lg([2.0, 1.0, 1.0], **TIGHT)
+        assert l0 < 1e-20 and np.abs(g0).max() < 1e-10, (l0, g0)
+        th = np.array([1.0, 0.5, 1.5])                      # the example's initial guess (pendulum_groundtruth.py:76)
+        l, g = lg(th, **TIGHT)
+        fd = np.zeros(3)
+        for i in range(3):
+            a, b = th.copy(), th.copy()
+            a[i] += 1e-5; b[i] -= 1e-5
+            fd[i] = (lg(a, **TIGHT)[0] - lg(b, **TIGHT)[0]) / 2e-5
+        err[n_grid] = np.abs(g - fd / 2).max() / np.abs(fd / 2).max()
+    assert err[10] < 3e-2 and err[20] < 1e-2 and err[20] < 0.5 * err[10], err
+
+
+def test_oracle_replays_the_pendulum_example_loop():
+    """Examples/pendulum_groundtruth.py:73-88 in the reference-faithful mode (BDF / RK45 at scipy's defaults): 100 plain gradient
+    steps at lr 1e-2 from [1, 0.5, 1.5] with the projection beta >= 1e-8.  The loss falls monotonically from 10.35 to 6e-4 and the
+    parameters move towards the truth [2, 1, 1] (measured end point [1.81, 1.27, 1.03]: the five waypoints identify beta best)."""
+    lg = _pendulum_example(10)
+    th = np.array([1.0, 0.5, 1.5])
+    trace = []
+    for j in range(100):
+        l, g = lg(th)
+        trace.append(l)
+        th = th - 1e-2 * g
+        th[0] = max(th[0], 1e-8)
+    assert abs(trace[0] - 10.348190669827167) < 1e-6      # (the tight and the reference-mode integrators agree on the loss: it only needs the OC solve)
+    assert np.all(np.diff(trace) < 0) and trace[-1] < 1e-3, (trace[0], trace[-1])
+    assert np.abs(th - np.array([2.0, 1.0, 1.0])).max() < 0.3, th
+
+
 # ---- the robot models against the reference's own source text (tests/golden/jinenv_points.npz) --------------------------
 def _jinenv_cases():
     import importlib.util
