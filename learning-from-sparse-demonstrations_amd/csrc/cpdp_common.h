@@ -358,7 +358,7 @@ namespace lfsd {
 // never-written shared memory cannot go unnoticed (tests build with -DLFSD_POISON_LDS)
 template <typename T> LFSD_DEV void poison_lds(T* p, int n) {
 #if defined(LFSD_POISON_LDS)
-  for (int i = threadIdx.x; i < n; i += 64) p[i] = T(0) / T(0);
+  for (int i = threadIdx.x; i < n; i += blockDim.x) p[i] = T(0) / T(0);
   __syncthreads();
 #else
   (void)p; (void)n;
@@ -409,24 +409,27 @@ struct f32x16 {
   float& operator[](int i) { return v[i]; }
   const float& operator[](int i) const { return v[i]; }
 };
+// (exchange buffers of the emulated cross-lane operations: one slot per thread of the workgroup, a wavefront = 64 consecutive
+//  threads -- workgroups of several wavefronts, oc_solve_wide_kernel<..., W>, exchange inside their own 64 slots)
+constexpr int EMU_MAXT = 256;
 inline void mfma4b(float a, float b, f32x16& acc) {
-  static float sa[64], sb[64];
-  const int l = threadIdx.x;
-  sa[l] = a; sb[l] = b;
+  static float sa[EMU_MAXT], sb[EMU_MAXT];
+  const int t = threadIdx.x, w0 = t & ~63, l = t & 63;
+  sa[t] = a; sb[t] = b;
   __syncthreads();
   for (int r = 0; r < 16; ++r) {
     const int blk = r / 4, i = 4 * (l >> 4) + r % 4, j = l & 15;
-    acc[r] = std::fmaf(sa[16 * blk + i], sb[16 * blk + j], acc[r]);      // the hardware's k-ordered fmaf chain
+    acc[r] = std::fmaf(sa[w0 + 16 * blk + i], sb[w0 + 16 * blk + j], acc[r]);      // the hardware's k-ordered fmaf chain
   }
   __syncthreads();
 }
 inline void tile_transpose(f32x16& acc) {
-  static float sx[64][16];
-  const int l = threadIdx.x, b = l >> 4, j = l & 15;
-  for (int r = 0; r < 16; ++r) sx[l][r] = acc[r];
+  static float sx[EMU_MAXT][16];
+  const int t = threadIdx.x, w0 = t & ~63, l = t & 63, b = l >> 4, j = l & 15;
+  for (int r = 0; r < 16; ++r) sx[t][r] = acc[r];
   __syncthreads();
   for (int q = 0; q < 4; ++q)
-    for (int r = 0; r < 4; ++r) acc[4 * q + r] = sx[16 * q + j][4 * b + r];
+    for (int r = 0; r < 4; ++r) acc[4 * q + r] = sx[w0 + 16 * q + j][4 * b + r];
   __syncthreads();
 }
 #else
@@ -465,10 +468,10 @@ LFSD_DEV void tile_transpose(f32x16& acc) {
 // reached by all 64 lanes.
 #if defined(LFSD_EMU)
 template <typename T> inline T lane_get(T v, int j) {
-  static T sb[64];
+  static T sb[EMU_MAXT];
   sb[threadIdx.x] = v;
   __syncthreads();
-  const T r = sb[j];
+  const T r = sb[(threadIdx.x & ~63) + j];
   __syncthreads();
   return r;
 }
@@ -481,11 +484,11 @@ LFSD_DEV double lane_get(double v, int j) { return __shfl(v, j); }
 // backward sweep splits the rows of its dense products over the four 16-lane quarters).  Must be reached by all 64 lanes.
 #if defined(LFSD_EMU)
 template <typename T> inline T quarter_sum(T v) {
-  static T sq[64];
-  const int l = threadIdx.x;
-  sq[l] = v;
+  static T sq[EMU_MAXT];
+  const int t = threadIdx.x, w0 = t & ~63, l = t & 15;
+  sq[t] = v;
   __syncthreads();
-  const T r = (sq[l & 15] + sq[(l & 15) + 16]) + (sq[(l & 15) + 32] + sq[(l & 15) + 48]);
+  const T r = (sq[w0 + l] + sq[w0 + l + 16]) + (sq[w0 + l + 32] + sq[w0 + l + 48]);
   __syncthreads();
   return r;
 }
@@ -517,6 +520,17 @@ LFSD_DEV double quarter_sum(double v) {
 #define LFSD_ISSUE_FENCE()
 #else
 #define LFSD_ISSUE_FENCE() asm volatile("" ::: "memory")
+#endif
+
+// sched_load / sched_add: the counter of finished trajectories of a two-launch wide solve (OcArgs::sched): relaxed device-scope
+// operations performed in the L2 (a plain load could be served by the scalar cache or the vector L1 for ever).  The emulator runs the
+// workgroups of a launch one after the other.
+#if defined(LFSD_EMU)
+inline int sched_load(const int* p) { return *p; }
+inline void sched_add(int* p, int v) { *p += v; }
+#else
+LFSD_DEV int sched_load(int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+LFSD_DEV void sched_add(int* p, int v) { __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 #endif
 
 // pin(x): the value is materialised HERE, unconditionally.  Needed where a load feeds one arm of a per-lane select
@@ -845,7 +859,7 @@ template <int Q> constexpr bool sub_ok() { return Q == 1 || Q == 2 || Q == 4; }
 template <int Q, typename T> inline T sub_bcast(T v, int k) {
   static_assert(sub_ok<Q>(), "sub-group of 1, 2 or 4 lanes");
   if (Q == 1) return v;
-  static T sb[64];
+  static T sb[EMU_MAXT];
   const int l = threadIdx.x;
   sb[l] = v;
   __syncthreads();

@@ -40,6 +40,13 @@ template <typename T> struct OcArgs {
   T x_rho;
   int start_mode;       // lean kernel: stage-Hessian model a trajectory WITH an initial guess starts from (0 Gauss-Newton, 1 Hamiltonian: a guess next to the answer)
   T mu_stage_frac;      // > 0: a stage whose Q_uu factorises with this fraction of the Levenberg shift keeps only that fraction (generic sweep)
+  // wide kernel, two-launch solves (lfsd_capi.cpp, coc_solve_t): sched[0] counts the trajectories of the launch that are finished; a
+  // trajectory that finds suspend_at or more of them finished at the top of an iteration parks its solver state in the workspace
+  // (OcLayout::WIDE_STATE) and leaves with status ST_RUNNING -- the next launch (resume == 2, several wavefronts per trajectory)
+  // takes it up exactly there.  sched == nullptr: no suspension.  suspend_it >= 0 (test hook): suspend at that iteration instead.
+  int* sched;
+  int suspend_at;
+  int suspend_it;
 };
 
 template <class M> struct OcLayout {
@@ -75,9 +82,16 @@ template <class M> struct OcLayout {
   // exact stage Hessian on ONE lane, as NVH packed pairs that share the nominal part of every evaluation (OcSolver::stage_hessian_all)
   static constexpr bool HALL = NXU <= 8;
   static constexpr int NVH = (NXU + 1) / 2;
+  // ... + the gaps of a multiple-shooting iterate (own words since round 6: the parked roll-outs of a refused step used to overwrite them)
+  // + the per-lane scratch of the exact-Hessian sweeps for the wavefronts 1..WIDE_WMAX-1 of a workgroup that gives one trajectory
+  // several wavefronts (oc_solve_wide_kernel<..., W>: the tail of a launch, re-launched) + the parked solver state of a suspended solve
+  static constexpr int WIDE_WMAX = 4;
+  static constexpr int WIDE_STATE = 64;
+  static constexpr long long WIDE_XW = 1LL * SMAX * NX * (1 + 64) + 1LL * SMAX * NX * 64;      // exws-shaped + exwu-shaped region of one extra wavefront
   LFSD_HD static long long ws_elems_wide(int N) {
     const long long n = ws_elems<64>(N) + 1LL * WIDE_NAL * ((N + 1) * NX + N * NU) + 1LL * SMAX * NX * 64 +
-                        (HALL ? 2LL * NVH * SMAX * NX * 64 + 2 : 0LL);      // + per-lane tangent sub-step starts of stage_hessian_all (8-byte aligned)
+                        (HALL ? 2LL * NVH * SMAX * NX * 64 + 2 : 0LL) +      // + per-lane tangent sub-step starts of stage_hessian_all (8-byte aligned)
+                        2LL * N * NX + (HALL ? 0LL : (WIDE_WMAX - 1) * WIDE_XW) + WIDE_STATE;
     return (n + 1) / 2 * 2;
   }
   // LDS per group (elements)
@@ -1982,11 +1996,19 @@ template <class M, typename T, int G, bool EXACT, bool BND = false> struct OcSol
 //   costate_sweep       lambda_k = q_x + A_k^T lambda_k+1 (sequential, NX FMAs per interval)
 //   hessians_parallel   exact stage Hessian columns for every (k, column): second-order adjoint sweeps, N*NXU/64 rounds
 // which leaves only the cheap Riccati-type recursion of OcSolver::backward sequential in k.
-template <class M, typename T, bool EXACT, bool BND = false> struct OcWide : OcSolver<M, T, 64, EXACT, BND> {
+// W > 1 (the re-launched tail of a wide launch, small batches): W wavefronts per trajectory in one workgroup.  Each wavefront keeps
+// its own LDS region and runs the SEQUENTIAL phases (roll-outs, backward sweep, step control) redundantly on identical inputs --
+// identical values, identical control flow, the same words of the workspace written with the same bits --; the interval-parallel
+// phases (linearisation, exact stage Hessians) are split: wavefront w takes the items w*64 + lane, + 64 W, ... and a workgroup
+// barrier publishes the results.  The items are computed by the same code whoever runs them: results do not depend on W.
+template <class M, typename T, bool EXACT, bool BND = false, int W = 1> struct OcWide : OcSolver<M, T, 64, EXACT, BND> {
   using Base = OcSolver<M, T, 64, EXACT, BND>;
   using Lay = OcLayout<M>;
   static constexpr int NX = M::NX, NU = M::NU, NP = M::NP, NXU = NX + NU;
   static constexpr int NAL = 16;                       // step lengths 2^0 .. 2^-15
+  static constexpr int NW = W, PSTRIDE = 64 * W;       // wavefronts per trajectory; stride of the item loops of the parallel phases
+  int wave = 0;                                        // this wavefront's index in the workgroup
+  LFSD_DEV int pitem() const { return wave * 64 + lane; }
   using Base::lane; using Base::N; using Base::S; using Base::e; using Base::c; using Base::x0; using Base::xb; using Base::ub; using Base::xbp; using Base::ubp; using Base::Mwp;
   using Base::Mws; using Base::Hws; using Base::lds; using Base::xa; using Base::ua; using Base::lam_out; using Base::DT;
 
@@ -2071,7 +2093,7 @@ template <class M, typename T, bool EXACT, bool BND = false> struct OcWide : OcS
   // linearise the shooting map along nominal `nxt`, all intervals at once
   LFSD_DEV void linearise_parallel(int nxt) {
     if constexpr (sizeof(T) == 4 && Lay::HALL && (LFSD_HESS_ALL) != 0) {
-      for (int k = lane; k < N; k += 64) {
+      for (int k = pitem(); k < N; k += PSTRIDE) {
         T x[NX], u[NU], q;
 #pragma unroll
         for (int i = 0; i < NX; ++i) x[i] = xbp(nxt)[k * NX + i];
@@ -2085,7 +2107,7 @@ template <class M, typename T, bool EXACT, bool BND = false> struct OcWide : OcS
     if constexpr (sizeof(T) == 4) {
       using V = pk2<T>;
       constexpr int NCT = (NXU + 1) / 2;
-      for (int t = lane; t < N * NCT; t += 64) {
+      for (int t = pitem(); t < N * NCT; t += PSTRIDE) {
         const int k = t / NCT, c0 = 2 * (t % NCT), c1 = c0 + 1;
         T x[NX], u[NU], q = T(0);
         V m[NX], du[NU], mq = V(T(0));
@@ -2101,7 +2123,7 @@ template <class M, typename T, bool EXACT, bool BND = false> struct OcWide : OcS
         Mk[NX * (Lay::NXUP / 2)] = mq;
       }
     } else {
-      for (int t = lane; t < N * NXU; t += 64) {
+      for (int t = pitem(); t < N * NXU; t += PSTRIDE) {
         const int k = t / NXU, col = t % NXU;
         T x[NX], u[NU], m[NX], du[NU], q = T(0), mq = T(0);
 #pragma unroll
@@ -2193,7 +2215,7 @@ template <class M, typename T, bool EXACT, bool BND = false> struct OcWide : OcS
   // exact stage Hessians of nominal `cur` (costates must be on lam_out), every (interval, column) at once
   LFSD_DEV void hessians_parallel(int cur) {
     if constexpr (sizeof(T) == 4 && Lay::HALL && (LFSD_HESS_ALL) != 0) {
-      for (int k = lane; k < N; k += 64) {
+      for (int k = pitem(); k < N; k += PSTRIDE) {
         T xk[NX], uk[NU], ln[NX];
 #pragma unroll
         for (int i = 0; i < NX; ++i) { xk[i] = xbp(cur)[k * NX + i]; ln[i] = lam_out[(k + 1) * NX + i]; }
@@ -2204,7 +2226,7 @@ template <class M, typename T, bool EXACT, bool BND = false> struct OcWide : OcS
       __syncthreads();
       return;
     }
-    for (int t = lane; t < N * NXU; t += 64) {
+    for (int t = pitem(); t < N * NXU; t += PSTRIDE) {
       const int k = t / NXU, col = t % NXU;
       T xk[NX], uk[NU], ln[NX], hx[NX], hu[NU];
 #pragma unroll
@@ -2495,10 +2517,10 @@ template <class M, typename T, bool EXACT, bool BND = false> struct OcWide : OcS
   //     du_k = k_k + K_k dx_k,   dx_k+1 = A_k dx_k + B_k du_k + d_k,   dx_0 = 0
   // -- the Newton step of the lifted KKT system (Gauss-Newton multiple shooting / the step of an SQP method on the NLP above).
   // Where the single-shooting iteration of this kernel pays N x S sequentially dependent RK4 steps for its roll-outs, this one
-  // pays S (per round of 64 items).  Only the FULL Newton step is ever taken this way (it closes the linearised gaps entirely), and
-  // only when the l1 penalty function  J + 2 sum |lambda_i| |d_i|  (one weight per constraint: the costates of the iterate) accepts it; otherwise
-  // the step is the closed-loop nonlinear roll-out around the node states, which closes every gap by construction.  Convergence
-  // is never declared on an iterate with gaps (oc_solve_wide_kernel).
+  // pays S (per round of 64 items).  The full Newton step (it closes the linearised gaps entirely) or ONE half step is taken this way,
+  // and only when the augmented Lagrangian  J + lambda^T d + rho/2 |d|^2  (costates of the iterate held fixed, rho = max(|lambda|_inf, 1);
+  // oc_solve_wide_kernel, "Merit function") accepts it by an Armijo test; otherwise the step is the closed-loop nonlinear roll-out
+  // around the node states, which closes every gap by construction.  Convergence is never declared on an iterate with gaps.
   T *gapb[2] = {nullptr, nullptr}, *dxw = nullptr, *duw = nullptr;      // [N][NX] gaps of the two nominal buffers; Newton step [N+1][NX], [N][NU]
   LFSD_DEV T* gapp(int i) const { return i ? gapb[1] : gapb[0]; }
   LFSD_DEV T wave_sum(T v) {
@@ -3287,27 +3309,45 @@ __global__ void __launch_bounds__(64, LFSD_WAVES_OC) oc_solve_kernel(OcArgs<T> a
 // once, so "optimistic full step, then line search" is a single phase: the largest step length that passes the Armijo
 // test is taken).  Control flow is uniform per workgroup -- no votes, no lock-step partners.  lfsd_coc_solve picks this
 // kernel when the lock-step mapping would leave most SIMDs without a wavefront (the `mapping` argument overrides).
-template <class M, typename T, bool EXACT, bool BND = false>
-__global__ void __launch_bounds__(64, 1) oc_solve_wide_kernel(OcArgs<T> a) {
-  using Sol = OcWide<M, T, EXACT, BND>;
+// W: wavefronts per trajectory (OcWide).  A launch with W > 1 is either the whole solve of a small batch or the second launch of a
+// two-launch solve (a.resume == 2): then a workgroup whose trajectory is finished leaves at once and the others continue from the
+// solver state their first launch parked in the workspace.
+template <class M, typename T, bool EXACT, bool BND = false, int W = 1>
+__global__ void __launch_bounds__(64 * W, 1) oc_solve_wide_kernel(OcArgs<T> a) {
+  using Sol = OcWide<M, T, EXACT, BND, W>;
   using Lay = OcLayout<M>;
   constexpr int NX = M::NX, NU = M::NU, NP = M::NP, NC = M::NC, NAL = Sol::NAL;
+  static_assert(W == 1 || (!Lay::HALL && W <= Lay::WIDE_WMAX), "several wavefronts per trajectory: the models whose parallel phases take several rounds");
   constexpr int RS = EXACT ? Lay::template lds_elems<64, (int)sizeof(T)>() : ((Lay::template lds_ex<64>() + 3) / 4) * 4;
-  __shared__ __attribute__((aligned(16))) T lds_all[RS];
-  if (blockDim.x != 64) return;
-  poison_lds(lds_all, RS);
-  Sol s;
-  s.lane = threadIdx.x;
+  __shared__ __attribute__((aligned(16))) T lds_all[W * RS];
+  if (blockDim.x != 64 * W) return;
   const long long traj = blockIdx.x;
-  oc_bind<M, T, 64>(s, a, lds_all, traj, true, traj);
+  const bool resuming = a.resume == 2;
+  if (resuming && a.status[traj] != ST_RUNNING) return;      // (uniform per workgroup)
+  poison_lds(lds_all, W * RS);
+  Sol s;
+  s.lane = threadIdx.x & 63;
+  s.wave = threadIdx.x >> 6;
+  oc_bind<M, T, 64>(s, a, lds_all + s.wave * RS, traj, true, traj);
   const int N = s.N;
+  T* wstate;      // [WIDE_STATE] parked solver state
   {
     T* w2 = a.ws + traj * a.ws_stride + Lay::template ws_elems<64>(N);
     s.xa = w2; s.ua = s.xa + (long long)NAL * (N + 1) * NX; s.exwu = s.ua + (long long)NAL * N * NU;
     s.exwm = s.exwu + (long long)Lay::SMAX * NX * 64;
     if ((((long long)(s.exwm - a.ws)) & 1) != 0) ++s.exwm;      // (8-byte aligned: it holds packed pairs; the region has a word to spare)
-    // the multiple-shooting iterate's gaps and Newton step live in the region of the parked step-length roll-outs (never in use together)
-    s.gapb[0] = s.xa; s.gapb[1] = s.xa + (long long)N * NX; s.dxw = s.xa + 2LL * N * NX; s.duw = s.dxw + (long long)(N + 1) * NX;
+    T* w3 = s.exwu + (long long)Lay::SMAX * NX * 64 + (Lay::HALL ? 2LL * Lay::NVH * Lay::SMAX * NX * 64 + 2 : 0LL);      // (the order of OcLayout::ws_elems_wide)
+    // the gaps of the two nominal buffers have words of their own; the Newton step of a multiple-shooting iterate lives in the
+    // region of the parked step-length roll-outs (dead by the time a roll-out is parked)
+    s.gapb[0] = w3; s.gapb[1] = w3 + (long long)N * NX; w3 += 2LL * N * NX;
+    s.dxw = s.xa; s.duw = s.dxw + (long long)(N + 1) * NX;
+    if constexpr (W > 1) {
+      if (s.wave > 0) {      // per-lane scratch of the exact-Hessian sweeps: every wavefront its own
+        T* xw = w3 + (long long)(s.wave - 1) * Lay::WIDE_XW;
+        s.exws = xw; s.exwu = xw + (long long)Lay::SMAX * NX * (1 + 64);
+      }
+    }
+    wstate = w3 + (Lay::HALL ? 0LL : (Lay::WIDE_WMAX - 1) * Lay::WIDE_XW);
     T* le = s.lds + Lay::template lds_e<64>();
     T* lc = s.lds + Lay::template lds_c<64>();
     T* lx = s.lds + Lay::template lds_x0<64>();
@@ -3327,6 +3367,57 @@ __global__ void __launch_bounds__(64, 1) oc_solve_wide_kernel(OcArgs<T> a) {
       s.xrho = a.x_rho;
     }
   }
+  // ---- the solver state that is carried from iteration to iteration (and, parked in the workspace, from the launch that suspends a
+  // solve to the launch that resumes it: `park` / `unpark` below list every one of them) ----
+  int cur = 0;
+  T alpha_l = T(0);
+  // Mesh continuation (see oc_solve_kernel): the 32-lane models only (quadrotor, rocket -- the rocket's cold start needs
+  // ~40-100 regularised Newton iterations of 2-5 % gain each before its last five quadratic ones, profiles/
+  // r03_f_rocket_trace_head.txt, and every one of them pays a second-order adjoint sweep through S x 4 RK4 stages per
+  // interval); never with an initial guess from the caller or with bounds (warm-started subproblems start next to their
+  // answer).  Smaller models keep the reference's grid: their parity cases follow the oracle's path into one of several minima.
+  constexpr bool CSW = !BND && (LFSD_COARSE_START != 0) && (NX + (NU > NP ? NU : NP) > 16);
+  // ... and only where the coarse grid still has as many RK4 steps as the reference's example grids have in all (n_grid
+  // 10-15 x 4): at n_grid 15 the rocket's coarse path ends in ANOTHER stationary point than the fine one (one with a
+  // conjugate point inside the horizon, where the Riccati sweep of the auxiliary pass has a finite escape; emulator tier,
+  // test_rocket_newton_mode_vs_oracle) -- a step of 0.2 s is too long for its attitude dynamics under aggressive controls.
+  bool coarse = false, relin = false;
+  // ... and on a coarser CONTROL grid as well (LFSD_COARSE_TIME, round 4): `tc` grid intervals share one control, i.e. the coarse
+  // phase solves the problem on n_grid / tc intervals of length tc * dgrid with tc RK4 steps each -- the same RK4 step as one step
+  // per original interval, but tc times fewer stages in the backward recursion and tc times fewer exact stage Hessians, the two
+  // phases that are 63 % of an iteration (profiles/r04_e_rocket_wide_clock.txt).  Leaving the coarse phase prolongates the
+  // controls (each held over its tc intervals) and goes through the same re-linearisation on the reference's discretisation.
+  const int N_full = s.N;
+  const T dgrid_full = s.dgrid;
+  int tc = 1;
+  // Multiple-shooting steps (OcWide::ms_*; the step logic is in the loop below): every level of the mesh continuation starts from a
+  // roll-out (no gaps); an iterate with gaps is closed by a closed-loop roll-out before any convergence test applies to it
+  // (`ms_check`: the cheap costate-only gradient test comes first then).
+  // Not for solves that run Newton from their first iteration (exact_after == 0, the rocket): their steps are regularised Newton
+  // steps at Levenberg shifts of 10^2 - 10^4 through strongly curved attitude dynamics; the linear prediction of the node states
+  // then leaves gaps as large as the step closes, the line search settles on steps of 1/4, and the phase needs as many or more
+  // iterations than the closed-loop nonlinear roll-out while saving only the roll-outs' 20 % of an iteration (measured:
+  // DESIGN.md; -DLFSD_MS_NEWTON=1 switches it on there as well).
+  const bool ms_on = !BND && (LFSD_MS) != 0 && a.n_grid >= (LFSD_MS_MIN_GRID) && a.max_iter > 8 && (a.exact_after != 0 || (LFSD_MS_NEWTON) != 0);
+  bool ms = ms_on, ms_check = false, ms_floor = false;
+  int n_acc_need = 4, n_ms = 0, n_half = 0;
+  T g1c = T(0), g2c = T(0), gmc = T(0);      // l1 norm, sum of squares and largest entry of the gaps of the current iterate (0: a roll-out)
+  T J = T(0), J_feas = T(0);                 // cost of the iterate; cost of the last iterate WITHOUT gaps (a roll-out)
+  T mu = T(0);
+  int mode = (EXACT && a.exact_after == 0) ? 2 : 0;
+  bool ham_ok = true, hess_ok = false, gn_crawl = false, costates_ok = false;
+  int status = ST_RUNNING, it = 0;
+  T gnorm = T(0), dV1 = T(0), dV2 = T(0), g_flat = T(-1), g_last = T(-1), dec_last = T(1e30), J_ref = T(0), mu_bad = T(-1);
+  int n_acc = 0, mu_hold = 0;
+#if defined(LFSD_OC_CLOCK)      // diagnostic build (tools/wide_clock.py): shader clocks of the phases of the slowest solves
+  long long wck[7] = {0, 0, 0, 0, 0, 0, 0}, wck_exit = 0;
+  int wck_it_exit = -1;
+  const long long wck_t0 = clock64();
+#define LFSD_WCK(i, stmt) { const long long c0_ = clock64(); stmt; wck[i] += clock64() - c0_; }
+#else
+#define LFSD_WCK(i, stmt) { stmt; }
+#endif
+  if (!resuming) {
   // initial guess into buffer 1 (the reference's w0: zero, or the midpoint of finite control bounds, CPDP.py:153), rolled out
   // without gains into buffer 0, linearised
   // (`warm`: the caller's initial guess of THIS trajectory is not all zero.  An all-zero row of u_init is the cold start -- a
@@ -3350,28 +3441,7 @@ __global__ void __launch_bounds__(64, 1) oc_solve_wide_kernel(OcArgs<T> a) {
     for (int l = 0; l < 64; ++l) warm = warm || !(ldsRed[l] == T(0));
   }
   __syncthreads();
-  int cur = 0;
-  T alpha_l = T(0);
-  // Mesh continuation (see oc_solve_kernel): the 32-lane models only (quadrotor, rocket -- the rocket's cold start needs
-  // ~40-100 regularised Newton iterations of 2-5 % gain each before its last five quadratic ones, profiles/
-  // r03_f_rocket_trace_head.txt, and every one of them pays a second-order adjoint sweep through S x 4 RK4 stages per
-  // interval); never with an initial guess from the caller or with bounds (warm-started subproblems start next to their
-  // answer).  Smaller models keep the reference's grid: their parity cases follow the oracle's path into one of several minima.
-  constexpr bool CSW = !BND && (LFSD_COARSE_START != 0) && (NX + (NU > NP ? NU : NP) > 16);
-  // ... and only where the coarse grid still has as many RK4 steps as the reference's example grids have in all (n_grid
-  // 10-15 x 4): at n_grid 15 the rocket's coarse path ends in ANOTHER stationary point than the fine one (one with a
-  // conjugate point inside the horizon, where the Riccati sweep of the auxiliary pass has a finite escape; emulator tier,
-  // test_rocket_newton_mode_vs_oracle) -- a step of 0.2 s is too long for its attitude dynamics under aggressive controls.
-  bool coarse = CSW && a.steps_per_grid > 1 && !warm && a.max_iter > 8 && a.n_grid >= LFSD_COARSE_MIN_GRID;
-  bool relin = false;
-  // ... and on a coarser CONTROL grid as well (LFSD_COARSE_TIME, round 4): `tc` grid intervals share one control, i.e. the coarse
-  // phase solves the problem on n_grid / tc intervals of length tc * dgrid with tc RK4 steps each -- the same RK4 step as one step
-  // per original interval, but tc times fewer stages in the backward recursion and tc times fewer exact stage Hessians, the two
-  // phases that are 63 % of an iteration (profiles/r04_e_rocket_wide_clock.txt).  Leaving the coarse phase prolongates the
-  // controls (each held over its tc intervals) and goes through the same re-linearisation on the reference's discretisation.
-  const int N_full = s.N;
-  const T dgrid_full = s.dgrid;
-  int tc = 1;
+  coarse = CSW && a.steps_per_grid > 1 && !warm && a.max_iter > 8 && a.n_grid >= LFSD_COARSE_MIN_GRID;
   if (coarse) {
     constexpr int TC0 = (NX + (NU > NP ? NU : NP) > 16) ? (LFSD_COARSE_TIME) : 1;      // (the small models: one RK4 step per interval only, measured)
     for (int f = TC0; f > 1; f /= 2) {
@@ -3380,15 +3450,7 @@ __global__ void __launch_bounds__(64, 1) oc_solve_wide_kernel(OcArgs<T> a) {
     s.N = N_full / tc; s.dgrid = dgrid_full * T(tc);
     s.S = ((LFSD_COARSE_TIME_S) > 0 && (LFSD_COARSE_TIME_S) < tc) ? (LFSD_COARSE_TIME_S) : tc; s.DT = s.dgrid / T(s.S);
   }
-#if defined(LFSD_OC_CLOCK)      // diagnostic build (tools/wide_clock.py): shader clocks of the phases of the slowest solves
-  long long wck[7] = {0, 0, 0, 0, 0, 0, 0}, wck_exit = 0;
-  int wck_it_exit = -1;
-  const long long wck_t0 = clock64();
-#define LFSD_WCK(i, stmt) { const long long c0_ = clock64(); stmt; wck[i] += clock64() - c0_; }
-#else
-#define LFSD_WCK(i, stmt) { stmt; }
-#endif
-  T J = s.rollout_alphas(1, false, alpha_l);             // (every lane rolls the same controls out; lane 0's copy is adopted)
+  J = s.rollout_alphas(1, false, alpha_l);             // (every lane rolls the same controls out; lane 0's copy is adopted)
   ldsRed[s.lane] = J;
   __syncthreads();
   J = ldsRed[0];
@@ -3404,28 +3466,61 @@ __global__ void __launch_bounds__(64, 1) oc_solve_wide_kernel(OcArgs<T> a) {
   }
   s.adopt_alpha(0, 0);
   s.linearise_parallel(0);
-  // Multiple-shooting steps (OcWide::ms_*; the step logic is in the loop below): every level of the mesh continuation starts from a
-  // roll-out (no gaps); an iterate with gaps is closed by a closed-loop roll-out before any convergence test applies to it
-  // (`ms_check`: the cheap costate-only gradient test comes first then).
-  // Not for solves that run Newton from their first iteration (exact_after == 0, the rocket): their steps are regularised Newton
-  // steps at Levenberg shifts of 10^2 - 10^4 through strongly curved attitude dynamics; the linear prediction of the node states
-  // then leaves gaps as large as the step closes, the line search settles on steps of 1/4, and the phase needs as many or more
-  // iterations than the closed-loop nonlinear roll-out while saving only the roll-outs' 20 % of an iteration (measured:
-  // DESIGN.md; -DLFSD_MS_NEWTON=1 switches it on there as well).
-  bool ms = !BND && (LFSD_MS) != 0 && a.n_grid >= (LFSD_MS_MIN_GRID) && a.max_iter > 8 && (a.exact_after != 0 || (LFSD_MS_NEWTON) != 0);
-  bool ms_check = false, ms_floor = false;
-  const bool ms_on = ms;
-  int n_acc_need = 4, n_ms = 0, n_half = 0;
-  T g1c = T(0), g2c = T(0), gmc = T(0);      // l1 norm, sum of squares and largest entry of the gaps of the current iterate (0: a roll-out)
-  T J_feas = J;                              // cost of the last iterate WITHOUT gaps (a roll-out)
-  T mu = T(0);
-  int mode = (EXACT && a.exact_after == 0) ? 2 : 0;
-  bool ham_ok = true, hess_ok = false, gn_crawl = false, costates_ok = false;
-  int status = t_finite(J) ? ST_RUNNING : ST_FAILED, it = 0;
-  T gnorm = T(0), dV1 = T(0), dV2 = T(0), g_flat = T(-1), g_last = T(-1), dec_last = T(1e30), J_ref = J, mu_bad = T(-1);
-  int n_acc = 0, mu_hold = 0;
+  J_feas = J; J_ref = J;
+  status = t_finite(J) ? ST_RUNNING : ST_FAILED;
+  }
+  // The parked state: every variable above, as numbers of the solve's own type (the integers are small: exact).  `it` is where
+  // the iteration loop continues; the buffers the state refers to (both nominal buffers, linearisations, gains, cached stage
+  // Hessians, costates, gaps) already live in the workspace / the output rows.
+  auto park = [&]() LFSD_LAMBDA_INLINE {
+    if (threadIdx.x == 0) {
+      T* w = wstate;
+      const T iv[] = {T(cur), T(coarse), T(relin), T(tc), T(s.N), T(s.S), T(ms), T(ms_check), T(ms_floor), T(n_acc_need), T(n_ms), T(n_half),
+                      T(mode), T(ham_ok), T(hess_ok), T(gn_crawl), T(costates_ok), T(it), T(n_acc), T(mu_hold), T(s.gap != nullptr)};
+      const T fv[] = {g1c, g2c, gmc, J, J_feas, mu, gnorm, dV1, dV2, g_flat, g_last, dec_last, J_ref, mu_bad};
+      constexpr int NI = sizeof(iv) / sizeof(T), NF = sizeof(fv) / sizeof(T);
+      static_assert(NI + NF <= Lay::WIDE_STATE, "parked solver state");
+#pragma unroll
+      for (int i = 0; i < NI; ++i) w[i] = iv[i];
+#pragma unroll
+      for (int i = 0; i < NF; ++i) w[NI + i] = fv[i];
+    }
+  };
+  if (resuming) {
+    const T* w = wstate;
+    int q = 0;
+    auto gi = [&]() LFSD_LAMBDA_INLINE { return (int)w[q++]; };
+    cur = gi(); coarse = gi() != 0; relin = gi() != 0; tc = gi(); s.N = gi(); s.S = gi(); ms = gi() != 0; ms_check = gi() != 0; ms_floor = gi() != 0;
+    n_acc_need = gi(); n_ms = gi(); n_half = gi(); mode = gi(); ham_ok = gi() != 0; hess_ok = gi() != 0; gn_crawl = gi() != 0; costates_ok = gi() != 0;
+    it = gi(); n_acc = gi(); mu_hold = gi();
+    const bool has_gap = gi() != 0;
+    g1c = w[q++]; g2c = w[q++]; gmc = w[q++]; J = w[q++]; J_feas = w[q++]; mu = w[q++]; gnorm = w[q++]; dV1 = w[q++]; dV2 = w[q++];
+    g_flat = w[q++]; g_last = w[q++]; dec_last = w[q++]; J_ref = w[q++]; mu_bad = w[q++];
+    s.dgrid = dgrid_full * T(tc); s.DT = s.dgrid / T(s.S);
+    s.gap = has_gap ? s.gapp(cur) : nullptr;
+    status = ST_RUNNING;
+  }
   const int mu_hold_need = LFSD_MU_HOLD;
   for (; it < a.max_iter && status == ST_RUNNING; ++it) {
+    if constexpr (W == 1) {
+      // two-launch solves: once enough trajectories of the launch are finished for the rest to have a workgroup of several
+      // wavefronts each, the rest park their state and leave (uniform per workgroup: one load, handed round through LDS)
+      if (a.sched != nullptr && !resuming) {
+        bool susp;
+        if (a.suspend_it >= 0) susp = it >= a.suspend_it;
+        else {
+          if (s.lane == 0) ldsRed[0] = T(sched_load(a.sched));
+          __syncthreads();
+          susp = (int)ldsRed[0] >= a.suspend_at;
+          __syncthreads();
+        }
+        if (susp) {
+          park();
+          if (threadIdx.x == 0) { a.iters[traj] = it; a.status[traj] = ST_RUNNING; }
+          return;
+        }
+      }
+    }
     if (coarse && (relin || it + 4 >= a.max_iter)) {
       // leave the coarse grid: the same controls rolled out (open loop) and linearised on the reference's discretisation; an
       // iteration without a sweep.  Every convergence test below only ever passes on this grid.
@@ -3693,6 +3788,21 @@ __global__ void __launch_bounds__(64, 1) oc_solve_wide_kernel(OcArgs<T> a) {
            (int)blockIdx.x, it, n_ms, clock64() - wck_t0, wck[0], wck[1], wck[2], wck[3], wck[4], wck[5], wck[6], wck_it_exit, wck_exit);
 #endif
 #undef LFSD_WCK
+  if (s.gap != nullptr) {
+    // the loop was left on an iterate of the lifted problem that still has gaps (iteration limit, or a failure while closing it): its
+    // node states are not the roll-out of its controls.  What is returned is always a trajectory of the reference's discretisation:
+    // the controls rolled out open loop, cost and costates of THAT trajectory (the reference returns IPOPT's last iterate as well)
+    const T Jr = s.rollout_alphas(cur, false, alpha_l);
+    ldsRed[s.lane] = Jr;
+    __syncthreads();
+    J = ldsRed[0];
+    __syncthreads();
+    s.adopt_alpha(0, cur ^ 1);
+    s.linearise_parallel(cur ^ 1);
+    cur ^= 1;
+    s.gap = nullptr; costates_ok = false;
+    if (!t_finite(J)) status = ST_FAILED;
+  }
   if (!costates_ok) s.costate_sweep(cur);                 // costates of the final nominal
   __syncthreads();
   {
@@ -3701,6 +3811,7 @@ __global__ void __launch_bounds__(64, 1) oc_solve_wide_kernel(OcArgs<T> a) {
     for (int i = s.lane; i < (N + 1) * NX; i += 64) xo[i] = s.xbp(cur)[i];
     for (int i = s.lane; i < (N + 1) * NU; i += 64) uo[i] = s.ubp(cur)[(i < N * NU) ? i : i - NU];
     if (s.lane == 0) { a.cost[traj] = J; a.iters[traj] = (status == ST_CONVERGED) ? it + 1 : it; a.status[traj] = status; }
+    if (a.sched != nullptr && threadIdx.x == 0) sched_add(a.sched, 1);      // one more trajectory of the launch finished
   }
 }
 

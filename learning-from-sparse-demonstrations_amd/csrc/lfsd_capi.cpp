@@ -92,6 +92,23 @@ struct SeedLayout {
   size_t total(size_t f64_bytes) const { return (f64_bytes + 255) / 256 * 256 + end; }
 };
 
+// ---- wide mapping with several wavefronts per trajectory (oc_solve_wide_kernel<..., W>; fp32, the models whose interval-parallel
+// phases take several rounds of one wavefront: rocket, quadrotor) ----
+// A wide launch lasts as long as its slowest trajectory (rocket learner step: median 53 iterations, slowest 160), and for most of that
+// time most SIMDs hold a finished workgroup.  A workgroup of WIDE_W wavefronts runs the two interval-parallel phases of ONE trajectory
+// (exact stage Hessians + linearisation: 53 % of a rocket iteration) on the four SIMDs of a CU; a CU holds one such workgroup (512
+// registers per wavefront, 116 KB of LDS).  So:  batch <= CUs -- every trajectory gets such a workgroup from the start;  otherwise the
+// solve is TWO launches on the stream: one wavefront per trajectory until all but `CUs` trajectories are finished (a device counter;
+// the rest park their solver state in the workspace), then the rest with WIDE_W wavefronts each.  No host read in between: the second
+// launch is enqueued unconditionally and its workgroups leave at once for finished rows.  Same arithmetic per item whoever runs it:
+// results do not depend on when a trajectory was handed over (asserted by the GPU tier: bit-identical to the one-launch solve).
+// Environment (test hooks / A-B): LFSD_WIDE_WAVES=1 one wavefront per trajectory always, =4 WIDE_W from the start at any batch;
+// LFSD_WIDE_CAPACITY=<n> in place of the CU count; LFSD_WIDE_SUSPEND_IT=<k> hand over at iteration k instead of by the counter.
+static constexpr int WIDE_W = 4;
+template <typename T> static constexpr bool wide_multi() { return sizeof(T) == 4 && !lfsd::OcLayout<Model>::HALL; }
+static int env_int(const char* name, int dflt) { const char* e = getenv(name); return (e && *e) ? atoi(e) : dflt; }
+static size_t wide_sched_offset(size_t solver_bytes) { return (solver_bytes + 255) / 256 * 256; }      // the counter behind the solver scratch
+
 // exactly what lfsd_coc_solve needs for the mapping the same arguments select (ABI 6; ABI 5 returned the larger of the two
 // layouts whatever the batch: 9.6 GB instead of 6.4 GB at 32768 quadrotor trajectories)
 LFSD_API size_t lfsd_coc_workspace_bytes(int dtype, int batch, int n_grid, int exact_after, int mapping, int bounded) {
@@ -99,7 +116,7 @@ LFSD_API size_t lfsd_coc_workspace_bytes(int dtype, int batch, int n_grid, int e
   if (mapping < LFSD_MAP_AUTO || mapping > LFSD_MAP_WIDE) return 0;
   const size_t es = dtype == LFSD_F32 ? 4 : 8;
   if (use_wide(dtype, batch, exact_after, mapping, bounded != 0))
-    return (size_t)batch * (size_t)lfsd::OcLayout<Model>::ws_elems_wide(n_grid) * es;
+    return wide_sched_offset((size_t)batch * (size_t)lfsd::OcLayout<Model>::ws_elems_wide(n_grid) * es) + 256;
   const size_t lock = (size_t)padded_batch(batch) * (size_t)lfsd::OcLayout<Model>::template ws_elems<G>(n_grid) * es;
   if (seeded_f64(dtype, batch, exact_after, mapping, bounded != 0)) return SeedLayout(batch, n_grid, 1).total(lock);
   return lock;
@@ -129,6 +146,7 @@ static int coc_solve_t(int batch, int n_grid, int steps_per_grid, const void* in
                               workspace_bytes, stream);
   }
   lfsd::OcArgs<T> a;
+  a.sched = nullptr; a.suspend_at = 0; a.suspend_it = -1;
   a.batch = batch; a.n_grid = n_grid; a.steps_per_grid = steps_per_grid; a.max_iter = max_iter;
   a.ini_state = (const T*)ini_state; a.horizon = (const T*)horizon; a.auxvar = (const T*)auxvar;
   a.consts = consts ? (const T*)consts : (const T*)horizon;      // NC_REAL == 0: any readable word, never used
@@ -145,11 +163,35 @@ static int coc_solve_t(int batch, int n_grid, int steps_per_grid, const void* in
   a.start_mode = start_mode;
   if (use_wide(sizeof(T) == 4 ? LFSD_F32 : LFSD_F64, batch, exact_after, mapping, control_lb != nullptr)) {       // bounded problems: the wide kernel at every batch size
     a.ws_stride = lfsd::OcLayout<Model>::ws_elems_wide(n_grid);
-    if (workspace_bytes < (size_t)batch * (size_t)a.ws_stride * sizeof(T)) return LFSD_ENOSPC;
+    const size_t solver_bytes = (size_t)batch * (size_t)a.ws_stride * sizeof(T);
+    if (workspace_bytes < solver_bytes) return LFSD_ENOSPC;
     a.it_start = 0; a.resume = 0; a.max_iter_total = max_iter;
+    a.sched = nullptr; a.suspend_at = 0; a.suspend_it = -1;
     if (control_lb) { LFSD_LAUNCH((lfsd::oc_solve_wide_kernel<Model, T, true, true>), (unsigned)batch, 64, stream, a); }
     else if (exact_after < 0) { LFSD_LAUNCH((lfsd::oc_solve_wide_kernel<Model, T, false>), (unsigned)batch, 64, stream, a); }
-    else { LFSD_LAUNCH((lfsd::oc_solve_wide_kernel<Model, T, true>), (unsigned)batch, 64, stream, a); }
+    else {
+      if constexpr (wide_multi<T>()) {
+        const int waves = env_int("LFSD_WIDE_WAVES", 0);
+        const int cap = std::max(1, env_int("LFSD_WIDE_CAPACITY", device_cu_count()));
+        if (waves == WIDE_W || (waves == 0 && batch <= cap)) {
+          LFSD_LAUNCH((lfsd::oc_solve_wide_kernel<Model, T, true, false, WIDE_W>), (unsigned)batch, 64 * WIDE_W, stream, a);
+          return launch_status();
+        }
+        if (waves == 0 && max_iter > 8 && workspace_bytes >= wide_sched_offset(solver_bytes) + 256) {
+          a.sched = (int*)((char*)workspace + wide_sched_offset(solver_bytes));
+          a.suspend_at = batch - cap;
+          a.suspend_it = env_int("LFSD_WIDE_SUSPEND_IT", -1);
+          LFSD_ZERO(a.sched, 256, stream);
+          LFSD_LAUNCH((lfsd::oc_solve_wide_kernel<Model, T, true>), (unsigned)batch, 64, stream, a);
+          int rc = launch_status();
+          if (rc) return rc;
+          a.resume = 2; a.sched = nullptr;
+          LFSD_LAUNCH((lfsd::oc_solve_wide_kernel<Model, T, true, false, WIDE_W>), (unsigned)batch, 64 * WIDE_W, stream, a);
+          return launch_status();
+        }
+      }
+      LFSD_LAUNCH((lfsd::oc_solve_wide_kernel<Model, T, true>), (unsigned)batch, 64, stream, a);
+    }
     return launch_status();
   }
   const size_t need = (size_t)padded_batch(batch) * (size_t)a.ws_stride * sizeof(T);

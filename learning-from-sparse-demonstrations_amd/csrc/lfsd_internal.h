@@ -15,7 +15,9 @@ static constexpr int GPB = 64 / G;
 
 #if defined(LFSD_EMU)
 #define LFSD_LAUNCH(kern, grid, block, stream, args) emu::launch(dim3(grid), dim3(block), [&] { kern(args); })
+#define LFSD_ZERO(ptr, bytes, stream) memset((ptr), 0, (bytes))
 static int launch_status() { return 0; }
+static int device_cu_count() { return 256; }
 #else
 #include <cstdio>
 #include <cstdlib>
@@ -37,7 +39,16 @@ static bool lfsd_sync_check() {
                 hipGetErrorString(e1_), hipGetErrorString(e2_));                                              \
     }                                                                                                         \
   } while (0)
+#define LFSD_ZERO(ptr, bytes, stream) (void)hipMemsetAsync((ptr), 0, (bytes), (hipStream_t)(stream))
 static int launch_status() { return (int)hipGetLastError(); }
+static int device_cu_count() {
+  static const int n = [] {
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+    return cus;
+  }();
+  return n;
+}
 #endif
 
 

@@ -760,3 +760,38 @@ def test_small_model_backward_sweep_matches_the_generic_one(kind, n_grid):
     assert float((a["state_grid"] - b["state_grid"]).abs().max() / b["state_grid"].abs().max()) < 3e-3
     assert float((a["costate_grid"] - b["costate_grid"]).abs().max() / b["costate_grid"].abs().max()) < 6e-2
     assert float(((a["cost"] - b["cost"]).abs() / b["cost"].abs()).max()) < 2e-5
+
+
+def test_wide_solve_with_several_wavefronts_and_two_launches_is_bit_identical(monkeypatch):
+    """Wide kernel, fp32, a model whose interval-parallel phases take several rounds of a wavefront (rocket: Newton from the first
+    iteration, mesh continuation with merged intervals at n_grid 40): the launch schemes of lfsd_capi.cpp's coc_solve_t -- one
+    wavefront per trajectory; four per trajectory from the start (each wavefront its own LDS region, sequential phases redundant,
+    parallel phases split, OcWide<..., W>); TWO launches with the solver state parked in the workspace in between, handed over by
+    the counter of finished trajectories (the emulator runs the workgroups one after the other: with a capacity of 2 the last two of
+    four trajectories are handed over before their first iteration) and at a fixed iteration (3: in the coarse phase; 30: later) --
+    return the same bits: states, controls, costates, cost, iteration count, status."""
+    from conftest import build_emu_library
+    oc, env, d = models.rocket(n_grid=40)
+    oc.use_library(build_emu_library(oc))
+    oc.compile()
+    oc.setDevice(dtype=torch.float32)
+    p = len(d["theta0"])
+    th = np.array(d["theta0"])[None, :] * (1 + 0.05 * np.random.default_rng(3).standard_normal((4, p)))
+    th[:, 0] = np.abs(th[:, 0]) + 0.1
+    x0 = np.tile(d["ini_state"], (4, 1))
+    keys = ("state_grid", "control_grid", "costate_grid", "cost", "iters", "status")
+    ref = None
+    for envs in (dict(LFSD_WIDE_WAVES="1"), dict(LFSD_WIDE_WAVES="4"), dict(LFSD_WIDE_CAPACITY="2"),
+                 dict(LFSD_WIDE_CAPACITY="2", LFSD_WIDE_SUSPEND_IT="3"), dict(LFSD_WIDE_CAPACITY="2", LFSD_WIDE_SUSPEND_IT="30")):
+        for k in ("LFSD_WIDE_WAVES", "LFSD_WIDE_CAPACITY", "LFSD_WIDE_SUSPEND_IT"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in envs.items():
+            monkeypatch.setenv(k, v)
+        sol = oc.cocSolverBatch(x0, d["horizon"], th)
+        assert set(sol["status"].tolist()) <= {1, 2}, (envs, sol["status"])
+        if ref is None:
+            ref = sol
+            assert int(sol["iters"].max()) > 30          # (the hand-over at iteration 30 really happens)
+        else:
+            for key in keys:
+                assert torch.equal(sol[key], ref[key]), (envs, key)
