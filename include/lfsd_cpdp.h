@@ -106,7 +106,15 @@ size_t lfsd_coc_workspace_bytes(int dtype, int batch, int n_grid, int exact_afte
  *   the fp32 solve failed on starts from its own row of u_init, or cold).  Every output and every convergence test is the fp64
  *   kernel's; iters[] counts both solves (so it may exceed max_iter, which bounds each of them); lfsd_coc_workspace_bytes
  *   includes the staging area.  LFSD_F64_SEED=0 in the environment switches the seeding off; a workspace without room for the
- *   staging area (sized while the switch was off) makes the call solve unseeded rather than fail.   */
+ *   staging area (sized while the switch was off) makes the call solve unseeded rather than fail.
+ *   Wide mapping, dtype LFSD_F32, no bounds, exact_after >= 0, models whose interval-parallel phases take several rounds of one
+ *   wavefront (more than 8 columns of [A B]: quadrotor, rocket): a trajectory may get a workgroup of FOUR wavefronts -- from the start
+ *   when batch <= the number of CUs, else in a SECOND launch on the same stream that takes over the trajectories still running once
+ *   all but one-per-CU are finished (their solver state is parked in the workspace; a device counter decides, the host reads nothing
+ *   in between; lfsd_coc_workspace_bytes includes the counters and the hand-over list).  The reference solves every seed on its own
+ *   (Examples/robotarm_random.py:60-73): a trajectory's outputs do not depend on the scheme or on the moment of the hand-over, bit
+ *   for bit.  Environment (test hooks): LFSD_WIDE_WAVES=1 never more than one wavefront per trajectory, =4 four from the start at any
+ *   batch; LFSD_WIDE_CAPACITY=<n> in place of the CU count; LFSD_WIDE_SUSPEND_IT=<k> hand over at iteration k.   */
 int lfsd_coc_solve(int dtype, int batch, int n_grid, int steps_per_grid,
                    const void* ini_state, const void* horizon, const void* auxvar,
                    const void* consts, int const_per_traj, const void* u_init,

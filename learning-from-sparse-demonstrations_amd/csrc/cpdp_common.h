@@ -527,10 +527,13 @@ LFSD_DEV double quarter_sum(double v) {
 // workgroups of a launch one after the other.
 #if defined(LFSD_EMU)
 inline int sched_load(const int* p) { return *p; }
-inline void sched_add(int* p, int v) { *p += v; }
+inline int sched_load_uniform(const int* p) { return *p; }
+inline int sched_add(int* p, int v) { const int o = *p; *p += v; return o; }
 #else
 LFSD_DEV int sched_load(int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-LFSD_DEV void sched_add(int* p, int v) { __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// ... by all lanes of a wavefront at once, the same value on every lane (no LDS hand-over, no barrier)
+LFSD_DEV int sched_load_uniform(int* p) { return __builtin_amdgcn_readfirstlane(sched_load(p)); }
+LFSD_DEV int sched_add(int* p, int v) { return __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 #endif
 
 // pin(x): the value is materialised HERE, unconditionally.  Needed where a load feeds one arm of a per-lane select

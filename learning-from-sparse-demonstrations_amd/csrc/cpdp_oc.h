@@ -2008,7 +2008,7 @@ template <class M, typename T, bool EXACT, bool BND = false, int W = 1> struct O
   static constexpr int NAL = 16;                       // step lengths 2^0 .. 2^-15
   static constexpr int NW = W, PSTRIDE = 64 * W;       // wavefronts per trajectory; stride of the item loops of the parallel phases
   int wave = 0;                                        // this wavefront's index in the workgroup
-  LFSD_DEV int pitem() const { return wave * 64 + lane; }
+  LFSD_DEV int pitem() const { return W == 1 ? lane : wave * 64 + lane; }
   using Base::lane; using Base::N; using Base::S; using Base::e; using Base::c; using Base::x0; using Base::xb; using Base::ub; using Base::xbp; using Base::ubp; using Base::Mwp;
   using Base::Mws; using Base::Hws; using Base::lds; using Base::xa; using Base::ua; using Base::lam_out; using Base::DT;
 
@@ -3321,13 +3321,13 @@ __global__ void __launch_bounds__(64 * W, 1) oc_solve_wide_kernel(OcArgs<T> a) {
   constexpr int RS = EXACT ? Lay::template lds_elems<64, (int)sizeof(T)>() : ((Lay::template lds_ex<64>() + 3) / 4) * 4;
   __shared__ __attribute__((aligned(16))) T lds_all[W * RS];
   if (blockDim.x != 64 * W) return;
-  const long long traj = blockIdx.x;
-  const bool resuming = a.resume == 2;
-  if (resuming && a.status[traj] != ST_RUNNING) return;      // (uniform per workgroup)
+  const bool resuming = W > 1 && a.resume == 2;      // (only launches with several wavefronts per trajectory take solves over)
+  if (resuming && (int)blockIdx.x >= a.sched[1]) return;      // (uniform per workgroup: the hand-over list is shorter than the grid)
+  const long long traj = resuming ? a.sched[2 + blockIdx.x] : (long long)blockIdx.x;
   poison_lds(lds_all, W * RS);
   Sol s;
-  s.lane = threadIdx.x & 63;
-  s.wave = threadIdx.x >> 6;
+  s.lane = W == 1 ? (int)threadIdx.x : (int)(threadIdx.x & 63);
+  s.wave = W == 1 ? 0 : (int)(threadIdx.x >> 6);
   oc_bind<M, T, 64>(s, a, lds_all + s.wave * RS, traj, true, traj);
   const int N = s.N;
   T* wstate;      // [WIDE_STATE] parked solver state
@@ -3469,23 +3469,6 @@ __global__ void __launch_bounds__(64 * W, 1) oc_solve_wide_kernel(OcArgs<T> a) {
   J_feas = J; J_ref = J;
   status = t_finite(J) ? ST_RUNNING : ST_FAILED;
   }
-  // The parked state: every variable above, as numbers of the solve's own type (the integers are small: exact).  `it` is where
-  // the iteration loop continues; the buffers the state refers to (both nominal buffers, linearisations, gains, cached stage
-  // Hessians, costates, gaps) already live in the workspace / the output rows.
-  auto park = [&]() LFSD_LAMBDA_INLINE {
-    if (threadIdx.x == 0) {
-      T* w = wstate;
-      const T iv[] = {T(cur), T(coarse), T(relin), T(tc), T(s.N), T(s.S), T(ms), T(ms_check), T(ms_floor), T(n_acc_need), T(n_ms), T(n_half),
-                      T(mode), T(ham_ok), T(hess_ok), T(gn_crawl), T(costates_ok), T(it), T(n_acc), T(mu_hold), T(s.gap != nullptr)};
-      const T fv[] = {g1c, g2c, gmc, J, J_feas, mu, gnorm, dV1, dV2, g_flat, g_last, dec_last, J_ref, mu_bad};
-      constexpr int NI = sizeof(iv) / sizeof(T), NF = sizeof(fv) / sizeof(T);
-      static_assert(NI + NF <= Lay::WIDE_STATE, "parked solver state");
-#pragma unroll
-      for (int i = 0; i < NI; ++i) w[i] = iv[i];
-#pragma unroll
-      for (int i = 0; i < NF; ++i) w[NI + i] = fv[i];
-    }
-  };
   if (resuming) {
     const T* w = wstate;
     int q = 0;
@@ -3494,39 +3477,36 @@ __global__ void __launch_bounds__(64 * W, 1) oc_solve_wide_kernel(OcArgs<T> a) {
     n_acc_need = gi(); n_ms = gi(); n_half = gi(); mode = gi(); ham_ok = gi() != 0; hess_ok = gi() != 0; gn_crawl = gi() != 0; costates_ok = gi() != 0;
     it = gi(); n_acc = gi(); mu_hold = gi();
     const bool has_gap = gi() != 0;
-    g1c = w[q++]; g2c = w[q++]; gmc = w[q++]; J = w[q++]; J_feas = w[q++]; mu = w[q++]; gnorm = w[q++]; dV1 = w[q++]; dV2 = w[q++];
+    g1c = w[q++]; g2c = w[q++]; gmc = w[q++]; J = w[q++]; J_feas = w[q++]; mu = w[q++];
     g_flat = w[q++]; g_last = w[q++]; dec_last = w[q++]; J_ref = w[q++]; mu_bad = w[q++];
     s.dgrid = dgrid_full * T(tc); s.DT = s.dgrid / T(s.S);
     s.gap = has_gap ? s.gapp(cur) : nullptr;
     status = ST_RUNNING;
   }
   const int mu_hold_need = LFSD_MU_HOLD;
+  bool suspended = false;
   for (; it < a.max_iter && status == ST_RUNNING; ++it) {
     if constexpr (W == 1) {
       // two-launch solves: once enough trajectories of the launch are finished for the rest to have a workgroup of several
-      // wavefronts each, the rest park their state and leave (uniform per workgroup: one load, handed round through LDS)
+      // wavefronts each, the rest park their state and leave (uniform per workgroup: every lane loads the same word, the first lane's value counts)
       if (a.sched != nullptr && !resuming) {
         bool susp;
         if (a.suspend_it >= 0) susp = it >= a.suspend_it;
-        else {
-          if (s.lane == 0) ldsRed[0] = T(sched_load(a.sched));
-          __syncthreads();
-          susp = (int)ldsRed[0] >= a.suspend_at;
-          __syncthreads();
-        }
-        if (susp) {
-          park();
-          if (threadIdx.x == 0) { a.iters[traj] = it; a.status[traj] = ST_RUNNING; }
-          return;
-        }
+        else susp = sched_load_uniform(a.sched) >= a.suspend_at;
+        if (__builtin_expect(susp, 0)) { suspended = true; break; }      // (the state is parked behind the loop: nothing of it is kept alive longer for that)
       }
     }
-    if (coarse && (relin || it + 4 >= a.max_iter)) {
+    // (... and the LAST iteration of a solve whose iterate still has gaps -- the iteration limit after sweeps that kept failing while
+    //  the gaps were to be closed -- takes the same path: what is returned is always a trajectory of the reference's discretisation,
+    //  the controls rolled out open loop with the cost and the costates of THAT trajectory, as the reference returns IPOPT's last
+    //  iterate; round 5 returned the node states of the lifted iterate beside a cost no feasible trajectory has)
+    const bool close_last = s.gap != nullptr && it + 1 >= a.max_iter;
+    if ((coarse && (relin || it + 4 >= a.max_iter)) || close_last) {
       // leave the coarse grid: the same controls rolled out (open loop) and linearised on the reference's discretisation; an
       // iteration without a sweep.  Every convergence test below only ever passes on this grid.
       // (LFSD_COARSE_MID_LEVEL: a coarse phase with merged intervals first hands over to the full control grid with ONE RK4 step per
       //  interval -- the lean kernels' coarse level -- and leaves that one by the same rules)
-      const bool to_mid = (LFSD_COARSE_MID_LEVEL) != 0 && tc > 1 && a.steps_per_grid > 1 && it + 8 < a.max_iter;
+      const bool to_mid = coarse && (LFSD_COARSE_MID_LEVEL) != 0 && tc > 1 && a.steps_per_grid > 1 && it + 8 < a.max_iter;
       coarse = to_mid; relin = false;
 #if defined(LFSD_OC_CLOCK)
       if (!to_mid) { wck_exit = clock64() - wck_t0; wck_it_exit = it; }
@@ -3704,17 +3684,25 @@ __global__ void __launch_bounds__(64 * W, 1) oc_solve_wide_kernel(OcArgs<T> a) {
     __syncthreads();
     int ia = -1, ib = -1;
     const T Jr = have_gaps ? J_feas : J;                // roll-outs that close an iterate with gaps: progress is measured from the last CLOSED trajectory
-    T Jmin = Jr, Jn = Jr, Jb = T(0), aa = T(1);
+    T Jmin = Jr, aa = T(1);
     const T flat = T(8) * epsT * t_abs(Jr);
     const bool flat_full = t_finite(ldsRed[0]) && t_abs(ldsRed[0] - Jr) <= T(64) * epsT * t_abs(Jr);
+    // (a ROLLED loop that only picks indices; the costs are read back at the indices it picked.  Round 6: fully unrolled, with the
+    //  costs carried in selects beside the indices, one build of this kernel -- rocket, fp32, one wavefront per trajectory -- adopted
+    //  the right roll-out and kept the OLD cost whenever a step shorter than the full one was taken: sixteen uniform conditions held
+    //  in SGPR pairs that were spilled to VGPR lanes around the select chain.  The same source with a printf in it, with another
+    //  scheduler or with an empty asm statement elsewhere in the kernel did not show it (profiles/r06_f_wide_stale_cost.txt); the GPU
+    //  tier now solves the rocket under every launch scheme and compares bit for bit.)
+#pragma unroll 1
     for (int l = 0; l < NAL; ++l) {
       const T Jl = ldsRed[l];
       const T expected = have_gaps ? T(0) : -(aa * dV1 + aa * aa * dV2);
       const bool okl = t_finite(Jl) && ((Jr - Jl) >= T(1e-4) * expected - flat) && (Jl < Jr);
-      if (okl && ia < 0) { ia = l; Jn = Jl; }
-      if (t_finite(Jl)) { Jmin = t_min(Jmin, Jl); if (ib < 0 || Jl < Jb) { ib = l; Jb = Jl; } }
+      if (okl && ia < 0) ia = l;
+      if (t_finite(Jl)) { Jmin = t_min(Jmin, Jl); if (ib < 0 || Jl < ldsRed[ib]) ib = l; }
       aa *= T(0.5);
     }
+    T Jn = (ia >= 0) ? ldsRed[ia] : Jr, Jb = (ib >= 0) ? ldsRed[ib] : T(0);
     __syncthreads();
     if (have_gaps && ia >= 0) { ia = ib; Jn = Jb; }     // (closing an iterate: the cheapest of the roll-outs below the last closed cost, not the longest)
     bool accept = ia >= 0;
@@ -3775,6 +3763,27 @@ __global__ void __launch_bounds__(64 * W, 1) oc_solve_wide_kernel(OcArgs<T> a) {
       }
     }
   }
+  // The parked state: every variable above, as numbers of the solve's own type (the integers are small: exact).  `it` is where
+  // the iteration loop continues; the buffers the state refers to (both nominal buffers, linearisations, gains, cached stage
+  // Hessians, costates, gaps) already live in the workspace / the output rows.
+  if (__builtin_expect(suspended, 0)) {
+    if (threadIdx.x == 0) {
+      T* w = wstate;
+      const T iv[] = {T(cur), T(coarse), T(relin), T(tc), T(s.N), T(s.S), T(ms), T(ms_check), T(ms_floor), T(n_acc_need), T(n_ms), T(n_half),
+                      T(mode), T(ham_ok), T(hess_ok), T(gn_crawl), T(costates_ok), T(it), T(n_acc), T(mu_hold), T(s.gap != nullptr)};
+      const T fv[] = {g1c, g2c, gmc, J, J_feas, mu, g_flat, g_last, dec_last, J_ref, mu_bad};      // (gnorm, dV1, dV2: outputs of the sweep every iteration starts with)
+      constexpr int NI = sizeof(iv) / sizeof(T), NF = sizeof(fv) / sizeof(T);
+      static_assert(NI + NF <= Lay::WIDE_STATE, "parked solver state");
+#pragma unroll
+      for (int i = 0; i < NI; ++i) w[i] = iv[i];
+#pragma unroll
+      for (int i = 0; i < NF; ++i) w[NI + i] = fv[i];
+      a.iters[traj] = it; a.status[traj] = ST_RUNNING;
+      // the hand-over list of the launch: the next launch runs one workgroup per entry (sched[1] counts them)
+      a.sched[2 + sched_add(a.sched + 1, 1)] = (int)traj;
+    }
+    return;
+  }
   if (status == ST_RUNNING) status = ST_MAXITER;
 #if defined(LFSD_MS_STATS)      // development aid (tools/ms_dev.py): iterations and multiple-shooting steps per trajectory
   if (threadIdx.x == 0) printf("msstat %d %d %d\n", (int)blockIdx.x, it, n_ms);
@@ -3788,21 +3797,6 @@ __global__ void __launch_bounds__(64 * W, 1) oc_solve_wide_kernel(OcArgs<T> a) {
            (int)blockIdx.x, it, n_ms, clock64() - wck_t0, wck[0], wck[1], wck[2], wck[3], wck[4], wck[5], wck[6], wck_it_exit, wck_exit);
 #endif
 #undef LFSD_WCK
-  if (s.gap != nullptr) {
-    // the loop was left on an iterate of the lifted problem that still has gaps (iteration limit, or a failure while closing it): its
-    // node states are not the roll-out of its controls.  What is returned is always a trajectory of the reference's discretisation:
-    // the controls rolled out open loop, cost and costates of THAT trajectory (the reference returns IPOPT's last iterate as well)
-    const T Jr = s.rollout_alphas(cur, false, alpha_l);
-    ldsRed[s.lane] = Jr;
-    __syncthreads();
-    J = ldsRed[0];
-    __syncthreads();
-    s.adopt_alpha(0, cur ^ 1);
-    s.linearise_parallel(cur ^ 1);
-    cur ^= 1;
-    s.gap = nullptr; costates_ok = false;
-    if (!t_finite(J)) status = ST_FAILED;
-  }
   if (!costates_ok) s.costate_sweep(cur);                 // costates of the final nominal
   __syncthreads();
   {

@@ -107,7 +107,8 @@ struct SeedLayout {
 static constexpr int WIDE_W = 4;
 template <typename T> static constexpr bool wide_multi() { return sizeof(T) == 4 && !lfsd::OcLayout<Model>::HALL; }
 static int env_int(const char* name, int dflt) { const char* e = getenv(name); return (e && *e) ? atoi(e) : dflt; }
-static size_t wide_sched_offset(size_t solver_bytes) { return (solver_bytes + 255) / 256 * 256; }      // the counter behind the solver scratch
+static size_t wide_sched_offset(size_t solver_bytes) { return (solver_bytes + 255) / 256 * 256; }      // the counters + hand-over list behind the solver scratch
+static size_t wide_sched_bytes(int batch) { return ((size_t)(2 + batch) * sizeof(int) + 255) / 256 * 256; }
 
 // exactly what lfsd_coc_solve needs for the mapping the same arguments select (ABI 6; ABI 5 returned the larger of the two
 // layouts whatever the batch: 9.6 GB instead of 6.4 GB at 32768 quadrotor trajectories)
@@ -116,7 +117,7 @@ LFSD_API size_t lfsd_coc_workspace_bytes(int dtype, int batch, int n_grid, int e
   if (mapping < LFSD_MAP_AUTO || mapping > LFSD_MAP_WIDE) return 0;
   const size_t es = dtype == LFSD_F32 ? 4 : 8;
   if (use_wide(dtype, batch, exact_after, mapping, bounded != 0))
-    return wide_sched_offset((size_t)batch * (size_t)lfsd::OcLayout<Model>::ws_elems_wide(n_grid) * es) + 256;
+    return wide_sched_offset((size_t)batch * (size_t)lfsd::OcLayout<Model>::ws_elems_wide(n_grid) * es) + wide_sched_bytes(batch);
   const size_t lock = (size_t)padded_batch(batch) * (size_t)lfsd::OcLayout<Model>::template ws_elems<G>(n_grid) * es;
   if (seeded_f64(dtype, batch, exact_after, mapping, bounded != 0)) return SeedLayout(batch, n_grid, 1).total(lock);
   return lock;
@@ -177,16 +178,17 @@ static int coc_solve_t(int batch, int n_grid, int steps_per_grid, const void* in
           LFSD_LAUNCH((lfsd::oc_solve_wide_kernel<Model, T, true, false, WIDE_W>), (unsigned)batch, 64 * WIDE_W, stream, a);
           return launch_status();
         }
-        if (waves == 0 && max_iter > 8 && workspace_bytes >= wide_sched_offset(solver_bytes) + 256) {
+        if (waves == 0 && max_iter > 8 && workspace_bytes >= wide_sched_offset(solver_bytes) + wide_sched_bytes(batch)) {
           a.sched = (int*)((char*)workspace + wide_sched_offset(solver_bytes));
           a.suspend_at = batch - cap;
           a.suspend_it = env_int("LFSD_WIDE_SUSPEND_IT", -1);
-          LFSD_ZERO(a.sched, 256, stream);
+          LFSD_ZERO(a.sched, 2 * sizeof(int), stream);
           LFSD_LAUNCH((lfsd::oc_solve_wide_kernel<Model, T, true>), (unsigned)batch, 64, stream, a);
           int rc = launch_status();
           if (rc) return rc;
-          a.resume = 2; a.sched = nullptr;
-          LFSD_LAUNCH((lfsd::oc_solve_wide_kernel<Model, T, true, false, WIDE_W>), (unsigned)batch, 64 * WIDE_W, stream, a);
+          // (by the counter at most `cap` trajectories are handed over: all but suspend_at = batch - cap were finished; the test hook may hand over all)
+          a.resume = 2;
+          LFSD_LAUNCH((lfsd::oc_solve_wide_kernel<Model, T, true, false, WIDE_W>), (unsigned)(a.suspend_it >= 0 ? batch : cap), 64 * WIDE_W, stream, a);
           return launch_status();
         }
       }

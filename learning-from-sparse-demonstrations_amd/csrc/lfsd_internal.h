@@ -52,13 +52,13 @@ static int device_cu_count() {
 #endif
 
 
-// Compiler settings are chosen per kernel (profiles/r01_tune_compiler_flags.txt).  clang's SLP vectoriser pairs scalar fp32
-// operations into v_pk_* instructions at the price of adjacent-register constraints: every kernel of this library is
-// faster without it (oc_solve 11.4 -> 8.2 ms, aux_forward 3.35 -> 2.97 ms; the Riccati sweep, the one kernel that gained
-// from it at one wave per SIMD, needs so few registers without it that it runs two waves per SIMD: 8.5 -> 7.1 ms).  The
-// max-ILP instruction scheduler takes another 5 % off oc_solve but costs the Riccati sweep 25 %, so the product build
-// (runtime.hipcc_commands, -DLFSD_SPLIT_RICCATI) compiles the Riccati sweep in its own translation unit; single-unit builds
-// (emulator, sanitizer, tuning tools) include the launcher below instead.
+// Compiler settings per kernel (profiles/r01_tune_compiler_flags.txt).  clang's SLP vectoriser pairs scalar fp32 operations into
+// v_pk_* instructions at the price of adjacent-register constraints: every kernel of this library is faster without it (oc_solve
+// 11.4 -> 8.2 ms, aux_forward 3.35 -> 2.97 ms; the Riccati sweep needs so few registers without it that it runs two waves per
+// SIMD: 8.5 -> 7.1 ms).  The Riccati sweep keeps its own translation unit (runtime.hipcc_commands, -DLFSD_SPLIT_RICCATI): rounds
+// 1-5 compiled everything else with the max-ILP instruction scheduler, which cost the Riccati sweep 25 %; round 6 dropped that
+// scheduler (two wrong builds of the wide OC kernel under it, no gain left: runtime.py, profiles/r06_f_wide_stale_cost.txt).
+// Single-unit builds (emulator, sanitizer, tuning tools) include the launcher below instead.
 namespace lfsd_detail {
 int launch_riccati_f32(unsigned grid, void* stream, const lfsd::AuxArgs<float>& a);
 int launch_riccati_f64(unsigned grid, void* stream, const lfsd::AuxArgs<double>& a);

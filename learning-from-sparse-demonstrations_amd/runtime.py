@@ -85,9 +85,13 @@ def hipcc_command(spec, out, extra=()):
     return _hipcc_flags(spec, extra) + ["-shared", os.path.join(CSRC_DIR, "lfsd_capi.cpp"), "-o", out]
 
 
-# measured per translation unit (profiles/r01_tune_compiler_flags.txt): max-ILP scheduling takes 5 % off oc_solve but
-# costs the Riccati sweep 25 %, which is why the latter keeps its own unit with the default scheduler
-TUNED_CAPI = ("-mllvm", "-amdgpu-sched-strategy=max-ilp")
+# Per translation unit.  Rounds 1-5 compiled the first unit with `-mllvm -amdgpu-sched-strategy=max-ilp` (round 1: 5 % off oc_solve;
+# the Riccati sweep lost 25 % with it, hence its own unit).  Round 6 dropped it: two builds of the wide OC kernel were WRONG under
+# that scheduler and right under the default one with the same source -- a stale cost in the rocket's fp32 kernel and a memory
+# fault in the robot arm's bounded fp64 kernel, both in code dominated by SGPR spills to VGPR lanes
+# (profiles/r06_f_wide_stale_cost.txt) -- and it no longer pays: headline 966 300 -> 966 700 it/s, rocket step 40.8 -> 38.8 ms,
+# robot arm 15.31 -> 15.41 ms, fp64 headline 13.5 -> 13.9 ms (profiles/r06_i_max_ilp_ab.txt).
+TUNED_CAPI = ()
 TUNED_RICCATI = ()
 
 

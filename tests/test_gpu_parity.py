@@ -564,8 +564,17 @@ def test_robotarm_theta1_vs_oracle_16_seeds():
     oc32, _ = gpu_model("robotarm", torch.float32, 50, substeps=8)
     sol32 = oc32.cocSolverBatch(x0[pick], d["horizon"], th1[pick])
     aux32 = oc32.auxSysSolverBatch(sol32, d["taus"], d["waypoints"], d["interface"])
+    # A/B of the SAME seeds on the build with every schedule off (single shooting, no coarse levels: `plain`): the fp32 bounds below
+    # are anchored to what that build measures on the same seeds, so a tolerance cannot simply follow the product any more
+    from conftest import build_variant_library, PLAIN_SCHEDULE
+    ocp, _ = gpu_model("robotarm", torch.float32, 50, substeps=8)
+    ocp.use_library(build_variant_library(ocp, "plain", PLAIN_SCHEDULE))
+    ocp.setDevice("cuda:0", torch.float32)
+    assert not ocp.compile().is_emulator
+    solp = ocp.cocSolverBatch(x0[pick], d["horizon"], th1[pick])
+    auxp = ocp.auxSysSolverBatch(solp, d["taus"], d["waypoints"], d["interface"])
     compared = 0
-    large_err = []
+    large_err, large_err_plain, typ_err, typ_err_plain = [], [], [], []
     for k, b in enumerate(pick):
         r = refs[k]
         if "error" in r:
@@ -581,24 +590,35 @@ def test_robotarm_theta1_vs_oracle_16_seeds():
         # conjugate point, where fp32 round-off of the solve itself moves the gradient by tens of percent
         typical = np.abs(r["grad"]).max() < 3 * np.median(gmax)
         e32 = rel(aux32["grad"][k], r["grad"])
+        e32p = rel(auxp["grad"][k], r["grad"])
+        what = "robot arm theta1 seed %d fp32 vs oracle (%s sensitivity)" % (b, "typical" if typical else "large")
+        parity_record(what + ", PLAIN build", "grad", e32p, float("inf"))      # (recorded, not asserted: the yardstick)
         if typical:
-            parity_record("robot arm theta1 seed %d fp32 vs oracle (typical sensitivity)" % b, "grad", e32, 2e-2)      # per seed: where the fp32 solve stops inside its tolerance decides (seed 889: 4.1e-4 and 6.2e-3 on two builds whose
-                # populations agree -- median 1.9e-4, 95th percentile 2.7e-3 / 3.6e-3 over the 1 024 seeds, asserted in test_robotarm_batch1024_random_seeds_configs1)
+            # round 4's bound, 5e-3 -- or, for a seed on which the plain build itself is above it, twice what the plain build measures
+            # (where the fp32 solve stops inside its tolerance decides: seed 889 measured 4.1e-4 and 6.2e-3 on two builds whose populations agree)
+            parity_record(what, "grad", e32, max(5e-3, 2 * e32p))
+            typ_err.append(e32); typ_err_plain.append(e32p)
         else:
-            # next to a conjugate point the fp32 gradient is a property of the rounding, not of the kernel: the SAME seed measured
-            # 0.27 (round 3), 0.45 and 0.66 (round 4, after sin / cos changed by an ulp) against a bound of 0.7.  Asserted per
-            # seed a finite cap of 5 (round 5: one such seed measured 2.5 on the multiple-shooting path, the same seeds 0.27 - 0.66 in
-            # rounds 3 / 4: the figure moves by its own size with any change of the fp32 path); the class is asserted through its
-            # median and its 70th percentile (below)
-            parity_record("robot arm theta1 seed %d fp32 vs oracle (large sensitivity)" % b, "grad", e32, 5.0)
-            large_err.append(e32)
+            # next to a conjugate point the fp32 gradient is a property of the rounding, not of the kernel: the SAME seed measured 0.27
+            # (round 3), 0.45 and 0.66 (round 4), 2.5 - 3.5 (round 5) -- the figure moves by its own size with any change of the fp32 path.
+            # Per seed: finite; the class is asserted below, against round 4's bounds AND against the plain build on the same seeds
+            assert np.isfinite(e32), (b, e32)
+            parity_record(what, "grad", e32, max(5.0, 2 * e32p))
+            large_err.append(e32); large_err_plain.append(e32p)
     assert compared >= 16, compared
     assert len(large_err) >= 6
-    # measured (profiles/r04_final_parity_floors.jsonl): 0.0 0.0 0.001 0.004 0.013 0.016 0.039 0.14 0.15 0.66
-    parity_record("robot arm theta1 fp32 vs oracle, large-sensitivity seeds", "median gradient error", float(np.median(large_err)), 0.1)
-    # (round 5, small-model backward sweep: 0.0002 0.0003 0.001 0.002 0.002 0.003 0.01 0.16 3.1 3.5 -- the median went 0.015 -> 0.0025, two
-    #  seeds instead of one landed beyond 1, and an 80th percentile of ten samples is the ninth of them: asserted on the 70th)
-    parity_record("robot arm theta1 fp32 vs oracle, large-sensitivity seeds", "70th percentile gradient error", float(np.quantile(large_err, 0.7)), 0.7)
+    # the product's class figures may not be worse than the plain build's on the same seeds by more than 2x, nor than round 4's bounds
+    # (measured in round 4, profiles/r04_final_parity_floors.jsonl: 0.0 0.0 0.001 0.004 0.013 0.016 0.039 0.14 0.15 0.66)
+    for name, q, floor in (("median", 0.5, 0.1), ("80th percentile", 0.8, 0.7)):
+        mine, ref_ = float(np.quantile(large_err, q)), float(np.quantile(large_err_plain, q))
+        parity_record("robot arm theta1 fp32 vs oracle, large-sensitivity seeds, PLAIN build", name + " gradient error", ref_, float("inf"))
+        parity_record("robot arm theta1 fp32 vs oracle, large-sensitivity seeds", name + " gradient error", mine, max(floor, 2 * ref_))
+    # ... and a FIXED count: at most one seed of the class beyond 1 more than the plain build has
+    n_mine, n_ref = int((np.array(large_err) > 1).sum()), int((np.array(large_err_plain) > 1).sum())
+    assert n_mine <= n_ref + 1, (n_mine, n_ref, sorted(large_err), sorted(large_err_plain))
+    if typ_err:
+        parity_record("robot arm theta1 fp32 vs oracle, typical seeds", "median gradient error", float(np.median(typ_err)),
+                      max(1e-3, 2 * float(np.median(typ_err_plain))))
 
 
 def test_robotarm_12_vanilla_steps_every_gradient_applied():
@@ -631,10 +651,11 @@ def test_robotarm_12_vanilla_steps_every_gradient_applied():
         J = L._sol["cost"].double().cpu().numpy()
         bad = ~np.isin(st, (1, 2))                     # every solve that did not converge (all of them excluded above) ...
         blown = ~np.isfinite(th).all(1) | (np.abs(th) >= 1e3).any(1)
-        # (round 5: how far a diverging cost gets within the iteration limit depends on the path -- with the multiple-shooting steps
-        #  one such row stood at -45.7 when its 120 iterations were spent; the bound between the two populations is now -42 / -40)
-        assert (blown[bad] | ~np.isfinite(J[bad]) | (J[bad] < -42.0)).all(), (k, J[bad], st[bad])      # ... is a cost running away
-        assert J[adm].min() > -40.0, (k, J[adm].min())
+        # (round 5 moved the bound between the two populations with the product, -50 -> -42 / -40: how far a diverging cost gets within
+        #  the iteration limit depends on the path.  Round 6: no constant of the product's -- every solve that did not converge has a
+        #  cost BELOW every admissible seed's of the same step (or blown-up parameters), and the admissible ones stay above round 4's -50)
+        assert (blown[bad] | ~np.isfinite(J[bad]) | (J[bad] < J[adm].min())).all(), (k, J[bad], st[bad], J[adm].min())      # ... is a cost running away
+        assert J[adm].min() > -50.0, (k, J[adm].min())
 
 
 
@@ -906,3 +927,43 @@ def test_fp64_solve_seeded_by_fp32_reaches_the_same_kkt_point():
     """lfsd_coc_solve in fp64 (lock-step mapping, quadrotor class) runs the fp32 lean kernel first and starts the fp64 kernel from
     its controls: same KKT point as the fp64 kernel from the cold start, a row the fp32 solve overflows on is started cold."""
     pc.seeded_f64_same_kkt_point(gpu_prepare, n_grid=50, batch=70)
+
+
+@pytest.mark.parametrize("kind,n_grid", [("rocket", 100), ("quadrotor", 50)])
+def test_wide_launch_schemes_bit_identical(kind, n_grid, monkeypatch):
+    """The wide OC solve under every launch scheme of lfsd_capi.cpp's coc_solve_t, 1 024 seeds, fp32: one wavefront per trajectory;
+    four per trajectory from the start; TWO launches -- the solver state parks in the workspace once all but one-CU-each
+    trajectories are finished (a device counter, no host read) and the tail resumes with four wavefronts per trajectory -- handed
+    over by the counter and at fixed iterations (3: inside the coarse phase, 10, 37).  Every output must be the same bits: an item of
+    an interval-parallel phase is computed by the same code whoever runs it, so a trajectory's result may not depend on when it
+    was handed over (nor on its partners: duplicated seeds included).  Rocket = BASELINE configs[4]'s per-GPU shard (Newton from the
+    first iteration, mesh continuation with merged intervals); quadrotor on the wide mapping runs the multiple-shooting steps.
+    Also the guard of profiles/r06_f_wide_stale_cost.txt: a build whose one-wavefront kernel kept a stale cost differed here."""
+    oc, d = gpu_model(kind, torch.float32, n_grid, substeps=4)
+    if kind == "quadrotor":
+        oc.setSolverOptions(mapping="wide")
+    B = 1024
+    p = len(d["theta0"])
+    rng = np.random.default_rng(0)
+    th = np.array(d["theta0"])[None, :] * (1 + 0.05 * rng.standard_normal((B, p)))
+    th[:, 0] = np.abs(th[:, 0]) + 0.1
+    th[B // 2:] = th[:B // 2]
+    x0 = np.tile(d["ini_state"], (B, 1))
+    keys = ("state_grid", "control_grid", "costate_grid", "cost", "iters", "status")
+    ref = None
+    for envs in (dict(LFSD_WIDE_WAVES="1"), dict(LFSD_WIDE_WAVES="4"), dict(), dict(LFSD_WIDE_SUSPEND_IT="3"),
+                 dict(LFSD_WIDE_SUSPEND_IT="10"), dict(LFSD_WIDE_SUSPEND_IT="37")):
+        for k in ("LFSD_WIDE_WAVES", "LFSD_WIDE_CAPACITY", "LFSD_WIDE_SUSPEND_IT"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in envs.items():
+            monkeypatch.setenv(k, v)
+        sol = oc.cocSolverBatch(x0, d["horizon"], th)
+        st = sol["status"].cpu().numpy()
+        assert np.isin(st, (1, 2)).all(), (envs, np.bincount(st, minlength=5))
+        if ref is None:
+            ref = sol
+            h = B // 2
+            assert torch.equal(sol["state_grid"][:h], sol["state_grid"][h:]) and torch.equal(sol["iters"][:h], sol["iters"][h:])
+        else:
+            for key in keys:
+                assert torch.equal(sol[key], ref[key]), (envs, key, int((sol[key] != ref[key]).sum()))

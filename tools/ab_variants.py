@@ -25,6 +25,8 @@ VARIANTS = {
     "slp": ((), None, True),
     "nomfma": (("-DLFSD_MFMA_BACKWARD=0",), None, False),
     "nostruct": (("-DLFSD_STRUCT_COLS=0",), None, False),
+    # round 6 (verdict item 4): the OC kernels held to 256 registers, two wavefronts per SIMD
+    "waves2": (("-DLFSD_WAVES_OC=2",), None, False),
 }
 
 
