@@ -86,7 +86,9 @@ template <class M, int LAY = 0> struct AuxLayout {
   // Riccati kernel only: one parking slot per lane for a column of Z (row i of lane l at [i*G + l]): of the unit's start value and
   // the coarse Richardson result only one has to be in registers at a time
   template <int G> static constexpr int ric_park() { return LDS_END; }
-  template <int G> static constexpr int lds_elems_ric() { return ((ric_park<G>() + NX * G + 3) / 4) * 4; }
+  // ... and a second one: the start value of a STEP of the step-size control inside a stiff interval (aux_riccati_kernel, "adaptive")
+  template <int G> static constexpr int ric_park2() { return ric_park<G>() + NX * G; }
+  template <int G> static constexpr int lds_elems_ric() { return ((ric_park2<G>() + NX * G + 3) / 4) * 4; }
 };
 
 // Lanes per trajectory of the forward sweep.  Only the NP columns of X = dx/dtheta advance there; the NX columns of P are
@@ -674,6 +676,80 @@ __global__ void __launch_bounds__(64, (sizeof(T) == 4 ? LFSD_WAVES_RIC : 1)) aux
     if (units < units_hint) units = (int)t_min((long long)units_hint, units_cap);
     T ratio_prev = T(-1);
     bool staged = (units == units_guess);
+    // Step-size control INSIDE a stiff interval (round 6).  The uniform refinement below sizes every unit of an interval for its
+    // stiffest point.  The interval before a heavy final cost is a transient: P starts at h_xx and decays like 1 / (1/P_0 + R tau) --
+    // on the robot arm dgrid x rate falls from 2 000 to 1 inside that one interval, which took 500 of the sweep's 565 units (and
+    // 2.6 ms of a 15 ms learner step).  From LFSD_RIC_ADAPT units up the interval is integrated with steps of its own: every step is a
+    // Richardson pair as before, judged on ITS estimate against the same tolerances; a refused step is redone from its parked start
+    // value with half the length; after a step whose estimate leaves an 8-fold margin the length doubles when the stiffness at the
+    // NEW position allows it (dt x rate <= rate_max, evaluated on the coefficients the step has just staged at its far node).
+    // Positions are integers on the interval's finest admissible grid (units_cap ticks), steps powers of two: the last step lands on
+    // the grid node exactly.  Quiet intervals (the headline's 1-4 units) keep the uniform path, bit for bit.
+    if (a.rtol > T(0) && units >= (LFSD_RIC_ADAPT) && units_cap % units == 0) {
+      const int R = (int)units_cap;
+      int stp = R / units, pos = R;
+      bool unmet = false;
+      T* zpark = s.lds + Lay::template ric_park<G>();
+      T* zstart = s.lds + Lay::template ric_park2<G>();
+      while (pos > 0) {
+        const T f = T(stp) / T(R), s_hi = T(pos) / T(R);
+        if (!(staged && pos == R && stp * units_guess == R)) s.stage_nodes(s_hi, -f * T(0.25));
+        staged = false;
+        const T hc = s.dgrid * f;
+#pragma unroll
+        for (int i = 0; i < NX; ++i) { zpark[i * G + lane] = z[i]; zstart[i * G + lane] = z[i]; }
+        s.ric_strang(z, 0, 2, 4, hc);
+#pragma unroll
+        for (int i = 0; i < NX; ++i) { const T z0 = zpark[i * G + lane]; zpark[i * G + lane] = z[i]; z[i] = z0; }
+        s.ric_strang2(z, hc);
+        T err_l = T(0), scl_l = T(0);
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+          const T zc = zpark[i * G + lane];
+          err_l = t_max(err_l, t_abs(z[i] - zc));
+          z[i] = (T(4) * z[i] - zc) * (T(1) / T(3));
+          scl_l = t_max(scl_l, t_abs(z[i]));
+        }
+        ++n_units;
+        ldsT[lane] = err_l; ldsT[G + lane] = scl_l;
+        LFSD_WAVE_SYNC();
+        T eP = T(0), sP = T(0), eW = T(0), sW = T(0);
+        for (int l = 0; l < NZ; ++l) {
+          if (l < NX) { eP = t_max(eP, ldsT[l]); sP = t_max(sP, ldsT[G + l]); }
+          else { eW = t_max(eW, ldsT[l]); sW = t_max(sW, ldsT[G + l]); }
+        }
+        LFSD_WAVE_SYNC();
+        const T tolP = T(3) * a.rtol * sP, tolW = T(3) * a.rtol * (sW + T(1e-3) * sP);
+        const bool fine_enough = (eP <= tolP && eW <= tolW) || !(t_finite(eP) && t_finite(eW));
+        const T ratio = t_max(eP / t_max(tolP, T(1e-30)), eW / t_max(tolW, T(1e-30)));
+        const bool no_gain = ratio_prev >= T(0) && ratio > T(0.5) * ratio_prev;      // (the halved step did not halve the estimate: next to a conjugate point)
+#if defined(LFSD_AUX_TRACE)
+        if (lane == 0 && slot < LFSD_AUX_TRACE) printf("ric traj %d k %d adaptive pos %d / %d step %d ratio %.3e\n", (int)slot, k, pos, R, stp, (double)ratio);
+#endif
+        if (fine_enough || no_gain || stp == 1 || !valid) {
+          if (!fine_enough) unmet = true;
+          pos -= stp;
+          ratio_prev = T(-1);
+          // (margin of the estimate before a step may grow: fp32 the 8-fold one of the uniform path -- its rounding floor, 1e-5, hides
+          //  the rest --; fp64 1024-fold: steps sized for the LOCAL stiffness each contribute what only the stiffest units of a uniform
+          //  interval did, and the fp64 parity floors ([P W] 1e-7 against the tight oracle) were set on that over-delivery: measured
+          //  6.1e-7 with 8, 7.0e-8 with 256, robot arm n_grid 30; units per trajectory 565 -> 100 / 140: profiles/r06_n_*)
+          constexpr int MARGIN = sizeof(T) == 4 ? (LFSD_AUX_DOWN) : 1024;
+          if (pos > 0 && eP * T(MARGIN) <= tolP && eW * T(MARGIN) <= tolW && pos % (2 * stp) == 0 && (long long)2 * stp * Sa <= R) {
+            // (the stiffness where the NEXT step starts: node 4 of this step's staging sits exactly there)
+            const int need = s.units_for(s.stiff_rate(z, s.node(4)), Sa, a.rate_max, refine_k);
+            if ((long long)need * 2 * stp <= R) stp *= 2;
+          }
+        } else {
+          ratio_prev = ratio;
+          stp /= 2;
+#pragma unroll
+          for (int i = 0; i < NX; ++i) z[i] = zstart[i * G + lane];
+        }
+      }
+      if (unmet) ++n_unmet;
+      units_hint = (int)t_max((long long)Sa, (long long)(R / stp));      // the next interval starts with the step this one ended on
+    } else
     // Error-controlled sub-stepping (a.rtol > 0): the Richardson pair gives |fine - coarse| / 3 as an estimate of the
     // second-order error that the extrapolation removes; while it exceeds rtol relative to the column's size the interval
     // is redone from its stored start value Z(t_k+1) with twice the units.  (solve_ivp's rtol of the reference, CPDP.py:335,

@@ -58,6 +58,11 @@
 #ifndef LFSD_AUX_DOWN
 #define LFSD_AUX_DOWN 8
 #endif
+// Riccati sweep: intervals that need at least this many uniform units are integrated with step-size control inside the interval
+// (cpdp_aux.h, aux_riccati_kernel); a very large value switches it off
+#ifndef LFSD_RIC_ADAPT
+#define LFSD_RIC_ADAPT 16
+#endif
 // outer per-node loops of the once-per-unit preparation (ric_cols; fwd_prep, fwd_cols): rolled.  Measured: 6 % faster in
 // the Riccati sweep; the forward sweep preferred them unrolled (7 %) until it was compiled with the max-ILP scheduler,
 // since then rolled is 5 % faster there too (profiles/r01_tune_aux_occupancy.txt, r01_tune_compiler_flags.txt)
