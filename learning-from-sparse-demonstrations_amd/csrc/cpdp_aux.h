@@ -87,8 +87,12 @@ template <class M, int LAY = 0> struct AuxLayout {
   // the coarse Richardson result only one has to be in registers at a time
   template <int G> static constexpr int ric_park() { return LDS_END; }
   // ... and a second one: the start value of a STEP of the step-size control inside a stiff interval (aux_riccati_kernel, "adaptive")
+  // (compiled into the fp32 instantiations with lane groups of at most 16 lanes -- pendulum, robot arm, cart-pole: the small models,
+  //  whose sweeps have registers to spare; the 32-lane sweeps of the quadrotor / rocket run two waves per SIMD at 252 registers, spilled
+  //  60 B per lane with it (headline aux_riccati 1.50 -> 1.545 ms) and stay exactly what they were)
+  template <int G> static constexpr bool ric_adaptive() { return G <= 16; }
   template <int G> static constexpr int ric_park2() { return ric_park<G>() + NX * G; }
-  template <int G> static constexpr int lds_elems_ric() { return ((ric_park2<G>() + NX * G + 3) / 4) * 4; }
+  template <int G> static constexpr int lds_elems_ric() { return ((ric_park2<G>() + (ric_adaptive<G>() ? NX * G : 0) + 3) / 4) * 4; }
 };
 
 // Lanes per trajectory of the forward sweep.  Only the NP columns of X = dx/dtheta advance there; the NX columns of P are
@@ -685,7 +689,12 @@ __global__ void __launch_bounds__(64, (sizeof(T) == 4 ? LFSD_WAVES_RIC : 1)) aux
     // NEW position allows it (dt x rate <= rate_max, evaluated on the coefficients the step has just staged at its far node).
     // Positions are integers on the interval's finest admissible grid (units_cap ticks), steps powers of two: the last step lands on
     // the grid node exactly.  Quiet intervals (the headline's 1-4 units) keep the uniform path, bit for bit.
+    // fp32 only: the fp64 sweep is the parity reference; its uniform intervals over-deliver by orders (steps sized for the stiffest point
+    // everywhere), its floors against the tight oracle were set on that, and it stays bit for bit what it was.
+    bool adaptive_done = false;
+    if constexpr (sizeof(T) == 4 && Lay::template ric_adaptive<G>()) {
     if (a.rtol > T(0) && units >= (LFSD_RIC_ADAPT) && units_cap % units == 0) {
+      adaptive_done = true;
       const int R = (int)units_cap;
       int stp = R / units, pos = R;
       bool unmet = false;
@@ -730,11 +739,11 @@ __global__ void __launch_bounds__(64, (sizeof(T) == 4 ? LFSD_WAVES_RIC : 1)) aux
           if (!fine_enough) unmet = true;
           pos -= stp;
           ratio_prev = T(-1);
-          // (margin of the estimate before a step may grow: fp32 the 8-fold one of the uniform path -- its rounding floor, 1e-5, hides
-          //  the rest --; fp64 1024-fold: steps sized for the LOCAL stiffness each contribute what only the stiffest units of a uniform
-          //  interval did, and the fp64 parity floors ([P W] 1e-7 against the tight oracle) were set on that over-delivery: measured
-          //  6.1e-7 with 8, 7.0e-8 with 256, robot arm n_grid 30; units per trajectory 565 -> 100 / 140: profiles/r06_n_*)
-          constexpr int MARGIN = sizeof(T) == 4 ? (LFSD_AUX_DOWN) : 1024;
+          // (the margin of the estimate before a step may grow is the uniform path's before it halves the next interval's units.  Steps
+          //  sized for the LOCAL stiffness each contribute what only the stiffest units of a uniform interval did: measured in fp64 -- robot
+          //  arm n_grid 30, [P W] against the tight oracle -- 1e-8 uniform, 6.1e-7 with this margin, 7.0e-8 with a 256-fold one; in fp32
+          //  the rounding floor of the sweep, 1e-5, hides the difference: [P W] 2.4e-6 / 8.7e-6 either way)
+          constexpr int MARGIN = LFSD_AUX_DOWN;
           if (pos > 0 && eP * T(MARGIN) <= tolP && eW * T(MARGIN) <= tolW && pos % (2 * stp) == 0 && (long long)2 * stp * Sa <= R) {
             // (the stiffness where the NEXT step starts: node 4 of this step's staging sits exactly there)
             const int need = s.units_for(s.stiff_rate(z, s.node(4)), Sa, a.rate_max, refine_k);
@@ -749,7 +758,9 @@ __global__ void __launch_bounds__(64, (sizeof(T) == 4 ? LFSD_WAVES_RIC : 1)) aux
       }
       if (unmet) ++n_unmet;
       units_hint = (int)t_max((long long)Sa, (long long)(R / stp));      // the next interval starts with the step this one ended on
-    } else
+    }
+    }
+    if (!adaptive_done)
     // Error-controlled sub-stepping (a.rtol > 0): the Richardson pair gives |fine - coarse| / 3 as an estimate of the
     // second-order error that the extrapolation removes; while it exceeds rtol relative to the column's size the interval
     // is redone from its stored start value Z(t_k+1) with twice the units.  (solve_ivp's rtol of the reference, CPDP.py:335,
