@@ -40,7 +40,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
 VALU_PEAK_TFLOPS = {"f32": 157.3, "f64": 78.6}
-PROFILE_TAG = "r05"            # profiles/<tag>_hbm_traffic.json, <tag>_issue_counters.json feed the roofline object
+PROFILE_TAG = "r06"            # profiles/<tag>_hbm_traffic.json, <tag>_issue_counters.json feed the roofline object
 
 # The workloads of BASELINE.json's configs that bench.py can emit a line for.  `batch` is per GPU.
 WORKLOADS = {

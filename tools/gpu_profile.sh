@@ -3,7 +3,7 @@
 # only beside --pmc), folded per FULL-BATCH dispatch.
 # usage (on the GPU box, via gpurun):  [LFSD_COMMIT=<short hash>] bash tools/gpu_profile.sh <tag> [bench.py arguments, e.g. --config rocket]
 #   -> gpurun_out/<tag>/{bench.json, kernel_stats.csv, pmc_*_counter_collection.csv, hbm_traffic.json, issue_counters.json}
-TAG=${1:-r05}; shift
+TAG=${1:-r06}; shift
 ARGS="$@"
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
@@ -11,7 +11,7 @@ cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
 STEPS=${STEPS:-20}; WARM=${WARM:-5}
 MODEL=quadrotor; case "$ARGS" in *robotarm*) MODEL=robotarm;; *rocket*) MODEL=rocket;; esac
 case "$ARGS" in *"--dtype f64"*) export LFSD_PROFILE_DTYPE=f64;; esac      # the folds keep the fp32 seeding solve apart from the fp64 kernel
-export LFSD_KERNEL_RESOURCES=${LFSD_KERNEL_RESOURCES:-profiles/r05_kernel_resources_$MODEL.json}      # (tools/kernel_resources.py <model> --json, made at build time)
+export LFSD_KERNEL_RESOURCES=${LFSD_KERNEL_RESOURCES:-profiles/r06_kernel_resources_$MODEL.json}      # (tools/kernel_resources.py <model> --json, made at build time)
 python3 bench.py --steps $STEPS --warmup $WARM $ARGS > $OUT/bench.json 2> $OUT/bench.err
 rocprofv3 --kernel-trace --stats -d $OUT/prof -o $TAG --output-format csv -- python3 bench.py --steps $STEPS --warmup $WARM --no-cpu-baseline --no-f64-leg $ARGS > $OUT/bench_prof.json 2> $OUT/prof.err
 pass() {  # name, counters...

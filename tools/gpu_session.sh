@@ -7,7 +7,7 @@
 #   configs  bench.py --config robotarm / rocket: lines with CPU legs + their evidence sets
 #   f64      the same for bench.py --dtype f64
 #   ab       tools/ab_variants.py run <names...>   (variants built beforehand with `ab_variants.py build`)
-S=${1:-quick}; TAG=${2:-r05_$S}; OUT=gpurun_out/$TAG
+S=${1:-quick}; TAG=${2:-r06_$S}; OUT=gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
 line() { python3 -c "
@@ -41,9 +41,9 @@ rocket)       # A/B of build variants on the rocket's cold OC solve (tools/model
 steps)        # CFGS="robotarm rocket": per-outer-iteration kernel times and unit / iteration distributions (tools/config_steps.py)
   for c in ${CFGS:-robotarm}; do python3 tools/config_steps.py $c ${NSTEPS:-6} > $OUT/steps_$c.txt 2>&1; cat $OUT/steps_$c.txt; done ;;
 final)        # the round's closing record: evidence sets (headline, fp64, the two configurations), default line, other batch / mode, RCCL with one rank, tier
-  bash tools/gpu_session.sh profile r05 > $OUT/profile.log 2>&1
-  bash tools/gpu_session.sh f64 r05_f64 > $OUT/f64.log 2>&1
-  bash tools/gpu_session.sh configs r05_c
+  bash tools/gpu_session.sh profile r06 > $OUT/profile.log 2>&1
+  bash tools/gpu_session.sh f64 r06_f64 > $OUT/f64.log 2>&1
+  bash tools/gpu_session.sh configs r06_c
   python3 bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err; line $OUT/bench_default.json
   python3 bench.py --batch 32768 --steps 5 --warmup 1 --no-cpu-baseline --no-f64-leg > $OUT/bench_f32_32768.json 2> /dev/null; line $OUT/bench_f32_32768.json
   python3 bench.py --batch 32768 --steps 3 --warmup 1 --dtype f64 --no-cpu-baseline > $OUT/bench_f64_32768.json 2> /dev/null; line $OUT/bench_f64_32768.json
