@@ -472,6 +472,13 @@ def main(argv=None):
             traffic += profile("hbm_traffic", "oc_solve_seed_f32").get("hbm_bytes_per_launch") or 0.0
         issue = profile("issue_counters")
         executed = issue.get("valu_flops_executed_per_launch")
+        if dom == "oc_solve":      # a two-launch wide solve (round 6): `oc_solve` is both launches, the folds keep the four-wavefront one apart
+            w4 = profile("hbm_traffic", "oc_solve_wide_w4").get("hbm_bytes_per_launch")
+            if traffic is not None and w4:
+                traffic += w4
+            w4 = profile("issue_counters", "oc_solve_wide_w4").get("valu_flops_executed_per_launch")
+            if executed is not None and w4:
+                executed += w4
         peak = VALU_PEAK_TFLOPS[dom_dtype]
         out = {
             "metric": "CPDP outer iterations/sec (batch trajectories)",

@@ -22,14 +22,17 @@ import re
 import sys
 from collections import defaultdict
 
-KERNELS = {"oc_solve": "oc_solve_kernel", "oc_solve_resume": "oc_solve_kernel", "oc_solve_wide": "oc_solve_wide_kernel",
+KERNELS = {"oc_solve": "oc_solve_kernel", "oc_solve_resume": "oc_solve_kernel", "oc_solve_wide": "oc_solve_wide_kernel", "oc_solve_wide_w4": "oc_solve_wide_kernel",
            "aux_riccati": "aux_riccati_kernel", "aux_forward": "aux_forward_kernel"}
 
 
 def classify(name):
     """bench key of a kernel name, or None."""
     if "oc_solve_wide_kernel" in name:
-        return "oc_solve_wide"
+        # oc_solve_wide_kernel<Model, T, EXACT, BND, W>: W > 1 is the launch with several wavefronts per trajectory (round 6: the second
+        # launch of a two-launch solve, or the whole solve of a small batch)
+        m = re.search(r"oc_solve_wide_kernel<.*,\s*(\d+)\s*>\s*\(", name)
+        return "oc_solve_wide_w4" if (m and int(m.group(1)) > 1) else "oc_solve_wide"
     if "oc_solve_kernel" in name:
         # oc_solve_kernel<Model, T, G, EXACT, PK>: EXACT = true is the resume launch of the two-launch solve
         m = re.search(r"oc_solve_kernel<.*?,\s*(float|double),\s*\d+,\s*(true|false)", name)

@@ -23,7 +23,7 @@ from collections import defaultdict
 from hbm_traffic import classify
 # resident waves per SIMD of the fp32 kernels (tools/kernel_resources.py: 256+80 / 246 / 256+256 registers per lane; the
 # VGPR_Count column of the rocprofv3 CSV does not include the accumulator half reliably)
-WAVES_PER_SIMD = {"oc_solve": 1, "oc_solve_wide": 1, "oc_solve_resume": 1, "oc_solve_seed_f32": 1, "aux_riccati": 2, "aux_forward": 1}
+WAVES_PER_SIMD = {"oc_solve": 1, "oc_solve_wide": 1, "oc_solve_wide_w4": 1, "oc_solve_resume": 1, "oc_solve_seed_f32": 1, "aux_riccati": 2, "aux_forward": 1}
 
 
 def code_object_registers(kernel_name):
