@@ -3310,8 +3310,8 @@ __global__ void __launch_bounds__(64, LFSD_WAVES_OC) oc_solve_kernel(OcArgs<T> a
 // test is taken).  Control flow is uniform per workgroup -- no votes, no lock-step partners.  lfsd_coc_solve picks this
 // kernel when the lock-step mapping would leave most SIMDs without a wavefront (the `mapping` argument overrides).
 // W: wavefronts per trajectory (OcWide).  A launch with W > 1 is either the whole solve of a small batch or the second launch of a
-// two-launch solve (a.resume == 2): then a workgroup whose trajectory is finished leaves at once and the others continue from the
-// solver state their first launch parked in the workspace.
+// two-launch solve (a.resume == 2): then workgroup b takes entry b of the hand-over list the first launch wrote (a.sched) and continues
+// from the solver state that launch parked in the workspace; workgroups beyond the list leave at once.
 template <class M, typename T, bool EXACT, bool BND = false, int W = 1>
 __global__ void __launch_bounds__(64 * W, 1) oc_solve_wide_kernel(OcArgs<T> a) {
   using Sol = OcWide<M, T, EXACT, BND, W>;

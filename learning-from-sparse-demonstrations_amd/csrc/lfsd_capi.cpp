@@ -100,7 +100,7 @@ struct SeedLayout {
 // registers per wavefront, 116 KB of LDS).  So:  batch <= CUs -- every trajectory gets such a workgroup from the start;  otherwise the
 // solve is TWO launches on the stream: one wavefront per trajectory until all but `CUs` trajectories are finished (a device counter;
 // the rest park their solver state in the workspace), then the rest with WIDE_W wavefronts each.  No host read in between: the second
-// launch is enqueued unconditionally and its workgroups leave at once for finished rows.  Same arithmetic per item whoever runs it:
+// launch is enqueued unconditionally, one workgroup per entry of the hand-over list the first one wrote (the others leave at once).  Same arithmetic per item whoever runs it:
 // results do not depend on when a trajectory was handed over (asserted by the GPU tier: bit-identical to the one-launch solve).
 // Environment (test hooks / A-B): LFSD_WIDE_WAVES=1 one wavefront per trajectory always, =4 WIDE_W from the start at any batch;
 // LFSD_WIDE_CAPACITY=<n> in place of the CU count; LFSD_WIDE_SUSPEND_IT=<k> hand over at iteration k instead of by the counter.

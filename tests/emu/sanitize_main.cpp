@@ -3,6 +3,7 @@
 #include <vector>
 #include <cstdio>
 #include <cstdlib>
+#include <stdlib.h>
 int main() {
   lfsd_model_info mi; lfsd_get_model_info(&mi);
   const int N = getenv("LFSD_SAN_N") ? atoi(getenv("LFSD_SAN_N")) : 6;      // (>= 40: the wide kernel's multiple-shooting steps run)
@@ -26,6 +27,25 @@ int main() {
     int rc = lfsd_coc_solve(dtype, B, N, 4, x0.data(), hz.data(), th.data(), nc ? cs.data() : nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0.0, X.data(), U.data(), L.data(),
                             cost.data(), it.data(), st.data(), 40, dtype ? 1e-9 : 1e-6, 3, mapping, ws.data(), wsb, nullptr);
     printf("dtype %d coc rc %d status %d iters %d\n", dtype, rc, st[0], it[0]);
+    if (pass == 2) {
+      // fp32 on the wide mapping: the launch schemes of lfsd_capi.cpp's coc_solve_t (batch 5 <= capacity runs four wavefronts per
+      // trajectory from the start where the model has them) -- one wavefront only; two launches handed over by the counter with a
+      // capacity of 2; two launches handed over at iteration 2 -- under the sanitizers, outputs compared byte for byte
+      const char* envs[3][3] = {{"LFSD_WIDE_WAVES", "1", nullptr}, {"LFSD_WIDE_CAPACITY", "2", nullptr}, {"LFSD_WIDE_CAPACITY", "2", "LFSD_WIDE_SUSPEND_IT"}};
+      for (int v = 0; v < 3; ++v) {
+        auto X2 = buf(B * (N + 1) * n), U2 = buf(B * (N + 1) * m), L2 = buf(B * (N + 1) * n), cost2 = buf(B);
+        std::vector<int> it2(B), st2(B);
+        setenv(envs[v][0], envs[v][1], 1);
+        if (envs[v][2]) setenv(envs[v][2], "2", 1);
+        std::vector<char> ws2(wsb);
+        const int rc2 = lfsd_coc_solve(dtype, B, N, 4, x0.data(), hz.data(), th.data(), nc ? cs.data() : nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0.0,
+                                       X2.data(), U2.data(), L2.data(), cost2.data(), it2.data(), st2.data(), 40, 1e-6, 3, mapping, ws2.data(), wsb, nullptr);
+        unsetenv("LFSD_WIDE_WAVES"); unsetenv("LFSD_WIDE_CAPACITY"); unsetenv("LFSD_WIDE_SUSPEND_IT");
+        const bool same = rc2 == 0 && X2 == X && U2 == U && L2 == L && cost2 == cost && it2 == it && st2 == st;
+        printf("launch scheme %d: code %d same %d\n", v, rc2, (int)same);
+        if (!same) return 3;
+      }
+    }
     rc = lfsd_aux_solve(dtype, B, N, hz.data(), th.data(), nc ? cs.data() : nullptr, 0, X.data(), U.data(), L.data(), Z.data(), nw, ni, iface.data(),
                         taus.data(), wps.data(), loss.data(), grad.data(), aX.data(), aU.data(), (pass & 2) ? 1 : 4, (pass & 2) ? 1e-3 : 0.0, stats.data(),
                         st.data(), (1 << LFSD_ST_FAILED) | ((pass & 1) ? (1 << st[1]) : 0), nullptr);      // (odd passes: row 1 is skipped whatever its status)

@@ -41,3 +41,4 @@ def test_asan_ubsan_clean(tmp_path, kind, n_grid):
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
     assert "ERROR: AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stderr[-4000:]
     assert r.stdout.count("rc 0") == 12, r.stdout
+    assert r.stdout.count("same 1") == 3, r.stdout          # the launch schemes of the wide fp32 solve, byte for byte (sanitize_main.cpp)
