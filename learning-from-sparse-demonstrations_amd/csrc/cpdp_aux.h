@@ -410,7 +410,7 @@ template <class M, typename T, int G, int LAY> struct AuxCtx {
   }
   // apply the prepared exact stiff step of stiff node r (0..2) over dt = hq (half == 0) or 2 hq (half == 1); r and half
   // may differ between the lanes (the two chains sit at different nodes)
-  static constexpr bool FETCH = ((LFSD_FWD_FETCH) & (sizeof(T) == 4 ? 1 : 2)) != 0;
+  static constexpr bool FETCH = sizeof(T) == 4;      // (fp64: the registers are not there, cpdp_common.h)
   LFSD_DEV void fwd_stiff(T* xa, int r, int half, T dt) {
     if constexpr (!FETCH) {
       const T* Kn = lds + Lay::LDS_KN + r * NX * NU;

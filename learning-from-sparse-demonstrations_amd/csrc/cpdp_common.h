@@ -77,9 +77,7 @@
 // r04_b): fp32 0.849 -> 0.625 ms (185 exposed LDS round trips per split unit become 7 batches); fp64 1.99 -> 2.30 ms (the
 // 96 + 13 doubles of a right-hand side do not fit beside the chain's state: scratch 144 -> 212 B/lane), so fp64 keeps
 // reading its operands where it uses them.
-#ifndef LFSD_FWD_FETCH
-#define LFSD_FWD_FETCH 1
-#endif
+// (LFSD_FWD_FETCH: shipped as on since the round it was measured in; the switch was removed in round 6, the alternative is in the history)
 #ifndef LFSD_WAVES_RIC
 #define LFSD_WAVES_RIC 2
 #endif
@@ -110,9 +108,7 @@
 #ifndef LFSD_MU_HOLD
 #define LFSD_MU_HOLD 1
 #endif
-#ifndef LFSD_GN_CRAWL
-#define LFSD_GN_CRAWL 1
-#endif
+// (LFSD_GN_CRAWL: shipped as on since the round it was measured in; the switch was removed in round 6, the alternative is in the history)
 // Levenberg shift of the Newton modes, measured on BASELINE configs[1] (robot arm, 1024 seeds, emulator + MI355X,
 // profiles/r02_arm_step_control.txt).  LFSD_REG_CONSISTENT: the value recursion continues with the SHIFTED Q_uu, i.e. the
 // sweep is the block LDL^T factorisation of (Lagrangian Hessian + mu I_u) -- the model the step actually minimises, and
@@ -206,26 +202,16 @@
 // ... consecutive accepted SHORT steps (step length < 1) after which the phase ends on the current level (cpdp_oc.h)
 // wide kernel, fp32, models with at most 8 columns of [A B]: all columns of an interval's exact stage Hessian on one lane (1,
 // OcSolver::stage_hessian_all) or one (interval, column) item per lane (0)
-#ifndef LFSD_HESS_ALL
-#define LFSD_HESS_ALL 1
-#endif
-#ifndef LFSD_LEAN_CTL_PREFETCH
-#define LFSD_LEAN_CTL_PREFETCH 1
-#endif
+// (LFSD_HESS_ALL: shipped as on since the round it was measured in; the switch was removed in round 6, the alternative is in the history)
+// (LFSD_LEAN_CTL_PREFETCH: shipped as on since the round it was measured in; the switch was removed in round 6, the alternative is in the history)
 // ... shorter multiple-shooting steps: after a refused full step, at most LFSD_MS_HALF HALF steps in a row are tried before the
 // closed-loop roll-outs (0: none).  A trial costs 25 k clocks against a roll-out's 580 k.  Measured on the robot-arm learner
 // (1 024 seeds, MI355X, oc_solve of outer iterations 0 / 1 / 4 / 5 / 6 / 7; profiles/r05_o_*): none 12.5 / 11.1 / 17.8 / 7.5 / 7.9 / 8.2 ms,
 // one 10.9 / 10.2 / 8.7 / 7.2 / 5.5 / 5.2, two in a row 9.6 / 9.8 / 9.6 / 8.2 / 5.7 / 5.5.  (A full line search along the linear
 // direction -- built first, removed -- lets the gaps pile up: 1 % of the trajectories then need 45-50 iterations.)
-#ifndef LFSD_MS_HALF
-#define LFSD_MS_HALF 1
-#endif
-#ifndef LFSD_MS_JFEAS
-#define LFSD_MS_JFEAS 1
-#endif
-#ifndef LFSD_MS_NEWTON
-#define LFSD_MS_NEWTON 0
-#endif
+// (LFSD_MS_HALF: shipped as on since the round it was measured in; the switch was removed in round 6, the alternative is in the history)
+// (LFSD_MS_JFEAS: shipped as on since the round it was measured in; the switch was removed in round 6, the alternative is in the history)
+// (LFSD_MS_NEWTON: shipped as off since the round it was measured in; the switch was removed in round 6, the alternative is in the history)
 // wide kernel (one trajectory per wavefront): smallest n_grid with a coarse phase
 #ifndef LFSD_COARSE_MIN_GRID
 #define LFSD_COARSE_MIN_GRID 40
@@ -236,9 +222,7 @@
 #define LFSD_COARSE_TIME 4
 #endif
 // wide kernel: 1 = between the merged-interval coarse level and the reference's grid, a level with one RK4 step per interval
-#ifndef LFSD_COARSE_MID_LEVEL
-#define LFSD_COARSE_MID_LEVEL 1
-#endif
+// (LFSD_COARSE_MID_LEVEL: shipped as on since the round it was measured in; the switch was removed in round 6, the alternative is in the history)
 // RK4 steps per merged interval of that phase (0: as many as merged intervals, i.e. the step of one step per interval)
 #ifndef LFSD_COARSE_TIME_S
 #define LFSD_COARSE_TIME_S 2
@@ -258,24 +242,16 @@
 #ifndef LFSD_COARSE_EXIT_MU
 #define LFSD_COARSE_EXIT_MU 1e-2
 #endif
-#ifndef LFSD_REG_CONSISTENT
-#define LFSD_REG_CONSISTENT 1
-#endif
+// (LFSD_REG_CONSISTENT: shipped as on since the round it was measured in; the switch was removed in round 6, the alternative is in the history)
 
 // ---- fp64 OC kernels (round 3; profiles/r03_o_fp64_backward.txt, r03_q_fp64_live_park.txt) --------------------------------
 // fp64 lean OC kernel of the 32-lane models on 16-lane groups (four trajectories per wavefront); 0: 32-lane groups (round 2)
-#ifndef LFSD_FP64_LIVE
-#define LFSD_FP64_LIVE 1
-#endif
+// (LFSD_FP64_LIVE: shipped as on since the round it was measured in; the switch was removed in round 6, the alternative is in the history)
 // ... with the between-stage values of its tangent RK4 step parked in LDS (OcSolver::rk4_step_parked)
-#ifndef LFSD_FP64_PARK
-#define LFSD_FP64_PARK 1
-#endif
+// (LFSD_FP64_PARK: shipped as on since the round it was measured in; the switch was removed in round 6, the alternative is in the history)
 // ... and with the one-pass backward sweep of the structural-column layout (backward_sc, LDS-fed products) instead of two
 // passes of the generic sweep on 32-lane groups
-#ifndef LFSD_FP64_SC
-#define LFSD_FP64_SC 1
-#endif
+// (LFSD_FP64_SC: shipped as on since the round it was measured in; the switch was removed in round 6, the alternative is in the history)
 // LFSD_FENCE64, bits: 1 = pin64 (row sums of the backward sweep's dense products are materialised where they are computed),
 // 2 = LFSD_SCHED_FENCE64 (a scheduling barrier per row), 4 = two row buffers (a row's LDS reads are issued while the previous
 // row is multiplied).  The pathology they remove: Q = [A B]^T Y is first used behind a branch; the compiler sank its FMAs
@@ -292,13 +268,9 @@
 #ifndef LFSD_BW_SMALL
 #define LFSD_BW_SMALL 1
 #endif
-#ifndef LFSD_BW_QSPLIT
-#define LFSD_BW_QSPLIT 1
-#endif
+// (LFSD_BW_QSPLIT: shipped as on since the round it was measured in; the switch was removed in round 6, the alternative is in the history)
 // two row buffers for the dense products, fp32 instantiations with NX >= 8 (fp64: LFSD_FENCE64 & 4)
-#ifndef LFSD_BW_ROWBUF32
-#define LFSD_BW_ROWBUF32 1
-#endif
+// (LFSD_BW_ROWBUF32: shipped as on since the round it was measured in; the switch was removed in round 6, the alternative is in the history)
 // LFSD_ROW_FENCE / LFSD_SCHED_FENCE64(T): the instruction scheduler moves nothing across this point (bounds the live ranges of
 // the fully unrolled contractions); LFSD_SCHED_FENCE: the same between the RK4 stages, off unless LFSD_USE_SCHED_FENCE is
 // defined.  No-ops in the emulator build.
@@ -337,10 +309,8 @@
 // `s_waitcnt vmcnt(0)` behind the stores is gone from the stage's ISA and oc_solve takes exactly as long -- 2.587 ms against
 // 2.589 with the old syncs, 2.629 with the next stage's loads prefetched on top (LFSD_BW_PREFETCH 1): the stores are long
 // acknowledged when the wait is reached; the sweep is bound by issue, as round 3 concluded.  Kept: it is the narrower fence.
-#ifndef LFSD_OC_LDS_SYNC
-#define LFSD_OC_LDS_SYNC 1
-#endif
-#if defined(LFSD_EMU) || !LFSD_OC_LDS_SYNC
+// (LFSD_OC_LDS_SYNC: shipped as on since the round it was measured in; the switch was removed in round 6, the alternative is in the history)
+#if defined(LFSD_EMU)
 #define LFSD_STAGE_SYNC() __syncthreads()
 #else
 #define LFSD_STAGE_SYNC() LFSD_WAVE_SYNC()
@@ -348,10 +318,8 @@
 // ... the same inside a stage of the GENERIC backward sweep (wide kernel, lock-step kernels without MFMA): there the next
 // stage's global loads ARE issued a stage ahead (LFSD_BW_PREFETCH_GEN), and every __syncthreads() of the stage drained them.
 // Measured (profiles/r04_k_ab_generic_stage_sync.txt): rocket 107.8 / 107.5 ms, robot arm 17.8 / 17.7 ms with / without: nothing.
-#ifndef LFSD_OC_LDS_SYNC_GEN
-#define LFSD_OC_LDS_SYNC_GEN 1
-#endif
-#if defined(LFSD_EMU) || !LFSD_OC_LDS_SYNC_GEN
+// (LFSD_OC_LDS_SYNC_GEN: shipped as on since the round it was measured in; the switch was removed in round 6, the alternative is in the history)
+#if defined(LFSD_EMU)
 #define LFSD_STAGE_SYNC_GEN() __syncthreads()
 #else
 #define LFSD_STAGE_SYNC_GEN() LFSD_WAVE_SYNC()
@@ -612,12 +580,10 @@ LFSD_DEV double t_rsqrt(double a) { return 1.0 / sqrt(a); }
 // products for |x| <= 100) + the two degree-7 / degree-8 minimax polynomials of cephes' sinf / cosf on [-pi/4, pi/4]; t_sin(a)
 // and t_cos(a) of the same argument share the reduction after inlining.  Measured against fp64 on 2^24 arguments in
 // [-100, 100] (trig_probe): see profiles/r04_l_trig_probe.txt.  Beyond |x| = 100, in fp64 and in the CPU emulator: the library.
-#ifndef LFSD_FAST_TRIG
-#define LFSD_FAST_TRIG 1
-#endif
+// (LFSD_FAST_TRIG: shipped as on since the round it was measured in; the switch was removed in round 6, the alternative is in the history)
 LFSD_DEV double t_sin(double a) { return sin(a); }
 LFSD_DEV double t_cos(double a) { return cos(a); }
-#if defined(LFSD_EMU) || !LFSD_FAST_TRIG
+#if defined(LFSD_EMU)
 LFSD_DEV float t_sin(float a) { return sinf(a); }
 LFSD_DEV float t_cos(float a) { return cosf(a); }
 #else

@@ -424,8 +424,7 @@ template <class M, typename T, int G, bool EXACT, bool BND = false> struct OcSol
       for (int a = 0; a < NU; ++a) du[a] = (col == NX + a) ? T(1) : T(0);
       const T t = tk(k);
       for (int s = 0; s < S; ++s) {
-        if (LFSD_FP64_PARK) rk4_step_parked<ZC_>(t, x, q, u, m, mq, du, qz);
-        else rk4_step<true, T, ZC_>(t, x, q, u, m, mq, du, qz);
+        rk4_step_parked<ZC_>(t, x, q, u, m, mq, du, qz);
       }
       LFSD_RCK(1)
       J += q;
@@ -831,7 +830,7 @@ template <class M, typename T, int G, bool EXACT, bool BND = false> struct OcSol
     // dense products  Y = V_xx m_j,  Q = [A B]^T Y  -- half of a stage's instructions -- are split four ways instead: every
     // 16-lane quarter holds the columns, quarter p computes rows p, p+4, p+8, (p+12) of Y and its share of the sum over
     // those rows in Q, and two cross-quarter exchanges per entry of Q add the shares up (quarter_sum).
-    constexpr bool QS = (G == 64) && (LFSD_BW_QSPLIT != 0) && NX >= 8 && NXU <= 16 && !BND;
+    constexpr bool QS = (G == 64) && NX >= 8 && NXU <= 16 && !BND;
     const int jcol = QS ? (lane & 15) : lane;
     auto load_stage = [&](int k_, T* m_, T& mq_, T* xk_, T* uk_, T* dk_) LFSD_LAMBDA_INLINE {
       if (gap != nullptr) {                      // (the gap of the interval: group-uniform, loaded with the rest of the stage -- a stage ahead)
@@ -948,7 +947,7 @@ template <class M, typename T, int G, bool EXACT, bool BND = false> struct OcSol
 #pragma unroll
         for (int r = 0; r < NXU; ++r) Qcol[r] = quarter_sum(Qp[r]);
         (void)Y;
-      } else if constexpr (sizeof(T) == 8 ? ((LFSD_FENCE64) & 4) != 0 : ((LFSD_BW_ROWBUF32) != 0 && NX >= 8)) {
+      } else if constexpr (sizeof(T) == 8 ? ((LFSD_FENCE64) & 4) != 0 : NX >= 8) {
         // a row's reads are issued while the previous row is multiplied (two row buffers, constant indices after the
         // unrolling).  fp64: with one buffer every row waited a full LDS round trip between the scheduling barriers; fp32
         // (wide kernel, lock-step kernels without MFMA): left to itself the compiler issued the 104 ds_read_b128 of a stage one
@@ -1098,7 +1097,7 @@ template <class M, typename T, int G, bool EXACT, bool BND = false> struct OcSol
       for (int i = 0; i < NU * NU; ++i) Lc[i] = Quu0[i];
 #pragma unroll
       for (int a = 0; a < NU; ++a) Lc[a * NU + a] += mu_k;
-      if (LFSD_REG_CONSISTENT) {
+      {      // (the value recursion continues with the SHIFTED Q_uu: cpdp_common.h, "Levenberg shift of the Newton modes")
 #pragma unroll
         for (int a = 0; a < NU; ++a) Quu0[a * NU + a] += mu_k;
       }
@@ -1361,7 +1360,7 @@ template <class M, typename T, int G, bool EXACT, bool BND = false> struct OcSol
 #pragma unroll
       for (int a = 0; a < NU; ++a) Lc[a * NU + a] += mu;
       if (ok) ok = chol_factor<NU>(Lc, dmin); else { T dd = T(0); chol_factor<NU>(Lc, dd); }
-      if (LFSD_REG_CONSISTENT) {
+      {      // (the value recursion continues with the SHIFTED Q_uu: cpdp_common.h, "Levenberg shift of the Newton modes")
 #pragma unroll
         for (int a = 0; a < NU; ++a) Quu0[a * NU + a] += mu;
       }
@@ -1516,7 +1515,6 @@ template <class M, typename T, int G, bool EXACT, bool BND = false> struct OcSol
 #pragma unroll
     for (int i = 0; i < NX; ++i) x[i] = x0[i];
     const int c0 = ZC + 2 * lane, c1 = c0 + 1;             // original column indices of this lane's pair of live columns
-#if LFSD_LEAN_CTL_PREFETCH
     // the operands of the control law (nominal, feed-forward, gains of interval k: group-uniform global loads) are fetched while
     // interval k-1 is integrated: on the one-step-per-interval levels of the mesh continuation an interval is ~4 000 clocks of
     // arithmetic, and its control law otherwise starts by waiting a global round trip for 73 words
@@ -1538,9 +1536,7 @@ template <class M, typename T, int G, bool EXACT, bool BND = false> struct OcSol
       }
     };
     load_ctl(0);
-#endif
     for (int k = 0; k < N; ++k) {
-#if LFSD_LEAN_CTL_PREFETCH
 #pragma unroll
       for (int a = 0; a < NU; ++a) u[a] = ubN[a];
       if (gains) {
@@ -1554,9 +1550,6 @@ template <class M, typename T, int G, bool EXACT, bool BND = false> struct OcSol
         }
       }
       if (k + 1 < N) { load_ctl(k + 1); LFSD_ISSUE_FENCE(); }
-#else
-      control(cur, k, x, alpha, gains, u);
-#endif
       if (lane == 0) {
 #pragma unroll
         for (int i = 0; i < NX; ++i) xbp(nxt)[k * NX + i] = x[i];
@@ -1671,7 +1664,7 @@ template <class M, typename T, int G, bool EXACT, bool BND = false> struct OcSol
     long long bwc_t = clock64();
 #endif
     for (int k = N - 1; k >= 0; --k) {
-      if constexpr (LFSD_OC_LDS_SYNC != 0) {
+      {
         // every global load of the stage lands HERE.  Loads and stores share one in-order counter on this hardware: the stage's
         // nominal control, first used in the middle of the stage, was waited for behind the global stores of the gains -- i.e.
         // the wavefront sat out the stores' round trip to the L2 once per stage (`s_waitcnt vmcnt(0)` in the ISA)
@@ -1808,7 +1801,7 @@ template <class M, typename T, int G, bool EXACT, bool BND = false> struct OcSol
 #pragma unroll
       for (int a = 0; a < NU; ++a) Lc[a * NU + a] += mu;
       if (ok) ok = chol_factor<NU>(Lc, dmin); else { T dd = T(0); chol_factor<NU>(Lc, dd); }
-      if (LFSD_REG_CONSISTENT) {
+      {      // (the value recursion continues with the SHIFTED Q_uu: cpdp_common.h, "Levenberg shift of the Newton modes")
 #pragma unroll
         for (int a = 0; a < NU; ++a) Quu0[a * NU + a] += mu;
       }
@@ -2092,7 +2085,7 @@ template <class M, typename T, bool EXACT, bool BND = false, int W = 1> struct O
   }
   // linearise the shooting map along nominal `nxt`, all intervals at once
   LFSD_DEV void linearise_parallel(int nxt) {
-    if constexpr (sizeof(T) == 4 && Lay::HALL && (LFSD_HESS_ALL) != 0) {
+    if constexpr (sizeof(T) == 4 && Lay::HALL) {
       for (int k = pitem(); k < N; k += PSTRIDE) {
         T x[NX], u[NU], q;
 #pragma unroll
@@ -2214,7 +2207,7 @@ template <class M, typename T, bool EXACT, bool BND = false, int W = 1> struct O
   }
   // exact stage Hessians of nominal `cur` (costates must be on lam_out), every (interval, column) at once
   LFSD_DEV void hessians_parallel(int cur) {
-    if constexpr (sizeof(T) == 4 && Lay::HALL && (LFSD_HESS_ALL) != 0) {
+    if constexpr (sizeof(T) == 4 && Lay::HALL) {
       for (int k = pitem(); k < N; k += PSTRIDE) {
         T xk[NX], uk[NU], ln[NX];
 #pragma unroll
@@ -2447,7 +2440,7 @@ template <class M, typename T, bool EXACT, bool BND = false, int W = 1> struct O
         for (int i = 0; i < NU * NU; ++i) Lc[i] = Quu0[i];
 #pragma unroll
         for (int a = 0; a < NU; ++a) Lc[a * NU + a] += mu_k;
-        if (LFSD_REG_CONSISTENT) {
+        {      // (the value recursion continues with the SHIFTED Q_uu: cpdp_common.h, "Levenberg shift of the Newton modes")
 #pragma unroll
           for (int a = 0; a < NU; ++a) Quu0[a * NU + a] += mu_k;
         }
@@ -2709,7 +2702,7 @@ template <class M, typename T, bool EXACT, bool BND = false, int W = 1> struct O
   LFSD_DEV void ms_trial(int cur, int nxt, T alpha, T& J, T& lamabs, T& lamd, T& g2, T& g1, T& gm) {
     T Jl = T(0), g1l = T(0), gml = T(0), lal = T(0), ldl = T(0), g2l = T(0);
     constexpr bool PK2 = sizeof(T) == 4;
-    constexpr bool ALLC = PK2 && Lay::HALL && (LFSD_HESS_ALL) != 0;      // one item per interval, all column pairs on its lane
+    constexpr bool ALLC = PK2 && Lay::HALL;      // one item per interval, all column pairs on its lane
     constexpr int NCT = ALLC ? 1 : (PK2 ? (NXU + 1) / 2 : NXU);
     using V = typename std::conditional<PK2, pk2<T>, T>::type;
     for (int t = lane; t < N * NCT; t += 64) {
@@ -2856,9 +2849,9 @@ __global__ void __launch_bounds__(64, LFSD_WAVES_OC) oc_solve_kernel(OcArgs<T> a
   static_assert(!PK || (!EXACT && G == 32 && (LV ? Lay::LIVE <= GR : 2 * GR >= NX + NU)), "packed / live-column roll-out: lean kernel of a 32-lane model");
   __shared__ T lds_all[GPB * RS];
   __shared__ T mbox[PK ? GPB * MB : 1];
-  __shared__ T park[(LV && LFSD_FP64_PARK) ? 2 * NX * 64 + GPB * 2 * NX : 1];      // rk4_step_parked: [2 NX][64 lanes], then [GPB][2 NX]
+  __shared__ T park[LV ? 2 * NX * 64 + GPB * 2 * NX : 1];      // rk4_step_parked: [2 NX][64 lanes], then [GPB][2 NX]
   // ... and the ONE-pass backward sweep of the structural layout (backward_sc with LDS-fed products) where the model has it
-  constexpr bool SC64 = LV && (LFSD_FP64_SC != 0) && Lay::sc_ok;
+  constexpr bool SC64 = LV && Lay::sc_ok;
   __shared__ T yzx[SC64 ? GPB * 16 * (Lay::ZC ? Lay::ZC : 1) : 1];
   __shared__ int vote[3];
   poison_lds(lds_all, GPB * RS);
@@ -2880,7 +2873,7 @@ __global__ void __launch_bounds__(64, LFSD_WAVES_OC) oc_solve_kernel(OcArgs<T> a
     __syncthreads();
   }
   oc_bind<M, T, G>(s, a, lds_all + gib * RS, slot, valid, traj);
-  if constexpr (LV && LFSD_FP64_PARK) { s.pkm = park + threadIdx.x; s.pkx = park + 2 * NX * 64 + gib * 2 * NX; }
+  if constexpr (LV) { s.pkm = park + threadIdx.x; s.pkx = park + 2 * NX * 64 + gib * 2 * NX; }
   if constexpr (SC64) s.yz64 = yzx + gib * 16 * Lay::ZC;
   {
     T* le = s.lds + Lay::template lds_e<G>();
@@ -3271,7 +3264,7 @@ __global__ void __launch_bounds__(64, LFSD_WAVES_OC) oc_solve_kernel(OcArgs<T> a
             mu = mu_next; mu_hold = 0;
           }
           if (mode == 0 && ham_ok && (J - Jn) < T(LFSD_HAM_SWITCH) * t_abs(Jn)) mode = 1;      // past the first big drops: Newton-like
-          else if (LFSD_GN_CRAWL && mode == 0 && !ham_ok && (J - Jn) < T(1e-2) * t_abs(Jn)) gn_crawl = true;
+          else if (mode == 0 && !ham_ok && (J - Jn) < T(1e-2) * t_abs(Jn)) gn_crawl = true;
         }
         J = Jn;
         if (++n_acc >= 4) {
@@ -3397,8 +3390,8 @@ __global__ void __launch_bounds__(64 * W, 1) oc_solve_wide_kernel(OcArgs<T> a) {
   // steps at Levenberg shifts of 10^2 - 10^4 through strongly curved attitude dynamics; the linear prediction of the node states
   // then leaves gaps as large as the step closes, the line search settles on steps of 1/4, and the phase needs as many or more
   // iterations than the closed-loop nonlinear roll-out while saving only the roll-outs' 20 % of an iteration (measured:
-  // DESIGN.md; -DLFSD_MS_NEWTON=1 switches it on there as well).
-  const bool ms_on = !BND && (LFSD_MS) != 0 && a.n_grid >= (LFSD_MS_MIN_GRID) && a.max_iter > 8 && (a.exact_after != 0 || (LFSD_MS_NEWTON) != 0);
+  // DESIGN.md).
+  const bool ms_on = !BND && (LFSD_MS) != 0 && a.n_grid >= (LFSD_MS_MIN_GRID) && a.max_iter > 8 && a.exact_after != 0;
   bool ms = ms_on, ms_check = false, ms_floor = false;
   int n_acc_need = 4, n_ms = 0, n_half = 0;
   T g1c = T(0), g2c = T(0), gmc = T(0);      // l1 norm, sum of squares and largest entry of the gaps of the current iterate (0: a roll-out)
@@ -3504,9 +3497,9 @@ __global__ void __launch_bounds__(64 * W, 1) oc_solve_wide_kernel(OcArgs<T> a) {
     if ((coarse && (relin || it + 4 >= a.max_iter)) || close_last) {
       // leave the coarse grid: the same controls rolled out (open loop) and linearised on the reference's discretisation; an
       // iteration without a sweep.  Every convergence test below only ever passes on this grid.
-      // (LFSD_COARSE_MID_LEVEL: a coarse phase with merged intervals first hands over to the full control grid with ONE RK4 step per
+      // (a coarse phase with merged intervals first hands over to the full control grid with ONE RK4 step per
       //  interval -- the lean kernels' coarse level -- and leaves that one by the same rules)
-      const bool to_mid = coarse && (LFSD_COARSE_MID_LEVEL) != 0 && tc > 1 && a.steps_per_grid > 1 && it + 8 < a.max_iter;
+      const bool to_mid = coarse && tc > 1 && a.steps_per_grid > 1 && it + 8 < a.max_iter;
       coarse = to_mid; relin = false;
 #if defined(LFSD_OC_CLOCK)
       if (!to_mid) { wck_exit = clock64() - wck_t0; wck_it_exit = it; }
@@ -3622,19 +3615,17 @@ __global__ void __launch_bounds__(64 * W, 1) oc_solve_wide_kernel(OcArgs<T> a) {
           T phit = Jt + ldt + T(0.5) * rho * g2t;
           const T flat = T(8) * epsT * t_abs(phi0);
           bool accept = t_finite(phit) && t_finite(g1t) && (phi0 - phit) >= T(1e-4) * pred_ms - flat && phit < phi0 &&
-                        ((LFSD_MS_JFEAS) == 0 || Jt <= J_feas + T(8) * epsT * t_abs(J_feas));
+                        Jt <= J_feas + T(8) * epsT * t_abs(J_feas);
           bool half = false;
-#if LFSD_MS_HALF
-          if (!accept && n_half < (LFSD_MS_HALF)) {
+          if (!accept && n_half < 1) {
             // ONE shorter step along the same linear direction before the closed-loop roll-outs (an item of 25 k clocks against
             // 580 k): half the Newton step, same tests; it leaves half of the old gaps, so no second one follows it directly
             LFSD_WCK(6, s.ms_trial(cur, cur ^ 1, T(0.5), Jt, lat, ldt, g2t, g1t, gmt));
             phit = Jt + ldt + T(0.5) * rho * g2t;
             accept = t_finite(phit) && t_finite(g1t) && (phi0 - phit) >= T(0.5e-4) * pred_ms - flat && phit < phi0 &&
-                     ((LFSD_MS_JFEAS) == 0 || Jt <= J_feas + T(8) * epsT * t_abs(J_feas));
+                     Jt <= J_feas + T(8) * epsT * t_abs(J_feas);
             half = accept;
           }
-#endif
 #if defined(LFSD_TRACE)
           if (s.lane == 0 && traj == 0) printf("wide ms it %d mode %d g %.6e J %.12e gap1 %.4e gapmax %.3e lam %.3e rho %.3e phi0 %.10e pred %.4e accept %d mu %g -> J %.12e gap1 %.4e phi %.10e\n", it, mode, (double)gnorm, (double)J, (double)g1c, (double)gmc, (double)lam_mx, (double)rho, (double)phi0, (double)pred_ms, (int)accept, (double)mu, (double)Jt, (double)g1t, (double)phit);
 #endif
@@ -3650,7 +3641,7 @@ __global__ void __launch_bounds__(64 * W, 1) oc_solve_wide_kernel(OcArgs<T> a) {
             if (!half) { mu = (mu > T(1e-8)) ? mu * T(LFSD_MU_DOWN) : T(0); mu_hold = 0; }
             n_half = half ? n_half + 1 : 0;
             if (mode == 0 && ham_ok && gain < T(LFSD_HAM_SWITCH) * t_abs(Jt)) mode = 1;
-            else if (LFSD_GN_CRAWL && mode == 0 && !ham_ok && gain < T(1e-2) * t_abs(Jt)) gn_crawl = true;
+            else if (mode == 0 && !ham_ok && gain < T(1e-2) * t_abs(Jt)) gn_crawl = true;
             if (coarse && gain < T(LFSD_COARSE_SWITCH) * t_abs(Jt)) {
               if ((LFSD_COARSE_EXIT_RULE) <= 1 || ((LFSD_COARSE_EXIT_RULE) == 2 && mu_taken <= T(LFSD_COARSE_EXIT_MU))) relin = true;
             }
@@ -3752,7 +3743,7 @@ __global__ void __launch_bounds__(64 * W, 1) oc_solve_wide_kernel(OcArgs<T> a) {
         if (mu > T(0) && mu_bad >= T(0) && mu_next <= mu_bad && mu_hold < mu_hold_need) ++mu_hold;
         else { mu = mu_next; mu_hold = 0; }
         if (mode == 0 && ham_ok && (Jr - Jn) < T(LFSD_HAM_SWITCH) * t_abs(Jn)) mode = 1;
-        else if (LFSD_GN_CRAWL && mode == 0 && !ham_ok && (Jr - Jn) < T(1e-2) * t_abs(Jn)) gn_crawl = true;
+        else if (mode == 0 && !ham_ok && (Jr - Jn) < T(1e-2) * t_abs(Jn)) gn_crawl = true;
       }
       // past the big drops: the reference's grid.  LFSD_COARSE_EXIT_RULE 0: any accepted step that gains less than the switch;
       // 1: full steps only (a short step through a badly modelled patch gains little too, and is no sign of convergence);

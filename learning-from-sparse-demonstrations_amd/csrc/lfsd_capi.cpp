@@ -201,7 +201,7 @@ static int coc_solve_t(int batch, int n_grid, int steps_per_grid, const void* in
   const unsigned grid = (unsigned)(padded_batch(batch) / GPB);
   a.it_start = 0; a.resume = 0; a.max_iter_total = max_iter;
   // fp32: packed roll-out (+ MFMA sweep); fp64: one live column per lane of a 16-lane group (OcSolver::rollout_sens_live)
-  constexpr bool PK = OC_PK && (sizeof(T) == 4 || (LFSD_FP64_LIVE != 0 && lfsd::OcLayout<Model>::LIVE <= 16));
+  constexpr bool PK = OC_PK && (sizeof(T) == 4 || lfsd::OcLayout<Model>::LIVE <= 16);
   const unsigned grid_lean = PK ? (unsigned)(padded_batch(batch) / OC_GPB) : grid;
   if (exact_after < 0) {                       // Gauss-Newton / Hamiltonian models only
     LFSD_LAUNCH((lfsd::oc_solve_kernel<Model, T, G, false, PK>), grid_lean, 64, stream, a);

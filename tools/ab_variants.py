@@ -19,7 +19,6 @@ sys.path.insert(0, ROOT)
 VARIANTS = {
     "base": ((), None, False),
     # round 5 (the switches of rounds 3-4 whose branches were measured negative are gone from csrc/; their results: profiles/HISTORY.md)
-    "ctlpf": (("-DLFSD_LEAN_CTL_PREFETCH=1",), None, False),      # lean roll-out: control-law operands fetched one interval ahead
     "nocoarse": (("-DLFSD_COARSE_START=0",), None, False),
     "notc": (("-DLFSD_LEAN_TC=1",), None, False),
     "slp": ((), None, True),

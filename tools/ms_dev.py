@@ -15,7 +15,7 @@ trace = len(sys.argv) > 5 and sys.argv[5] == "trace"
 off = int(sys.argv[6]) if len(sys.argv) > 6 else 0
 rng = np.random.default_rng(1234)
 res = {}
-VAR = {"ms": (), "ss": ("-DLFSD_MS=0",), "nojf": ("-DLFSD_MS_JFEAS=0",), "clk": ("-DLFSD_OC_CLOCK=1000",), "msn": ("-DLFSD_MS_NEWTON=1",)}
+VAR = {"ms": (), "ss": ("-DLFSD_MS=0",), "clk": ("-DLFSD_OC_CLOCK=1000",)}
 import os as _os
 for tag in _os.environ.get("VARIANTS", "ms ss").split():
   flags = VAR[tag]

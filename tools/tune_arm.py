@@ -6,11 +6,12 @@ import numpy as np, torch
 import lfsd_amd
 from lfsd_amd import models, runtime
 FINE = ["-DLFSD_MU_UP=3.1623", "-DLFSD_MU_DOWN=0.31623", "-DLFSD_MU_HOLD_BACKOFF=0"]
-VARIANTS = [("base", ["-DLFSD_GN_CRAWL=0", "-DLFSD_MU_HOLD=0", "-DLFSD_MU_UP=10", "-DLFSD_MU_DOWN=0.1"]),   # the rule before this sweep
-            ("fine0", ["-DLFSD_GN_CRAWL=0", "-DLFSD_MU_HOLD=0"] + FINE),
-            ("fine1", ["-DLFSD_GN_CRAWL=0", "-DLFSD_MU_HOLD=1"] + FINE),
-            ("crawl_fine0", ["-DLFSD_GN_CRAWL=1", "-DLFSD_MU_HOLD=0"] + FINE),
-            ("crawl_fine1", ["-DLFSD_GN_CRAWL=1", "-DLFSD_MU_HOLD=1"] + FINE)]
+# (round 6: the LFSD_GN_CRAWL switch of this sweep is gone from csrc/ -- shipped on since round 1; the crawl_* rows now equal the fine* rows)
+VARIANTS = [("base", ["-DLFSD_MU_HOLD=0", "-DLFSD_MU_UP=10", "-DLFSD_MU_DOWN=0.1"]),   # the rule before this sweep
+            ("fine0", ["-DLFSD_MU_HOLD=0"] + FINE),
+            ("fine1", ["-DLFSD_MU_HOLD=1"] + FINE),
+            ("crawl_fine0", ["-DLFSD_MU_HOLD=0"] + FINE),
+            ("crawl_fine1", ["-DLFSD_MU_HOLD=1"] + FINE)]
 def lib(kind, tag):
     oc, _, _ = models.ZOO[kind]()
     return os.path.join(runtime.BUILD_DIR, "tune_%s_%s.so" % (oc.model_spec().hash(), tag))
