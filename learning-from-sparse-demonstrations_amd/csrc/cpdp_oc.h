@@ -3478,6 +3478,9 @@ __global__ void __launch_bounds__(64 * W, 1) oc_solve_wide_kernel(OcArgs<T> a) {
   }
   const int mu_hold_need = LFSD_MU_HOLD;
   bool suspended = false;
+#if defined(LFSD_TEST_REFUSE_GAPPED)
+  int n_test_refused = 0;
+#endif
   for (; it < a.max_iter && status == ST_RUNNING; ++it) {
     if constexpr (W == 1) {
       // two-launch solves: once enough trajectories of the launch are finished for the rest to have a workgroup of several
@@ -3700,6 +3703,9 @@ __global__ void __launch_bounds__(64 * W, 1) oc_solve_wide_kernel(OcArgs<T> a) {
     T Jn = (ia >= 0) ? ldsRed[ia] : Jr, Jb = (ib >= 0) ? ldsRed[ib] : T(0);
     __syncthreads();
     if (have_gaps && ia >= 0) { ia = ib; Jn = Jb; }     // (closing an iterate: the cheapest of the roll-outs below the last closed cost, not the longest)
+#if defined(LFSD_TEST_REFUSE_GAPPED)      // test hook (tests/test_emu_kernels.py): the first LFSD_TEST_REFUSE_GAPPED roll-outs from an iterate WITH gaps are refused
+    if (have_gaps && !close_now && n_test_refused < (LFSD_TEST_REFUSE_GAPPED)) { ia = -1; ++n_test_refused; }
+#endif
     bool accept = ia >= 0;
     if (!accept) {
       if (mode >= 1 && flat_full && (g_flat < T(0) || gnorm < T(0.7) * g_flat)) {
