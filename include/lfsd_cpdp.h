@@ -143,7 +143,7 @@ int lfsd_coc_solve(int dtype, int batch, int n_grid, int steps_per_grid,
  *           same ODEs with scipy's solve_ivp at its default rtol 1e-3, CPDP.py:335, 368, which is the host side's default here too:
  *           measured gradient error 1e-5..1e-4 of the exact ODE solution against the reference integrator's 2.6e-3).
  *           0: fixed `substeps`.  With oc_status given, a row whose solve did NOT end converged / at working precision (its grids
- *           are not a KKT point) stops refining once it has spent 64 x n_grid x substeps split units in a sweep; reported in `stats`.
+ *           are not a KKT point) stops refining once it has spent 24 x n_grid x substeps split units in a sweep (64 x until round 5); reported in `stats`.
  *   stats   [B][4] int32 or NULL: per trajectory, {split units executed by the Riccati sweep (rejected attempts included),
  *           intervals of it that were accepted ABOVE rtol because refinement stopped gaining (next to a conjugate point) or hit
  *           its cap, the same two numbers of the forward sweep}.  A non-zero second or fourth entry marks a loss / gradient
