@@ -34,7 +34,9 @@ for k in range(steps):
     print("step %d: oc %.2f ms, status %s, iterations mean %.1f p50 %d p90 %d p99 %d max %d" %
           (k, kt["oc_solve"], np.bincount(st, minlength=5).tolist(), it.mean(), np.median(it), np.quantile(it, .9), np.quantile(it, .99), it.max()), flush=True)
 order = np.argsort(-it)
-th = L._sol["auxvar"].double().cpu().numpy()      # the parameters the last solve actually used (a Nesterov learner solves at the look-ahead point)
+# the parameters the last solve actually used: a Nesterov learner solves at the look-ahead point (its own array); a vanilla learner
+# hands the solver its parameter array itself, which the update that followed has already changed -- take the copy made before the step
+th = (L._sol["auxvar"] if w["method"] == "Nesterov" else th_in).double().cpu().numpy()
 x0n = np.asarray(x0.double().cpu().numpy() if hasattr(x0, "cpu") else x0)
 if x0n.ndim == 1:
     x0n = np.tile(x0n, (len(th), 1))
