@@ -3687,10 +3687,12 @@ __global__ void __launch_bounds__(64 * W, 1) oc_solve_wide_kernel(OcArgs<T> a) {
     const bool flat_full = t_finite(ldsRed[0]) && t_abs(ldsRed[0] - Jr) <= T(64) * epsT * t_abs(Jr);
     // (a ROLLED loop that only picks indices; the costs are read back at the indices it picked.  Round 6: fully unrolled, with the
     //  costs carried in selects beside the indices, one build of this kernel -- rocket, fp32, one wavefront per trajectory -- adopted
-    //  the right roll-out and kept the OLD cost whenever a step shorter than the full one was taken: sixteen uniform conditions held
-    //  in SGPR pairs that were spilled to VGPR lanes around the select chain.  The same source with a printf in it, with another
-    //  scheduler or with an empty asm statement elsewhere in the kernel did not show it (profiles/r06_f_wide_stale_cost.txt); the GPU
-    //  tier now solves the rocket under every launch scheme and compares bit for bit.)
+    //  the right roll-out and kept the OLD cost whenever a step shorter than the full one was taken; the same source with a printf in
+    //  it, with another scheduler or with an empty asm statement elsewhere did not (profiles/r06_f_wide_stale_cost.txt).  The cause,
+    //  found later on a build of THIS form of the loop: the register allocator's spills of J, mu, dV1, ... placed before the exec
+    //  restore behind adopt_alpha's copy loop, so that lanes >= 3 N kept the previous iterate's values -- nothing this loop's shape
+    //  decides (profiles/r06_v_spill_before_exec_restore.txt).  Every build is scanned for that placement (lfsd_amd/isa_check.py),
+    //  and the GPU tier solves the rocket under every launch scheme and compares bit for bit.)
 #pragma unroll 1
     for (int l = 0; l < NAL; ++l) {
       const T Jl = ldsRed[l];

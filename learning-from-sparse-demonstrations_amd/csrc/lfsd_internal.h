@@ -57,7 +57,9 @@ static int device_cu_count() {
 // 11.4 -> 8.2 ms, aux_forward 3.35 -> 2.97 ms; the Riccati sweep needs so few registers without it that it runs two waves per
 // SIMD: 8.5 -> 7.1 ms).  The Riccati sweep keeps its own translation unit (runtime.hipcc_commands, -DLFSD_SPLIT_RICCATI): rounds
 // 1-5 compiled everything else with the max-ILP instruction scheduler, which cost the Riccati sweep 25 %; round 6 dropped that
-// scheduler (two wrong builds of the wide OC kernel under it, no gain left: runtime.py, profiles/r06_f_wide_stale_cost.txt).
+// scheduler (two wrong builds of the wide OC kernel under it, no gain left: runtime.py, profiles/r06_f_wide_stale_cost.txt; the
+// cause -- register spills placed before the exec restore of a join block, also seen under the default scheduler -- is what
+// runtime.py scans every build's assembly for: lfsd_amd/isa_check.py).
 // Single-unit builds (emulator, sanitizer, tuning tools) include the launcher below instead.
 namespace lfsd_detail {
 int launch_riccati_f32(unsigned grid, void* stream, const lfsd::AuxArgs<float>& a);

@@ -87,10 +87,10 @@ def hipcc_command(spec, out, extra=()):
 
 # Per translation unit.  Rounds 1-5 compiled the first unit with `-mllvm -amdgpu-sched-strategy=max-ilp` (round 1: 5 % off oc_solve;
 # the Riccati sweep lost 25 % with it, hence its own unit).  Round 6 dropped it: two builds of the wide OC kernel were WRONG under
-# that scheduler and right under the default one with the same source -- a stale cost in the rocket's fp32 kernel and a memory
-# fault in the robot arm's bounded fp64 kernel, both in code dominated by SGPR spills to VGPR lanes
-# (profiles/r06_f_wide_stale_cost.txt) -- and it no longer pays: headline 966 300 -> 966 700 it/s, rocket step 40.8 -> 38.8 ms,
-# robot arm 15.31 -> 15.41 ms, fp64 headline 13.5 -> 13.9 ms (profiles/r06_i_max_ilp_ab.txt).
+# that scheduler and right under the default one with the same source (profiles/r06_f_wide_stale_cost.txt), and it no longer pays:
+# headline 966 300 -> 966 700 it/s, rocket step 40.8 -> 38.8 ms, robot arm 15.31 -> 15.41 ms, fp64 headline 13.5 -> 13.9 ms
+# (profiles/r06_i_max_ilp_ab.txt).  The cause turned out to be independent of the scheduler -- VGPR spills placed before the exec restore
+# of a join block, which a third wrong build showed under the DEFAULT one -- and every build is now scanned for it (_checked_build below).
 TUNED_CAPI = ()
 TUNED_RICCATI = ()
 
@@ -111,36 +111,119 @@ KERNEL_SOURCES = ("cpdp_kernels.h", "cpdp_common.h", "cpdp_oc.h", "cpdp_aux.h", 
                   "lfsd_riccati.inc", "lfsd_riccati.cpp")
 
 
+# Every build is compiled with -save-temps and its gfx950 assembly scanned by lfsd_amd.isa_check (VGPR spills placed before the
+# exec restore of a join block: two wrong builds of the wide OC kernel in round 6 -- isa_check.py, profiles/
+# r06_v_spill_before_exec_restore.txt).  A translation unit whose assembly shows the pattern is recompiled with the next entry of
+# this list -- other instruction schedulers: the placement moves with any perturbation of the kernel -- until the scan is clean;
+# if none is, the build FAILS (no library is better than a library whose upper lanes read stale spill slots).
+SCHEDULE_ALTERNATES = ((), ("-mllvm", "-amdgpu-sched-strategy=max-ilp"), ("-mllvm", "-amdgpu-sched-strategy=max-memory-clause"),
+                       ("-mllvm", "-amdgpu-use-amdgpu-trackers"), ("-mllvm", "-greedy-reverse-local-assignment"))
+ISA_CHECK_VERSION = 1
+
+
+def isa_record_path(lib_path):
+    return lib_path + ".isa.json"
+
+
+def isa_record_clean(lib_path):
+    """The library was built by _checked_build of this version and both units passed (a library without such a record -- built by an
+    older tree or by hand -- counts as stale: build_library compiles it again)."""
+    import json
+    try:
+        rec = json.load(open(isa_record_path(lib_path)))
+    except (OSError, ValueError):
+        return False
+    units = rec.get("units", {})
+    return rec.get("isa_check") == ISA_CHECK_VERSION and set(units) == {"capi", "riccati"} and all(u.get("hazards") == 0 for u in units.values()) \
+        and rec.get("sha256") == _sha256(lib_path)      # (the record belongs to THIS file, not to one a later hand build replaced)
+
+
+def _sha256(path):
+    import hashlib
+    h = hashlib.sha256()
+    with open(path, "rb") as f:
+        for chunk in iter(lambda: f.read(1 << 20), b""):
+            h.update(chunk)
+    return h.hexdigest()
+
+
+def _checked_build(spec, out, extra=(), verbose=False, what="model"):
+    """Compile the two translation units into `out` (csrc/build/...), each with the first entry of SCHEDULE_ALTERNATES whose device
+    assembly passes isa_check; writes `<out>.isa.json` (what was scanned, which flags each unit was built with).  Raises LfsdError."""
+    import json, shutil, tempfile
+    from . import isa_check
+    os.makedirs(BUILD_DIR, exist_ok=True)
+    work = tempfile.mkdtemp(prefix="obj%d_" % os.getpid(), dir=BUILD_DIR)
+    try:
+        tmp = os.path.join(work, "lib.so")
+        record = {"isa_check": ISA_CHECK_VERSION, "units": {}}
+        objs = []
+        for unit in ("capi", "riccati"):
+            tuned = TUNED_CAPI if unit == "capi" else TUNED_RICCATI
+            tried, built = [], False
+            for alt in SCHEDULE_ALTERNATES:
+                kw = {"extra_capi": tuple(tuned) + tuple(alt)} if unit == "capi" else {"extra_riccati": tuple(tuned) + tuple(alt)}
+                cmds, obj_paths = hipcc_commands(spec, tmp, list(extra), **kw)
+                cmd = cmds[0 if unit == "capi" else 1] + ["-save-temps=obj"]
+                if verbose:
+                    print(" ".join(cmd))
+                for f in os.listdir(work):      # (the temporaries of the previous attempt)
+                    if f.endswith(".s"):
+                        os.remove(os.path.join(work, f))
+                r = subprocess.run(cmd, cwd=CSRC_DIR, capture_output=True, text=True)
+                if r.returncode != 0:
+                    if alt:      # a toolchain that does not know this -mllvm option: next
+                        tried.append({"flags": list(alt), "error": r.stderr[-300:]})
+                        continue
+                    raise LfsdError("hipcc failed for %s %s:\n%s\n%s" % (what, spec.name, r.stdout[-4000:], r.stderr[-4000:]))
+                asm = [f for f in os.listdir(work) if f.endswith("gfx950.s")]
+                if len(asm) != 1:
+                    raise LfsdError("no device assembly to check for %s %s (%s): %s" % (what, spec.name, unit, sorted(os.listdir(work))))
+                text = open(os.path.join(work, asm[0])).read()
+                hz = isa_check.find_exec_hazards(text)
+                if hz:
+                    tried.append({"flags": list(alt), "hazards": len(hz), "first": hz[0]})
+                    if verbose:
+                        print("isa_check: %d spill(s) before an exec restore in %s (%s, flags %s): %s" % (len(hz), spec.name, unit, list(alt), hz[0]))
+                    continue
+                record["units"][unit] = dict(isa_check.summary(text), flags=list(tuned) + list(alt), hazards=0, rejected=tried)
+                objs.append(obj_paths[0 if unit == "capi" else 1])
+                built = True
+                break
+            if not built:
+                raise LfsdError("every build of %s %s (%s) has VGPR spills before an exec restore (lfsd_amd/isa_check.py): %s"
+                                % (what, spec.name, unit, tried))
+        link = hipcc_commands(spec, tmp, list(extra))[0][2]
+        r = subprocess.run(link, cwd=CSRC_DIR, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise LfsdError("link failed for %s %s:\n%s" % (what, spec.name, r.stderr[-3000:]))
+        record["sha256"] = _sha256(tmp)
+        with open(isa_record_path(out) + ".tmp%d" % os.getpid(), "w") as f:
+            json.dump(record, f, indent=1, sort_keys=True, default=str)
+        os.replace(tmp, out)
+        os.replace(isa_record_path(out) + ".tmp%d" % os.getpid(), isa_record_path(out))
+        return record
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
+
+
+def build_checked(spec, out, flags=(), verbose=False):
+    """A diagnostic / experiment build (tools/): the product's two-unit build with extra flags into `out`, assembly-checked the same way
+    -- an instrumented build that is silently wrong misleads (round 6: a clock-reading build of the wide kernel was)."""
+    write_header(spec)
+    return _checked_build(spec, out, extra=list(flags), verbose=verbose, what="diagnostic build of model")
+
+
 def build_library(spec, force=False, verbose=False):
-    """Generate the model header and compile the gfx950 shared library in-tree (csrc/build/)."""
+    """Generate the model header and compile the gfx950 shared library in-tree (csrc/build/), assembly checked (above)."""
     os.makedirs(BUILD_DIR, exist_ok=True)
     out = library_path(spec.hash())
     write_header(spec, force=force)
     deps = [header_path(spec.hash()), os.path.join(INCLUDE_DIR, "lfsd_cpdp.h")] + \
         [os.path.join(CSRC_DIR, f) for f in KERNEL_SOURCES]
-    if not force and os.path.exists(out) and all(os.path.getmtime(out) >= os.path.getmtime(d) for d in deps):
+    if not force and os.path.exists(out) and all(os.path.getmtime(out) >= os.path.getmtime(d) for d in deps) and isa_record_clean(out):
         return out
-    tmp = out + ".tmp%d" % os.getpid()
-    def run(cmds, objs):
-        try:
-            for cmd in cmds:
-                if verbose:
-                    print(" ".join(cmd))
-                r = subprocess.run(cmd, cwd=CSRC_DIR, capture_output=True, text=True)
-                if r.returncode != 0:
-                    return "%s\n%s" % (r.stdout[-4000:], r.stderr[-4000:])
-            return None
-        finally:
-            for o in objs:
-                if os.path.exists(o):
-                    os.remove(o)
-
-    err = run(*hipcc_commands(spec, tmp))
-    if err is not None:        # a toolchain that does not know the tuned -mllvm options: same sources, plain flags
-        err2 = run(*hipcc_commands(spec, tmp, extra_capi=(), extra_riccati=()))
-        if err2 is not None:
-            raise LfsdError("hipcc failed for model %s:\n%s" % (spec.name, err))
-    os.replace(tmp, out)
+    _checked_build(spec, out, verbose=verbose)
     return out
 
 
@@ -151,23 +234,13 @@ def variant_library_path(spec, tag):
 def build_variant_library(spec, tag, flags):
     """hipcc build of a VARIANT of a model library (experiment switches of csrc/cpdp_common.h set on the command line) into
     csrc/build/ab_<hash>_<tag>.so, rebuilt when a kernel source is newer.  The A/B tests of the GPU tier compare the product
-    build with such variants; never loaded by the product path."""
+    build with such variants; never loaded by the product path.  Same assembly check as the product build."""
     write_header(spec)
     out = variant_library_path(spec, tag)
     deps = [header_path(spec.hash())] + [os.path.join(CSRC_DIR, f) for f in KERNEL_SOURCES]
-    if os.path.exists(out) and all(os.path.getmtime(out) >= os.path.getmtime(p) for p in deps):
+    if os.path.exists(out) and all(os.path.getmtime(out) >= os.path.getmtime(p) for p in deps) and isa_record_clean(out):
         return out
-    os.makedirs(BUILD_DIR, exist_ok=True)
-    cmds, objs = hipcc_commands(spec, out, list(flags))
-    try:
-        for c in cmds:
-            r = subprocess.run(c, cwd=CSRC_DIR, capture_output=True, text=True)
-            if r.returncode != 0:
-                raise LfsdError("hipcc failed for variant %s of model %s:\n%s" % (tag, spec.name, r.stderr[-3000:]))
-    finally:
-        for o in objs:
-            if os.path.exists(o):
-                os.remove(o)
+    _checked_build(spec, out, extra=list(flags), what="variant %s of model" % tag)
     return out
 
 

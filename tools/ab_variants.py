@@ -44,6 +44,10 @@ def build(names):
     for name in names:
         extra, capi, slp = VARIANTS[name]
         out = variant_path(spec, name)
+        if capi is None and not slp:      # (the common case: assembly-checked like the product build, lfsd_amd/isa_check.py)
+            runtime.build_checked(spec, out, list(extra))
+            print("built", name, out, flush=True)
+            continue
         cmds, objs = runtime.hipcc_commands(spec, out, list(extra), **({} if capi is None else {"extra_capi": capi}))
         if slp:
             cmds[0] = [c for c in cmds[0] if c != "-fno-slp-vectorize"]

@@ -15,12 +15,7 @@ if __name__ == "__main__":
         oc, env, d = models.ZOO[kind]()
         spec = oc.model_spec(); runtime.write_header(spec)
         out = oc_trace.variant_path(spec, sys.argv[3])
-        cmds, objs = runtime.hipcc_commands(spec, out, sys.argv[4:])
-        for c in cmds:
-            r = subprocess.run(c, cwd=runtime.CSRC_DIR, capture_output=True, text=True)
-            assert r.returncode == 0, r.stderr[-3000:]
-        for o in objs:
-            os.remove(o)
+        runtime.build_checked(spec, out, sys.argv[4:])      # (assembly-checked like the product build: lfsd_amd/isa_check.py)
         print(out)
     else:
         n_grid, B, dt = int(sys.argv[3]), int(sys.argv[4]), sys.argv[5]

@@ -18,12 +18,7 @@ def build():
     oc, env, d = models.quadrotor(n_grid=50)
     spec = oc.model_spec(); runtime.write_header(spec)
     out = variant_path(spec)
-    cmds, objs = runtime.hipcc_commands(spec, out, ["-DLFSD_TRACE"])
-    for c in cmds:
-        r = subprocess.run(c, cwd=runtime.CSRC_DIR, capture_output=True, text=True)
-        assert r.returncode == 0, r.stderr[-3000:]
-    for o in objs:
-        os.remove(o)
+    runtime.build_checked(spec, out, ["-DLFSD_TRACE"])      # (assembly-checked like the product build: lfsd_amd/isa_check.py)
     print(out)
 
 

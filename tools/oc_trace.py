@@ -20,12 +20,7 @@ def build(kind, extra, tag="trace"):
     oc, env, d = models.ZOO[kind]()
     spec = oc.model_spec(); runtime.write_header(spec)
     out = variant_path(spec, tag)
-    cmds, objs = runtime.hipcc_commands(spec, out, ["-DLFSD_TRACE"] + list(extra))
-    for c in cmds:
-        r = subprocess.run(c, cwd=runtime.CSRC_DIR, capture_output=True, text=True)
-        assert r.returncode == 0, r.stderr[-3000:]
-    for o in objs:
-        os.remove(o)
+    runtime.build_checked(spec, out, ["-DLFSD_TRACE"] + list(extra))      # (assembly-checked like the product build: lfsd_amd/isa_check.py)
     print(out)
 
 
