@@ -18,7 +18,8 @@ The compiler keeps such spills behind the exec restore unless the join block beg
 which both wrong builds had.  Nothing in the source is wrong and nothing in the source controls it; whether it happens changes with
 any perturbation of the kernel (a printf, a clock read, another instruction scheduler).
 
-So every build is scanned: in a block that is the target of an `s_cbranch_execz` (a join block), between the label and the
+So every build is scanned: in a block that is the target of an `s_cbranch_execz` (a join block) or that follows the back edge of a
+divergent loop (`s_cbranch_execnz`: the loop's exit), between the label and the
 `s_or_b64 exec, exec, ...` that re-enables the lanes,
   * a VGPR spill store (`v_accvgpr_write_b32 aN, vM`, `scratch_store_* ; ... Folded Spill`) is a HAZARD;
   * a spill reload (`v_accvgpr_read_b32`, `scratch_load_* ; ... Folded Reload`) is a hazard when the reloaded register is read
@@ -32,6 +33,7 @@ import re
 _FUNC = re.compile(r"^([A-Za-z_][\w$.]*):")
 _BLOCK = re.compile(r"^(\.LBB\d+_\d+):")
 _EXECZ = re.compile(r"^\s+s_cbranch_execz\s+(\.LBB\d+_\d+)")
+_EXECNZ = re.compile(r"^\s+s_cbranch_execnz\s+(\.LBB\d+_\d+)")
 _RESTORE = re.compile(r"^s_or_b64\s+exec,\s*exec,")
 _SPILL_STORE = re.compile(r"^(v_accvgpr_write_b32\s+a\d+,\s*v\d+|scratch_store_\w+\s.*Folded Spill)")
 _SPILL_LOAD = re.compile(r"^(v_accvgpr_read_b32\s+(v\d+),\s*a\d+|scratch_load_(\w+)\s+(v\d+|v\[\d+:\d+\]),.*Folded Reload)")
@@ -83,9 +85,19 @@ def find_exec_hazards(asm_text):
             func = m.group(1)
             continue
         m = _BLOCK.match(ln)
-        if not m or m.group(1) not in targets:
+        if m and m.group(1) in targets:
+            label = m.group(1)
+        elif _EXECNZ.match(ln):      # the fall-through behind the back edge of a divergent loop is its exit whether or not a skip branch targets it
+            label = "behind line %d" % (i + 1)
+        else:
             continue
-        label, j, stores, loads, restore_at = m.group(1), i + 1, [], [], -1
+        j, stores, loads, restore_at = i + 1, [], [], -1
+        while j < n and (not lines[j].strip() or lines[j].strip().startswith(";") or (label.startswith("behind") and _BLOCK.match(lines[j]))):
+            if _BLOCK.match(lines[j]) and _BLOCK.match(lines[j]).group(1) in targets:
+                break                # (that block is examined under its own label)
+            j += 1
+        if j < n and _BLOCK.match(lines[j]) and label.startswith("behind"):
+            continue
         while j < n:
             t = lines[j].strip()
             if not t or t.startswith(";"):

@@ -77,6 +77,12 @@ def test_only_join_blocks_are_examined():
     body = REGION + "\ts_andn2_saveexec_b64 s[0:1], s[0:1]\n\tv_accvgpr_write_b32 a12, v10\n\ts_or_b64 exec, exec, s[0:1]\n"
     assert isa_check.find_exec_hazards(_fn(body)) == []
     assert isa_check.summary(_fn(REGION)) == {"functions": 1, "join_blocks": 1}
+    # the exit of a divergent loop that no skip branch targets (a loop every lane group enters) is examined too
+    loop = ("\ts_mov_b64 s[0:1], exec\n.LBB0_2:\n\tglobal_load_dword v5, v[0:1], off\n\ts_andn2_b64 exec, exec, s[14:15]\n\ts_cbranch_execnz .LBB0_2\n"
+            "; %bb.3:\n\tv_accvgpr_write_b32 a12, v10\n\ts_or_b64 exec, exec, s[0:1]\n")
+    assert [h["kind"] for h in isa_check.find_exec_hazards(_fn(loop))] == ["spill"]
+    assert isa_check.find_exec_hazards(_fn(loop.replace("\tv_accvgpr_write_b32 a12, v10\n\ts_or_b64 exec, exec, s[0:1]\n",
+                                                        "\ts_or_b64 exec, exec, s[0:1]\n\tv_accvgpr_write_b32 a12, v10\n"))) == []
 
 
 def test_every_product_library_carries_a_clean_assembly_record():
