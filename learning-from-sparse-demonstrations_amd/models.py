@@ -123,14 +123,20 @@ def build_all(verbose=False, force=False):
     import json
     import os
     from . import runtime
-    out, keep = {}, set()
+    from concurrent.futures import ThreadPoolExecutor
+    out, keep, specs = {}, set(), {}
     for name, fac in ZOO.items():
         oc, _, _ = fac()
-        spec = oc.model_spec()
-        keep.add(spec.hash())
-        out[name] = runtime.build_library(spec, force=force, verbose=verbose)
-        if verbose:
-            print("built", name, spec.hash(), out[name])
+        specs[name] = oc.model_spec()
+        keep.add(specs[name].hash())
+    # (hipcc runs as child processes, every build in a work directory of its own: a few at a time -- a fresh clone builds the zoo in
+    #  ~4 minutes instead of ~11)
+    with ThreadPoolExecutor(max_workers=max(1, min(4, (os.cpu_count() or 2) // 2))) as pool:
+        futs = {name: pool.submit(runtime.build_library, spec, force, verbose) for name, spec in specs.items()}
+        for name, fut in futs.items():
+            out[name] = fut.result()
+            if verbose:
+                print("built", name, specs[name].hash(), out[name])
     manifest = os.path.join(runtime.GEN_DIR, "ZOO_MANIFEST.json")
     old = set()
     if os.path.exists(manifest):
@@ -139,7 +145,7 @@ def build_all(verbose=False, force=False):
         except Exception:
             old = set()
     for h in old - keep:
-        for path in (runtime.header_path(h), runtime.library_path(h)):
+        for path in (runtime.header_path(h), runtime.library_path(h), runtime.isa_record_path(runtime.library_path(h))):
             if os.path.exists(path):
                 os.remove(path)
     with open(manifest, "w") as f:

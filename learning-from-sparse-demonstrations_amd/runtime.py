@@ -254,16 +254,21 @@ GPU_TIER_VARIANTS = (("quadrotor", 50, "nocoarse", ("-DLFSD_COARSE_START=0",)),
 def build_gpu_tier_variants(verbose=False):
     """Prebuild the variants above so that they travel with the tree (optional: a failure here is reported, not raised --
     the product libraries do not depend on them)."""
+    from concurrent.futures import ThreadPoolExecutor
     from . import models
     built = {}
-    for kind, n_grid, tag, flags in GPU_TIER_VARIANTS:
-        try:
+    with ThreadPoolExecutor(max_workers=max(1, min(4, (os.cpu_count() or 2) // 2))) as pool:
+        futs = {}
+        for kind, n_grid, tag, flags in GPU_TIER_VARIANTS:
             oc = models.ZOO[kind](n_grid=n_grid)[0]
-            built[(kind, tag)] = build_variant_library(oc.model_spec(), tag, flags)
-            if verbose:
-                print("variant", kind, tag, built[(kind, tag)])
-        except Exception as exc:      # noqa: BLE001
-            print("WARNING: test variant %s/%s not built: %s" % (kind, tag, str(exc)[:300]))
+            futs[(kind, tag)] = pool.submit(build_variant_library, oc.model_spec(), tag, flags)
+        for (kind, tag), fut in futs.items():
+            try:
+                built[(kind, tag)] = fut.result()
+                if verbose:
+                    print("variant", kind, tag, built[(kind, tag)])
+            except Exception as exc:      # noqa: BLE001
+                print("WARNING: test variant %s/%s not built: %s" % (kind, tag, str(exc)[:300]))
     return built
 
 
