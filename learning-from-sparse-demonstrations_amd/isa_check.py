@@ -20,7 +20,7 @@ any perturbation of the kernel (a printf, a clock read, another instruction sche
 
 So every build is scanned: in a block that is the target of an `s_cbranch_execz` (a join block) or that follows the back edge of a
 divergent loop (`s_cbranch_execnz`: the loop's exit), between the label and the
-`s_or_b64 exec, exec, ...` that re-enables the lanes,
+`s_or_b64 exec, exec, ...` (or `s_or_saveexec` / `s_andn2_saveexec` / `s_xor_b64 exec`: the entry of an else-region) that re-enables lanes,
   * a VGPR spill store (`v_accvgpr_write_b32 aN, vM`, `scratch_store_* ; ... Folded Spill`) is a HAZARD;
   * a spill reload (`v_accvgpr_read_b32`, `scratch_load_* ; ... Folded Reload`) is a hazard when the reloaded register is read
     after the restore before it is written again (inactive lanes would read what the register held before).
@@ -34,7 +34,9 @@ _FUNC = re.compile(r"^([A-Za-z_][\w$.]*):")
 _BLOCK = re.compile(r"^(\.LBB\d+_\d+):")
 _EXECZ = re.compile(r"^\s+s_cbranch_execz\s+(\.LBB\d+_\d+)")
 _EXECNZ = re.compile(r"^\s+s_cbranch_execnz\s+(\.LBB\d+_\d+)")
-_RESTORE = re.compile(r"^s_or_b64\s+exec,\s*exec,")
+# what switches lanes back on at the top of a join block: the plain restore, and the entry of an else-region / of the next round of a
+# waterfall (s_or_saveexec, s_andn2_saveexec, s_xor exec): a spill in front of any of them stores the lanes of the region just left
+_RESTORE = re.compile(r"^(s_or_b64\s+exec,\s*exec,|s_or_saveexec_b64|s_andn2_saveexec_b64|s_xor_b64\s+exec,\s*exec,)")
 _SPILL_STORE = re.compile(r"^(v_accvgpr_write_b32\s+a\d+,\s*v\d+|scratch_store_\w+\s.*Folded Spill)")
 _SPILL_LOAD = re.compile(r"^(v_accvgpr_read_b32\s+(v\d+),\s*a\d+|scratch_load_(\w+)\s+(v\d+|v\[\d+:\d+\]),.*Folded Reload)")
 _VREG = re.compile(r"\bv(\d+)\b|\bv\[(\d+):(\d+)\]")

@@ -118,7 +118,7 @@ KERNEL_SOURCES = ("cpdp_kernels.h", "cpdp_common.h", "cpdp_oc.h", "cpdp_aux.h", 
 # if none is, the build FAILS (no library is better than a library whose upper lanes read stale spill slots).
 SCHEDULE_ALTERNATES = ((), ("-mllvm", "-amdgpu-sched-strategy=max-ilp"), ("-mllvm", "-amdgpu-sched-strategy=max-memory-clause"),
                        ("-mllvm", "-amdgpu-use-amdgpu-trackers"), ("-mllvm", "-greedy-reverse-local-assignment"))
-ISA_CHECK_VERSION = 2      # (2: loop exits without a skip branch are examined too)
+ISA_CHECK_VERSION = 3      # (2: loop exits without a skip branch are examined too; 3: the entries of else-regions count as restores)
 
 
 def isa_record_path(lib_path):

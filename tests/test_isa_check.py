@@ -73,8 +73,13 @@ def test_only_join_blocks_are_examined():
     body = ("\ts_and_saveexec_b64 s[0:1], vcc\n\ts_cbranch_execz .LBB0_3\n.LBB0_2:\n\tv_accvgpr_write_b32 a12, v10\n"
             "\ts_or_b64 exec, exec, s[0:1]\n.LBB0_3:\n\ts_or_b64 exec, exec, s[0:1]\n\tv_accvgpr_write_b32 a13, v11\n")
     assert isa_check.find_exec_hazards(_fn(body)) == []
-    # another exec manipulation ends the scan of a join block (nested regions)
+    # the entry of an else-region switches lanes on as well: a spill in front of it is flagged, one inside the else-region is not
     body = REGION + "\ts_andn2_saveexec_b64 s[0:1], s[0:1]\n\tv_accvgpr_write_b32 a12, v10\n\ts_or_b64 exec, exec, s[0:1]\n"
+    assert isa_check.find_exec_hazards(_fn(body)) == []
+    body = REGION + "\tv_accvgpr_write_b32 a12, v10\n\ts_or_saveexec_b64 s[0:1], s[0:1]\n\ts_xor_b64 exec, exec, s[0:1]\n"
+    assert [h["kind"] for h in isa_check.find_exec_hazards(_fn(body))] == ["spill"]
+    # any other write of exec ends the scan of a join block
+    body = REGION + "\ts_mov_b64 exec, s[4:5]\n\tv_accvgpr_write_b32 a12, v10\n\ts_or_b64 exec, exec, s[0:1]\n"
     assert isa_check.find_exec_hazards(_fn(body)) == []
     assert isa_check.summary(_fn(REGION)) == {"functions": 1, "join_blocks": 1}
     # the exit of a divergent loop that no skip branch targets (a loop every lane group enters) is examined too
