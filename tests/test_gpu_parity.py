@@ -993,3 +993,40 @@ def test_wide_launch_schemes_bit_identical(kind, n_grid, monkeypatch):
         else:
             for key in keys:
                 assert torch.equal(sol[key], ref[key]), (envs, key, int((sol[key] != ref[key]).sum()))
+
+
+def test_the_libraries_this_box_loads_passed_the_assembly_check():
+    """Every model library the tier can load on this box -- the ones that travelled with the tree and the ones built here -- went through
+    runtime._checked_build: a record of ITS bytes (sha256) says both translation units are free of VGPR spills before an exec restore
+    (lfsd_amd/isa_check.py; the cause of round 6's wrong builds of the wide kernel, profiles/r06_v_spill_before_exec_restore.txt).  And
+    the rocket's wide fp32 solve -- the kernel two of those builds got wrong -- gives the SAME iterates with one and with four wavefronts
+    per trajectory on cold starts that shorten steps on the coarse level (the wrong builds needed ~60 iterations to status 2 here)."""
+    import glob
+    from lfsd_amd import runtime
+    for kind in models.ZOO:
+        oc, env, d = models.ZOO[kind]()
+        oc.setDevice("cuda:0", torch.float32)
+        lib = oc.compile()
+        path = runtime.library_path(oc.model_spec().hash())
+        assert runtime.isa_record_clean(path), (kind, path)
+    for path in glob.glob(os.path.join(runtime.BUILD_DIR, "*.so")):
+        assert runtime.isa_record_clean(path), path
+    oc, env, d = models.ZOO["rocket"](n_grid=100)
+    oc.setDevice("cuda:0", torch.float32)
+    rng = np.random.default_rng(0)
+    B = 256
+    th = np.array(d["theta0"])[None, :] * (1 + 0.05 * rng.standard_normal((B, len(d["theta0"]))))
+    th[:, 0] = np.abs(th[:, 0]) + 0.1
+    x0 = np.tile(d["ini_state"], (B, 1))
+    res = {}
+    try:
+        for waves in ("1", "4"):
+            os.environ["LFSD_WIDE_WAVES"] = waves
+            s = oc.cocSolverBatch(x0, d["horizon"], th)
+            res[waves] = {k: s[k].clone() for k in ("state_grid", "control_grid", "cost", "iters", "status")}
+    finally:
+        os.environ.pop("LFSD_WIDE_WAVES", None)
+    for k in res["1"]:
+        assert torch.equal(res["1"][k], res["4"][k]), k
+    st, it = res["1"]["status"].cpu().numpy(), res["1"]["iters"].cpu().numpy()
+    assert (st == 1).mean() > 0.95 and it.mean() < 50, (np.bincount(st, minlength=5), it.mean())
