@@ -1009,8 +1009,11 @@ def test_the_libraries_this_box_loads_passed_the_assembly_check():
         lib = oc.compile()
         path = runtime.library_path(oc.model_spec().hash())
         assert runtime.isa_record_clean(path), (kind, path)
-    for path in glob.glob(os.path.join(runtime.BUILD_DIR, "*.so")):
+    for path in glob.glob(os.path.join(runtime.BUILD_DIR, "liblfsd_*.so")):      # (+ the models other tests of the tier compiled on this box)
         assert runtime.isa_record_clean(path), path
+    for kind, n_grid, tag, flags in runtime.GPU_TIER_VARIANTS:                      # the variants the tier's A/B tests load
+        path = runtime.variant_library_path(models.ZOO[kind](n_grid=n_grid)[0].model_spec(), tag)
+        assert not os.path.exists(path) or runtime.isa_record_clean(path), path
     oc, env, d = models.ZOO["rocket"](n_grid=100)
     oc.setDevice("cuda:0", torch.float32)
     rng = np.random.default_rng(0)
